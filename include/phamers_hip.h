@@ -1,0 +1,168 @@
+/*
+ * phamers_hip.h -- C ABI of libphamers_hip.so, the MI355X (gfx950) k-mer count +
+ * phage-score path behind PhaMers' Python hot-path functions.
+ *
+ * The reference (jondeaton/PhaMers, Python 2.7) has no FFI / plugin interface: its
+ * boundary for this path is a set of Python call signatures.  Each entry point below
+ * names the reference function (file:line, relative to the PhaMers tree) whose
+ * arithmetic it replaces; phamers_amd/{kmer,learning,phamer}.py bind them with ctypes
+ * and reproduce the Python-level names, defaults, return shapes and soft-failure
+ * behaviour (INTEGRATION.md shows the stub a PhaMers maintainer would add).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.  Every function returns
+ *     PHK_OK (0) or a negative PHK_ERR_* code; phk_last_error() gives the text
+ *     (thread-local).
+ *   - the library never allocates caller-visible memory: outputs are caller-allocated.
+ *   - "host API" functions take HOST pointers, are synchronous, and stage through a
+ *     per-context device workspace.  "device API" functions (suffix _dev) take DEVICE
+ *     pointers (hipMalloc / torch data_ptr), enqueue on the context's HIP stream and
+ *     return without synchronising (phk_sync() to wait).
+ *   - one context per (process, GPU); calls on one context are serialised on its
+ *     stream; distinct contexts may be used from distinct threads.
+ *
+ * Packed base stream (the device-side sequence format; this library's own layout)
+ *   All contigs of a batch are concatenated into ONE stream of T bases with no padding.
+ *   offsets[n+1] (uint64, in bases, offsets[0] = 0, offsets[n] = T) delimits contig c as
+ *   stream positions [offsets[c], offsets[c+1]).
+ *   packed : uint32 words, ceil(T/16)+1 of them (one zero pad word).  Base g is the 2-bit
+ *            field at bits [30-2*(g%16), 31-2*(g%16)] of word g/16 -- the FIRST base of a
+ *            word sits in the MOST significant bits, so a k-mer read off the word is
+ *            already the reference's bin index (first base = most significant base-4
+ *            digit, scripts/kmer.py:50).  Codes follow the symbols string: for the
+ *            default 'ATGC' A=0 T=1 G=2 C=3 (scripts/kmer.py:28).
+ *   mask   : optional validity bits, uint32 words, ceil(T/32)+1 of them; bit 31-(g%32) of
+ *            word g/32 is 1 when base g is one of the 4 symbols (case-sensitive) and 0
+ *            otherwise (the reference's '-', scripts/kmer.py:190-191).  NULL = all valid.
+ *   A window is counted iff all k of its bases lie inside one contig and are valid
+ *   (scripts/kmer.py:47-50).
+ */
+#ifndef PHAMERS_HIP_H
+#define PHAMERS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHK_ABI_VERSION 1
+
+#define PHK_OK 0
+#define PHK_ERR_ARG (-1)         /* bad argument (null pointer, bad k, bad shape) */
+#define PHK_ERR_HIP (-2)         /* HIP runtime error; text has hipGetErrorString */
+#define PHK_ERR_NOMEM (-3)       /* device allocation failed */
+#define PHK_ERR_UNSUPPORTED (-4) /* outside the implemented path (e.g. k > PHK_MAX_K) */
+#define PHK_ERR_NAN (-5)         /* a query row contains NaN (zero-count contig), see phk_score_* */
+
+#define PHK_MAX_K 7              /* 4^k uint32 bins must fit one wave's LDS histogram */
+
+#define PHK_METHOD_KNN 1         /* scripts/phamer.py:268-273 */
+#define PHK_METHOD_KMEANS 2      /* scripts/phamer.py:240-256 (centroids supplied) */
+#define PHK_METHOD_COMBO 3       /* scripts/phamer.py:303-313 */
+
+typedef struct phk_ctx phk_ctx;
+typedef struct phk_model phk_model;
+
+/* ---- library / context ------------------------------------------------------------- */
+int phk_abi_version(void);
+const char *phk_last_error(void);
+int phk_device_count(int *count);
+/* stream: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or
+ * NULL to let the context create and own a stream. */
+int phk_create(int device_id, void *stream, phk_ctx **out);
+int phk_destroy(phk_ctx *ctx);
+int phk_sync(phk_ctx *ctx);
+
+/* device buffers for hosts that do not bring their own allocator */
+int phk_malloc(phk_ctx *ctx, uint64_t bytes, void **dptr);
+int phk_free(phk_ctx *ctx, void *dptr);
+int phk_memcpy_h2d(phk_ctx *ctx, void *dst_dev, const void *src_host, uint64_t bytes);
+int phk_memcpy_d2h(phk_ctx *ctx, void *dst_host, const void *src_dev, uint64_t bytes);
+
+/* ---- host API: counting ------------------------------------------------------------ */
+/* kmer.count_string / kmer.count (scripts/kmer.py:32-50, 82-111): n sequences given as
+ * concatenated ASCII `bases` + offsets[n+1]; counts[n][4^k] int64 (NumPy's default int, as
+ * the reference returns).  symbols: the 4 characters that code 0..3 (the reference's
+ * `symbols` argument when it has exactly 4 characters; "ATGC" by default). */
+int phk_count_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n, int k,
+                    const char *symbols4, int64_t *counts);
+
+/* kmer.normalize_counts (scripts/kmer.py:209-221): out[r][j] = (double)counts[r][j] /
+ * (double)sum_j counts[r][j]; a zero row gives NaN exactly as the reference does. */
+int phk_normalize_i64(phk_ctx *ctx, const int64_t *counts, uint64_t n, uint64_t D, double *out);
+/* same for an already-float matrix (row sum taken left to right in float64) */
+int phk_normalize_f64(phk_ctx *ctx, const double *rows, uint64_t n, uint64_t D, double *out);
+
+/* ---- scoring model ----------------------------------------------------------------- */
+/* The training side of phamer_scorer.score_points (scripts/phamer.py:177-195): positive /
+ * negative reference rows (float64, normalised, row-major [n][D]); train = vstack(pos, neg),
+ * labels = 1 for pos rows, 0 for neg rows (scripts/phamer.py:186-187).  cpos / cneg are the
+ * k-means centroids of the two classes (scripts/phamer.py:245-248, learning.get_centroids
+ * scripts/learning.py:69-81) and may be NULL / 0 when only PHK_METHOD_KNN will be used.
+ * kn = k_neighbors (scripts/phamer.py:79, default 3).  All pointers are HOST pointers; the
+ * model keeps device copies. */
+int phk_model_create(phk_ctx *ctx, const double *pos, uint64_t n_pos, const double *neg,
+                     uint64_t n_neg, const double *cpos, uint64_t n_cpos, const double *cneg,
+                     uint64_t n_cneg, uint64_t D, int kn, phk_model **out);
+int phk_model_destroy(phk_ctx *ctx, phk_model *model);
+
+/* ---- host API: scoring ------------------------------------------------------------- */
+/* phamer.score_points / phamer_scorer.score_points (scripts/phamer.py:451-468, 177-195) for
+ * method in {knn, kmeans, combo}: Q[N][D] float64 host rows -> scores[N] float64.
+ *   knn    : 2*(majority label of the kn nearest train rows) - 1   (scripts/learning.py:118-128)
+ *   kmeans : tanh((e- - e+)/(e+ + e-)), e+/- = distance to the nearest positive / negative
+ *            centroid (scripts/phamer.py:198-210, 250-256; scripts/learning.py:47-66)
+ *   combo  : knn + kmeans (scripts/phamer.py:303-313)
+ * Returns PHK_ERR_NAN (scores untouched) if any query element is NaN -- the reference's
+ * scikit-learn call raises on such input. */
+int phk_score(phk_ctx *ctx, const phk_model *model, const double *Q, uint64_t N, int method,
+              double *scores);
+
+/* ---- device API -------------------------------------------------------------------- */
+/* ASCII -> packed stream (+ mask).  d_any_invalid (one uint32, device) is set non-zero when
+ * some base is not one of symbols4; it may be NULL. */
+int phk_pack_ascii_dev(phk_ctx *ctx, const char *d_bases, uint64_t total_bases,
+                       const char *symbols4, uint32_t *d_packed, uint32_t *d_mask,
+                       uint32_t *d_any_invalid);
+/* packed stream -> d_counts[n][4^k] uint32 and d_nwin[n] (= row sums = number of counted
+ * windows; may be NULL).  d_mask may be NULL (all bases valid). */
+int phk_count_dev(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
+                  uint64_t total_bases, const uint64_t *d_offsets, uint64_t n, int k,
+                  uint32_t *d_counts, uint32_t *d_nwin);
+int phk_normalize_dev(phk_ctx *ctx, const uint32_t *d_counts, uint64_t n, uint64_t D,
+                      double *d_out);
+/* scores for device-resident float64 rows / for device-resident uint32 count rows (the
+ * rows are normalised on the fly exactly as kmer.normalize_counts would).  d_status: one
+ * uint32 (device), set to the number of NaN (zero-count) rows seen; their scores are NaN. */
+int phk_score_dev(phk_ctx *ctx, const phk_model *model, const double *d_Q, uint64_t N,
+                  int method, double *d_scores, uint32_t *d_status);
+int phk_score_counts_dev(phk_ctx *ctx, const phk_model *model, const uint32_t *d_counts,
+                         uint64_t N, int method, double *d_scores, uint32_t *d_status);
+/* the whole hot path on device-resident input: count -> normalise -> score.  d_counts
+ * ([n][4^k] uint32) receives the materialised counts. */
+int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const uint32_t *d_packed,
+                        const uint32_t *d_mask, uint64_t total_bases, const uint64_t *d_offsets,
+                        uint64_t n, int k, int method, uint32_t *d_counts, double *d_scores,
+                        uint32_t *d_status);
+
+/* seeded synthetic batch generated on the device (phamers_amd/synth.py defines the hash):
+ * n contigs of L bases, contig ids first_contig..first_contig+n-1; writes the packed stream,
+ * the mask (if d_mask != NULL; required when invalid_ppm > 0) and offsets[n+1]. */
+int phk_synth_packed_dev(phk_ctx *ctx, uint64_t seed, uint64_t first_contig, uint64_t n,
+                         uint64_t L, uint32_t invalid_ppm, uint32_t *d_packed, uint32_t *d_mask,
+                         uint64_t *d_offsets);
+
+/* ---- in-library kernel timing (HIP events on the context's stream) ------------------ */
+int phk_profile_enable(phk_ctx *ctx, int on);
+int phk_profile_reset(phk_ctx *ctx);
+/* number of distinct kernels timed since the last reset */
+int phk_profile_count(phk_ctx *ctx, int *count);
+/* idx-th kernel: name (NUL-terminated, truncated to cap), total milliseconds, launches */
+int phk_profile_get(phk_ctx *ctx, int idx, char *name, int cap, double *total_ms,
+                    uint64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHAMERS_HIP_H */

@@ -1,0 +1,209 @@
+"""
+ctypes binding of libphamers_hip.so (include/phamers_hip.h).
+
+The library is the product: there is no CPU fallback.  If the shared object is
+missing, or no gfx950 device can be opened, every operation raises.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libphamers_hip.so")
+
+PHK_OK = 0
+PHK_ERR_ARG, PHK_ERR_HIP, PHK_ERR_NOMEM, PHK_ERR_UNSUPPORTED, PHK_ERR_NAN = -1, -2, -3, -4, -5
+METHOD_KNN, METHOD_KMEANS, METHOD_COMBO = 1, 2, 3
+METHODS = {"knn": METHOD_KNN, "kmeans": METHOD_KMEANS, "combo": METHOD_COMBO}
+MAX_K = 7
+
+c_void_p, c_int, c_u32, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
+c_char_p, c_double = ctypes.c_char_p, ctypes.c_double
+P = ctypes.POINTER
+
+# name -> (restype, argtypes); one entry per function declared in include/phamers_hip.h
+SIGNATURES = {
+    "phk_abi_version": (c_int, []),
+    "phk_last_error": (c_char_p, []),
+    "phk_device_count": (c_int, [P(c_int)]),
+    "phk_create": (c_int, [c_int, c_void_p, P(c_void_p)]),
+    "phk_destroy": (c_int, [c_void_p]),
+    "phk_sync": (c_int, [c_void_p]),
+    "phk_malloc": (c_int, [c_void_p, c_u64, P(c_void_p)]),
+    "phk_free": (c_int, [c_void_p, c_void_p]),
+    "phk_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_u64]),
+    "phk_memcpy_d2h": (c_int, [c_void_p, c_void_p, c_void_p, c_u64]),
+    "phk_count_ascii": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_char_p, c_void_p]),
+    "phk_normalize_i64": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p]),
+    "phk_normalize_f64": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p]),
+    "phk_model_create": (c_int, [c_void_p, c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_u64,
+                                 c_void_p, c_u64, c_u64, c_int, P(c_void_p)]),
+    "phk_model_destroy": (c_int, [c_void_p, c_void_p]),
+    "phk_score": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_void_p]),
+    "phk_pack_ascii_dev": (c_int, [c_void_p, c_void_p, c_u64, c_char_p, c_void_p, c_void_p, c_void_p]),
+    "phk_count_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_void_p, c_u64, c_int,
+                              c_void_p, c_void_p]),
+    "phk_normalize_dev": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p]),
+    "phk_score_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_void_p, c_void_p]),
+    "phk_score_counts_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_void_p, c_void_p]),
+    "phk_count_score_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_void_p, c_u64,
+                                    c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "phk_synth_packed_dev": (c_int, [c_void_p, c_u64, c_u64, c_u64, c_u64, c_u32, c_void_p,
+                                     c_void_p, c_void_p]),
+    "phk_profile_enable": (c_int, [c_void_p, c_int]),
+    "phk_profile_reset": (c_int, [c_void_p]),
+    "phk_profile_count": (c_int, [c_void_p, P(c_int)]),
+    "phk_profile_get": (c_int, [c_void_p, c_int, c_char_p, c_int, P(c_double), P(c_u64)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+_contexts = {}
+
+
+class PhkError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "libphamers_hip: %s (code %d)" % (message, code))
+        self.code = code
+
+
+def load():
+    """dlopen the in-tree library and declare every signature; raises if it is absent."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise ImportError(
+                        "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or `make -C phamers_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+                lib = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(lib, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != PHK_OK:
+        raise PhkError(rc, load().phk_last_error().decode("utf-8", "replace"))
+
+
+def default_device():
+    for var in ("PHAMERS_HIP_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v not in (None, ""):
+            return int(v)
+    return 0
+
+
+def ptr(a):
+    """void* of a C-contiguous NumPy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class Context(object):
+    """One per (process, GPU).  ``stream`` may be a raw hipStream_t integer
+    (e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+
+    def __init__(self, device=None, stream=None):
+        self.lib = load()
+        self.device = default_device() if device is None else int(device)
+        h = ctypes.c_void_p()
+        check(self.lib.phk_create(self.device, ctypes.c_void_p(stream) if stream else None, ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.phk_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.phk_sync(self.handle))
+
+    # ---- timing ----
+    def profile_enable(self, on=True):
+        check(self.lib.phk_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        check(self.lib.phk_profile_reset(self.handle))
+
+    def profile(self):
+        """{kernel name: (total_ms, launches)} since the last reset."""
+        n = ctypes.c_int()
+        check(self.lib.phk_profile_count(self.handle, ctypes.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name = ctypes.create_string_buffer(128)
+            ms, cnt = ctypes.c_double(), ctypes.c_uint64()
+            check(self.lib.phk_profile_get(self.handle, i, name, 128, ctypes.byref(ms), ctypes.byref(cnt)))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+
+class Model(object):
+    """Device-resident training side of phamer_scorer.score_points."""
+
+    def __init__(self, ctx, positive, negative, positive_centroids=None, negative_centroids=None,
+                 k_neighbors=3):
+        self.ctx = ctx
+        pos = np.ascontiguousarray(positive, dtype=np.float64)
+        neg = np.ascontiguousarray(negative, dtype=np.float64)
+        if pos.ndim != 2 or neg.ndim != 2 or pos.shape[1] != neg.shape[1]:
+            raise ValueError("positive / negative data must be 2-D with the same number of columns")
+        cp = cn = None
+        if positive_centroids is not None:
+            cp = np.ascontiguousarray(positive_centroids, dtype=np.float64)
+            cn = np.ascontiguousarray(negative_centroids, dtype=np.float64)
+        self.D = pos.shape[1]
+        h = ctypes.c_void_p()
+        check(ctx.lib.phk_model_create(ctx.handle, ptr(pos), pos.shape[0], ptr(neg), neg.shape[0],
+                                       ptr(cp), 0 if cp is None else cp.shape[0],
+                                       ptr(cn), 0 if cn is None else cn.shape[0],
+                                       self.D, int(k_neighbors), ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.phk_model_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def score(self, Q, method="combo"):
+        Q = np.ascontiguousarray(Q, dtype=np.float64)
+        if Q.ndim != 2 or Q.shape[1] != self.D:
+            raise ValueError("query rows must be (N, %d)" % self.D)
+        out = np.empty(Q.shape[0], dtype=np.float64)
+        check(self.ctx.lib.phk_score(self.ctx.handle, self.handle, ptr(Q), Q.shape[0], METHODS[method], ptr(out)))
+        return out
+
+
+def get_context(device=None):
+    """Process-wide default context for ``device`` (created on first use)."""
+    dev = default_device() if device is None else int(device)
+    with _lock:
+        ctx = _contexts.get(dev)
+    if ctx is None:
+        ctx = Context(dev)
+        with _lock:
+            _contexts.setdefault(dev, ctx)
+            ctx = _contexts[dev]
+    return ctx

@@ -1,0 +1,373 @@
+// phk_api.hip -- the extern "C" surface of libphamers_hip.so (include/phamers_hip.h):
+// context / workspace / timing plumbing and the host- and device-pointer entry points.
+#include <string.h>
+
+#include "phk_common.h"
+#include "score_model.h"
+
+static thread_local char g_err[512] = "";
+
+void phk_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *phk_last_error(void) { return g_err; }
+extern "C" int phk_abi_version(void) { return PHK_ABI_VERSION; }
+
+extern "C" int phk_device_count(int *count) {
+    PHK_REQUIRE(count, "phk_device_count: NULL");
+    PHK_HIP(hipGetDeviceCount(count));
+    return PHK_OK;
+}
+
+extern "C" int phk_create(int device_id, void *stream, phk_ctx **out) {
+    PHK_REQUIRE(out, "phk_create: NULL out");
+    int ndev = 0;
+    PHK_HIP(hipGetDeviceCount(&ndev));
+    PHK_REQUIRE(device_id >= 0 && device_id < ndev, "phk_create: device %d not present (%d devices)",
+                device_id, ndev);
+    PHK_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    PHK_HIP(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        phk_set_error("phk_create: device %d is %s; this library is built for gfx950 only", device_id,
+                      prop.gcnArchName);
+        return PHK_ERR_UNSUPPORTED;
+    }
+    phk_ctx *ctx = new phk_ctx();
+    ctx->device = device_id;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+        ctx->own_stream = false;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            phk_set_error("phk_create: hipStreamCreate failed: %s", hipGetErrorString(e));
+            delete ctx;
+            return PHK_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return PHK_OK;
+}
+
+extern "C" int phk_destroy(phk_ctx *ctx) {
+    if (!ctx) return PHK_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < WS_SLOTS; ++i)
+        if (ctx->ws[i].ptr) (void)hipFree(ctx->ws[i].ptr);
+    for (auto &t : ctx->timed)
+        for (auto e : t.ev) (void)hipEventDestroy(e);
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PHK_OK;
+}
+
+extern "C" int phk_sync(phk_ctx *ctx) {
+    PHK_REQUIRE(ctx, "phk_sync: NULL ctx");
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    return PHK_OK;
+}
+
+int phk_ws(phk_ctx *ctx, int slot, uint64_t bytes, void **out) {
+    PhkBuf &b = ctx->ws[slot];
+    if (bytes == 0) bytes = 16;
+    if (b.bytes < bytes) {
+        if (b.ptr) {
+            // kernels already enqueued may still read the old buffer
+            PHK_HIP(hipStreamSynchronize(ctx->stream));
+            PHK_HIP(hipFree(b.ptr));
+            b.ptr = nullptr;
+            b.bytes = 0;
+        }
+        uint64_t want = (bytes + 255) & ~255ull;
+        hipError_t e = hipMalloc(&b.ptr, want);
+        if (e != hipSuccess) {
+            b.ptr = nullptr;
+            phk_set_error("workspace slot %d: hipMalloc(%llu) failed: %s", slot, (unsigned long long)want,
+                          hipGetErrorString(e));
+            return PHK_ERR_NOMEM;
+        }
+        b.bytes = want;
+    }
+    *out = b.ptr;
+    return PHK_OK;
+}
+
+extern "C" int phk_malloc(phk_ctx *ctx, uint64_t bytes, void **dptr) {
+    PHK_REQUIRE(ctx && dptr, "phk_malloc: NULL");
+    PHK_HIP(hipSetDevice(ctx->device));
+    PHK_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+    return PHK_OK;
+}
+extern "C" int phk_free(phk_ctx *ctx, void *dptr) {
+    PHK_REQUIRE(ctx, "phk_free: NULL ctx");
+    if (dptr) {
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+        PHK_HIP(hipFree(dptr));
+    }
+    return PHK_OK;
+}
+extern "C" int phk_memcpy_h2d(phk_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    PHK_REQUIRE(ctx && (bytes == 0 || (dst && src)), "phk_memcpy_h2d: NULL");
+    if (bytes) {
+        PHK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PHK_OK;
+}
+extern "C" int phk_memcpy_d2h(phk_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    PHK_REQUIRE(ctx && (bytes == 0 || (dst && src)), "phk_memcpy_d2h: NULL");
+    if (bytes) {
+        PHK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PHK_OK;
+}
+
+// ---- kernel timing --------------------------------------------------------------------
+static int fold_events(phk_ctx *ctx, PhkTimed &t) {
+    for (size_t i = 0; i + 1 < t.ev.size(); i += 2) {
+        PHK_HIP(hipEventSynchronize(t.ev[i + 1]));
+        float ms = 0.f;
+        PHK_HIP(hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]));
+        t.ms += ms;
+        t.launches += 1;
+        ctx->ev_pool.push_back(t.ev[i]);
+        ctx->ev_pool.push_back(t.ev[i + 1]);
+    }
+    t.ev.clear();
+    return PHK_OK;
+}
+
+static int get_event(phk_ctx *ctx, hipEvent_t *e) {
+    if (!ctx->ev_pool.empty()) {
+        *e = ctx->ev_pool.back();
+        ctx->ev_pool.pop_back();
+        return PHK_OK;
+    }
+    PHK_HIP(hipEventCreate(e));
+    return PHK_OK;
+}
+
+int phk_prof_begin(phk_ctx *ctx, const char *name, int *slot) {
+    int idx = -1;
+    for (size_t i = 0; i < ctx->timed.size(); ++i)
+        if (ctx->timed[i].name == name) { idx = (int)i; break; }
+    if (idx < 0) {
+        ctx->timed.push_back(PhkTimed());
+        ctx->timed.back().name = name;
+        idx = (int)ctx->timed.size() - 1;
+    }
+    PhkTimed &t = ctx->timed[idx];
+    if (t.ev.size() >= 4096) PHK_TRY(fold_events(ctx, t));
+    hipEvent_t a, b;
+    PHK_TRY(get_event(ctx, &a));
+    PHK_TRY(get_event(ctx, &b));
+    t.ev.push_back(a);
+    t.ev.push_back(b);
+    PHK_HIP(hipEventRecord(a, ctx->stream));
+    *slot = idx;
+    return PHK_OK;
+}
+
+int phk_prof_end(phk_ctx *ctx, int slot) {
+    PhkTimed &t = ctx->timed[slot];
+    PHK_HIP(hipEventRecord(t.ev.back(), ctx->stream));
+    return PHK_OK;
+}
+
+extern "C" int phk_profile_enable(phk_ctx *ctx, int on) {
+    PHK_REQUIRE(ctx, "phk_profile_enable: NULL ctx");
+    ctx->profile = on != 0;
+    return PHK_OK;
+}
+extern "C" int phk_profile_reset(phk_ctx *ctx) {
+    PHK_REQUIRE(ctx, "phk_profile_reset: NULL ctx");
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &t : ctx->timed) {
+        for (auto e : t.ev) ctx->ev_pool.push_back(e);
+        t.ev.clear();
+    }
+    ctx->timed.clear();
+    return PHK_OK;
+}
+extern "C" int phk_profile_count(phk_ctx *ctx, int *count) {
+    PHK_REQUIRE(ctx && count, "phk_profile_count: NULL");
+    *count = (int)ctx->timed.size();
+    return PHK_OK;
+}
+extern "C" int phk_profile_get(phk_ctx *ctx, int idx, char *name, int cap, double *total_ms,
+                               uint64_t *launches) {
+    PHK_REQUIRE(ctx && idx >= 0 && idx < (int)ctx->timed.size(), "phk_profile_get: bad index");
+    PhkTimed &t = ctx->timed[idx];
+    PHK_TRY(fold_events(ctx, t));
+    if (name && cap > 0) {
+        strncpy(name, t.name.c_str(), cap - 1);
+        name[cap - 1] = 0;
+    }
+    if (total_ms) *total_ms = t.ms;
+    if (launches) *launches = t.launches;
+    return PHK_OK;
+}
+
+// ---- host API ---------------------------------------------------------------------------
+extern "C" int phk_count_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n,
+                               int k, const char *symbols4, int64_t *counts) {
+    PHK_REQUIRE(ctx, "phk_count_ascii: NULL ctx");
+    PHK_REQUIRE(k >= 1, "phk_count_ascii: k must be >= 1 (got %d)", k);
+    if (k > PHK_MAX_K) {
+        phk_set_error("phk_count_ascii: k=%d is above PHK_MAX_K=%d", k, PHK_MAX_K);
+        return PHK_ERR_UNSUPPORTED;
+    }
+    if (n == 0) return PHK_OK;
+    PHK_REQUIRE(offsets && counts, "phk_count_ascii: NULL offsets/counts");
+    const char *sym = symbols4 ? symbols4 : "ATGC";
+    PHK_REQUIRE(strlen(sym) == 4, "phk_count_ascii: symbols must be exactly 4 characters");
+    PHK_REQUIRE(offsets[0] == 0, "phk_count_ascii: offsets[0] must be 0");
+    for (uint64_t c = 0; c < n; ++c)
+        PHK_REQUIRE(offsets[c + 1] >= offsets[c], "phk_count_ascii: offsets must be non-decreasing");
+    const uint64_t T = offsets[n];
+    PHK_REQUIRE(T == 0 || bases, "phk_count_ascii: NULL bases");
+    PHK_HIP(hipSetDevice(ctx->device));
+    const uint64_t D = phk_pow4(k);
+    void *d_ascii, *d_packed, *d_mask, *d_off, *d_counts, *d_wide, *d_flags;
+    PHK_TRY(phk_ws(ctx, WS_ASCII, T, &d_ascii));
+    PHK_TRY(phk_ws(ctx, WS_PACKED, (phk_div_up(T, 16) + 1) * 4, &d_packed));
+    PHK_TRY(phk_ws(ctx, WS_MASK, (phk_div_up(T, 32) + 1) * 4, &d_mask));
+    PHK_TRY(phk_ws(ctx, WS_OFFSETS, (n + 1) * 8, &d_off));
+    PHK_TRY(phk_ws(ctx, WS_COUNTS, n * D * 4, &d_counts));
+    PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &d_wide));
+    PHK_TRY(phk_ws(ctx, WS_FLAGS, 64, &d_flags));
+    if (T) PHK_HIP(hipMemcpyAsync(d_ascii, bases, T, hipMemcpyHostToDevice, ctx->stream));
+    PHK_HIP(hipMemcpyAsync(d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    PHK_TRY(phk_launch_pack(ctx, (const char *)d_ascii, T, sym, (uint32_t *)d_packed, (uint32_t *)d_mask,
+                            (uint32_t *)d_flags));
+    uint32_t any_invalid = 1;
+    PHK_HIP(hipMemcpyAsync(&any_invalid, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    PHK_TRY(phk_launch_count(ctx, (const uint32_t *)d_packed, any_invalid ? (const uint32_t *)d_mask : nullptr,
+                             T, (const uint64_t *)d_off, n, k, (uint32_t *)d_counts, nullptr));
+    PHK_TRY(phk_launch_widen(ctx, (const uint32_t *)d_counts, n * D, (int64_t *)d_wide));
+    PHK_HIP(hipMemcpyAsync(counts, d_wide, n * D * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    return PHK_OK;
+}
+
+extern "C" int phk_normalize_i64(phk_ctx *ctx, const int64_t *counts, uint64_t n, uint64_t D, double *out) {
+    PHK_REQUIRE(ctx, "phk_normalize_i64: NULL ctx");
+    if (n == 0 || D == 0) return PHK_OK;
+    PHK_REQUIRE(counts && out, "phk_normalize_i64: NULL pointer");
+    PHK_HIP(hipSetDevice(ctx->device));
+    void *d_in, *d_out;
+    PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &d_in));
+    PHK_TRY(phk_ws(ctx, WS_Q64, n * D * 8, &d_out));
+    PHK_HIP(hipMemcpyAsync(d_in, counts, n * D * 8, hipMemcpyHostToDevice, ctx->stream));
+    PHK_TRY(phk_launch_normalize_i64(ctx, (const int64_t *)d_in, n, D, (double *)d_out));
+    PHK_HIP(hipMemcpyAsync(out, d_out, n * D * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    return PHK_OK;
+}
+
+extern "C" int phk_normalize_f64(phk_ctx *ctx, const double *rows, uint64_t n, uint64_t D, double *out) {
+    PHK_REQUIRE(ctx, "phk_normalize_f64: NULL ctx");
+    if (n == 0 || D == 0) return PHK_OK;
+    PHK_REQUIRE(rows && out, "phk_normalize_f64: NULL pointer");
+    PHK_HIP(hipSetDevice(ctx->device));
+    void *d_in, *d_out;
+    PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &d_in));
+    PHK_TRY(phk_ws(ctx, WS_Q64, n * D * 8, &d_out));
+    PHK_HIP(hipMemcpyAsync(d_in, rows, n * D * 8, hipMemcpyHostToDevice, ctx->stream));
+    PHK_TRY(phk_launch_normalize_f64(ctx, (const double *)d_in, n, D, (double *)d_out));
+    PHK_HIP(hipMemcpyAsync(out, d_out, n * D * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    return PHK_OK;
+}
+
+extern "C" int phk_score(phk_ctx *ctx, const phk_model *model, const double *Q, uint64_t N, int method,
+                         double *scores) {
+    PHK_REQUIRE(ctx && model, "phk_score: NULL ctx/model");
+    if (N == 0) return PHK_OK;
+    PHK_REQUIRE(Q && scores, "phk_score: NULL pointer");
+    PHK_HIP(hipSetDevice(ctx->device));
+    const uint64_t D = model->D;
+    void *d_q, *d_s, *d_flags;
+    PHK_TRY(phk_ws(ctx, WS_WIDE, N * D * 8, &d_q));
+    PHK_TRY(phk_ws(ctx, WS_COUNTS, N * 8, &d_s));
+    PHK_TRY(phk_ws(ctx, WS_FLAGS, 64, &d_flags));
+    PHK_HIP(hipMemcpyAsync(d_q, Q, N * D * 8, hipMemcpyHostToDevice, ctx->stream));
+    PHK_TRY(phk_score_rows(ctx, model, (const double *)d_q, nullptr, N, method, (double *)d_s,
+                           (uint32_t *)d_flags));
+    uint32_t nan_rows = 0;
+    PHK_HIP(hipMemcpyAsync(&nan_rows, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    if (nan_rows) {
+        phk_set_error("phk_score: %u query row(s) contain NaN (zero-count contigs?)", nan_rows);
+        return PHK_ERR_NAN;
+    }
+    PHK_HIP(hipMemcpyAsync(scores, d_s, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    return PHK_OK;
+}
+
+// ---- device API -------------------------------------------------------------------------
+extern "C" int phk_pack_ascii_dev(phk_ctx *ctx, const char *d_bases, uint64_t total_bases,
+                                  const char *symbols4, uint32_t *d_packed, uint32_t *d_mask,
+                                  uint32_t *d_any_invalid) {
+    PHK_REQUIRE(ctx, "phk_pack_ascii_dev: NULL ctx");
+    const char *sym = symbols4 ? symbols4 : "ATGC";
+    PHK_REQUIRE(strlen(sym) == 4, "phk_pack_ascii_dev: symbols must be exactly 4 characters");
+    return phk_launch_pack(ctx, d_bases, total_bases, sym, d_packed, d_mask, d_any_invalid);
+}
+
+extern "C" int phk_count_dev(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
+                             uint64_t total_bases, const uint64_t *d_offsets, uint64_t n, int k,
+                             uint32_t *d_counts, uint32_t *d_nwin) {
+    PHK_REQUIRE(ctx, "phk_count_dev: NULL ctx");
+    return phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets, n, k, d_counts, d_nwin);
+}
+
+extern "C" int phk_normalize_dev(phk_ctx *ctx, const uint32_t *d_counts, uint64_t n, uint64_t D,
+                                 double *d_out) {
+    PHK_REQUIRE(ctx && (n == 0 || (d_counts && d_out)), "phk_normalize_dev: NULL pointer");
+    return phk_launch_normalize_u32(ctx, d_counts, n, D, d_out);
+}
+
+extern "C" int phk_score_dev(phk_ctx *ctx, const phk_model *model, const double *d_Q, uint64_t N,
+                             int method, double *d_scores, uint32_t *d_status) {
+    PHK_REQUIRE(ctx && model, "phk_score_dev: NULL ctx/model");
+    PHK_REQUIRE(N == 0 || d_Q, "phk_score_dev: NULL query pointer");
+    return phk_score_rows(ctx, model, d_Q, nullptr, N, method, d_scores, d_status);
+}
+
+extern "C" int phk_score_counts_dev(phk_ctx *ctx, const phk_model *model, const uint32_t *d_counts,
+                                    uint64_t N, int method, double *d_scores, uint32_t *d_status) {
+    PHK_REQUIRE(ctx && model, "phk_score_counts_dev: NULL ctx/model");
+    PHK_REQUIRE(N == 0 || d_counts, "phk_score_counts_dev: NULL counts pointer");
+    return phk_score_rows(ctx, model, nullptr, d_counts, N, method, d_scores, d_status);
+}
+
+extern "C" int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const uint32_t *d_packed,
+                                   const uint32_t *d_mask, uint64_t total_bases,
+                                   const uint64_t *d_offsets, uint64_t n, int k, int method,
+                                   uint32_t *d_counts, double *d_scores, uint32_t *d_status) {
+    PHK_REQUIRE(ctx && model, "phk_count_score_dev: NULL ctx/model");
+    PHK_REQUIRE(phk_pow4(k) == model->D, "phk_count_score_dev: 4^k (k=%d) != model dimension %llu", k,
+                (unsigned long long)model->D);
+    PHK_TRY(phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets, n, k, d_counts, nullptr));
+    return phk_score_rows(ctx, model, nullptr, d_counts, n, method, d_scores, d_status);
+}
+
+extern "C" int phk_synth_packed_dev(phk_ctx *ctx, uint64_t seed, uint64_t first_contig, uint64_t n,
+                                    uint64_t L, uint32_t invalid_ppm, uint32_t *d_packed,
+                                    uint32_t *d_mask, uint64_t *d_offsets) {
+    PHK_REQUIRE(ctx, "phk_synth_packed_dev: NULL ctx");
+    return phk_launch_synth(ctx, seed, first_contig, n, L, invalid_ppm, d_packed, d_mask, d_offsets);
+}

@@ -1,0 +1,122 @@
+// phk_common.h -- context, workspace, error and kernel-timing plumbing shared by the
+// translation units of libphamers_hip.so.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/phamers_hip.h"
+
+#define PHK_WAVE 64
+
+void phk_set_error(const char *fmt, ...);
+
+#define PHK_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            phk_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                          __LINE__);                                                       \
+            return e__ == hipErrorOutOfMemory ? PHK_ERR_NOMEM : PHK_ERR_HIP;               \
+        }                                                                                  \
+    } while (0)
+
+#define PHK_REQUIRE(cond, ...)        \
+    do {                              \
+        if (!(cond)) {                \
+            phk_set_error(__VA_ARGS__); \
+            return PHK_ERR_ARG;       \
+        }                             \
+    } while (0)
+
+#define PHK_TRY(call)               \
+    do {                            \
+        int rc__ = (call);          \
+        if (rc__ != PHK_OK) return rc__; \
+    } while (0)
+
+// workspace slots (device scratch owned by the context, grown on demand, reused)
+enum PhkSlot {
+    WS_ASCII = 0,   // host API: uploaded ASCII bases
+    WS_PACKED,      // host API: packed stream
+    WS_MASK,        // host API: validity mask
+    WS_OFFSETS,     // host API: offsets
+    WS_COUNTS,      // host API: uint32 counts
+    WS_WIDE,        // host API: int64 / float64 staging
+    WS_FLAGS,       // small flags / status words
+    WS_Q64,         // scoring: float64 query rows
+    WS_SCORES,      // scoring: float64 scores
+    WS_DIST,        // scoring (exact path): distance tiles
+    WS_QF32,        // scoring (MFMA path): fragment-ordered fp32 queries
+    WS_CAND,        // scoring (MFMA path): candidate lists
+    WS_NWIN,        // row sums
+    WS_SLOTS
+};
+
+struct PhkBuf {
+    void *ptr = nullptr;
+    uint64_t bytes = 0;
+};
+
+struct PhkTimed {
+    std::string name;
+    std::vector<hipEvent_t> ev;  // start/stop pairs not yet folded
+    double ms = 0.0;
+    uint64_t launches = 0;
+};
+
+struct phk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    PhkBuf ws[WS_SLOTS];
+    bool profile = false;
+    std::vector<PhkTimed> timed;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+int phk_ws(phk_ctx *ctx, int slot, uint64_t bytes, void **out);
+
+// kernel timing: PHK_LAUNCH(ctx, "name", kernel<<<...>>>(...)) brackets the launch with HIP
+// events on the context's stream when profiling is on.
+int phk_prof_begin(phk_ctx *ctx, const char *name, int *slot);
+int phk_prof_end(phk_ctx *ctx, int slot);
+
+#define PHK_LAUNCH(ctx, name, ...)                         \
+    do {                                                   \
+        int ps__ = -1;                                     \
+        if ((ctx)->profile) PHK_TRY(phk_prof_begin((ctx), (name), &ps__)); \
+        __VA_ARGS__;                                       \
+        PHK_HIP(hipGetLastError());                        \
+        if ((ctx)->profile) PHK_TRY(phk_prof_end((ctx), ps__)); \
+    } while (0)
+
+static inline uint64_t phk_pow4(int k) { return 1ull << (2 * k); }
+static inline uint64_t phk_div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// ---- internal entry points implemented across translation units ----
+// count.hip
+int phk_launch_pack(phk_ctx *ctx, const char *d_bases, uint64_t T, const char *symbols4,
+                    uint32_t *d_packed, uint32_t *d_mask, uint32_t *d_any_invalid);
+int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t T,
+                     const uint64_t *d_offsets, uint64_t n, int k, uint32_t *d_counts,
+                     uint32_t *d_nwin);
+int phk_launch_widen(phk_ctx *ctx, const uint32_t *d_in, uint64_t count, int64_t *d_out);
+int phk_launch_normalize_u32(phk_ctx *ctx, const uint32_t *d_counts, uint64_t n, uint64_t D,
+                             double *d_out);
+int phk_launch_normalize_i64(phk_ctx *ctx, const int64_t *d_counts, uint64_t n, uint64_t D,
+                             double *d_out);
+int phk_launch_normalize_f64(phk_ctx *ctx, const double *d_rows, uint64_t n, uint64_t D,
+                             double *d_out);
+// synth.hip
+int phk_launch_synth(phk_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, uint64_t L,
+                     uint32_t invalid_ppm, uint32_t *d_packed, uint32_t *d_mask,
+                     uint64_t *d_offsets);
+// score.hip
+struct phk_model;
+int phk_score_rows(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
+                   uint64_t N, int method, double *d_scores, uint32_t *d_status);

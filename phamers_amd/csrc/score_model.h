@@ -1,0 +1,34 @@
+// score_model.h -- the device-resident scoring model (train rows, labels, centroids and the
+// MFMA path's derived operands).
+#pragma once
+#include "phk_common.h"
+
+struct phk_model {
+    uint64_t D = 0, M = 0, n_pos = 0, n_neg = 0, n_cpos = 0, n_cneg = 0;
+    int kn = 3;
+    // exact path
+    double *d_R64 = nullptr;      // [M][D] train = vstack(pos, neg)  (scripts/phamer.py:186)
+    uint8_t *d_labels = nullptr;  // [M] 1 = positive row           (scripts/phamer.py:187)
+    double *d_C64 = nullptr;      // [n_cpos + n_cneg][D] centroids
+    // MFMA path (score_mfma.hip); null when the shape is outside it
+    bool fast = false;
+    float *d_Bf = nullptr;        // fragment-ordered centred fp32 columns (train rows, then centroids)
+    float *d_colnorm = nullptr;   // ||r'||^2 per column (+inf on padding)
+    float *d_mu32 = nullptr;      // centring vector, fp32
+    double *d_mu64 = nullptr;     // centring vector, fp64
+    uint32_t n_rblk_ref = 0, n_rblk_pos = 0, n_rblk_neg = 0;  // 32-column blocks per segment
+    double max_colnorm = 0.0;     // max ||r'|| over real columns (error bound)
+    double mu_norm = 0.0;         // ||mu||
+};
+
+// exact float64 batch scorer (score.hip)
+int phk_score_exact_batch(phk_ctx *ctx, const phk_model *m, const double *d_Q, uint64_t nq, int method,
+                          double *d_knn, double *d_cen, uint32_t *d_status);
+
+// MFMA path hooks (score_mfma.hip)
+int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const double *neg,
+                         const double *cpos, const double *cneg);
+void phk_model_free_fast(phk_model *m);
+static inline bool phk_model_has_fast(const phk_model *m) { return m->fast; }
+int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
+                   uint64_t N, int method, double *d_scores, uint32_t *d_status);

@@ -1,0 +1,181 @@
+"""
+kmer.py -- drop-in for the hot-path functions of PhaMers' scripts/kmer.py, executed
+by hand-written HIP kernels on an MI355X through libphamers_hip.so.
+
+Same names, argument meaning, defaults and return shapes as the reference:
+
+    count_string(sequence, kmer_length, symbols=DNA, normalize=False)   scripts/kmer.py:32
+    count(data, kmer_length, symbols=DNA, normalize=False)              scripts/kmer.py:82
+    count_file(input_file, kmer_length, symbols=DNA, normalize=False)   scripts/kmer.py:114
+    normalize_counts(counts)                                            scripts/kmer.py:209
+    kmers(k, symbols=DNA), sequence_to_integers, get_kmer_index         scripts/kmer.py:183-251
+
+Scope notes: only 4-symbol alphabets run on the GPU (the reference's
+integer-replacement branch with DNA/RNA); other alphabets raise NotImplementedError --
+there is no CPU fallback in this package.
+"""
+import gzip
+import logging
+import os
+
+import numpy as np
+
+from . import _lib
+from . import id_parser
+
+logging.basicConfig(format='[%(asctime)s][%(levelname)s][%(funcName)s] - %(message)s')
+logger = logging.getLogger(__name__)
+logger.setLevel(logging.WARNING)
+
+DNA = 'ATGC'
+RNA = 'AUGC'
+protein = 'RHKDESTNQCUGPAVILMFYW'
+
+
+def _check_symbols(symbols):
+    if len(symbols) != 4 or len(set(symbols)) != 4:
+        raise NotImplementedError(
+            "phamers_amd counts k-mers over 4-symbol alphabets (DNA/RNA) on the GPU; symbols=%r is "
+            "outside the accelerated path (use PhaMers' own kmer.py for it)" % (symbols,))
+    try:
+        return symbols.encode('latin-1')
+    except UnicodeEncodeError:
+        raise NotImplementedError("symbols must be single-byte characters")
+
+
+def _count_batch(sequences, kmer_length, symbols):
+    """n sequences -> (n, 4^k) int64 via phk_count_ascii (one upload, one launch chain)."""
+    k = int(kmer_length)
+    sym = _check_symbols(symbols)
+    n = len(sequences)
+    D = 4 ** k
+    raw = [s.encode('latin-1', 'replace') for s in sequences]
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    if n:
+        offsets[1:] = np.cumsum([len(r) for r in raw], dtype=np.uint64)
+    bases = np.frombuffer(b''.join(raw) or b'\0', dtype=np.uint8)
+    out = np.zeros((n, D), dtype=np.int64)
+    ctx = _lib.get_context()
+    _lib.check(ctx.lib.phk_count_ascii(ctx.handle, _lib.ptr(np.ascontiguousarray(bases)), _lib.ptr(offsets),
+                                       n, k, sym, _lib.ptr(out)))
+    return out
+
+
+def count_string(sequence, kmer_length, symbols=DNA, normalize=False):
+    """k-mer counting function (scripts/kmer.py:32-79): forward-strand, stride-1 windows;
+    windows touching a character outside ``symbols`` (case-sensitive) are skipped; bin index
+    has the first base as the most significant base-4 digit ('AAAT' -> 1).  Returns a 1-D
+    int64 array of length 4^k, or float64 frequencies when ``normalize`` (all zeros stay
+    zeros)."""
+    counts = _count_batch([sequence], kmer_length, symbols)[0]
+    if normalize:
+        counts = counts.astype(float)
+        if np.sum(counts) > 0:
+            counts = normalize_counts(counts)
+    return counts
+
+
+def count(data, kmer_length, symbols=DNA, normalize=False):
+    """K-mer counting dispatcher (scripts/kmer.py:82-111): str -> 1-D; list of one string ->
+    1-D; list of n strings -> (n, 4^k); anything else -> None (logged)."""
+    if isinstance(data, list):
+        if len(data) == 1:
+            return count(data[0], kmer_length, symbols=symbols, normalize=normalize)
+        logger.info("Counting %d-mers in %d sequences..." % (kmer_length, len(data)))
+        kmer_count = _count_batch(data, kmer_length, symbols)
+        if normalize:
+            # per-row count_string(normalize=True): zero rows stay zero (scripts/kmer.py:77)
+            sums = kmer_count.sum(axis=1)
+            kmer_count = normalize_counts(kmer_count) if len(data) else kmer_count.astype(float)
+            kmer_count[sums == 0] = 0.0
+    elif isinstance(data, str):
+        kmer_count = count_string(data, kmer_length, symbols=symbols, normalize=normalize)
+    else:
+        logger.info("Data was not str or list: %s\n%s ..." % (type(data), data.__str__()[:25]))
+        kmer_count = None
+    return kmer_count
+
+
+def read_fasta_records(input_file):
+    """(headers, sequences) of a FASTA file; '.gz' files are read through gzip
+    (scripts/kmer.py:131-135).  The header is the text after '>' up to the first white space
+    (Biopython's record.id)."""
+    opener = gzip.open if input_file.endswith('.gz') else open
+    headers, seqs, cur = [], [], None
+    with opener(input_file, 'rt') as f:
+        for line in f:
+            if line.startswith('>'):
+                if cur is not None:
+                    seqs.append(''.join(cur))
+                fields = line[1:].split()
+                headers.append(fields[0] if fields else '')
+                cur = []
+            elif cur is not None:
+                cur.append(line.strip())
+    if cur is not None:
+        seqs.append(''.join(cur))
+    return headers, seqs
+
+
+def count_file(input_file, kmer_length, symbols=DNA, normalize=False):
+    """Counts k-mers of every record of a FASTA file (scripts/kmer.py:114-140).  Returns
+    (ids, counts): ids parsed by the reference's header rules (scripts/id_parser.py:89-100),
+    counts (n, 4^k).  An unreadable file gives (None, None)."""
+    try:
+        headers, seqs = read_fasta_records(input_file)
+    except IOError:
+        logger.warning("Could not read file: %s" % os.path.basename(input_file))
+        return None, None
+    ids = np.array([id_parser.get_id(h) for h in headers])
+    counts = np.zeros((len(ids), pow(len(symbols), kmer_length)), dtype=(int, float)[normalize])
+    if len(seqs):
+        got = _count_batch(seqs, kmer_length, symbols)
+        if normalize:
+            sums = got.sum(axis=1)
+            got = normalize_counts(got)
+            got[sums == 0] = 0.0
+        counts[:, :] = got
+    return ids, counts
+
+
+def normalize_counts(counts):
+    """Row-normalise a count array (scripts/kmer.py:209-221): float64 copy, each row divided
+    by its sum; a zero row becomes NaN, exactly as in the reference."""
+    counts = np.asarray(counts)
+    shape = counts.shape
+    if counts.ndim not in (1, 2):
+        raise ValueError("normalize_counts expects a 1-D or 2-D array")
+    rows = counts.reshape(1, -1) if counts.ndim == 1 else counts
+    n, D = rows.shape
+    out = np.empty((n, D), dtype=np.float64)
+    if n == 0 or D == 0:
+        return out.reshape(shape)
+    ctx = _lib.get_context()
+    if np.issubdtype(rows.dtype, np.integer) or rows.dtype == np.bool_:
+        src = np.ascontiguousarray(rows, dtype=np.int64)
+        _lib.check(ctx.lib.phk_normalize_i64(ctx.handle, _lib.ptr(src), n, D, _lib.ptr(out)))
+    else:
+        src = np.ascontiguousarray(rows, dtype=np.float64)
+        _lib.check(ctx.lib.phk_normalize_f64(ctx.handle, _lib.ptr(src), n, D, _lib.ptr(out)))
+    return out.reshape(shape)
+
+
+# ---- label utilities (host-side strings; not arithmetic) ---------------------------------
+def sequence_to_integers(sequence, symbols):
+    """scripts/kmer.py:183-196: non-symbol characters -> '-', symbol i -> str(i)."""
+    table = {s: str(i) for i, s in enumerate(symbols)}
+    return ''.join(table.get(ch, '-') for ch in sequence)
+
+
+def get_kmer_index(kmer, symbols):
+    """scripts/kmer.py:199-206 (NB the reference parses in base len(kmer), right only when
+    k == len(symbols); reproduced as is)."""
+    return int(sequence_to_integers(kmer, symbols), len(kmer))
+
+
+def kmers(k, symbols=DNA):
+    """All k-mers in bin order (scripts/kmer.py:224-251)."""
+    mers = ['']
+    for _ in range(k):
+        mers = [m + s for m in mers for s in symbols]
+    return mers

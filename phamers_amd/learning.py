@@ -1,0 +1,62 @@
+"""
+learning.py -- drop-in for the hot-path helpers of PhaMers' scripts/learning.py.
+
+    knn(queries, ref_data, ref_labels, k=3)       scripts/learning.py:118-128   -> GPU
+    kmeans(data, k, ...)                          scripts/learning.py:131-146   -> scikit-learn
+    get_centroids(data, assignment)               scripts/learning.py:69-81     -> NumPy (86 means)
+
+k-means stays on scikit-learn exactly as in the reference (a per-run fit that does not
+depend on the number of query contigs); its centroids are an explicit
+input of the GPU scorer.  A deterministic GPU Lloyd k-means is listed under "next" in
+DESIGN.md.
+"""
+import logging
+
+import numpy as np
+
+from . import _lib
+
+kmeans_seed = 10  # scripts/learning.py:21
+
+logging.basicConfig(format='[%(asctime)s][%(levelname)s][%(funcName)s] - %(message)s')
+logger = logging.getLogger(__name__)
+logger.setLevel(logging.WARNING)
+
+
+def knn(queries, ref_data, ref_labels, k=3):
+    """K-nearest-neighbours vote (scripts/learning.py:118-128): Euclidean, uniform weights,
+    labels in {0, 1}; returns 2*(predicted label - 0.5), i.e. -1.0 / +1.0 per query."""
+    ref_data = np.asarray(ref_data, dtype=np.float64)
+    labels = np.asarray(ref_labels)
+    if not np.all((labels == 0) | (labels == 1)):
+        raise NotImplementedError("phamers_amd.learning.knn handles the reference's {0,1} labels only")
+    queries = np.asarray(queries, dtype=np.float64)
+    if np.isnan(queries).any() or np.isnan(ref_data).any():
+        raise ValueError("Input contains NaN.")  # what scikit-learn raises for the reference
+    ctx = _lib.get_context()
+    model = _lib.Model(ctx, ref_data[labels == 1], ref_data[labels == 0], k_neighbors=k)
+    try:
+        return model.score(queries, "knn")
+    finally:
+        model.close()
+
+
+def kmeans(data, k, verbose=False, sort_by_size=False):
+    """K-means labels through scikit-learn with the reference's seed
+    (scripts/learning.py:131-146)."""
+    from sklearn.cluster import KMeans
+    assignment = KMeans(n_clusters=k, random_state=kmeans_seed).fit(data).labels_
+    if type(assignment) != np.ndarray:
+        assignment = np.array(assignment)
+    if sort_by_size:
+        raise NotImplementedError("sort_by_size is outside the accelerated path")
+    return assignment
+
+
+def get_centroids(data, assignment):
+    """Mean of the member rows per sorted label, -1 excluded (scripts/learning.py:69-81)."""
+    data = np.asarray(data)
+    labels = sorted(set(assignment) - set([-1]))
+    if len(labels) == 0:
+        logger.warning("No clusters assigned to data.")
+    return np.array([np.mean(data[assignment == c], axis=0) for c in labels])

@@ -1,0 +1,142 @@
+"""GPU parity: counting / packing / normalising through the C ABI (host facade and device
+API) against the golden vectors and the CPU oracle.  Bit-exact."""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def kmer():
+    from phamers_amd import kmer
+    return kmer
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from phamers_amd import _lib
+    return _lib.get_context()
+
+
+def test_count_string_golden(kmer):
+    golden = helpers.load_npz("counts.npz")
+    seqs, doc = helpers.count_cases()
+    n = 0
+    for key, want in golden.items():
+        name, _, ktag = key.rpartition("__k")
+        if name not in seqs:
+            continue
+        got = kmer.count_string(seqs[name], int(ktag))
+        assert got.dtype == np.int64 and got.shape == want.shape, key
+        assert np.array_equal(got, want), key
+        n += 1
+    assert n > 100
+
+
+def test_count_list_shapes_and_soft_failure(kmer):
+    golden = helpers.load_npz("counts.npz")
+    seqs, doc = helpers.count_cases()
+    lst = [seqs[n] for n in doc["list5"]]
+    got = kmer.count(lst, 4)
+    assert got.shape == (5, 256) and np.array_equal(got, golden["list5__k4"])
+    one = kmer.count([lst[0]], 4)
+    assert one.shape == (256,) and np.array_equal(one, golden["list1__k4"])
+    assert kmer.count(12345, 4) is None                       # scripts/kmer.py:108-110
+    a = kmer.count_string(lst[0], 4, normalize=True)
+    assert np.array_equal(a, golden["norm_mixed_invalid__k4"])
+    z = kmer.count_string("N" * 40, 4, normalize=True)
+    assert np.array_equal(z, golden["norm_all_N__k4"])
+    with pytest.raises(NotImplementedError):
+        kmer.count_string("ATGC", 2, symbols="RHKDESTNQCUGPAVILMFYW")
+    from phamers_amd import _lib
+    with pytest.raises(_lib.PhkError):
+        kmer.count_string("ATGC", 9)
+
+
+def test_count_other_alphabet_vs_oracle(kmer):
+    from oracle import oracle
+    s = "AUGCAUGGCCAUUAGCNAUGCaugc" * 7
+    for k in (2, 4):
+        assert np.array_equal(kmer.count_string(s, k, symbols="AUGC"), oracle.count_string(s, k, symbols="AUGC"))
+
+
+def test_count_ragged_batch_vs_oracle(kmer):
+    from oracle import oracle
+    from phamers_amd import synth
+    rng = np.random.default_rng(5)
+    lens = [0, 1, 3, 4, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 1023, 1024, 1025, 4999, 5000, 5001] + \
+        [int(x) for x in rng.integers(0, 3000, 40)]
+    seqs = [synth.synth_contig(9, i, L, invalid_ppm=(0 if i % 3 else 30000)) for i, L in enumerate(lens)]
+    for k in (1, 3, 4, 5, 6, 7):
+        got = kmer.count(seqs, k)
+        want = oracle.count(seqs, k)
+        assert np.array_equal(got, want), k
+
+
+def test_normalize_bit_exact(kmer):
+    g = helpers.load_npz("normalize.npz")
+    got = kmer.normalize_counts(g["in2d"])
+    assert got.dtype == np.float64
+    assert np.array_equal(np.isnan(got), np.isnan(g["out2d"]))
+    ok = ~np.isnan(got)
+    assert np.array_equal(got[ok].view(np.uint64), g["out2d"][ok].view(np.uint64))
+    assert np.isnan(got[3]).all()
+    got1 = kmer.normalize_counts(g["in1d"])
+    assert got1.shape == g["out1d"].shape and np.array_equal(got1, g["out1d"])
+    # float input (renormalising frequencies): bit-exact with NumPy's own row division
+    f = g["out2d"][[0, 1, 2, 4]] * 3.7
+    want = f.copy()
+    for i in range(want.shape[0]):
+        want[i, :] /= np.sum(want[i, :])
+    assert np.array_equal(kmer.normalize_counts(f).view(np.uint64), want.view(np.uint64))
+
+
+def test_device_pack_and_count_match_host_statement(ctx):
+    """Device packer vs the NumPy statement of the packed format; device counter on the packed
+    stream (with and without mask) vs the oracle; nwin = row sums."""
+    from oracle import oracle
+    from phamers_amd import device, synth
+    lens = [5000, 37, 0, 5000, 4, 3, 129, 70000, 5000]
+    seqs = [synth.synth_contig(4, i, L, invalid_ppm=(20000 if i in (1, 3, 7) else 0)) for i, L in enumerate(lens)]
+    T = sum(lens)
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    codes = np.concatenate([oracle.sequence_to_codes(s) for s in seqs])
+    want_packed, want_mask = helpers.pack_codes(codes)
+    raw = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    d_raw = device.DeviceArray.from_host(ctx, raw)
+    d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    d_mask = device.DeviceArray(ctx, device.mask_words(T), np.uint32)
+    d_flag = device.DeviceArray(ctx, 1, np.uint32)
+    device.pack_ascii(ctx, d_raw, T, d_packed, d_mask, d_flag)
+    assert np.array_equal(d_packed.to_host(), want_packed)
+    assert np.array_equal(d_mask.to_host(), want_mask)
+    assert d_flag.to_host()[0] != 0
+    d_off = device.DeviceArray.from_host(ctx, offsets)
+    for k in (4, 5, 6):
+        D = 4 ** k
+        d_counts = device.DeviceArray(ctx, (len(lens), D), np.uint32)
+        d_nwin = device.DeviceArray(ctx, len(lens), np.uint32)
+        device.count(ctx, d_packed, d_mask, T, d_off, len(lens), k, d_counts, d_nwin)
+        got = d_counts.to_host()
+        want = oracle.count(seqs, k)
+        assert np.array_equal(got.astype(np.int64), want), k
+        assert np.array_equal(d_nwin.to_host().astype(np.int64), want.sum(axis=1))
+
+
+def test_device_synth_matches_host_generator(ctx):
+    from oracle import oracle
+    from phamers_amd import device, synth
+    for (n, L, ppm) in ((7, 5000, 0), (5, 333, 50000), (3, 32, 0), (4, 1, 0)):
+        T = n * L
+        d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+        d_mask = device.DeviceArray(ctx, device.mask_words(T), np.uint32)
+        d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+        device.synth_packed(ctx, 3, 11, n, L, d_packed, d_off, d_mask, ppm)
+        codes = np.concatenate([synth.synth_codes(3, 11 + c, L, ppm) for c in range(n)])
+        want_packed, want_mask = helpers.pack_codes(codes)
+        assert np.array_equal(d_packed.to_host(), want_packed), (n, L, ppm)
+        assert np.array_equal(d_mask.to_host(), want_mask), (n, L, ppm)
+        assert np.array_equal(d_off.to_host(), np.arange(n + 1, dtype=np.uint64) * L)

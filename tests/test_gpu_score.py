@@ -1,0 +1,147 @@
+"""GPU parity: scoring through the C ABI (facade + device API) against the golden vectors
+produced by the reference's phamer.score_points.  knn scores exact (+-1); float scores within
+1e-6 relative (BASELINE.json north_star tolerance)."""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-6   # north_star: "within 1e-6 relative for the float scores"
+
+
+def _ref_matrices(oracle_norm=True):
+    from oracle import oracle
+    ref = helpers.load_npz("ref_features.npz")
+    pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))
+    neg = oracle.normalize_counts(ref["neg_counts"].astype(np.int64))
+    return pos, neg
+
+
+@pytest.mark.parametrize("tag", ["eq", "full"])
+def test_model_score_k4_golden(tag):
+    from phamers_amd import _lib
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    if tag == "eq":
+        n = min(pos.shape[0], neg.shape[0])
+        pos, neg = pos[:n], neg[:n]
+    ctx = _lib.get_context()
+    model = _lib.Model(ctx, pos, neg, g["cpos_" + tag], g["cneg_" + tag], k_neighbors=3)
+    q = g["q"]
+    assert np.array_equal(model.score(q, "knn"), g["knn_" + tag])
+    assert helpers.rel_err(model.score(q, "kmeans"), g["kmeans_" + tag]) < RTOL
+    assert helpers.rel_err(model.score(q, "combo"), g["combo_" + tag]) < RTOL
+    model.close()
+
+
+def test_facade_score_points_matches_reference():
+    """phamer.score_points end to end (k-means through scikit-learn, as the reference)."""
+    from phamers_amd import phamer
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    assert np.array_equal(phamer.score_points(g["q"], pos, neg, method="knn"), g["knn_full"])
+    sc = phamer.phamer_scorer()
+    sc.data_points, sc.positive_data, sc.negative_data = g["q"], pos, neg
+    sc.equalize_reference_data()
+    assert sc.positive_data.shape[0] == sc.negative_data.shape[0] == 2255
+    sc.scoring_method = "combo"
+    combo = sc.score_points()
+    # centroids come from this box's scikit-learn; equal to the golden ones when versions match
+    if np.allclose(sc.positive_centroids, g["cpos_eq"], rtol=0, atol=1e-15):
+        assert helpers.rel_err(combo, g["combo_eq"]) < RTOL
+    else:
+        from oracle import oracle
+        want = oracle.score_points(g["q"], sc.positive_data, sc.negative_data, "combo", 3,
+                                   sc.positive_centroids, sc.negative_centroids)
+        assert helpers.rel_err(combo, want) < RTOL
+    with pytest.raises(NotImplementedError):
+        phamer.score_points(g["q"], pos, neg, method="svm")
+    bad = g["q"].copy()
+    bad[3, :] = np.nan
+    with pytest.raises(ValueError):
+        phamer.score_points(bad, pos, neg, method="knn")
+
+
+def test_other_neighbour_counts_and_adversarial_queries():
+    from phamers_amd import _lib, learning
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    train = np.vstack((pos, neg))
+    labels = np.append(np.ones(pos.shape[0]), np.zeros(neg.shape[0]))
+    for kn in (1, 5, 7):
+        assert np.array_equal(learning.knn(g["q"], train, labels, k=kn), g["knn_full_kn%d" % kn])
+    ctx = _lib.get_context()
+    model = _lib.Model(ctx, pos, neg, g["cpos_full"], g["cneg_full"], 3)
+    assert np.array_equal(model.score(g["adv_q"], "knn"), g["adv_knn_full"])
+    assert helpers.rel_err(model.score(g["adv_q"], "kmeans"), g["adv_kmeans_full"]) < RTOL
+    assert helpers.rel_err(model.score(g["adv_q"], "combo"), g["adv_combo_full"]) < RTOL
+    model.close()
+
+
+def test_highdim_golden():
+    from phamers_amd import _lib
+    g = helpers.load_npz("scoring_highdim.npz")
+    ctx = _lib.get_context()
+    for tag in ("k5", "k6"):
+        model = _lib.Model(ctx, g["pos_" + tag], g["neg_" + tag], g["cpos_" + tag], g["cneg_" + tag], 3)
+        assert np.array_equal(model.score(g["q_" + tag], "knn"), g["knn_" + tag])
+        assert helpers.rel_err(model.score(g["q_" + tag], "kmeans"), g["kmeans_" + tag]) < RTOL
+        model.close()
+
+
+def test_device_pipeline_count_score_vs_oracle():
+    """phk_count_score_dev on a device-generated synthetic batch (with invalid bases) vs the
+    oracle on the host-regenerated contigs: counts bit-exact, scores within tolerance, and the
+    score of a zero-count contig is NaN and reported through the status word."""
+    from oracle import oracle
+    from phamers_amd import _lib, device, synth
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    n_eq = min(pos.shape[0], neg.shape[0])
+    pos, neg = pos[:n_eq], neg[:n_eq]
+    ctx = _lib.get_context()
+    model = _lib.Model(ctx, pos, neg, g["cpos_eq"], g["cneg_eq"], 3)
+    n, L, ppm = 700, 5000, 1000
+    T = n * L
+    d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    d_mask = device.DeviceArray(ctx, device.mask_words(T), np.uint32)
+    d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+    device.synth_packed(ctx, 0, 0, n, L, d_packed, d_off, d_mask, ppm)
+    d_counts = device.DeviceArray(ctx, (n, 256), np.uint32)
+    d_scores = device.DeviceArray(ctx, n, np.float64)
+    d_status = device.DeviceArray(ctx, 1, np.uint32)
+    device.count_score(ctx, model, d_packed, d_mask, T, d_off, n, 4, "combo", d_counts, d_scores, d_status)
+    seqs = synth.synth_contigs(0, n, L, ppm)
+    want_counts = oracle.count(seqs, 4)
+    assert np.array_equal(d_counts.to_host().astype(np.int64), want_counts)
+    q = oracle.normalize_counts(want_counts)
+    want = oracle.knn_score_points(q, pos, neg, 3) + oracle.centroid_score_points_fast(q, g["cpos_eq"], g["cneg_eq"])
+    got = d_scores.to_host()
+    assert d_status.to_host()[0] == 0
+    assert helpers.rel_err(got, want) < RTOL
+    # no-mask path on all-valid input gives the same counts as the masked path
+    device.synth_packed(ctx, 0, 0, n, L, d_packed, d_off, None, 0)
+    device.count_score(ctx, model, d_packed, None, T, d_off, n, 4, "knn", d_counts, d_scores, d_status)
+    seqs0 = synth.synth_contigs(0, 64, L, 0)
+    assert np.array_equal(d_counts.to_host()[:64].astype(np.int64), oracle.count(seqs0, 4))
+    model.close()
+
+
+def test_zero_count_contig_is_nan_and_flagged():
+    from phamers_amd import _lib, device
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    ctx = _lib.get_context()
+    model = _lib.Model(ctx, pos, neg, g["cpos_full"], g["cneg_full"], 3)
+    counts = g["q_counts"][:8].astype(np.uint32).copy()
+    counts[2, :] = 0
+    d_counts = device.DeviceArray.from_host(ctx, counts)
+    d_scores = device.DeviceArray(ctx, 8, np.float64)
+    d_status = device.DeviceArray(ctx, 1, np.uint32)
+    device.score_counts(ctx, model, d_counts, 8, "combo", d_scores, d_status)
+    got = d_scores.to_host()
+    assert np.isnan(got[2]) and not np.isnan(np.delete(got, 2)).any()
+    assert d_status.to_host()[0] == 1
+    assert helpers.rel_err(np.delete(got, 2), np.delete(g["combo_full"][:8], 2)) < RTOL
+    model.close()
