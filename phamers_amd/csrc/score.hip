@@ -10,6 +10,8 @@
 // (scripts/learning.py:56 form) tiled through LDS, then per-query selection.  It serves any
 // D / M / kn and is the fall-back of the MFMA path (score_mfma.hip) for queries whose
 // candidate margin cannot be certified.
+#include <stdlib.h>
+
 #include "phk_common.h"
 #include "score_model.h"
 
@@ -268,7 +270,11 @@ int phk_score_rows(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     if (N == 0) return PHK_OK;
     const uint64_t D = m->D;
 
-    if (phk_model_has_fast(m)) return phk_score_fast(ctx, m, d_Q, d_counts, N, method, d_scores, d_status);
+    // PHK_FORCE_EXACT=1 routes every model through the float64 path (used by the parity tests to
+    // cross-check the two GPU paths against each other)
+    const char *force = getenv("PHK_FORCE_EXACT");
+    if (phk_model_has_fast(m) && !(force && force[0] == '1'))
+        return phk_score_fast(ctx, m, d_Q, d_counts, N, method, d_scores, d_status);
 
     // exact path in batches sized to a 512 MiB distance scratch
     const uint64_t widest = m->M > (m->n_cpos + m->n_cneg) ? m->M : (m->n_cpos + m->n_cneg);

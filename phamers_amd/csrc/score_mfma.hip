@@ -1,22 +1,592 @@
-// score_mfma.hip -- MFMA candidate search + exact re-rank (filled in after the exact path is
-// validated on hardware; until then every model takes the exact float64 path).
+// score_mfma.hip -- the fast scoring path for D = 256 (k = 4):
+//
+//   1. phk_knn_mfma_kernel   fp32-input MFMA (v_mfma_f32_32x32x2_f32) "distance GEMM" of the
+//      centred queries against the centred train rows + centroids, with a fused running
+//      top-4 per (query, column segment, half-list) kept in registers -- nothing of the
+//      N x (M+C) product ever reaches memory.  This is the dense contraction behind
+//      scikit-learn's brute-force k-NN (scripts/learning.py:127) and behind the
+//      nearest-centroid search (scripts/learning.py:59-66).
+//   2. phk_rerank_kernel     per query: certify the candidate order against a rigorous fp32
+//      error bound; where certified take the vote from the labels, otherwise (and always for
+//      the two nearest-centroid distances the proximity metric needs, scripts/phamer.py:
+//      198-210) recompute direct-difference float64 distances for the candidates.  A query
+//      whose candidate set cannot be certified to contain the true neighbours is queued for
+//   3. phk_knn_fallback_kernel  exact float64 brute force over every column.
+//
+// So the MFMA pass only ever PROPOSES candidates; every emitted number is decided by float64
+// arithmetic of the same form as the reference's (direct differences), or by a certified
+// ordering.
+//
+// Ranking quantity.  With mu = mean train row, r' = r - mu, q' = q - mu (distances are
+// translation invariant) the kernel maximises  v = q'.r' - |r'|^2/2  = (|q'|^2 - |q-r|^2)/2.
+// The -|r'|^2/2 term rides through the MFMA as a 129th k-step (A = -|r'|^2/2, B = 1).
+//
+// Operand layout ("fragment order").  v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31]
+// [kk = l>>5] and B[kk = l>>5][j = l&31].  The summation index is relabelled so that lane
+// half h = l>>5 covers dimensions 128h .. 128h+127: MFMA step s (0..127) contracts
+// dimensions {s, 128+s}.  Column block cb (32 train rows / centroids) is stored as
+//     Bf[cb][g = 0..32][lane][4]  (float4 per lane per group, 1 KiB per wave-load):
+//     g < 32 : element e = r'[32cb + (lane&31)][128*(lane>>5) + 4g + e]
+//     g = 32 : element 0 = (lane < 32) ? -|r'|^2/2 : 0        (norm step), rest 0
+// and a wave keeps its 32 queries' q' in 128 VGPRs for the whole sweep (q'[j][128h + s]).
 #include "phk_common.h"
 #include "score_model.h"
 
-int phk_model_build_fast(phk_ctx *, phk_model *m, const double *, const double *, const double *,
-                         const double *) {
+#include <cmath>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define FAST_D 256
+#define NG 33          // 32 k-groups + the norm group
+#define CAND 4         // list depth per (query, segment, half)
+#define NSEG 3         // train rows, positive centroids, negative centroids
+#define PAD_V (-1.0e30f)
+
+// ------------------------------------------------------------------------------------
+// model build (host): centre, round to fp32, fragment-order, upload
+// ------------------------------------------------------------------------------------
+static void pack_segment(const double *rows, uint64_t n, const std::vector<double> &mu, std::vector<float> &bf,
+                         uint64_t cb0, double &max_norm) {
+    const uint64_t nblk = phk_div_up(n, 32);
+    for (uint64_t b = 0; b < nblk; ++b) {
+        float *blk = bf.data() + (cb0 + b) * NG * 64 * 4;
+        for (int i = 0; i < 32; ++i) {
+            const uint64_t r = b * 32 + i;
+            if (r >= n) {  // padding column: zeros, never selectable
+                blk[(32 * 64 + i) * 4 + 0] = PAD_V;
+                continue;
+            }
+            double nrm2 = 0.0;
+            for (int h = 0; h < 2; ++h)
+                for (int s = 0; s < 128; ++s) {
+                    const int d = 128 * h + s;
+                    const float v = (float)(rows[r * FAST_D + d] - mu[d]);
+                    blk[((s >> 2) * 64 + h * 32 + i) * 4 + (s & 3)] = v;
+                    nrm2 += (double)v * (double)v;
+                }
+            blk[(32 * 64 + i) * 4 + 0] = (float)(-0.5 * nrm2);
+            const double nrm = std::sqrt(nrm2);
+            if (nrm > max_norm) max_norm = nrm;
+        }
+    }
+}
+
+int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const double *neg,
+                         const double *cpos, const double *cneg) {
+    (void)ctx;
     m->fast = false;
+    if (m->D != FAST_D || m->kn > CAND - 1) return PHK_OK;  // exact path serves other shapes
+    if (m->M >= (1ull << 31)) return PHK_OK;
+    std::vector<double> mu(FAST_D, 0.0);
+    for (uint64_t r = 0; r < m->n_pos; ++r)
+        for (int d = 0; d < FAST_D; ++d) mu[d] += pos[r * FAST_D + d];
+    for (uint64_t r = 0; r < m->n_neg; ++r)
+        for (int d = 0; d < FAST_D; ++d) mu[d] += neg[r * FAST_D + d];
+    double mu2 = 0.0;
+    std::vector<float> mu32(FAST_D);
+    for (int d = 0; d < FAST_D; ++d) {
+        mu[d] /= (double)m->M;
+        if (!(mu[d] == mu[d]) || std::isinf(mu[d])) return PHK_OK;  // NaN/inf train data: exact path
+        mu32[d] = (float)mu[d];
+        mu[d] = (double)mu32[d];  // centre by the fp32-representable vector: q' is then formed alike on both paths
+        mu2 += mu[d] * mu[d];
+    }
+    m->n_rblk_ref = (uint32_t)phk_div_up(m->M, 32);
+    m->n_rblk_pos = (uint32_t)phk_div_up(m->n_cpos, 32);
+    m->n_rblk_neg = (uint32_t)phk_div_up(m->n_cneg, 32);
+    const uint64_t nblk = (uint64_t)m->n_rblk_ref + m->n_rblk_pos + m->n_rblk_neg;
+    std::vector<float> bf((nblk * NG + 16) * 64 * 4, 0.0f);  // + 16 groups: the kernel's prefetch ring runs past the end
+    double max_norm = 0.0;
+    // train = vstack(pos, neg): gather into one row array for packing
+    {
+        std::vector<double> train(m->M * FAST_D);
+        std::copy(pos, pos + m->n_pos * FAST_D, train.begin());
+        std::copy(neg, neg + m->n_neg * FAST_D, train.begin() + m->n_pos * FAST_D);
+        pack_segment(train.data(), m->M, mu, bf, 0, max_norm);
+    }
+    if (m->n_cpos) pack_segment(cpos, m->n_cpos, mu, bf, m->n_rblk_ref, max_norm);
+    if (m->n_cneg) pack_segment(cneg, m->n_cneg, mu, bf, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, max_norm);
+    if (!(max_norm == max_norm) || std::isinf(max_norm)) return PHK_OK;
+    if (hipMalloc(&m->d_Bf, bf.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMalloc(&m->d_mu32, FAST_D * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMalloc(&m->d_mu64, FAST_D * sizeof(double)) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMemcpy(m->d_Bf, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_mu32, mu32.data(), FAST_D * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_mu64, mu.data(), FAST_D * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return PHK_ERR_HIP;
+    m->max_colnorm = max_norm;
+    m->mu_norm = std::sqrt(mu2);
+    m->fast = true;
     return PHK_OK;
 }
+
 void phk_model_free_fast(phk_model *m) {
     if (m->d_Bf) (void)hipFree(m->d_Bf);
     if (m->d_colnorm) (void)hipFree(m->d_colnorm);
     if (m->d_mu32) (void)hipFree(m->d_mu32);
     if (m->d_mu64) (void)hipFree(m->d_mu64);
-    m->d_Bf = nullptr; m->d_colnorm = nullptr; m->d_mu32 = nullptr; m->d_mu64 = nullptr;
+    m->d_Bf = nullptr;
+    m->d_colnorm = nullptr;
+    m->d_mu32 = nullptr;
+    m->d_mu64 = nullptr;
 }
-int phk_score_fast(phk_ctx *, const phk_model *, const double *, const uint32_t *, uint64_t, int,
-                   double *, uint32_t *) {
-    phk_set_error("phk_score_fast: MFMA path not built");
-    return PHK_ERR_UNSUPPORTED;
+
+// ------------------------------------------------------------------------------------
+// 1. MFMA candidate search
+// ------------------------------------------------------------------------------------
+// sorted (descending) insert of (x, c) into a 4-deep list held in registers
+__device__ __forceinline__ void list_insert(float (&v)[CAND], uint32_t (&ix)[CAND], float x, uint32_t c) {
+    const bool g0 = x > v[0], g1 = x > v[1], g2 = x > v[2], g3 = x > v[3];
+    v[3] = g2 ? v[2] : (g3 ? x : v[3]);
+    ix[3] = g2 ? ix[2] : (g3 ? c : ix[3]);
+    v[2] = g1 ? v[1] : (g2 ? x : v[2]);
+    ix[2] = g1 ? ix[1] : (g2 ? c : ix[2]);
+    v[1] = g0 ? v[0] : (g1 ? x : v[1]);
+    ix[1] = g0 ? ix[0] : (g1 ? c : ix[1]);
+    v[0] = g0 ? x : v[0];
+    ix[0] = g0 ? c : ix[0];
+}
+
+// SRC 0: uint32 count rows (normalised here as kmer.normalize_counts would, in fp32 for the
+// proposal pass);  SRC 1: float64 rows.
+template <int SRC>
+__global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__restrict__ src, uint64_t N,
+                                                              const float4 *__restrict__ Bf,
+                                                              const float *__restrict__ mu32,
+                                                              const double *__restrict__ mu64,
+                                                              uint32_t nblk_ref, uint32_t nblk_pos,
+                                                              uint32_t nblk_neg,
+                                                              float4 *__restrict__ cand_v,
+                                                              uint4 *__restrict__ cand_i) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const uint64_t q0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    if (q0 >= N) return;
+    const uint64_t qrow = (q0 + j < N) ? q0 + j : N - 1;
+
+    // ---- prologue: this lane's 128 centred query elements q'[qrow][128h .. 128h+127] ----
+    float q[128];
+    if (SRC == 0) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + qrow * FAST_D + 128 * h);
+        uint32_t sum = 0;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            const uint4 c = row[g];
+            sum += c.x + c.y + c.z + c.w;
+        }
+        const uint32_t tot = sum + __shfl_xor(sum, 32);
+        const float inv = (float)(1.0 / (double)tot);
+        const float4 *mp = reinterpret_cast<const float4 *>(mu32 + 128 * h);
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            const uint4 c = row[g];
+            const float4 mm = mp[g];
+            q[4 * g + 0] = fmaf((float)c.x, inv, -mm.x);
+            q[4 * g + 1] = fmaf((float)c.y, inv, -mm.y);
+            q[4 * g + 2] = fmaf((float)c.z, inv, -mm.z);
+            q[4 * g + 3] = fmaf((float)c.w, inv, -mm.w);
+        }
+    } else {
+        const double2 *row = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + qrow * FAST_D + 128 * h);
+        const double2 *mp = reinterpret_cast<const double2 *>(mu64 + 128 * h);
+#pragma unroll
+        for (int g = 0; g < 64; ++g) {
+            const double2 c = row[g], mm = mp[g];
+            q[2 * g + 0] = (float)(c.x - mm.x);
+            q[2 * g + 1] = (float)(c.y - mm.y);
+        }
+    }
+    const float bone = h == 0 ? 1.0f : 0.0f;  // B operand of the norm step
+    const uint32_t seg_end0 = nblk_ref, seg_end1 = nblk_ref + nblk_pos, total = seg_end1 + nblk_neg;
+    const float4 *bp = Bf + lane;
+
+    // The A-fragment stream (33 x 1 KiB per column block, identical for every wave) is software
+    // pipelined through a ring of PF float4 registers: group g+PF is requested while group g feeds
+    // its 4 MFMAs, and the ring runs across column-block boundaries (Bf carries >= PF groups of tail
+    // padding), so L2 latency hides behind ~PF*4*64 MFMA cycles.
+    constexpr int PF = 11;  // divides NG = 33, so the ring needs no rotation between blocks
+    float4 ring[PF];
+#pragma unroll
+    for (int g = 0; g < PF; ++g) ring[g] = bp[g * 64];
+
+    float lv[CAND];
+    uint32_t li[CAND];
+#pragma unroll
+    for (int c = 0; c < CAND; ++c) {
+        lv[c] = -3.0e38f;
+        li[c] = 0xFFFFFFFFu;
+    }
+    int seg = 0;
+    uint32_t seg_first = 0;  // first block of the current segment
+    for (uint32_t blk = 0; blk < total; ++blk, bp += NG * 64) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float4 a = ring[g % PF];
+            ring[g % PF] = bp[(g + PF) * 64];  // group g+PF of this block, or the head of the next one
+            if (g < 32) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[4 * (g & 31) + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[4 * (g & 31) + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[4 * (g & 31) + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[4 * (g & 31) + 3], acc, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bone, acc, 0, 0, 0);  // norm step
+            }
+        }
+        // pin the issue order hipcc would otherwise undo (it sinks the loads next to their use):
+        // one fragment load, then the 4 (or 1) MFMAs of the group loaded PF groups earlier
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMA
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        // epilogue: D[i][j] sits in lane (j, h') register r with i = (r&3) + 8(r>>2) + 4h'
+        const uint32_t cbase = 32u * (blk - seg_first) + 4u * (uint32_t)h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) list_insert(lv, li, acc[r], cbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
+
+        // segment boundary: flush this (query, segment, half) list and start the next segment
+        while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
+            if (q0 + j < N) {
+                const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
+                cand_v[o] = make_float4(lv[0], lv[1], lv[2], lv[3]);
+                cand_i[o] = make_uint4(li[0], li[1], li[2], li[3]);
+            }
+#pragma unroll
+            for (int c = 0; c < CAND; ++c) {
+                lv[c] = -3.0e38f;
+                li[c] = 0xFFFFFFFFu;
+            }
+            ++seg;
+            seg_first = blk + 1;
+        }
+    }
+    // segments with no blocks at all (method without that part) still get an (empty) list
+    for (; seg < NSEG; ++seg) {
+        if (q0 + j < N) {
+            const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
+            cand_v[o] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+            cand_i[o] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 2. certify / exact re-rank: one wavefront per query, lane = 4 dimensions
+// ------------------------------------------------------------------------------------
+struct RerankParams {
+    uint64_t N, M, n_cpos, n_cneg;
+    int kn, method;
+    double rmax, mu_norm;
+    const double *R64, *C64, *mu64;
+    const uint8_t *labels;
+    const float4 *cand_v;
+    const uint4 *cand_i;
+    double *scores;
+    uint32_t *status;       // NaN-row counter (may be null)
+    uint32_t *fb_count;     // fallback queue length
+    uint32_t *fb_list;      // fallback queue (query indices)
+    uint64_t q_base;        // index of this batch's first query within the caller's arrays
+};
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s);
+    return x;
+}
+
+// exact direct-difference squared distance of the wave's query (4 dims per lane) to `row`
+__device__ __forceinline__ double exact_d2(const double (&qd)[4], const double *row, int lane) {
+    const double2 a = reinterpret_cast<const double2 *>(row)[2 * lane];
+    const double2 b = reinterpret_cast<const double2 *>(row)[2 * lane + 1];
+    const double d0 = qd[0] - a.x, d1 = qd[1] - a.y, d2 = qd[2] - b.x, d3 = qd[3] - b.y;
+    return wave_sum(fma(d0, d0, fma(d1, d1, fma(d2, d2, d3 * d3))));
+}
+
+// Resolve one segment for the wave's query: find the `need` best columns.
+//   returns false if the candidate set cannot be certified (-> fallback queue);
+//   out_idx[0..need) = column indices of the best, in order; out_d2 = exact d^2 of the best
+//   (only computed when want_d2 or when the order was not certified by the margin).
+__device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
+                                const double (&qd)[4], double nqp2, double eps, const double *rows,
+                                bool want_d2, int lane, uint32_t (&out_idx)[3], double &out_d2) {
+    // lanes 0..7 hold the 8 candidates (half = lane>>2, slot = lane&3)
+    float v = -3.0e38f;
+    uint32_t ix = 0xFFFFFFFFu;
+    if (lane < 8) {
+        const uint64_t o = (q * NSEG + seg) * 2 + (lane >> 2);
+        const float4 cv = p.cand_v[o];
+        const uint4 ci = p.cand_i[o];
+        const int s = lane & 3;
+        v = s == 0 ? cv.x : s == 1 ? cv.y : s == 2 ? cv.z : cv.w;
+        ix = s == 0 ? ci.x : s == 1 ? ci.y : s == 2 ? ci.z : ci.w;
+        if (ix >= ncols) v = -3.0e38f;  // padding / empty slot
+    }
+    // bound on every non-candidate's computed value: the larger of the two lists' 4th entries
+    const float u0 = __shfl(v, 3), u1 = __shfl(v, 7);
+    const bool full0 = __shfl(ix, 3) < ncols, full1 = __shfl(ix, 7) < ncols;
+    // a list that is not full has seen fewer than 4 real columns: nothing was dropped from it
+    const double U = fmax(full0 ? (double)u0 : -INFINITY, full1 ? (double)u1 : -INFINITY);
+    // rank of each candidate among the 8 (descending v, ties by lane)
+    int rank = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const float ov = __shfl(v, m);
+        rank += (lane < 8 && (ov > v || (ov == v && m < lane))) ? 1 : 0;
+    }
+    // values / indices by rank
+    float rv[4];
+    uint32_t ri[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned long long bal = __ballot(lane < 8 && rank == r);
+        const int srcl = __ffsll((long long)bal) - 1;
+        rv[r] = __shfl(v, srcl);
+        ri[r] = __shfl(ix, srcl);
+    }
+    // certified by margin: the need-th and (need+1)-th computed values are more than 2 eps apart
+    const bool margin_ok = ((double)rv[need - 1] - (double)rv[need]) > 2.0 * eps && ri[need - 1] < ncols;
+    if (margin_ok) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) out_idx[r] = ri[r];
+        if (want_d2) out_d2 = exact_d2(qd, rows + (uint64_t)ri[0] * FAST_D, lane);
+        return true;
+    }
+    // not certified: exact float64 distances for all (valid) candidates
+    double best[3] = {INFINITY, INFINITY, INFINITY};
+    uint32_t bidx[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (int m = 0; m < 8; ++m) {
+        const uint32_t c = __shfl(ix, m);
+        if (c >= ncols) continue;
+        const double d2 = exact_d2(qd, rows + (uint64_t)c * FAST_D, lane);
+        // insert (d2, c) ascending; ties to the lower column index
+        if (d2 < best[2] || (d2 == best[2] && c < bidx[2])) {
+            best[2] = d2; bidx[2] = c;
+            if (best[2] < best[1] || (best[2] == best[1] && bidx[2] < bidx[1])) {
+                double t = best[1]; best[1] = best[2]; best[2] = t;
+                uint32_t ti = bidx[1]; bidx[1] = bidx[2]; bidx[2] = ti;
+                if (best[1] < best[0] || (best[1] == best[0] && bidx[1] < bidx[0])) {
+                    t = best[0]; best[0] = best[1]; best[1] = t;
+                    ti = bidx[0]; bidx[0] = bidx[1]; bidx[1] = ti;
+                }
+            }
+        }
+    }
+    if (bidx[need - 1] == 0xFFFFFFFFu) return false;
+    // the true value of the need-th best must beat what any dropped column could reach
+    const double tv = 0.5 * (nqp2 - best[need - 1]);
+    if (!(tv > U + eps)) return false;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) out_idx[r] = bidx[r];
+    out_d2 = best[0];
+    return true;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict__ src, RerankParams p) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (q >= p.N) return;
+    // exact float64 query elements for this lane's 4 dimensions (kmer.normalize_counts arithmetic)
+    double qd[4];
+    bool nan_row = false;
+    if (SRC == 0) {
+        const uint4 c = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D)[lane];
+        uint32_t s = c.x + c.y + c.z + c.w;
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+        nan_row = s == 0;
+        const double ds = (double)s;
+        qd[0] = (double)c.x / ds; qd[1] = (double)c.y / ds; qd[2] = (double)c.z / ds; qd[3] = (double)c.w / ds;
+    } else {
+        const double2 a = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D)[2 * lane];
+        const double2 b = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D)[2 * lane + 1];
+        qd[0] = a.x; qd[1] = a.y; qd[2] = b.x; qd[3] = b.y;
+        nan_row = __any(qd[0] != qd[0] || qd[1] != qd[1] || qd[2] != qd[2] || qd[3] != qd[3]);
+    }
+    if (nan_row) {  // zero-count contig: the reference's normalised row is NaN
+        if (lane == 0) {
+            p.scores[p.q_base + q] = __builtin_nan("");
+            if (p.status) atomicAdd(p.status, 1u);
+        }
+        return;
+    }
+    const double2 m0 = reinterpret_cast<const double2 *>(p.mu64)[2 * lane];
+    const double2 m1 = reinterpret_cast<const double2 *>(p.mu64)[2 * lane + 1];
+    const double c0 = qd[0] - m0.x, c1 = qd[1] - m0.y, c2 = qd[2] - m1.x, c3 = qd[3] - m1.y;
+    const double nq2 = wave_sum(fma(qd[0], qd[0], fma(qd[1], qd[1], fma(qd[2], qd[2], qd[3] * qd[3]))));
+    const double nqp2 = wave_sum(fma(c0, c0, fma(c1, c1, fma(c2, c2, c3 * c3))));
+    // rigorous bound on |computed v - true v| of the fp32 MFMA pass ("error bound")
+    const double u32r = 5.9604644775390625e-08;  // 2^-24
+    const double A = sqrt(nq2) + p.mu_norm, nqp = sqrt(nqp2);
+    const double eps = u32r * p.rmax * (8.0 * A + 264.0 * nqp + 136.0 * p.rmax);
+
+    bool ok = true;
+    double knn = 0.0, cen = 0.0;
+    uint32_t idx[3];
+    double d2;
+    if (p.method & PHK_METHOD_KNN) {
+        ok = resolve_segment(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eps, p.R64, false, lane, idx, d2);
+        if (ok) {
+            int votes = 0;
+            for (int r = 0; r < p.kn; ++r) votes += p.labels[idx[r]] ? 1 : 0;
+            knn = (2 * votes > p.kn) ? 1.0 : -1.0;
+        }
+    }
+    if (ok && (p.method & PHK_METHOD_KMEANS)) {
+        double dp2 = 0.0, dn2 = 0.0;
+        ok = resolve_segment(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eps, p.C64, true, lane, idx, dp2);
+        if (ok)
+            ok = resolve_segment(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eps, p.C64 + p.n_cpos * FAST_D, true,
+                                 lane, idx, dn2);
+        if (ok) {
+            const double ep = sqrt(dp2), en = sqrt(dn2);
+            cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
+        }
+    }
+    if (lane == 0) {
+        if (ok) {
+            p.scores[p.q_base + q] = knn + cen;  // scripts/phamer.py:313
+        } else {
+            const uint32_t slot = atomicAdd(p.fb_count, 1u);
+            p.fb_list[slot] = (uint32_t)q;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 3. exact brute force for queued queries: one block per query, one wave per column
+// ------------------------------------------------------------------------------------
+template <int SRC>
+__global__ __launch_bounds__(256) void phk_knn_fallback_kernel(const void *__restrict__ src, RerankParams p) {
+    extern __shared__ double fb_dist[];  // M + n_cpos + n_cneg distances
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t count = *p.fb_count;
+    const uint64_t ncols = p.M + p.n_cpos + p.n_cneg;
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
+        const uint64_t q = p.fb_list[it];
+        double qd[4];
+        if (SRC == 0) {
+            const uint4 c = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D)[lane];
+            uint32_t s = c.x + c.y + c.z + c.w;
+#pragma unroll
+            for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+            const double ds = (double)s;
+            qd[0] = (double)c.x / ds; qd[1] = (double)c.y / ds; qd[2] = (double)c.z / ds; qd[3] = (double)c.w / ds;
+        } else {
+            const double2 a = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D)[2 * lane];
+            const double2 b = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D)[2 * lane + 1];
+            qd[0] = a.x; qd[1] = a.y; qd[2] = b.x; qd[3] = b.y;
+        }
+        for (uint64_t c = wave; c < ncols; c += 4) {
+            const double *row = c < p.M ? p.R64 + c * FAST_D : p.C64 + (c - p.M) * FAST_D;
+            const double d2 = exact_d2(qd, row, lane);
+            if (lane == 0) fb_dist[c] = d2;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            double knn = 0.0, cen = 0.0;
+            if (p.method & PHK_METHOD_KNN) {
+                double last_d = -1.0;
+                uint64_t last_i = 0;
+                bool first = true;
+                int votes = 0;
+                for (int r = 0; r < p.kn; ++r) {
+                    double bd = INFINITY;
+                    uint64_t bi = ~0ull;
+                    for (uint64_t c = lane; c < p.M; c += 64) {
+                        const double d = fb_dist[c];
+                        const bool after = first || d > last_d || (d == last_d && c > last_i);
+                        if (after && (d < bd || (d == bd && c < bi))) { bd = d; bi = c; }
+                    }
+#pragma unroll
+                    for (int s = 32; s > 0; s >>= 1) {
+                        const double od = __shfl_xor(bd, s);
+                        const uint64_t oi = __shfl_xor(bi, s);
+                        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+                    }
+                    last_d = bd; last_i = bi; first = false;
+                    votes += p.labels[bi] ? 1 : 0;
+                }
+                knn = (2 * votes > p.kn) ? 1.0 : -1.0;
+            }
+            if (p.method & PHK_METHOD_KMEANS) {
+                double bp = INFINITY, bn = INFINITY;
+                for (uint64_t c = lane; c < p.n_cpos; c += 64) bp = fmin(bp, fb_dist[p.M + c]);
+                for (uint64_t c = lane; c < p.n_cneg; c += 64) bn = fmin(bn, fb_dist[p.M + p.n_cpos + c]);
+#pragma unroll
+                for (int s = 32; s > 0; s >>= 1) {
+                    bp = fmin(bp, __shfl_xor(bp, s));
+                    bn = fmin(bn, __shfl_xor(bn, s));
+                }
+                const double ep = sqrt(bp), en = sqrt(bn);
+                cen = tanh((en - ep) / (ep + en));
+            }
+            if (lane == 0) p.scores[p.q_base + q] = knn + cen;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// driver
+// ------------------------------------------------------------------------------------
+int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
+                   uint64_t N, int method, double *d_scores, uint32_t *d_status) {
+    const uint64_t BATCH = 1ull << 22;  // bounds the candidate workspace (192 B / query)
+    const uint64_t nb_max = N < BATCH ? N : BATCH;
+    void *cv, *ci, *fb;
+    PHK_TRY(phk_ws(ctx, WS_CAND, nb_max * NSEG * 2 * (sizeof(float4) + sizeof(uint4)), &cv));
+    ci = (char *)cv + nb_max * NSEG * 2 * sizeof(float4);
+    PHK_TRY(phk_ws(ctx, WS_DIST, (nb_max + 16) * sizeof(uint32_t), &fb));
+    uint32_t *fb_count = (uint32_t *)fb, *fb_list = (uint32_t *)fb + 16;
+    const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
+    const size_t fb_lds = ncols * sizeof(double);
+    PHK_REQUIRE(fb_lds <= 160 * 1024, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);
+    static bool attr_set = false;
+    if (!attr_set && fb_lds > 64 * 1024) {
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_fallback_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_fallback_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    for (uint64_t s = 0; s < N; s += BATCH) {
+        const uint64_t nb = N - s < BATCH ? N - s : BATCH;
+        const void *src = d_counts ? (const void *)(d_counts + s * FAST_D) : (const void *)(d_Q + s * FAST_D);
+        const unsigned gblocks = (unsigned)phk_div_up(nb, 128);
+        // segments the method does not need are skipped by giving them zero blocks
+        const uint32_t nref = (method & PHK_METHOD_KNN) ? m->n_rblk_ref : 0;
+        const uint32_t npos = (method & PHK_METHOD_KMEANS) ? m->n_rblk_pos : 0;
+        const uint32_t nneg = (method & PHK_METHOD_KMEANS) ? m->n_rblk_neg : 0;
+        const float4 *bf = (const float4 *)m->d_Bf + (uint64_t)(nref ? 0 : m->n_rblk_ref) * NG * 64;
+        PHK_HIP(hipMemsetAsync(fb_count, 0, 64, ctx->stream));
+        RerankParams p;
+        p.N = nb; p.M = m->M; p.n_cpos = m->n_cpos; p.n_cneg = m->n_cneg;
+        p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
+        p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.labels = m->d_labels;
+        p.cand_v = (const float4 *)cv; p.cand_i = (const uint4 *)ci;
+        p.scores = d_scores; p.status = d_status; p.fb_count = fb_count; p.fb_list = fb_list; p.q_base = s;
+        if (d_counts) {
+            PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
+                       phk_knn_mfma_kernel<0><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
+                           src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, (uint4 *)ci));
+            PHK_LAUNCH(ctx, "phk_rerank_kernel",
+                       phk_rerank_kernel<0><<<dim3((unsigned)phk_div_up(nb, 4)), dim3(256), 0, ctx->stream>>>(src, p));
+            PHK_LAUNCH(ctx, "phk_knn_fallback_kernel",
+                       phk_knn_fallback_kernel<0><<<dim3(1024), dim3(256), fb_lds, ctx->stream>>>(src, p));
+        } else {
+            PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
+                       phk_knn_mfma_kernel<1><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
+                           src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, (uint4 *)ci));
+            PHK_LAUNCH(ctx, "phk_rerank_kernel",
+                       phk_rerank_kernel<1><<<dim3((unsigned)phk_div_up(nb, 4)), dim3(256), 0, ctx->stream>>>(src, p));
+            PHK_LAUNCH(ctx, "phk_knn_fallback_kernel",
+                       phk_knn_fallback_kernel<1><<<dim3(1024), dim3(256), fb_lds, ctx->stream>>>(src, p));
+        }
+    }
+    return PHK_OK;
 }

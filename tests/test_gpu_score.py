@@ -145,3 +145,67 @@ def test_zero_count_contig_is_nan_and_flagged():
     assert d_status.to_host()[0] == 1
     assert helpers.rel_err(np.delete(got, 2), np.delete(g["combo_full"][:8], 2)) < RTOL
     model.close()
+
+
+def test_fast_and_exact_gpu_paths_agree_on_a_larger_batch(monkeypatch):
+    """20k synthetic contigs through the MFMA candidate path and through the float64 brute-force
+    path (PHK_FORCE_EXACT=1): identical votes, float scores equal to rounding."""
+    from phamers_amd import _lib, device
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    ctx = _lib.get_context()
+    model = _lib.Model(ctx, pos, neg, g["cpos_full"], g["cneg_full"], 3)
+    n, L = 20000, 5000
+    T = n * L
+    d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+    device.synth_packed(ctx, 5, 0, n, L, d_packed, d_off)
+    d_counts = device.DeviceArray(ctx, (n, 256), np.uint32)
+    d_nwin = device.DeviceArray(ctx, n, np.uint32)
+    device.count(ctx, d_packed, None, T, d_off, n, 4, d_counts, d_nwin)
+    out = {}
+    for force in ("0", "1"):
+        monkeypatch.setenv("PHK_FORCE_EXACT", force)
+        for method in ("knn", "kmeans", "combo"):
+            d_scores = device.DeviceArray(ctx, n, np.float64)
+            d_status = device.DeviceArray(ctx, 1, np.uint32)
+            device.score_counts(ctx, model, d_counts, n, method, d_scores, d_status)
+            out[(force, method)] = d_scores.to_host()
+            assert d_status.to_host()[0] == 0
+    assert np.array_equal(out[("0", "knn")], out[("1", "knn")])
+    assert set(np.unique(out[("0", "knn")])) <= {-1.0, 1.0}
+    assert helpers.rel_err(out[("0", "kmeans")], out[("1", "kmeans")]) < 1e-9
+    assert helpers.rel_err(out[("0", "combo")], out[("1", "combo")]) < 1e-9
+    assert np.allclose(out[("0", "combo")], out[("0", "knn")] + out[("0", "kmeans")], rtol=0, atol=1e-15)
+    model.close()
+
+
+def test_duplicate_train_rows_take_the_certified_or_fallback_route():
+    """Many identical train rows with mixed labels around the query: the fp32 proposal cannot
+    separate them, so the query must be resolved exactly (ties -> lower train index, as the
+    oracle's stable sort)."""
+    from oracle import oracle
+    from phamers_amd import _lib
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    pos, neg = pos[:600].copy(), neg[:600].copy()
+    q = g["q"][:40].copy()
+    # 12 copies of one vector close to query 0, alternating classes, scattered over the index range
+    base = 0.98 * q[0] + 0.02 * pos[5]
+    for t, r in enumerate((3, 77, 150, 151, 310, 599)):
+        pos[r] = base
+        neg[(r * 7 + t) % 600] = base
+    # and exact duplicates of queries themselves (distance 0)
+    pos[20], neg[21], neg[22] = q[1], q[1], q[1]
+    cp = np.stack([pos[i::8].mean(axis=0) for i in range(8)] + [base])
+    cn = np.stack([neg[i::8].mean(axis=0) for i in range(8)] + [base, base])
+    ctx = _lib.get_context()
+    model = _lib.Model(ctx, pos, neg, cp, cn, 3)
+    got_knn = model.score(q, "knn")
+    want_knn = oracle.knn_score_points(q, pos, neg, 3)
+    assert np.array_equal(got_knn, want_knn)
+    got = model.score(q, "kmeans")
+    want = oracle.centroid_score_points(q, cp, cn)
+    # identical nearest centroids in both classes give exactly 0 for query 0-like points
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-12)
+    model.close()
