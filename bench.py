@@ -149,6 +149,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     prof = ctx.profile()
+    n_fallback, n_exact = ctx.score_stats()
 
     if rank != 0:
         if dist:
@@ -168,7 +169,8 @@ def main():
     got = scores[:npar].cpu().numpy()
     parity = {"contigs_checked": npar, "counts_bit_exact": bool(np.array_equal(got_counts, want_counts)),
               "max_rel_score_err": float(np.max(np.abs(got - want) / np.abs(want))),
-              "nan_rows": int(status.item())}
+              "nan_rows": int(status.item()), "fallback_queries": n_fallback,
+              "orderings_decided_by_exact_distances": n_exact}
 
     # ---- roofline of the dominant kernel (algorithmic work / HIP-event time in this run) ----
     alg = {  # kernel -> (bound, unit, peak, algorithmic work per step on this rank)

@@ -146,6 +146,12 @@ int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const uint32_t *d_
                         uint64_t n, int k, int method, uint32_t *d_counts, double *d_scores,
                         uint32_t *d_status);
 
+/* Diagnostics of the most recent scoring call on this context (synchronises the stream):
+ * how many queries were resolved by the float64 brute-force fallback kernel and how many
+ * (query, segment) orderings had to be decided by exact candidate distances rather than by
+ * the certified fp32 margin.  Both are 0 on the all-float64 path. */
+int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_exact_resolved);
+
 /* seeded synthetic batch generated on the device (phamers_amd/synth.py defines the hash):
  * n contigs of L bases, contig ids first_contig..first_contig+n-1; writes the packed stream,
  * the mask (if d_mask != NULL; required when invalid_ppm > 0) and offsets[n+1]. */

@@ -50,6 +50,7 @@ SIGNATURES = {
     "phk_score_counts_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_void_p, c_void_p]),
     "phk_count_score_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_void_p, c_u64,
                                     c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "phk_score_stats": (c_int, [c_void_p, P(c_u64), P(c_u64)]),
     "phk_synth_packed_dev": (c_int, [c_void_p, c_u64, c_u64, c_u64, c_u64, c_u32, c_void_p,
                                      c_void_p, c_void_p]),
     "phk_profile_enable": (c_int, [c_void_p, c_int]),
@@ -133,6 +134,13 @@ class Context(object):
 
     def sync(self):
         check(self.lib.phk_sync(self.handle))
+
+    def score_stats(self):
+        """(queries sent to the float64 fallback, orderings decided by exact candidate distances)
+        of the most recent scoring call."""
+        a, b = ctypes.c_uint64(), ctypes.c_uint64()
+        check(self.lib.phk_score_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     # ---- timing ----
     def profile_enable(self, on=True):

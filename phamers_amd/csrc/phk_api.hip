@@ -365,6 +365,18 @@ extern "C" int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const u
     return phk_score_rows(ctx, model, nullptr, d_counts, n, method, d_scores, d_status);
 }
 
+extern "C" int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_exact_resolved) {
+    PHK_REQUIRE(ctx, "phk_score_stats: NULL ctx");
+    uint32_t c[2] = {0, 0};
+    if (ctx->last_score_fast && ctx->ws[WS_DIST].ptr) {
+        PHK_HIP(hipMemcpyAsync(c, ctx->ws[WS_DIST].ptr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (n_fallback) *n_fallback = c[0];
+    if (n_exact_resolved) *n_exact_resolved = c[1];
+    return PHK_OK;
+}
+
 extern "C" int phk_synth_packed_dev(phk_ctx *ctx, uint64_t seed, uint64_t first_contig, uint64_t n,
                                     uint64_t L, uint32_t invalid_ppm, uint32_t *d_packed,
                                     uint32_t *d_mask, uint64_t *d_offsets) {

@@ -75,6 +75,7 @@ struct phk_ctx {
     int num_cus = 256;
     PhkBuf ws[WS_SLOTS];
     bool profile = false;
+    bool last_score_fast = false;  // WS_DIST holds the MFMA path's counters
     std::vector<PhkTimed> timed;
     std::vector<hipEvent_t> ev_pool;
 };

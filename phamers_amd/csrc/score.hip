@@ -273,8 +273,11 @@ int phk_score_rows(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // PHK_FORCE_EXACT=1 routes every model through the float64 path (used by the parity tests to
     // cross-check the two GPU paths against each other)
     const char *force = getenv("PHK_FORCE_EXACT");
-    if (phk_model_has_fast(m) && !(force && force[0] == '1'))
+    ctx->last_score_fast = false;
+    if (phk_model_has_fast(m) && !(force && force[0] == '1')) {
+        ctx->last_score_fast = true;
         return phk_score_fast(ctx, m, d_Q, d_counts, N, method, d_scores, d_status);
+    }
 
     // exact path in batches sized to a 512 MiB distance scratch
     const uint64_t widest = m->M > (m->n_cpos + m->n_cneg) ? m->M : (m->n_cpos + m->n_cneg);

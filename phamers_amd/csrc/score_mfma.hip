@@ -47,7 +47,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // model build (host): centre, round to fp32, fragment-order, upload
 // ------------------------------------------------------------------------------------
 static void pack_segment(const double *rows, uint64_t n, const std::vector<double> &mu, std::vector<float> &bf,
-                         uint64_t cb0, double &max_norm) {
+                         uint64_t cb0, double &max_norm, double *colnorm) {
     const uint64_t nblk = phk_div_up(n, 32);
     for (uint64_t b = 0; b < nblk; ++b) {
         float *blk = bf.data() + (cb0 + b) * NG * 64 * 4;
@@ -67,6 +67,7 @@ static void pack_segment(const double *rows, uint64_t n, const std::vector<doubl
                 }
             blk[(32 * 64 + i) * 4 + 0] = (float)(-0.5 * nrm2);
             const double nrm = std::sqrt(nrm2);
+            colnorm[r] = nrm;
             if (nrm > max_norm) max_norm = nrm;
         }
     }
@@ -98,19 +99,25 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
     const uint64_t nblk = (uint64_t)m->n_rblk_ref + m->n_rblk_pos + m->n_rblk_neg;
     std::vector<float> bf((nblk * NG + 16) * 64 * 4, 0.0f);  // + 16 groups: the kernel's prefetch ring runs past the end
     double max_norm = 0.0;
+    std::vector<double> colnorm(m->M + m->n_cpos + m->n_cneg + 1, 0.0);  // |r'| of every real column
     // train = vstack(pos, neg): gather into one row array for packing
     {
         std::vector<double> train(m->M * FAST_D);
         std::copy(pos, pos + m->n_pos * FAST_D, train.begin());
         std::copy(neg, neg + m->n_neg * FAST_D, train.begin() + m->n_pos * FAST_D);
-        pack_segment(train.data(), m->M, mu, bf, 0, max_norm);
+        pack_segment(train.data(), m->M, mu, bf, 0, max_norm, colnorm.data());
     }
-    if (m->n_cpos) pack_segment(cpos, m->n_cpos, mu, bf, m->n_rblk_ref, max_norm);
-    if (m->n_cneg) pack_segment(cneg, m->n_cneg, mu, bf, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, max_norm);
+    if (m->n_cpos) pack_segment(cpos, m->n_cpos, mu, bf, m->n_rblk_ref, max_norm, colnorm.data() + m->M);
+    if (m->n_cneg)
+        pack_segment(cneg, m->n_cneg, mu, bf, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, max_norm,
+                     colnorm.data() + m->M + m->n_cpos);
     if (!(max_norm == max_norm) || std::isinf(max_norm)) return PHK_OK;
     if (hipMalloc(&m->d_Bf, bf.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMalloc(&m->d_mu32, FAST_D * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMalloc(&m->d_mu64, FAST_D * sizeof(double)) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMalloc(&m->d_colnorm, colnorm.size() * sizeof(double)) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMemcpy(m->d_colnorm, colnorm.data(), colnorm.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return PHK_ERR_HIP;
     if (hipMemcpy(m->d_Bf, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(m->d_mu32, mu32.data(), FAST_D * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(m->d_mu64, mu.data(), FAST_D * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
@@ -283,7 +290,7 @@ struct RerankParams {
     uint64_t N, M, n_cpos, n_cneg;
     int kn, method;
     double rmax, mu_norm;
-    const double *R64, *C64, *mu64;
+    const double *R64, *C64, *mu64, *colnorm;
     const uint8_t *labels;
     const float4 *cand_v;
     const uint4 *cand_i;
@@ -308,13 +315,28 @@ __device__ __forceinline__ double exact_d2(const double (&qd)[4], const double *
     return wave_sum(fma(d0, d0, fma(d1, d1, fma(d2, d2, d3 * d3))));
 }
 
+// Rigorous bound on |computed v - true v| of the MFMA pass for a column with |r'| <= R
+// (derivation: DESIGN.md "fp32 proposal error bound").  u = 2^-24; A = |q| + |mu|; P = |q'|.
+//   input rounding   : q' to fp32 (<= 4uA in norm), r' to fp32 (<= uR), stored -|r'|^2/2 (<= uR^2/2)
+//   accumulation     : 258 fused roundings, each <= u * |partial sum|; the 256 product partials are
+//                      <= (P + 4uA) R by Cauchy-Schwarz and the norm step comes LAST in the chain
+struct ErrBound {
+    double A, P;
+    __device__ double operator()(double R) const {
+        return 5.9604644775390625e-08 * R * (6.0 * A + 264.0 * P + 4.0 * R);
+    }
+};
+
 // Resolve one segment for the wave's query: find the `need` best columns.
 //   returns false if the candidate set cannot be certified (-> fallback queue);
-//   out_idx[0..need) = column indices of the best, in order; out_d2 = exact d^2 of the best
-//   (only computed when want_d2 or when the order was not certified by the margin).
+//   out_idx[0..need) = column indices of the best; out_d2 = exact d^2 of the best (computed when
+//   want_d2, or when the order had to be decided by exact distances).
+// Columns with |r'| > |q'| + d_need cannot be among the `need` nearest (triangle inequality), so the
+// error bound only has to hold for columns with |r'| <= R0 = |q'| + (upper bound of d_need).
 __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
-                                const double (&qd)[4], double nqp2, double eps, const double *rows,
-                                bool want_d2, int lane, uint32_t (&out_idx)[3], double &out_d2) {
+                                const double (&qd)[4], double nqp2, const ErrBound &eb, const double *rows,
+                                const double *colnorm, bool want_d2, int lane, uint32_t (&out_idx)[3],
+                                double &out_d2) {
     // lanes 0..7 hold the 8 candidates (half = lane>>2, slot = lane&3)
     float v = -3.0e38f;
     uint32_t ix = 0xFFFFFFFFu;
@@ -327,7 +349,7 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
         ix = s == 0 ? ci.x : s == 1 ? ci.y : s == 2 ? ci.z : ci.w;
         if (ix >= ncols) v = -3.0e38f;  // padding / empty slot
     }
-    // bound on every non-candidate's computed value: the larger of the two lists' 4th entries
+    // every column a list dropped has a computed value <= that list's 4th entry
     const float u0 = __shfl(v, 3), u1 = __shfl(v, 7);
     const bool full0 = __shfl(ix, 3) < ncols, full1 = __shfl(ix, 7) < ncols;
     // a list that is not full has seen fewer than 4 real columns: nothing was dropped from it
@@ -339,7 +361,6 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
         const float ov = __shfl(v, m);
         rank += (lane < 8 && (ov > v || (ov == v && m < lane))) ? 1 : 0;
     }
-    // values / indices by rank
     float rv[4];
     uint32_t ri[4];
 #pragma unroll
@@ -349,14 +370,24 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
         rv[r] = __shfl(v, srcl);
         ri[r] = __shfl(ix, srcl);
     }
-    // certified by margin: the need-th and (need+1)-th computed values are more than 2 eps apart
-    const bool margin_ok = ((double)rv[need - 1] - (double)rv[need]) > 2.0 * eps && ri[need - 1] < ncols;
-    if (margin_ok) {
+    const double nqp = sqrt(nqp2);
+    const double eps_g = eb(p.rmax);  // holds for every column
+    if (ri[need - 1] < ncols) {
+        // upper bound of the true need-th nearest distance from the computed candidates
+        const double d2up = fmax(nqp2 - 2.0 * ((double)rv[need - 1] - eps_g), 0.0);
+        const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
+        bool near = true;  // the top `need` computed candidates all lie within R0
+        for (int r = 0; r < need; ++r) near = near && colnorm[ri[r]] <= R0;
+        const double eps_m = near ? eb(R0) : eps_g;
+        // certified by margin: the need-th and (need+1)-th computed values are > 2 eps apart
+        if (((double)rv[need - 1] - (double)rv[need]) > 2.0 * eps_m) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) out_idx[r] = ri[r];
-        if (want_d2) out_d2 = exact_d2(qd, rows + (uint64_t)ri[0] * FAST_D, lane);
-        return true;
+            for (int r = 0; r < 3; ++r) out_idx[r] = ri[r];
+            if (want_d2) out_d2 = exact_d2(qd, rows + (uint64_t)ri[0] * FAST_D, lane);
+            return true;
+        }
     }
+    if (lane == 0) atomicAdd(p.fb_count + 1, 1u);  // statistics: resolved by exact distances
     // not certified: exact float64 distances for all (valid) candidates
     double best[3] = {INFINITY, INFINITY, INFINITY};
     uint32_t bidx[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -378,9 +409,10 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
         }
     }
     if (bidx[need - 1] == 0xFFFFFFFFu) return false;
-    // the true value of the need-th best must beat what any dropped column could reach
+    // the need-th best (exact) must beat what any dropped column within reach could be
+    const double R0x = fmin(p.rmax, (nqp + sqrt(best[need - 1])) * (1.0 + 1e-6));
     const double tv = 0.5 * (nqp2 - best[need - 1]);
-    if (!(tv > U + eps)) return false;
+    if (!(tv > U + eb(R0x))) return false;
 #pragma unroll
     for (int r = 0; r < 3; ++r) out_idx[r] = bidx[r];
     out_d2 = best[0];
@@ -421,17 +453,16 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
     const double c0 = qd[0] - m0.x, c1 = qd[1] - m0.y, c2 = qd[2] - m1.x, c3 = qd[3] - m1.y;
     const double nq2 = wave_sum(fma(qd[0], qd[0], fma(qd[1], qd[1], fma(qd[2], qd[2], qd[3] * qd[3]))));
     const double nqp2 = wave_sum(fma(c0, c0, fma(c1, c1, fma(c2, c2, c3 * c3))));
-    // rigorous bound on |computed v - true v| of the fp32 MFMA pass ("error bound")
-    const double u32r = 5.9604644775390625e-08;  // 2^-24
-    const double A = sqrt(nq2) + p.mu_norm, nqp = sqrt(nqp2);
-    const double eps = u32r * p.rmax * (8.0 * A + 264.0 * nqp + 136.0 * p.rmax);
+    ErrBound eb;
+    eb.A = sqrt(nq2) + p.mu_norm;
+    eb.P = sqrt(nqp2);
 
     bool ok = true;
     double knn = 0.0, cen = 0.0;
     uint32_t idx[3];
     double d2;
     if (p.method & PHK_METHOD_KNN) {
-        ok = resolve_segment(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eps, p.R64, false, lane, idx, d2);
+        ok = resolve_segment(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, p.R64, p.colnorm, false, lane, idx, d2);
         if (ok) {
             int votes = 0;
             for (int r = 0; r < p.kn; ++r) votes += p.labels[idx[r]] ? 1 : 0;
@@ -440,10 +471,10 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
     }
     if (ok && (p.method & PHK_METHOD_KMEANS)) {
         double dp2 = 0.0, dn2 = 0.0;
-        ok = resolve_segment(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eps, p.C64, true, lane, idx, dp2);
+        ok = resolve_segment(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, p.C64, p.colnorm + p.M, true, lane, idx, dp2);
         if (ok)
-            ok = resolve_segment(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eps, p.C64 + p.n_cpos * FAST_D, true,
-                                 lane, idx, dn2);
+            ok = resolve_segment(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, p.C64 + p.n_cpos * FAST_D,
+                                 p.colnorm + p.M + p.n_cpos, true, lane, idx, dn2);
         if (ok) {
             const double ep = sqrt(dp2), en = sqrt(dn2);
             cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
@@ -460,33 +491,40 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
 }
 
 // ------------------------------------------------------------------------------------
-// 3. exact brute force for queued queries: one block per query, one wave per column
+// 3. exact brute force for queued queries: one block per query, one thread per column
 // ------------------------------------------------------------------------------------
 template <int SRC>
 __global__ __launch_bounds__(256) void phk_knn_fallback_kernel(const void *__restrict__ src, RerankParams p) {
-    extern __shared__ double fb_dist[];  // M + n_cpos + n_cneg distances
+    extern __shared__ double fb_lds[];  // [0, 256): the query; then M + n_cpos + n_cneg distances
+    double *fb_q = fb_lds, *fb_dist = fb_lds + FAST_D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t count = *p.fb_count;
     const uint64_t ncols = p.M + p.n_cpos + p.n_cneg;
     for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
         const uint64_t q = p.fb_list[it];
-        double qd[4];
+        // the query row in float64 (kmer.normalize_counts arithmetic), one element per thread
         if (SRC == 0) {
-            const uint4 c = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D)[lane];
-            uint32_t s = c.x + c.y + c.z + c.w;
+            const uint32_t *row = static_cast<const uint32_t *>(src) + q * FAST_D;
+            uint32_t s = row[lane] + row[lane + 64] + row[lane + 128] + row[lane + 192];
 #pragma unroll
             for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
-            const double ds = (double)s;
-            qd[0] = (double)c.x / ds; qd[1] = (double)c.y / ds; qd[2] = (double)c.z / ds; qd[3] = (double)c.w / ds;
+            fb_q[threadIdx.x] = (double)row[threadIdx.x] / (double)s;
         } else {
-            const double2 a = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D)[2 * lane];
-            const double2 b = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D)[2 * lane + 1];
-            qd[0] = a.x; qd[1] = a.y; qd[2] = b.x; qd[3] = b.y;
+            fb_q[threadIdx.x] = static_cast<const double *>(src)[q * FAST_D + threadIdx.x];
         }
-        for (uint64_t c = wave; c < ncols; c += 4) {
-            const double *row = c < p.M ? p.R64 + c * FAST_D : p.C64 + (c - p.M) * FAST_D;
-            const double d2 = exact_d2(qd, row, lane);
-            if (lane == 0) fb_dist[c] = d2;
+        __syncthreads();
+        for (uint64_t c = threadIdx.x; c < ncols; c += 256) {
+            const double2 *row = reinterpret_cast<const double2 *>(c < p.M ? p.R64 + c * FAST_D
+                                                                            : p.C64 + (c - p.M) * FAST_D);
+            double acc = 0.0;
+#pragma unroll 8
+            for (int d = 0; d < FAST_D / 2; ++d) {
+                const double2 r = row[d];
+                const double d0 = fb_q[2 * d] - r.x, d1 = fb_q[2 * d + 1] - r.y;
+                acc = fma(d0, d0, acc);
+                acc = fma(d1, d1, acc);
+            }
+            fb_dist[c] = acc;
         }
         __syncthreads();
         if (wave == 0) {
@@ -546,7 +584,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     PHK_TRY(phk_ws(ctx, WS_DIST, (nb_max + 16) * sizeof(uint32_t), &fb));
     uint32_t *fb_count = (uint32_t *)fb, *fb_list = (uint32_t *)fb + 16;
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
-    const size_t fb_lds = ncols * sizeof(double);
+    const size_t fb_lds = (ncols + FAST_D) * sizeof(double);
     PHK_REQUIRE(fb_lds <= 160 * 1024, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);
     static bool attr_set = false;
     if (!attr_set && fb_lds > 64 * 1024) {
@@ -567,7 +605,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         RerankParams p;
         p.N = nb; p.M = m->M; p.n_cpos = m->n_cpos; p.n_cneg = m->n_cneg;
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
-        p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.labels = m->d_labels;
+        p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.colnorm = m->d_colnorm; p.labels = m->d_labels;
         p.cand_v = (const float4 *)cv; p.cand_i = (const uint4 *)ci;
         p.scores = d_scores; p.status = d_status; p.fb_count = fb_count; p.fb_list = fb_list; p.q_base = s;
         if (d_counts) {

@@ -13,7 +13,7 @@ struct phk_model {
     // MFMA path (score_mfma.hip); null when the shape is outside it
     bool fast = false;
     float *d_Bf = nullptr;        // fragment-ordered centred fp32 columns (train rows, then centroids)
-    float *d_colnorm = nullptr;   // ||r'||^2 per column (+inf on padding)
+    double *d_colnorm = nullptr;  // |r'| per real column (train rows, pos centroids, neg centroids)
     float *d_mu32 = nullptr;      // centring vector, fp32
     double *d_mu64 = nullptr;     // centring vector, fp64
     uint32_t n_rblk_ref = 0, n_rblk_pos = 0, n_rblk_neg = 0;  // 32-column blocks per segment
