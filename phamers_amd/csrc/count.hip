@@ -4,6 +4,8 @@
 // Replaces the arithmetic of kmer.sequence_to_integers (scripts/kmer.py:183-196),
 // kmer.count_string's window loop (scripts/kmer.py:47-50) and kmer.normalize_counts
 // (scripts/kmer.py:209-221).  Packed-stream layout: include/phamers_hip.h.
+#include <stdlib.h>
+
 #include "phk_common.h"
 
 // ------------------------------------------------------------------------------------
@@ -80,104 +82,314 @@ int phk_launch_pack(phk_ctx *ctx, const char *d_bases, uint64_t T, const char *s
 }
 
 // ------------------------------------------------------------------------------------
-// count: one wavefront per contig, 4^K uint32 bins per wave in LDS
+// count: one wavefront per contig; per-wave LDS histogram replicated over COPIES lanes
 // ------------------------------------------------------------------------------------
 // Lane l of a wave-iteration owns packed word w = w0 + l (16 window starts) and reads word
 // w+1 for the K-1 bases a window may reach into; the 64-bit funnel X = w:w+1 makes window i
 // the bit field X[63-2i .. 64-2K-2i], which IS the reference's bin index
 // int(window, 4) (first base most significant, scripts/kmer.py:50).
-template <int K, bool MASK>
-__global__ __launch_bounds__(256) void phk_count_kernel(const uint32_t *__restrict__ packed,
-                                                        const uint32_t *__restrict__ mask,
-                                                        const uint64_t *__restrict__ offsets,
-                                                        uint64_t n, uint32_t *__restrict__ counts,
-                                                        uint32_t *__restrict__ nwin) {
-    constexpr uint32_t D = 1u << (2 * K);
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int wpb = blockDim.x >> 6;
-    uint32_t *bins = lds + (size_t)wave * D;
-    for (uint32_t b = lane * 4; b < D; b += 256) *reinterpret_cast<uint4 *>(bins + b) = make_uint4(0, 0, 0, 0);
-
-    const uint64_t total_waves = (uint64_t)gridDim.x * wpb;
-    for (uint64_t c = (uint64_t)blockIdx.x * wpb + wave; c < n; c += total_waves) {
-        const uint64_t start = offsets[c], end = offsets[c + 1];
-        uint32_t cnt = 0;
-        if (end >= start + K) {
-            const uint64_t last = end - K;  // last window start
-            const uint64_t wb = start >> 4, we = last >> 4;
-            for (uint64_t w0 = wb; w0 <= we; w0 += 64) {
-                const uint64_t w = w0 + lane;
-                if (w <= we) {
-                    const uint32_t a = packed[w], b = packed[w + 1];
-                    const uint64_t X = ((uint64_t)a << 32) | b;
-                    const uint64_t g0 = w << 4;
-                    // window starts i in [lo, hi] of this word belong to the contig
-                    const int lo = start > g0 ? (int)(start - g0) : 0;
-                    const int hi = last - g0 < 15 ? (int)(last - g0) : 15;
-                    uint32_t VB = 0xFFFFFFFFu;
-                    if (MASK) {
-                        const uint64_t mi = w >> 1;
-                        const uint64_t V = ((uint64_t)mask[mi] << 32) | mask[mi + 1];
-                        VB = (uint32_t)(V >> (32 - 16 * (int)(w & 1)));
-                    }
+//
+// LDS layout per wave: lane l adds into copy l % COPIES of each bin, so the 32 lanes of an LDS
+// group spread over COPIES banks per bin (random bins then collide ~2-way, which the 4-cycle
+// ds_add data path hides).
+//   PACK16 = false (k <= 4): bins[4^K][COPIES] uint32.
+//   PACK16 = true  (k >= 5): rows[4^K/2][COPIES] uint32, row r = bins 2r (low half) and 2r+1 (high
+//     half); at most 63 wave iterations (64512 windows) go between flushes, so no half can carry.
+// A flush sums the copies with 16-byte LDS reads, clears them, and stores / accumulates uint32.
+template <int K, int COPIES, bool PACK16>
+__device__ __forceinline__ void phk_flush_bins(uint32_t *bins, uint32_t *row_out, bool first, int lane) {
+    constexpr int D = 1 << (2 * K);
+    constexpr int ROWS = PACK16 ? D / 2 : D;
+    constexpr int W = ROWS * COPIES;        // dwords per wave
+    constexpr int PER = PACK16 ? 2 : 1;     // output bins per row
+    for (int base = 0; base < W; base += 256) {
+        const int i4 = base + lane * 4;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i4 < W) {
+            v = *reinterpret_cast<uint4 *>(bins + i4);
+            *reinterpret_cast<uint4 *>(bins + i4) = make_uint4(0, 0, 0, 0);
+        }
+        if (COPIES >= 4) {  // 4 copies of one row per lane; COPIES/4 neighbouring lanes share the row
+            uint32_t sum = v.x + v.y + v.z + v.w;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        bool ok = (i >= lo) & (i <= hi);
-                        if (MASK) ok &= ((VB << i) >> (32 - K)) == ((1u << K) - 1u);
-                        const uint32_t idx = (uint32_t)(X >> (64 - 2 * K - 2 * i)) & (D - 1);
-                        if (ok) {
-                            atomicAdd(&bins[idx], 1u);
-                            ++cnt;
-                        }
+            for (int m = 1; m < COPIES / 4; m <<= 1) sum += __shfl_xor(sum, m);
+            const int row = i4 / COPIES;
+            if (i4 < W && (lane % (COPIES >= 4 ? COPIES / 4 : 1)) == 0) {
+                uint32_t *dst = row_out + PER * row;
+                if (PACK16) {
+                    uint2 o = make_uint2(sum & 0xFFFFu, sum >> 16);
+                    if (!first) {
+                        const uint2 old = *reinterpret_cast<uint2 *>(dst);
+                        o.x += old.x;
+                        o.y += old.y;
                     }
+                    *reinterpret_cast<uint2 *>(dst) = o;
+                } else {
+                    *dst = first ? sum : *dst + sum;
                 }
             }
-        }
-        // flush this contig's histogram (coalesced 16-byte stores) and clear the bins
-        uint32_t *row = counts + c * D;
-        for (uint32_t b = lane * 4; b < D; b += 256) {
-            uint4 v = *reinterpret_cast<uint4 *>(bins + b);
-            *reinterpret_cast<uint4 *>(row + b) = v;
-            *reinterpret_cast<uint4 *>(bins + b) = make_uint4(0, 0, 0, 0);
-        }
-        if (nwin) {
-#pragma unroll
-            for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s);
-            if (lane == 0) nwin[c] = cnt;
+        } else if (!PACK16) {  // COPIES 1 or 2, plain uint32 bins: 4 or 2 bins per lane
+            if (i4 < W) {
+                if (COPIES == 1) {
+                    uint4 *dst = reinterpret_cast<uint4 *>(row_out + i4);
+                    if (!first) {
+                        const uint4 o = *dst;
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *dst = v;
+                } else {
+                    uint2 o = make_uint2(v.x + v.y, v.z + v.w);
+                    uint2 *dst = reinterpret_cast<uint2 *>(row_out + i4 / 2);
+                    if (!first) {
+                        const uint2 old = *dst;
+                        o.x += old.x; o.y += old.y;
+                    }
+                    *dst = o;
+                }
+            }
+        } else {  // COPIES == 1 (k = 7, PACK16): four rows per lane -> bins 2*i4 .. 2*i4+7
+            if (i4 < W) {
+                uint4 o0 = make_uint4(v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16);
+                uint4 o1 = make_uint4(v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16);
+                uint4 *dst = reinterpret_cast<uint4 *>(row_out + 2 * i4);
+                if (!first) {
+                    const uint4 a0 = dst[0], a1 = dst[1];
+                    o0.x += a0.x; o0.y += a0.y; o0.z += a0.z; o0.w += a0.w;
+                    o1.x += a1.x; o1.y += a1.y; o1.z += a1.z; o1.w += a1.w;
+                }
+                dst[0] = o0;
+                dst[1] = o1;
+            }
         }
     }
 }
 
-template <int K>
-static int launch_count_k(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
-                          const uint64_t *d_offsets, uint64_t n, uint32_t *d_counts,
-                          uint32_t *d_nwin) {
+// one wave-iteration: 16 window starts per lane from the funnel a:b of packed word wc
+template <int K, int COPIES, bool PACK16, bool MASK>
+__device__ __forceinline__ uint32_t phk_count_word(uint32_t *mybins, uint32_t a, uint32_t b, bool active, uint64_t wc,
+                                                   uint64_t start, uint64_t last,
+                                                   const uint32_t *__restrict__ mask) {
     constexpr uint32_t D = 1u << (2 * K);
+    constexpr int LOGC = COPIES == 16 ? 4 : COPIES == 8 ? 3 : COPIES == 4 ? 2 : COPIES == 2 ? 1 : 0;
+    const uint64_t X = ((uint64_t)a << 32) | b;
+    const uint64_t g0 = wc << 4;
+    // window starts i in [lo, hi] of this word belong to the contig
+    const int lo = start > g0 ? (int)(start - g0) : 0;
+    const int hi = last - g0 < 15 ? (int)(last - g0) : 15;
+    uint32_t okbits = active ? ((2u << hi) - 1u) & ~((1u << lo) - 1u) : 0u;  // bit i = window i counted
+    if (MASK) {
+        const uint64_t mi = wc >> 1;
+        const uint64_t V = ((uint64_t)mask[mi] << 32) | mask[mi + 1];
+        const uint32_t vb = (uint32_t)(V >> (32 - 16 * (int)(wc & 1)));  // bit 31-i = base g0+i valid
+        // window i is valid iff bases i .. i+K-1 are: AND the K shifted copies
+        uint32_t wv = vb;
+#pragma unroll
+        for (int j = 1; j < K; ++j) wv &= vb << j;  // bit 31-i = window i valid
+        okbits &= __brev(wv);
+    }
+    if (!MASK && __all(okbits == 0xFFFFu)) {
+        // every lane holds 16 counted windows: no predicates at all
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t idx = (uint32_t)(X >> (64 - 2 * K - 2 * i)) & (D - 1);
+            if (PACK16)
+                atomicAdd(mybins + ((idx >> 1) << LOGC), 1u + __umul24(idx & 1u, 0xFFFFu));
+            else
+                atomicAdd(mybins + (idx << LOGC), 1u);
+        }
+        return 16;
+    }
+    // edge / masked words: uncounted windows add 0 (no exec-mask churn)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t idx = (uint32_t)(X >> (64 - 2 * K - 2 * i)) & (D - 1);
+        const uint32_t ok = (okbits >> i) & 1u;
+        if (PACK16)
+            atomicAdd(mybins + ((idx >> 1) << LOGC), ok + __umul24(ok & idx, 0xFFFFu));
+        else
+            atomicAdd(mybins + (idx << LOGC), ok);
+    }
+    return __popc(okbits);
+}
+
+// The kernel is latency-bound unless loads run ahead of the LDS work, so it is software pipelined
+// at the contig level: offsets are fetched two contigs ahead, the first PF wave-iterations of
+// packed words one contig ahead (a register ring; longer contigs refill the ring as they go).
+template <int K, int COPIES, bool PACK16, bool MASK>
+__global__ __launch_bounds__(256) void phk_count_kernel(const uint32_t *__restrict__ packed,
+                                                        const uint32_t *__restrict__ mask,
+                                                        const uint64_t *__restrict__ offsets,
+                                                        uint64_t n, uint64_t max_word,
+                                                        uint32_t *__restrict__ counts,
+                                                        uint32_t *__restrict__ nwin) {
+    static_assert(COPIES >= 4 || !PACK16 || COPIES == 1, "unsupported replication");
+    constexpr uint32_t D = 1u << (2 * K);
+    constexpr int W = (int)(PACK16 ? D / 2 : D) * COPIES;
+    constexpr int SEG_ITERS = 63;  // wave iterations between flushes (PACK16 carry bound)
+    constexpr int PF = 5;          // prefetched wave-iterations (5120 bases) per contig
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    uint32_t *bins = lds + (size_t)wave * W;
+    for (int b = lane * 4; b < W; b += 256) *reinterpret_cast<uint4 *>(bins + b) = make_uint4(0, 0, 0, 0);
+    uint32_t *mybins = bins + (lane & (COPIES - 1));  // this lane's copy
+
+    const uint64_t S = (uint64_t)gridDim.x * wpb;
+    uint64_t c = (uint64_t)blockIdx.x * wpb + wave;
+    if (c >= n) return;
+
+    uint32_t ra[PF], rb[PF], na[PF], nb[PF];
+    // words of wave-iterations 0..PF-1 of contig [st, en) into (xa, xb).  The loads are
+    // UNCONDITIONAL (indices clamped into the stream) so that they issue back to back: a load under
+    // its own branch gets a vmcnt(0) at the join and the prefetch degenerates into serial round trips.
+    auto issue = [&](uint64_t st, uint64_t en, uint32_t (&xa)[PF], uint32_t (&xb)[PF]) {
+        const uint64_t wb = st >> 4;
+        uint64_t we = en >= st + K ? (en - K) >> 4 : wb;
+        we = we < max_word ? we : max_word;
+#pragma unroll
+        for (int t = 0; t < PF; ++t) {
+            const uint64_t w = wb + 64ull * t + lane;
+            const uint64_t wc = w <= we ? w : we;
+            xa[t] = packed[wc];
+            xb[t] = packed[wc + 1];
+        }
+    };
+    // count one contig whose first PF iterations sit in (xa, xb); later iterations (contigs longer
+    // than 1024*PF bases) are loaded as they come
+    auto process = [&](uint64_t cc, uint64_t start, uint64_t end, uint32_t (&xa)[PF], uint32_t (&xb)[PF]) {
+        uint32_t *row_out = counts + cc * D;
+        uint32_t cnt = 0;
+        bool first = true;
+        if (end >= start + K) {
+            const uint64_t last = end - K;  // last window start
+            const uint64_t wb = start >> 4, we = last >> 4;
+            const uint64_t niter = (we - wb) / 64 + 1;
+            int since_flush = 0;
+            for (uint64_t t = 0; t < niter; ++t) {
+                const uint64_t w = wb + 64 * t + lane;
+                const bool active = w <= we;
+                const uint64_t wc = active ? w : we;
+                uint32_t a, b;
+                if (t < PF) {  // wave-uniform: pick ring slot t (select chain keeps the ring in registers)
+                    a = xa[0];
+                    b = xb[0];
+#pragma unroll
+                    for (int j = 1; j < PF; ++j) {
+                        a = (t == (uint64_t)j) ? xa[j] : a;
+                        b = (t == (uint64_t)j) ? xb[j] : b;
+                    }
+                } else {
+                    a = packed[wc];
+                    b = packed[wc + 1];
+                }
+                cnt += phk_count_word<K, COPIES, PACK16, MASK>(mybins, a, b, active, wc, start, last, mask);
+                if (++since_flush == SEG_ITERS && t + 1 < niter) {  // keep 16-bit halves from carrying
+                    phk_flush_bins<K, COPIES, PACK16>(bins, row_out, first, lane);
+                    first = false;
+                    since_flush = 0;
+                }
+            }
+        }
+        phk_flush_bins<K, COPIES, PACK16>(bins, row_out, first, lane);
+        if (nwin) {
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s);
+            if (lane == 0) nwin[cc] = cnt;
+        }
+    };
+
+    // two rings in ping-pong: while contig c is counted out of one, contig c+S streams into the other
+    uint64_t s0 = offsets[c], e0 = offsets[c + 1];
+    uint64_t s1 = 0, e1 = 0;
+    if (c + S < n) {
+        s1 = offsets[c + S];
+        e1 = offsets[c + S + 1];
+    }
+    issue(s0, e0, ra, rb);
+    for (;;) {
+        // --- even phase: process (s0,e0) from ra/rb, stream contig c+S into na/nb
+        uint64_t s2 = 0, e2 = 0;
+        if (c + 2 * S < n) {
+            s2 = offsets[c + 2 * S];
+            e2 = offsets[c + 2 * S + 1];
+        }
+        if (c + S < n) issue(s1, e1, na, nb);
+        process(c, s0, e0, ra, rb);
+        c += S;
+        if (c >= n) break;
+        // --- odd phase: process (s1,e1) from na/nb, stream contig c+S into ra/rb
+        uint64_t s3 = 0, e3 = 0;
+        if (c + 2 * S < n) {
+            s3 = offsets[c + 2 * S];
+            e3 = offsets[c + 2 * S + 1];
+        }
+        if (c + S < n) issue(s2, e2, ra, rb);
+        process(c, s1, e1, na, nb);
+        c += S;
+        if (c >= n) break;
+        s0 = s2; e0 = e2;
+        s1 = s3; e1 = e3;
+    }
+}
+
+// replication / packing per k: keep a wave's bins <= 32 KiB
+template <int K> struct PhkCountCfg {
+    static constexpr bool pack16 = K >= 6;
+    static constexpr int copies = K <= 4 ? 4 : 1;  // measured best, profiles/r01/count_lds_study.md
+};
+
+template <int K, int COPIES, bool P16>
+static int launch_count_cfg(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
+                            const uint64_t *d_offsets, uint64_t n, uint64_t max_word, uint32_t *d_counts,
+                            uint32_t *d_nwin) {
+    constexpr uint32_t D = 1u << (2 * K);
+    constexpr size_t wave_bytes = (size_t)(P16 ? D / 2 : D) * COPIES * 4u;
     // waves per block so that a block's bins stay <= 64 KiB
-    const int wpb = (D * 4u * 4u <= 65536u) ? 4 : (D * 4u * 2u <= 65536u ? 2 : 1);
-    const size_t lds = (size_t)wpb * D * 4u;
+    const int wpb = wave_bytes * 4 <= 65536 ? 4 : (wave_bytes * 2 <= 65536 ? 2 : 1);
+    const size_t lds = wave_bytes * wpb;
+    int per_cu = (int)((160u * 1024u) / lds);
+    per_cu = per_cu > 8 ? 8 : (per_cu < 1 ? 1 : per_cu);
     uint64_t blocks = phk_div_up(n, wpb);
-    const uint64_t cap = (uint64_t)ctx->num_cus * 8;
+    const uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) return PHK_OK;
     if (d_mask) {
         PHK_LAUNCH(ctx, "phk_count_kernel",
-                   phk_count_kernel<K, true><<<dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream>>>(
-                       d_packed, d_mask, d_offsets, n, d_counts, d_nwin));
+                   phk_count_kernel<K, COPIES, P16, true><<<dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream>>>(
+                       d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin));
     } else {
         PHK_LAUNCH(ctx, "phk_count_kernel",
-                   phk_count_kernel<K, false><<<dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream>>>(
-                       d_packed, d_mask, d_offsets, n, d_counts, d_nwin));
+                   phk_count_kernel<K, COPIES, P16, false><<<dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream>>>(
+                       d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin));
     }
     return PHK_OK;
+}
+
+template <int K>
+static int launch_count_k(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
+                          const uint64_t *d_offsets, uint64_t n, uint64_t max_word, uint32_t *d_counts,
+                          uint32_t *d_nwin) {
+    // tuning knob for the LDS replication study: PHK_COUNT_CFG="<copies>,<pack16>", k = 4 / 5 / 6 only
+    if (K == 4 || K == 5 || K == 6) {
+        const char *cfg = getenv("PHK_COUNT_CFG");
+        int copies = 0, p16 = 0;
+        if (cfg && sscanf(cfg, "%d,%d", &copies, &p16) == 2) {
+#define PHK_CFG(C, P) if (copies == C && p16 == P) return launch_count_cfg<(K == 4 || K == 5 || K == 6) ? K : 4, C, P != 0>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin)
+            PHK_CFG(1, 0); PHK_CFG(2, 0); PHK_CFG(4, 0); PHK_CFG(8, 0); PHK_CFG(16, 0);
+            PHK_CFG(1, 1); PHK_CFG(4, 1); PHK_CFG(8, 1); PHK_CFG(16, 1);
+#undef PHK_CFG
+            phk_set_error("PHK_COUNT_CFG=%s is not one of the built variants", cfg);
+            return PHK_ERR_ARG;
+        }
+    }
+    return launch_count_cfg<K, PhkCountCfg<K>::copies, PhkCountCfg<K>::pack16>(ctx, d_packed, d_mask, d_offsets, n,
+                                                                              max_word, d_counts, d_nwin);
 }
 
 int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t T,
                      const uint64_t *d_offsets, uint64_t n, int k, uint32_t *d_counts,
                      uint32_t *d_nwin) {
-    (void)T;
     PHK_REQUIRE(k >= 1, "phk_count: k must be >= 1 (got %d)", k);
     if (k > PHK_MAX_K) {
         phk_set_error("phk_count: k=%d is above PHK_MAX_K=%d (4^k bins no longer fit LDS)", k, PHK_MAX_K);
@@ -186,14 +398,20 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
     if (n == 0) return PHK_OK;
     PHK_REQUIRE(d_packed && d_offsets && d_counts, "phk_count: NULL device pointer");
     PHK_REQUIRE(((uintptr_t)d_counts & 15) == 0, "phk_count: counts must be 16-byte aligned");
+    if (T == 0) {  // only empty contigs: all-zero rows, nothing to read
+        PHK_HIP(hipMemsetAsync(d_counts, 0, n * phk_pow4(k) * sizeof(uint32_t), ctx->stream));
+        if (d_nwin) PHK_HIP(hipMemsetAsync(d_nwin, 0, n * sizeof(uint32_t), ctx->stream));
+        return PHK_OK;
+    }
+    const uint64_t max_word = (T - 1) >> 4;  // last word holding a base; word max_word + 1 exists (pad)
     switch (k) {
-        case 1: return launch_count_k<1>(ctx, d_packed, d_mask, d_offsets, n, d_counts, d_nwin);
-        case 2: return launch_count_k<2>(ctx, d_packed, d_mask, d_offsets, n, d_counts, d_nwin);
-        case 3: return launch_count_k<3>(ctx, d_packed, d_mask, d_offsets, n, d_counts, d_nwin);
-        case 4: return launch_count_k<4>(ctx, d_packed, d_mask, d_offsets, n, d_counts, d_nwin);
-        case 5: return launch_count_k<5>(ctx, d_packed, d_mask, d_offsets, n, d_counts, d_nwin);
-        case 6: return launch_count_k<6>(ctx, d_packed, d_mask, d_offsets, n, d_counts, d_nwin);
-        default: return launch_count_k<7>(ctx, d_packed, d_mask, d_offsets, n, d_counts, d_nwin);
+        case 1: return launch_count_k<1>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin);
+        case 2: return launch_count_k<2>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin);
+        case 3: return launch_count_k<3>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin);
+        case 4: return launch_count_k<4>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin);
+        case 5: return launch_count_k<5>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin);
+        case 6: return launch_count_k<6>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin);
+        default: return launch_count_k<7>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin);
     }
 }
 

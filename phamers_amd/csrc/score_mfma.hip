@@ -143,8 +143,12 @@ void phk_model_free_fast(phk_model *m) {
 // 1. MFMA candidate search
 // ------------------------------------------------------------------------------------
 // sorted (descending) insert of (x, c) into a 4-deep list held in registers
-__device__ __forceinline__ void list_insert(float (&v)[CAND], uint32_t (&ix)[CAND], float x, uint32_t c) {
+// and track the largest value that ever fell off the list (`drop`): every column this list does
+// not hold has a computed value <= drop.
+__device__ __forceinline__ void list_insert(float (&v)[CAND], uint32_t (&ix)[CAND], float &drop, float x,
+                                            uint32_t c) {
     const bool g0 = x > v[0], g1 = x > v[1], g2 = x > v[2], g3 = x > v[3];
+    drop = fmaxf(drop, g3 ? v[3] : x);
     v[3] = g2 ? v[2] : (g3 ? x : v[3]);
     ix[3] = g2 ? ix[2] : (g3 ? c : ix[3]);
     v[2] = g1 ? v[1] : (g2 ? x : v[2]);
@@ -165,7 +169,8 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
                                                               uint32_t nblk_ref, uint32_t nblk_pos,
                                                               uint32_t nblk_neg,
                                                               float4 *__restrict__ cand_v,
-                                                              uint4 *__restrict__ cand_i) {
+                                                              uint4 *__restrict__ cand_i,
+                                                              float *__restrict__ cand_u) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
     const uint64_t q0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
@@ -219,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
 
     float lv[CAND];
     uint32_t li[CAND];
+    float ldrop = -3.0e38f;
 #pragma unroll
     for (int c = 0; c < CAND; ++c) {
         lv[c] = -3.0e38f;
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
         // epilogue: D[i][j] sits in lane (j, h') register r with i = (r&3) + 8(r>>2) + 4h'
         const uint32_t cbase = 32u * (blk - seg_first) + 4u * (uint32_t)h;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) list_insert(lv, li, acc[r], cbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        for (int r = 0; r < 16; ++r) list_insert(lv, li, ldrop, acc[r], cbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
 
         // segment boundary: flush this (query, segment, half) list and start the next segment
         while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
@@ -263,12 +269,14 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
                 const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
                 cand_v[o] = make_float4(lv[0], lv[1], lv[2], lv[3]);
                 cand_i[o] = make_uint4(li[0], li[1], li[2], li[3]);
+                cand_u[o] = ldrop;
             }
 #pragma unroll
             for (int c = 0; c < CAND; ++c) {
                 lv[c] = -3.0e38f;
                 li[c] = 0xFFFFFFFFu;
             }
+            ldrop = -3.0e38f;
             ++seg;
             seg_first = blk + 1;
         }
@@ -279,6 +287,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
             const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
             cand_v[o] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
             cand_i[o] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            cand_u[o] = -3.0e38f;
         }
     }
 }
@@ -294,6 +303,8 @@ struct RerankParams {
     const uint8_t *labels;
     const float4 *cand_v;
     const uint4 *cand_i;
+    const float *cand_u;
+    void *fb_rec;           // fallback partial records
     double *scores;
     uint32_t *status;       // NaN-row counter (may be null)
     uint32_t *fb_count;     // fallback queue length
@@ -349,11 +360,10 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
         ix = s == 0 ? ci.x : s == 1 ? ci.y : s == 2 ? ci.z : ci.w;
         if (ix >= ncols) v = -3.0e38f;  // padding / empty slot
     }
-    // every column a list dropped has a computed value <= that list's 4th entry
-    const float u0 = __shfl(v, 3), u1 = __shfl(v, 7);
-    const bool full0 = __shfl(ix, 3) < ncols, full1 = __shfl(ix, 7) < ncols;
-    // a list that is not full has seen fewer than 4 real columns: nothing was dropped from it
-    const double U = fmax(full0 ? (double)u0 : -INFINITY, full1 ? (double)u1 : -INFINITY);
+    // every column the two half-lists dropped has a computed value <= the larger of their
+    // best-dropped values (-3e38 when nothing real was dropped)
+    const uint64_t ou = (q * NSEG + seg) * 2;
+    const double U = fmax((double)p.cand_u[ou], (double)p.cand_u[ou + 1]);
     // rank of each candidate among the 8 (descending v, ties by lane)
     int rank = 0;
 #pragma unroll
@@ -491,17 +501,37 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
 }
 
 // ------------------------------------------------------------------------------------
-// 3. exact brute force for queued queries: one block per query, one thread per column
+// 3. exact brute force for queued queries.  Work item = (queued query, column chunk): a block
+//    computes the direct-difference float64 distances of its chunk (one thread per column), then
+//    reduces them to a partial record (3 nearest train columns of the chunk + nearest positive /
+//    negative centroid of the chunk).  A second kernel merges the FB_CHUNKS records of a query.
 // ------------------------------------------------------------------------------------
+#define FB_CHUNKS 16
+struct FbRecord {
+    double d[3];
+    uint32_t i[3];
+    uint32_t pad;
+    double minpos, minneg;
+};
+
+__device__ __forceinline__ bool fb_less(double da, uint64_t ia, double db, uint64_t ib) {
+    return da < db || (da == db && ia < ib);
+}
+
 template <int SRC>
-__global__ __launch_bounds__(256) void phk_knn_fallback_kernel(const void *__restrict__ src, RerankParams p) {
-    extern __shared__ double fb_lds[];  // [0, 256): the query; then M + n_cpos + n_cneg distances
+__global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *__restrict__ src, RerankParams p) {
+    extern __shared__ double fb_lds[];  // [0, 256): the query; then one chunk of distances
     double *fb_q = fb_lds, *fb_dist = fb_lds + FAST_D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t count = *p.fb_count;
     const uint64_t ncols = p.M + p.n_cpos + p.n_cneg;
-    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {
-        const uint64_t q = p.fb_list[it];
+    const uint64_t cw = (ncols + FB_CHUNKS - 1) / FB_CHUNKS;
+    FbRecord *rec = static_cast<FbRecord *>(p.fb_rec);
+    const uint64_t items = (uint64_t)count * FB_CHUNKS;
+    for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const uint64_t qi = it / FB_CHUNKS, ch = it % FB_CHUNKS;
+        const uint64_t q = p.fb_list[qi];
+        const uint64_t c0 = ch * cw, c1 = (c0 + cw < ncols) ? c0 + cw : ncols;
         // the query row in float64 (kmer.normalize_counts arithmetic), one element per thread
         if (SRC == 0) {
             const uint32_t *row = static_cast<const uint32_t *>(src) + q * FAST_D;
@@ -513,7 +543,7 @@ __global__ __launch_bounds__(256) void phk_knn_fallback_kernel(const void *__res
             fb_q[threadIdx.x] = static_cast<const double *>(src)[q * FAST_D + threadIdx.x];
         }
         __syncthreads();
-        for (uint64_t c = threadIdx.x; c < ncols; c += 256) {
+        for (uint64_t c = c0 + threadIdx.x; c < c1; c += 256) {
             const double2 *row = reinterpret_cast<const double2 *>(c < p.M ? p.R64 + c * FAST_D
                                                                             : p.C64 + (c - p.M) * FAST_D);
             double acc = 0.0;
@@ -524,50 +554,85 @@ __global__ __launch_bounds__(256) void phk_knn_fallback_kernel(const void *__res
                 acc = fma(d0, d0, acc);
                 acc = fma(d1, d1, acc);
             }
-            fb_dist[c] = acc;
+            fb_dist[c - c0] = acc;
         }
         __syncthreads();
         if (wave == 0) {
-            double knn = 0.0, cen = 0.0;
-            if (p.method & PHK_METHOD_KNN) {
-                double last_d = -1.0;
-                uint64_t last_i = 0;
-                bool first = true;
-                int votes = 0;
-                for (int r = 0; r < p.kn; ++r) {
-                    double bd = INFINITY;
-                    uint64_t bi = ~0ull;
-                    for (uint64_t c = lane; c < p.M; c += 64) {
-                        const double d = fb_dist[c];
-                        const bool after = first || d > last_d || (d == last_d && c > last_i);
-                        if (after && (d < bd || (d == bd && c < bi))) { bd = d; bi = c; }
-                    }
-#pragma unroll
-                    for (int s = 32; s > 0; s >>= 1) {
-                        const double od = __shfl_xor(bd, s);
-                        const uint64_t oi = __shfl_xor(bi, s);
-                        if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
-                    }
-                    last_d = bd; last_i = bi; first = false;
-                    votes += p.labels[bi] ? 1 : 0;
+            FbRecord r;
+            double last_d = -1.0;
+            uint64_t last_i = 0;
+            bool first = true;
+            for (int k = 0; k < 3; ++k) {  // (distance, index)-ordered selection among train columns
+                double bd = INFINITY;
+                uint64_t bi = ~0ull;
+                for (uint64_t c = c0 + lane; c < c1 && c < p.M; c += 64) {
+                    const double d = fb_dist[c - c0];
+                    const bool after = first || fb_less(last_d, last_i, d, c);
+                    if (after && fb_less(d, c, bd, bi)) { bd = d; bi = c; }
                 }
-                knn = (2 * votes > p.kn) ? 1.0 : -1.0;
-            }
-            if (p.method & PHK_METHOD_KMEANS) {
-                double bp = INFINITY, bn = INFINITY;
-                for (uint64_t c = lane; c < p.n_cpos; c += 64) bp = fmin(bp, fb_dist[p.M + c]);
-                for (uint64_t c = lane; c < p.n_cneg; c += 64) bn = fmin(bn, fb_dist[p.M + p.n_cpos + c]);
 #pragma unroll
-                for (int s = 32; s > 0; s >>= 1) {
-                    bp = fmin(bp, __shfl_xor(bp, s));
-                    bn = fmin(bn, __shfl_xor(bn, s));
+                for (int sft = 32; sft > 0; sft >>= 1) {
+                    const double od = __shfl_xor(bd, sft);
+                    const uint64_t oi = __shfl_xor(bi, sft);
+                    if (fb_less(od, oi, bd, bi)) { bd = od; bi = oi; }
                 }
-                const double ep = sqrt(bp), en = sqrt(bn);
-                cen = tanh((en - ep) / (ep + en));
+                r.d[k] = bd;
+                r.i[k] = (uint32_t)bi;  // 0xFFFFFFFF when the chunk has fewer train columns
+                last_d = bd; last_i = bi; first = false;
             }
-            if (lane == 0) p.scores[p.q_base + q] = knn + cen;
+            double bp = INFINITY, bn = INFINITY;
+            for (uint64_t c = c0 + lane; c < c1; c += 64) {
+                if (c >= p.M && c < p.M + p.n_cpos) bp = fmin(bp, fb_dist[c - c0]);
+                if (c >= p.M + p.n_cpos) bn = fmin(bn, fb_dist[c - c0]);
+            }
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                bp = fmin(bp, __shfl_xor(bp, sft));
+                bn = fmin(bn, __shfl_xor(bn, sft));
+            }
+            r.minpos = bp; r.minneg = bn; r.pad = 0;
+            if (lane == 0) rec[it] = r;
         }
         __syncthreads();
+    }
+}
+
+// one thread per queued query: merge its FB_CHUNKS partial records and emit the score
+__global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p) {
+    const uint32_t count = *p.fb_count;
+    const FbRecord *rec = static_cast<const FbRecord *>(p.fb_rec);
+    for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < count;
+         qi += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t q = p.fb_list[qi];
+        double bd[3] = {INFINITY, INFINITY, INFINITY};
+        uint64_t bi[3] = {~0ull, ~0ull, ~0ull};
+        double bp = INFINITY, bn = INFINITY;
+        for (int ch = 0; ch < FB_CHUNKS; ++ch) {
+            const FbRecord r = rec[qi * FB_CHUNKS + ch];
+            for (int k = 0; k < 3; ++k) {
+                if (r.i[k] == 0xFFFFFFFFu) continue;
+                double d = r.d[k];
+                uint64_t c = r.i[k];
+                for (int s = 0; s < 3; ++s)
+                    if (fb_less(d, c, bd[s], bi[s])) {
+                        const double td = bd[s]; const uint64_t ti = bi[s];
+                        bd[s] = d; bi[s] = c; d = td; c = ti;
+                    }
+            }
+            bp = fmin(bp, r.minpos);
+            bn = fmin(bn, r.minneg);
+        }
+        double knn = 0.0, cen = 0.0;
+        if (p.method & PHK_METHOD_KNN) {
+            int votes = 0;
+            for (int k = 0; k < p.kn; ++k) votes += p.labels[bi[k]] ? 1 : 0;
+            knn = (2 * votes > p.kn) ? 1.0 : -1.0;
+        }
+        if (p.method & PHK_METHOD_KMEANS) {
+            const double ep = sqrt(bp), en = sqrt(bn);
+            cen = tanh((en - ep) / (ep + en));
+        }
+        p.scores[p.q_base + q] = knn + cen;
     }
 }
 
@@ -576,22 +641,18 @@ __global__ __launch_bounds__(256) void phk_knn_fallback_kernel(const void *__res
 // ------------------------------------------------------------------------------------
 int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
                    uint64_t N, int method, double *d_scores, uint32_t *d_status) {
-    const uint64_t BATCH = 1ull << 22;  // bounds the candidate workspace (192 B / query)
+    const uint64_t BATCH = 1ull << 20;  // bounds the candidate (200 B/query) and fallback (1 KiB/query) workspaces
     const uint64_t nb_max = N < BATCH ? N : BATCH;
-    void *cv, *ci, *fb;
-    PHK_TRY(phk_ws(ctx, WS_CAND, nb_max * NSEG * 2 * (sizeof(float4) + sizeof(uint4)), &cv));
-    ci = (char *)cv + nb_max * NSEG * 2 * sizeof(float4);
+    const uint64_t per_list = nb_max * NSEG * 2;
+    void *cv, *fb, *rec;
+    PHK_TRY(phk_ws(ctx, WS_CAND, per_list * (sizeof(float4) + sizeof(uint4) + sizeof(float)), &cv));
+    uint4 *ci = (uint4 *)((char *)cv + per_list * sizeof(float4));
+    float *cu = (float *)((char *)ci + per_list * sizeof(uint4));
     PHK_TRY(phk_ws(ctx, WS_DIST, (nb_max + 16) * sizeof(uint32_t), &fb));
+    PHK_TRY(phk_ws(ctx, WS_QF32, nb_max * FB_CHUNKS * sizeof(FbRecord), &rec));
     uint32_t *fb_count = (uint32_t *)fb, *fb_list = (uint32_t *)fb + 16;
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
-    const size_t fb_lds = (ncols + FAST_D) * sizeof(double);
-    PHK_REQUIRE(fb_lds <= 160 * 1024, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);
-    static bool attr_set = false;
-    if (!attr_set && fb_lds > 64 * 1024) {
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_fallback_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_fallback_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + FAST_D) * sizeof(double);
     for (uint64_t s = 0; s < N; s += BATCH) {
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
         const void *src = d_counts ? (const void *)(d_counts + s * FAST_D) : (const void *)(d_Q + s * FAST_D);
@@ -606,25 +667,28 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.N = nb; p.M = m->M; p.n_cpos = m->n_cpos; p.n_cneg = m->n_cneg;
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
         p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.colnorm = m->d_colnorm; p.labels = m->d_labels;
-        p.cand_v = (const float4 *)cv; p.cand_i = (const uint4 *)ci;
+        p.cand_v = (const float4 *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
         p.scores = d_scores; p.status = d_status; p.fb_count = fb_count; p.fb_list = fb_list; p.q_base = s;
+        const unsigned rblocks = (unsigned)phk_div_up(nb, 4);
         if (d_counts) {
             PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
                        phk_knn_mfma_kernel<0><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
-                           src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, (uint4 *)ci));
+                           src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, ci, cu));
             PHK_LAUNCH(ctx, "phk_rerank_kernel",
-                       phk_rerank_kernel<0><<<dim3((unsigned)phk_div_up(nb, 4)), dim3(256), 0, ctx->stream>>>(src, p));
-            PHK_LAUNCH(ctx, "phk_knn_fallback_kernel",
-                       phk_knn_fallback_kernel<0><<<dim3(1024), dim3(256), fb_lds, ctx->stream>>>(src, p));
+                       phk_rerank_kernel<0><<<dim3(rblocks), dim3(256), 0, ctx->stream>>>(src, p));
+            PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
+                       phk_fallback_partial_kernel<0><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, p));
         } else {
             PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
                        phk_knn_mfma_kernel<1><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
-                           src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, (uint4 *)ci));
+                           src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, ci, cu));
             PHK_LAUNCH(ctx, "phk_rerank_kernel",
-                       phk_rerank_kernel<1><<<dim3((unsigned)phk_div_up(nb, 4)), dim3(256), 0, ctx->stream>>>(src, p));
-            PHK_LAUNCH(ctx, "phk_knn_fallback_kernel",
-                       phk_knn_fallback_kernel<1><<<dim3(1024), dim3(256), fb_lds, ctx->stream>>>(src, p));
+                       phk_rerank_kernel<1><<<dim3(rblocks), dim3(256), 0, ctx->stream>>>(src, p));
+            PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
+                       phk_fallback_partial_kernel<1><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, p));
         }
+        PHK_LAUNCH(ctx, "phk_fallback_merge_kernel",
+                   phk_fallback_merge_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(p));
     }
     return PHK_OK;
 }
