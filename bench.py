@@ -95,13 +95,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if args.gpus > 1 or world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
 
@@ -195,7 +195,7 @@ def main():
         "value": world * n * L * args.steps / elapsed / 1e9,
         "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32 counts; f32 MFMA candidate search + f64 exact re-rank",
+        "vs_baseline": None, "dtype": "u32 counts + f32-input MFMA proposal + f64 decision",
         "data": "synthetic (seeded uniform ATGC contigs, device-generated); reference matrix: " + ref_name,
         "config": {"workload": "k=%d, %d x %d-base contigs per GPU, count+normalise+%s score, "
                                "%d reference rows + %d centroids" % (k, n, L, args.method, M, C),

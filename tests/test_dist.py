@@ -1,0 +1,126 @@
+"""Multi-rank path on CPU: sharding arithmetic (single process) and the sharded driver with the
+final score gather over gloo, world_size 2 and 3 (the oracle stands in for the per-rank GPU
+scorer, which lets the collective + ordering be checked without a GPU)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from tests.helpers import REPO
+
+WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["PHK_REPO"])
+import torch.distributed as dist
+from oracle import oracle
+from phamers_amd import dist as pdist, synth
+from tests import helpers
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+g = helpers.load_npz("scoring_k4.npz")
+ref = helpers.load_npz("ref_features.npz")
+pos = oracle.normalize_counts(ref["pos_counts"][:300].astype(np.int64))
+neg = oracle.normalize_counts(ref["neg_counts"][:300].astype(np.int64))
+cp, cn = g["cpos_full"][:10], g["cneg_full"][:10]
+lens = [5000, 0, 3, 1200, 5000, 800, 6000, 40, 5000, 2500, 5000]
+seqs = [synth.synth_contig(2, i, L) for i, L in enumerate(lens)]
+seqs[1] = "ATGCATGCAT"   # keep every row non-zero (zero rows -> NaN, compared separately)
+seqs[2] = "GGATCCAATT"
+
+def oracle_scorer(sequences, k, method, p, n, cpos, cneg, kn):
+    if len(sequences) == 0:
+        return np.zeros(0)
+    q = oracle.normalize_counts(oracle.count(list(sequences), k).reshape(len(sequences), -1))
+    return oracle.score_points(q, p, n, method, kn, cpos, cneg)
+
+full = pdist.score_contigs_distributed(seqs, pos, neg, cp, cn, 4, "combo", 3, scorer=oracle_scorer)
+want = oracle_scorer(seqs, 4, "combo", pos, neg, cp, cn, 3)
+assert full.shape == want.shape, (full.shape, want.shape)
+assert np.array_equal(full, want), np.abs(full - want).max()
+# the raw collective with ragged (and empty) shards
+import torch
+r = dist.get_rank()
+mine = torch.arange(r * 10, r * 10 + (0 if r == 1 else r + 2), dtype=torch.float64)
+got = pdist.gather_variable(mine)
+exp = torch.cat([torch.arange(q * 10, q * 10 + (0 if q == 1 else q + 2), dtype=torch.float64)
+                 for q in range(dist.get_world_size())])
+assert torch.equal(got, exp)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", r, "ok")
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_driver_and_gather_over_gloo(world, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PHK_REPO=REPO, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out)
+        assert "ok" in out
+
+
+def test_shard_bounds_cover_and_balance():
+    from phamers_amd import dist as pdist
+    rng = np.random.default_rng(3)
+    for n, world in ((0, 4), (1, 8), (5, 8), (100, 1), (1000, 8), (17, 3)):
+        lens = rng.integers(0, 20000, n)
+        b = pdist.shard_bounds(lens, world)
+        assert len(b) == world and b[0][0] == 0 and b[-1][1] == n
+        for (lo, hi), (lo2, hi2) in zip(b[:-1], b[1:]):
+            assert lo <= hi == lo2 <= hi2
+        if n >= 100:
+            per = np.array([lens[lo:hi].sum() for lo, hi in b], dtype=float)
+            assert per.max() - per.min() <= 2 * lens.max()
+    # uniform contigs split evenly
+    assert pdist.shard_bounds([5000] * 800, 8) == [(i * 100, (i + 1) * 100) for i in range(8)]
+
+
+def test_shard_count_invariance_single_process():
+    """Scores are identical for 1/2/4/8 shards: run the sharding logic with a fake gather
+    (concatenate) -- no cross-contig arithmetic exists on the path."""
+    from oracle import oracle
+    from phamers_amd import dist as pdist, synth
+    g = helpers.load_npz("scoring_k4.npz")
+    ref = helpers.load_npz("ref_features.npz")
+    pos = oracle.normalize_counts(ref["pos_counts"][:200].astype(np.int64))
+    neg = oracle.normalize_counts(ref["neg_counts"][:200].astype(np.int64))
+    seqs = [synth.synth_contig(8, i, 700 + 37 * i) for i in range(24)]
+    q = oracle.normalize_counts(oracle.count(seqs, 4))
+    want = oracle.score_points(q, pos, neg, "combo", 3, g["cpos_full"][:6], g["cneg_full"][:6])
+    for world in (1, 2, 4, 8):
+        parts = []
+        for lo, hi in pdist.shard_bounds([len(s) for s in seqs], world):
+            if hi > lo:
+                qq = oracle.normalize_counts(oracle.count(seqs[lo:hi], 4).reshape(hi - lo, -1))
+                parts.append(oracle.score_points(qq, pos, neg, "combo", 3, g["cpos_full"][:6], g["cneg_full"][:6]))
+        assert np.array_equal(np.concatenate(parts), want)
