@@ -28,6 +28,7 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak
 F64_PEAK_TF = 78.6             # fp64 vector / matrix peak
+MFMA_F16_PEAK_TF = 2500.0      # f16/bf16 dense MFMA peak (the split-f16 kernel issues 3 MFMA flops per algorithmic flop)
 
 
 def load_model_inputs(D):
@@ -176,6 +177,7 @@ def main():
     alg = {  # kernel -> (bound, unit, peak, algorithmic work per step on this rank)
         "phk_count_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, n * ((L + 3) // 4 + 8 + 4 * D + 8) / 1e9),
         "phk_knn_mfma_kernel": ("mfma", "TFLOP/s", MFMA_F32_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
+        "phk_knn_f16_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
         "phk_dist2_f64_kernel": ("mfma", "TFLOP/s", F64_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
     }
     kernels = {}

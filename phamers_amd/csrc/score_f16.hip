@@ -1,0 +1,277 @@
+// score_f16.hip -- split-f16 MFMA proposal kernel for D = 256 (k = 4).
+//
+// Same role as phk_knn_mfma_kernel (score_mfma.hip): PROPOSE the 4 best columns per (query, segment,
+// half-list) of  v = q'.r' - |r'|^2/2 ; the float64 decision stage (phk_rerank_kernel) certifies or
+// recomputes.  Instead of fp32-input MFMA (64 cycles per 32x32x2 step) it runs on the f16 matrix
+// pipe at 1/16 of the cycles per flop:
+//
+//   each centred operand value x is scaled by S = 2^12 and split into two fp16 numbers,
+//   x*S = hi + lo (+ <= 2^-22 |x*S|), and the contraction keeps three of the four cross terms:
+//       a.b  ~=  a_hi.b_hi + a_hi.b_lo + a_lo.b_hi              (dropped: a_lo.b_lo <= 2^-22 |a||b|)
+//   i.e. 3 x v_mfma_f32_32x32x16_f16 per 16 dimensions, fp32 accumulation inside the MFMA.
+//   That is ~22 significant bits per operand -- enough for the decision stage's margin test to
+//   certify most orderings (its bound is evaluated with this kernel's own error model).
+//
+// Column blocks (32 train rows / centroids) are shared by the 4 waves of a workgroup through LDS:
+// a block record is 33 pieces of 1 KiB in MFMA fragment order,
+//     piece 2s   : a_hi of step s   (lane l: row l&31, dims 128*(l>>5) + 8s .. +7, 8 halves = 16 B)
+//     piece 2s+1 : a_lo of step s
+//     piece 32   : 32 floats  -S^2 |r~'|^2 / 2  (r~' = (hi+lo)/S, the column as the kernel sees it)
+// streamed with LDS-DMA (global_load_lds_dwordx4: no VGPR staging, lane-linear = fragment order) into
+// a double buffer, one barrier per block.  A wave keeps its 32 queries' b_hi / b_lo fragments in 128
+// VGPRs for the whole sweep, exactly like the fp32 kernel keeps q'.
+#include "phk_common.h"
+#include "score_lists.h"
+#include "score_model.h"
+
+#include <cmath>
+#include <vector>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+#define F16_PIECES 33
+#define F16_BLOCK_BYTES (F16_PIECES * 1024)
+#define F16_SCALE_LOG2 12
+#define F16_SCALE 4096.0f
+
+// ------------------------------------------------------------------------------------
+// host: build the split-f16 fragment-ordered operand
+// ------------------------------------------------------------------------------------
+static void split_f16(double x, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (double)hi);
+}
+
+static void pack_segment_f16(const double *rows, uint64_t n, const double *mu, std::vector<uint8_t> &rec, uint64_t cb0) {
+    const uint64_t nblk = phk_div_up(n, 32);
+    for (uint64_t b = 0; b < nblk; ++b) {
+        uint8_t *blk = rec.data() + (cb0 + b) * F16_BLOCK_BYTES;
+        float *cn = reinterpret_cast<float *>(blk + 32 * 1024);
+        for (int i = 0; i < 32; ++i) {
+            const uint64_t r = b * 32 + i;
+            if (r >= n) {  // padding column: zero operand, never selectable
+                cn[i] = PAD_V;
+                continue;
+            }
+            double nrm2 = 0.0;
+            for (int h = 0; h < 2; ++h)
+                for (int s = 0; s < 16; ++s)
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int d = 128 * h + 8 * s + jj;
+                        const double x = (rows[r * FAST_D + d] - mu[d]) * (double)F16_SCALE;
+                        _Float16 hi, lo;
+                        split_f16(x, hi, lo);
+                        const int lane = h * 32 + i;
+                        reinterpret_cast<_Float16 *>(blk + (2 * s) * 1024 + lane * 16)[jj] = hi;
+                        reinterpret_cast<_Float16 *>(blk + (2 * s + 1) * 1024 + lane * 16)[jj] = lo;
+                        const double xt = (double)hi + (double)lo;  // the column as the kernel sees it (scaled)
+                        nrm2 += xt * xt;
+                    }
+            cn[i] = (float)(-0.5 * nrm2);  // already in S^2 units
+        }
+    }
+}
+
+int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, const double *cpos,
+                        const double *cneg, const double *mu) {
+    const uint64_t nblk = (uint64_t)m->n_rblk_ref + m->n_rblk_pos + m->n_rblk_neg;
+    std::vector<uint8_t> rec((nblk + 1) * F16_BLOCK_BYTES, 0);  // + one block: the DMA prefetch runs one past the end
+    {
+        std::vector<double> train(m->M * FAST_D);
+        std::copy(pos, pos + m->n_pos * FAST_D, train.begin());
+        std::copy(neg, neg + m->n_neg * FAST_D, train.begin() + m->n_pos * FAST_D);
+        pack_segment_f16(train.data(), m->M, mu, rec, 0);
+    }
+    if (m->n_cpos) pack_segment_f16(cpos, m->n_cpos, mu, rec, m->n_rblk_ref);
+    if (m->n_cneg) pack_segment_f16(cneg, m->n_cneg, mu, rec, (uint64_t)m->n_rblk_ref + m->n_rblk_pos);
+    if (hipMalloc(&m->d_Af16, rec.size()) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMemcpy(m->d_Af16, rec.data(), rec.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    return PHK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// device
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void f16_split8(const float (&x)[8], half8 &hi, half8 &lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)x[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(x[j] - (float)h);
+    }
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restrict__ src, uint64_t N,
+                                                             const uint4 *__restrict__ Af,
+                                                             const float *__restrict__ mu32,
+                                                             const double *__restrict__ mu64,
+                                                             uint32_t nblk_ref, uint32_t nblk_pos,
+                                                             uint32_t nblk_neg,
+                                                             float4 *__restrict__ cand_v,
+                                                             uint4 *__restrict__ cand_i,
+                                                             float *__restrict__ cand_u) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x F16_BLOCK_BYTES
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const uint64_t q0 = ((uint64_t)blockIdx.x * 4 + wave) * 32;
+    // NB: every wave of the workgroup takes part in the DMA + barriers even if its queries are padding
+    const uint64_t qrow = (q0 + j < N) ? q0 + j : N - 1;
+    const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
+    const uint32_t seg_end0 = nblk_ref, seg_end1 = nblk_ref + nblk_pos;
+
+    // one block record -> LDS buffer `buf`: 33 pieces, piece p by wave p % 4.  The LDS-DMA is issued
+    // from inline asm: a builtin DMA makes hipcc put s_waitcnt vmcnt(0) in front of the next ds_read
+    // (it cannot tell the two LDS buffers apart), which would serialise the prefetch with the MFMAs.
+    // The asm loads are invisible to hipcc's counters; they are drained by the explicit vmcnt(0) in
+    // front of the barrier below (M0 = LDS byte address of the piece, written in the same statement).
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    auto dma_block = [&](uint32_t blk, int buf) {
+        const uint4 *g = Af + (uint64_t)blk * (F16_BLOCK_BYTES / 16) + lane;
+        const uint32_t l = lds_base + (uint32_t)buf * F16_BLOCK_BYTES;
+        for (int p = wave; p < F16_PIECES; p += 4) {
+            const uint4 *gp = g + p * 64;
+            const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
+        }
+    };
+    if (total) dma_block(0, 0);
+
+    // ---- prologue: this lane's scaled, split query elements b[s] (dims 128h + 8s .. +7) ----
+    half8 bh[16], bl[16];
+    if (SRC == 0) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + qrow * FAST_D + 128 * h);
+        uint32_t sum = 0;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            const uint4 c = row[g];
+            sum += c.x + c.y + c.z + c.w;
+        }
+        const uint32_t tot = sum + __shfl_xor(sum, 32);
+        const float inv = (float)(1.0 / (double)tot) * F16_SCALE;
+        const float4 *mp = reinterpret_cast<const float4 *>(mu32 + 128 * h);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const uint4 c0 = row[2 * s], c1 = row[2 * s + 1];
+            const float4 m0 = mp[2 * s], m1 = mp[2 * s + 1];
+            float x[8];
+            x[0] = fmaf((float)c0.x, inv, -m0.x * F16_SCALE);
+            x[1] = fmaf((float)c0.y, inv, -m0.y * F16_SCALE);
+            x[2] = fmaf((float)c0.z, inv, -m0.z * F16_SCALE);
+            x[3] = fmaf((float)c0.w, inv, -m0.w * F16_SCALE);
+            x[4] = fmaf((float)c1.x, inv, -m1.x * F16_SCALE);
+            x[5] = fmaf((float)c1.y, inv, -m1.y * F16_SCALE);
+            x[6] = fmaf((float)c1.z, inv, -m1.z * F16_SCALE);
+            x[7] = fmaf((float)c1.w, inv, -m1.w * F16_SCALE);
+            f16_split8(x, bh[s], bl[s]);
+        }
+    } else {
+        const double2 *row = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + qrow * FAST_D + 128 * h);
+        const double2 *mp = reinterpret_cast<const double2 *>(mu64 + 128 * h);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float x[8];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double2 c = row[4 * s + t], mm = mp[4 * s + t];
+                x[2 * t + 0] = (float)((c.x - mm.x) * (double)F16_SCALE);
+                x[2 * t + 1] = (float)((c.y - mm.y) * (double)F16_SCALE);
+            }
+            f16_split8(x, bh[s], bl[s]);
+        }
+    }
+
+    float lv[CAND];
+    uint32_t li[CAND];
+    float ldrop = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < CAND; ++c) {
+        lv[c] = -3.0e38f;
+        li[c] = 0xFFFFFFFFu;
+    }
+    int seg = 0;
+    uint32_t seg_first = 0;
+    for (uint32_t blk = 0; blk < total; ++blk) {
+        // block blk has landed (every wave waits for its own pieces, then the barrier), and every wave
+        // is done reading the other buffer, which the next DMA overwrites
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        dma_block(blk + 1, (blk + 1) & 1);  // one past the end on the last block: the record array is padded
+        const uint8_t *buf = smem + (blk & 1) * F16_BLOCK_BYTES;
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        const half8 *fr = reinterpret_cast<const half8 *>(buf) + lane;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const half8 ah = fr[(2 * s) * 64];
+            const half8 al = fr[(2 * s + 1) * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc, 0, 0, 0);
+        }
+        // epilogue: most values no longer reach any lane's list once the lists have warmed up
+        // D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h'; add its norm term
+        const uint32_t cbase = 32u * (blk - seg_first) + 4u * (uint32_t)h;
+        const float4 *cn = reinterpret_cast<const float4 *>(buf + 32 * 1024) + h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float4 c4 = cn[2 * (r >> 2)];
+            const float x = acc[r] + ((r & 3) == 0 ? c4.x : (r & 3) == 1 ? c4.y : (r & 3) == 2 ? c4.z : c4.w);
+            if (__any(x > lv[3]))
+                list_insert(lv, li, ldrop, x, cbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
+            else
+                ldrop = fmaxf(ldrop, x);
+        }
+        while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
+            if (q0 + j < N) {
+                const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
+                cand_v[o] = make_float4(lv[0], lv[1], lv[2], lv[3]);
+                cand_i[o] = make_uint4(li[0], li[1], li[2], li[3]);
+                cand_u[o] = ldrop;
+            }
+#pragma unroll
+            for (int c = 0; c < CAND; ++c) {
+                lv[c] = -3.0e38f;
+                li[c] = 0xFFFFFFFFu;
+            }
+            ldrop = -3.0e38f;
+            ++seg;
+            seg_first = blk + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch before the LDS is released
+    for (; seg < NSEG; ++seg) {
+        if (q0 + j < N) {
+            const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
+            cand_v[o] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+            cand_i[o] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            cand_u[o] = -3.0e38f;
+        }
+    }
+}
+
+int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, uint64_t nb,
+                            uint32_t nref, uint32_t npos, uint32_t nneg, float4 *cv, uint4 *ci, float *cu) {
+    static bool attr_set = false;
+    const size_t lds = 2 * F16_BLOCK_BYTES;
+    if (!attr_set) {
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const uint4 *af = (const uint4 *)m->d_Af16 + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16_BLOCK_BYTES / 16);
+    const unsigned gblocks = (unsigned)phk_div_up(nb, 128);
+    if (src_counts) {
+        PHK_LAUNCH(ctx, "phk_knn_f16_kernel",
+                   phk_knn_f16_kernel<0><<<dim3(gblocks), dim3(256), lds, ctx->stream>>>(
+                       src, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu));
+    } else {
+        PHK_LAUNCH(ctx, "phk_knn_f16_kernel",
+                   phk_knn_f16_kernel<1><<<dim3(gblocks), dim3(256), lds, ctx->stream>>>(
+                       src, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu));
+    }
+    return PHK_OK;
+}

@@ -29,19 +29,17 @@
 //     g < 32 : element e = r'[32cb + (lane&31)][128*(lane>>5) + 4g + e]
 //     g = 32 : element 0 = (lane < 32) ? -|r'|^2/2 : 0        (norm step), rest 0
 // and a wave keeps its 32 queries' q' in 128 VGPRs for the whole sweep (q'[j][128h + s]).
+#include <stdlib.h>
+
 #include "phk_common.h"
 #include "score_model.h"
 
 #include <cmath>
 #include <vector>
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+#include "score_lists.h"
 
-#define FAST_D 256
 #define NG 33          // 32 k-groups + the norm group
-#define CAND 4         // list depth per (query, segment, half)
-#define NSEG 3         // train rows, positive centroids, negative centroids
-#define PAD_V (-1.0e30f)
 
 // ------------------------------------------------------------------------------------
 // model build (host): centre, round to fp32, fragment-order, upload
@@ -122,6 +120,7 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
         hipMemcpy(m->d_mu32, mu32.data(), FAST_D * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(m->d_mu64, mu.data(), FAST_D * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         return PHK_ERR_HIP;
+    PHK_TRY(phk_model_build_f16(m, pos, neg, cpos, cneg, mu.data()));
     m->max_colnorm = max_norm;
     m->mu_norm = std::sqrt(mu2);
     m->fast = true;
@@ -131,6 +130,8 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
 void phk_model_free_fast(phk_model *m) {
     if (m->d_Bf) (void)hipFree(m->d_Bf);
     if (m->d_colnorm) (void)hipFree(m->d_colnorm);
+    if (m->d_Af16) (void)hipFree(m->d_Af16);
+    m->d_Af16 = nullptr;
     if (m->d_mu32) (void)hipFree(m->d_mu32);
     if (m->d_mu64) (void)hipFree(m->d_mu64);
     m->d_Bf = nullptr;
@@ -142,23 +143,6 @@ void phk_model_free_fast(phk_model *m) {
 // ------------------------------------------------------------------------------------
 // 1. MFMA candidate search
 // ------------------------------------------------------------------------------------
-// sorted (descending) insert of (x, c) into a 4-deep list held in registers
-// and track the largest value that ever fell off the list (`drop`): every column this list does
-// not hold has a computed value <= drop.
-__device__ __forceinline__ void list_insert(float (&v)[CAND], uint32_t (&ix)[CAND], float &drop, float x,
-                                            uint32_t c) {
-    const bool g0 = x > v[0], g1 = x > v[1], g2 = x > v[2], g3 = x > v[3];
-    drop = fmaxf(drop, g3 ? v[3] : x);
-    v[3] = g2 ? v[2] : (g3 ? x : v[3]);
-    ix[3] = g2 ? ix[2] : (g3 ? c : ix[3]);
-    v[2] = g1 ? v[1] : (g2 ? x : v[2]);
-    ix[2] = g1 ? ix[1] : (g2 ? c : ix[2]);
-    v[1] = g0 ? v[0] : (g1 ? x : v[1]);
-    ix[1] = g0 ? ix[0] : (g1 ? c : ix[1]);
-    v[0] = g0 ? x : v[0];
-    ix[0] = g0 ? c : ix[0];
-}
-
 // SRC 0: uint32 count rows (normalised here as kmer.normalize_counts would, in fp32 for the
 // proposal pass);  SRC 1: float64 rows.
 template <int SRC>
@@ -299,6 +283,8 @@ struct RerankParams {
     uint64_t N, M, n_cpos, n_cneg;
     int kn, method;
     double rmax, mu_norm;
+    double vscale;          // computed values are in units of 1/vscale (split-f16 path: S^2)
+    double eb_cA, eb_cP, eb_cR, eb_abs;  // error model of the proposal pass (see ErrBound)
     const double *R64, *C64, *mu64, *colnorm;
     const uint8_t *labels;
     const float4 *cand_v;
@@ -326,15 +312,19 @@ __device__ __forceinline__ double exact_d2(const double (&qd)[4], const double *
     return wave_sum(fma(d0, d0, fma(d1, d1, fma(d2, d2, d3 * d3))));
 }
 
-// Rigorous bound on |computed v - true v| of the MFMA pass for a column with |r'| <= R
-// (derivation: DESIGN.md "fp32 proposal error bound").  u = 2^-24; A = |q| + |mu|; P = |q'|.
-//   input rounding   : q' to fp32 (<= 4uA in norm), r' to fp32 (<= uR), stored -|r'|^2/2 (<= uR^2/2)
-//   accumulation     : 258 fused roundings, each <= u * |partial sum|; the 256 product partials are
-//                      <= (P + 4uA) R by Cauchy-Schwarz and the norm step comes LAST in the chain
+// Rigorous bound on |computed v - true v| of the proposal pass for a column with |r'| <= R
+// (derivation: DESIGN.md "proposal error bound").  u = 2^-24; A = |q| + |mu|; P = |q'|:
+//     eps(R) = u R (cA A + cP P + cR R) + c_abs (R + P)
+//   fp32 MFMA  : cA 6, cP 264, cR 4, c_abs 0 -- q' to fp32 (<= 4uA), r' to fp32 (<= uR), 258 fused
+//                roundings each <= u |partial|, product partials <= (P + 4uA) R (Cauchy-Schwarz), the norm
+//                step LAST in the chain.
+//   split f16  : cA 6, cP 1600, cR 6, c_abs 2^-20/S -- operands carry 22 bits (|x - hi - lo| <= 2^-22 |x|
+//                + one fp16 subnormal quantum), the dropped lo.lo term <= 2^-22 P R, and 768 product
+//                accumulations each charged 2u |partial| (covers truncating accumulation in the MFMA).
 struct ErrBound {
-    double A, P;
+    double A, P, cA, cP, cR, cabs;
     __device__ double operator()(double R) const {
-        return 5.9604644775390625e-08 * R * (6.0 * A + 264.0 * P + 4.0 * R);
+        return 5.9604644775390625e-08 * R * (cA * A + cP * P + cR * R) + cabs * (R + P);
     }
 };
 
@@ -360,10 +350,11 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
         ix = s == 0 ? ci.x : s == 1 ? ci.y : s == 2 ? ci.z : ci.w;
         if (ix >= ncols) v = -3.0e38f;  // padding / empty slot
     }
+    const double vs = p.vscale;  // exact power of two: computed values -> v units
     // every column the two half-lists dropped has a computed value <= the larger of their
     // best-dropped values (-3e38 when nothing real was dropped)
     const uint64_t ou = (q * NSEG + seg) * 2;
-    const double U = fmax((double)p.cand_u[ou], (double)p.cand_u[ou + 1]);
+    const double U = fmax((double)p.cand_u[ou], (double)p.cand_u[ou + 1]) * vs;
     // rank of each candidate among the 8 (descending v, ties by lane)
     int rank = 0;
 #pragma unroll
@@ -384,13 +375,13 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
     const double eps_g = eb(p.rmax);  // holds for every column
     if (ri[need - 1] < ncols) {
         // upper bound of the true need-th nearest distance from the computed candidates
-        const double d2up = fmax(nqp2 - 2.0 * ((double)rv[need - 1] - eps_g), 0.0);
+        const double d2up = fmax(nqp2 - 2.0 * ((double)rv[need - 1] * vs - eps_g), 0.0);
         const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
         bool near = true;  // the top `need` computed candidates all lie within R0
         for (int r = 0; r < need; ++r) near = near && colnorm[ri[r]] <= R0;
         const double eps_m = near ? eb(R0) : eps_g;
         // certified by margin: the need-th and (need+1)-th computed values are > 2 eps apart
-        if (((double)rv[need - 1] - (double)rv[need]) > 2.0 * eps_m) {
+        if (((double)rv[need - 1] - (double)rv[need]) * vs > 2.0 * eps_m) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) out_idx[r] = ri[r];
             if (want_d2) out_d2 = exact_d2(qd, rows + (uint64_t)ri[0] * FAST_D, lane);
@@ -466,6 +457,7 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs;
 
     bool ok = true;
     double knn = 0.0, cen = 0.0;
@@ -653,6 +645,9 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     uint32_t *fb_count = (uint32_t *)fb, *fb_list = (uint32_t *)fb + 16;
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
     const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + FAST_D) * sizeof(double);
+    // proposal pass: split-f16 MFMA by default; PHK_PROPOSAL=f32 selects the fp32-input MFMA kernel
+    const char *prop = getenv("PHK_PROPOSAL");
+    const bool use_f16 = !(prop && prop[0] == 'f' && prop[1] == '3');
     for (uint64_t s = 0; s < N; s += BATCH) {
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
         const void *src = d_counts ? (const void *)(d_counts + s * FAST_D) : (const void *)(d_Q + s * FAST_D);
@@ -669,19 +664,31 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.colnorm = m->d_colnorm; p.labels = m->d_labels;
         p.cand_v = (const float4 *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
         p.scores = d_scores; p.status = d_status; p.fb_count = fb_count; p.fb_list = fb_list; p.q_base = s;
+        if (use_f16) {
+            p.vscale = 1.0 / (4096.0 * 4096.0);
+            p.eb_cA = 6.0; p.eb_cP = 1600.0; p.eb_cR = 6.0; p.eb_abs = 9.5367431640625e-07 / 4096.0;
+        } else {
+            p.vscale = 1.0;
+            p.eb_cA = 6.0; p.eb_cP = 264.0; p.eb_cR = 4.0; p.eb_abs = 0.0;
+        }
         const unsigned rblocks = (unsigned)phk_div_up(nb, 4);
-        if (d_counts) {
+        if (use_f16) {
+            PHK_TRY(phk_launch_proposal_f16(ctx, m, src, d_counts != nullptr, nb, nref, npos, nneg, (float4 *)cv, ci, cu));
+        } else if (d_counts) {
             PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
                        phk_knn_mfma_kernel<0><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
                            src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, ci, cu));
+        } else {
+            PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
+                       phk_knn_mfma_kernel<1><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
+                           src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, ci, cu));
+        }
+        if (d_counts) {
             PHK_LAUNCH(ctx, "phk_rerank_kernel",
                        phk_rerank_kernel<0><<<dim3(rblocks), dim3(256), 0, ctx->stream>>>(src, p));
             PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
                        phk_fallback_partial_kernel<0><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, p));
         } else {
-            PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
-                       phk_knn_mfma_kernel<1><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
-                           src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, ci, cu));
             PHK_LAUNCH(ctx, "phk_rerank_kernel",
                        phk_rerank_kernel<1><<<dim3(rblocks), dim3(256), 0, ctx->stream>>>(src, p));
             PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",

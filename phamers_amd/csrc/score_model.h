@@ -14,6 +14,7 @@ struct phk_model {
     bool fast = false;
     float *d_Bf = nullptr;        // fragment-ordered centred fp32 columns (train rows, then centroids)
     double *d_colnorm = nullptr;  // |r'| per real column (train rows, pos centroids, neg centroids)
+    void *d_Af16 = nullptr;       // split-f16 fragment-ordered block records (score_f16.hip)
     float *d_mu32 = nullptr;      // centring vector, fp32
     double *d_mu64 = nullptr;     // centring vector, fp64
     uint32_t n_rblk_ref = 0, n_rblk_pos = 0, n_rblk_neg = 0;  // 32-column blocks per segment
@@ -30,5 +31,10 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
                          const double *cpos, const double *cneg);
 void phk_model_free_fast(phk_model *m);
 static inline bool phk_model_has_fast(const phk_model *m) { return m->fast; }
+// split-f16 proposal (score_f16.hip)
+int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, const double *cpos,
+                        const double *cneg, const double *mu);
+int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, uint64_t nb,
+                            uint32_t nref, uint32_t npos, uint32_t nneg, float4 *cv, uint4 *ci, float *cu);
 int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
                    uint64_t N, int method, double *d_scores, uint32_t *d_status);

@@ -148,7 +148,7 @@ def test_zero_count_contig_is_nan_and_flagged():
 
 
 def test_fast_and_exact_gpu_paths_agree_on_a_larger_batch(monkeypatch):
-    """20k synthetic contigs through the MFMA candidate path and through the float64 brute-force
+    """20k synthetic contigs through both MFMA proposal kernels and through the float64 brute-force
     path (PHK_FORCE_EXACT=1): identical votes, float scores equal to rounding."""
     from phamers_amd import _lib, device
     g = helpers.load_npz("scoring_k4.npz")
@@ -164,19 +164,25 @@ def test_fast_and_exact_gpu_paths_agree_on_a_larger_batch(monkeypatch):
     d_nwin = device.DeviceArray(ctx, n, np.uint32)
     device.count(ctx, d_packed, None, T, d_off, n, 4, d_counts, d_nwin)
     out = {}
-    for force in ("0", "1"):
-        monkeypatch.setenv("PHK_FORCE_EXACT", force)
+    # proposal kernel: split-f16 MFMA (default) and fp32 MFMA; "exact" = float64 brute force path
+    for path in ("f16", "f32", "exact"):
+        monkeypatch.setenv("PHK_FORCE_EXACT", "1" if path == "exact" else "0")
+        monkeypatch.setenv("PHK_PROPOSAL", "f32" if path == "f32" else "f16")
         for method in ("knn", "kmeans", "combo"):
             d_scores = device.DeviceArray(ctx, n, np.float64)
             d_status = device.DeviceArray(ctx, 1, np.uint32)
             device.score_counts(ctx, model, d_counts, n, method, d_scores, d_status)
-            out[(force, method)] = d_scores.to_host()
+            out[(path, method)] = d_scores.to_host()
             assert d_status.to_host()[0] == 0
-    assert np.array_equal(out[("0", "knn")], out[("1", "knn")])
-    assert set(np.unique(out[("0", "knn")])) <= {-1.0, 1.0}
-    assert helpers.rel_err(out[("0", "kmeans")], out[("1", "kmeans")]) < 1e-9
-    assert helpers.rel_err(out[("0", "combo")], out[("1", "combo")]) < 1e-9
-    assert np.allclose(out[("0", "combo")], out[("0", "knn")] + out[("0", "kmeans")], rtol=0, atol=1e-15)
+        if path != "exact":
+            n_fallback, n_exact = ctx.score_stats()
+            assert n_fallback < n // 100, (path, n_fallback)     # the proposal must certify nearly everything
+    for path in ("f16", "f32"):
+        assert np.array_equal(out[(path, "knn")], out[("exact", "knn")]), path
+        assert set(np.unique(out[(path, "knn")])) <= {-1.0, 1.0}
+        assert helpers.rel_err(out[(path, "kmeans")], out[("exact", "kmeans")]) < 1e-9, path
+        assert helpers.rel_err(out[(path, "combo")], out[("exact", "combo")]) < 1e-9, path
+        assert np.allclose(out[(path, "combo")], out[(path, "knn")] + out[(path, "kmeans")], rtol=0, atol=1e-15)
     model.close()
 
 
