@@ -188,9 +188,20 @@ def main():
             ach = work * args.steps / (ms / 1e3)
             kernels[name].update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
     dom = max((kname for kname in kernels if kname in alg), key=lambda kname: kernels[kname]["ms_per_step"])
+    # HBM traffic of the dominant kernel: PMC measurement of this same command (FETCH_SIZE / WRITE_SIZE
+    # in separate rocprofv3 passes, corrected as MI355X_MICROARCH.md prescribes), stored per contig
+    traffic = None
+    tfile = os.path.join(REPO, "profiles", "r01", "traffic.json")
+    if os.path.exists(tfile):
+        tk = json.load(open(tfile)).get("kernels", {}).get(dom)
+        if tk:
+            traffic = tk["hbm_bytes_per_contig"] * n
     roofline = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
                 "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
-                "traffic": None}
+                "traffic": traffic}
+    if dom == "phk_knn_f16_kernel":
+        # the split-f16 kernel issues 3 MFMA flops per algorithmic flop (hi.hi + hi.lo + lo.hi)
+        roofline["mfma_issue_frac"] = 3.0 * kernels[dom]["frac"]
 
     out = {
         "metric": "Gbases/s k-mer-count+score, k=%d, %d kb contigs" % (k, L // 1000),
