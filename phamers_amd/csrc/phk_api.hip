@@ -303,7 +303,7 @@ extern "C" int phk_score(phk_ctx *ctx, const phk_model *model, const double *Q, 
     PHK_TRY(phk_ws(ctx, WS_COUNTS, N * 8, &d_s));
     PHK_TRY(phk_ws(ctx, WS_FLAGS, 64, &d_flags));
     PHK_HIP(hipMemcpyAsync(d_q, Q, N * D * 8, hipMemcpyHostToDevice, ctx->stream));
-    PHK_TRY(phk_score_rows(ctx, model, (const double *)d_q, nullptr, N, method, (double *)d_s,
+    PHK_TRY(phk_score_rows(ctx, model, (const double *)d_q, nullptr, nullptr, N, method, (double *)d_s,
                            (uint32_t *)d_flags));
     uint32_t nan_rows = 0;
     PHK_HIP(hipMemcpyAsync(&nan_rows, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -344,14 +344,14 @@ extern "C" int phk_score_dev(phk_ctx *ctx, const phk_model *model, const double 
                              int method, double *d_scores, uint32_t *d_status) {
     PHK_REQUIRE(ctx && model, "phk_score_dev: NULL ctx/model");
     PHK_REQUIRE(N == 0 || d_Q, "phk_score_dev: NULL query pointer");
-    return phk_score_rows(ctx, model, d_Q, nullptr, N, method, d_scores, d_status);
+    return phk_score_rows(ctx, model, d_Q, nullptr, nullptr, N, method, d_scores, d_status);
 }
 
 extern "C" int phk_score_counts_dev(phk_ctx *ctx, const phk_model *model, const uint32_t *d_counts,
                                     uint64_t N, int method, double *d_scores, uint32_t *d_status) {
     PHK_REQUIRE(ctx && model, "phk_score_counts_dev: NULL ctx/model");
     PHK_REQUIRE(N == 0 || d_counts, "phk_score_counts_dev: NULL counts pointer");
-    return phk_score_rows(ctx, model, nullptr, d_counts, N, method, d_scores, d_status);
+    return phk_score_rows(ctx, model, nullptr, d_counts, nullptr, N, method, d_scores, d_status);
 }
 
 extern "C" int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const uint32_t *d_packed,
@@ -361,8 +361,10 @@ extern "C" int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const u
     PHK_REQUIRE(ctx && model, "phk_count_score_dev: NULL ctx/model");
     PHK_REQUIRE(phk_pow4(k) == model->D, "phk_count_score_dev: 4^k (k=%d) != model dimension %llu", k,
                 (unsigned long long)model->D);
-    PHK_TRY(phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets, n, k, d_counts, nullptr));
-    return phk_score_rows(ctx, model, nullptr, d_counts, n, method, d_scores, d_status);
+    void *d_nwin;  // row sums straight from the count kernel (saves the scorer a pass over the counts)
+    PHK_TRY(phk_ws(ctx, WS_NWIN, n * sizeof(uint32_t), &d_nwin));
+    PHK_TRY(phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets, n, k, d_counts, (uint32_t *)d_nwin));
+    return phk_score_rows(ctx, model, nullptr, d_counts, (const uint32_t *)d_nwin, n, method, d_scores, d_status);
 }
 
 extern "C" int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_exact_resolved) {

@@ -120,4 +120,4 @@ int phk_launch_synth(phk_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, ui
 // score.hip
 struct phk_model;
 int phk_score_rows(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
-                   uint64_t N, int method, double *d_scores, uint32_t *d_status);
+                   const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status);

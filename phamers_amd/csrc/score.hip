@@ -263,7 +263,7 @@ static int check_method(const phk_model *m, int method) {
 // Scores N rows given either as float64 rows (d_Q) or as uint32 count rows (d_counts, normalised
 // on the fly as kmer.normalize_counts would).  Exactly one of d_Q / d_counts is non-NULL.
 int phk_score_rows(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
-                   uint64_t N, int method, double *d_scores, uint32_t *d_status) {
+                   const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status) {
     PHK_REQUIRE(m && d_scores && (d_Q || d_counts), "phk_score: NULL pointer");
     PHK_TRY(check_method(m, method));
     if (d_status) PHK_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), ctx->stream));
@@ -276,7 +276,7 @@ int phk_score_rows(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     ctx->last_score_fast = false;
     if (phk_model_has_fast(m) && !(force && force[0] == '1')) {
         ctx->last_score_fast = true;
-        return phk_score_fast(ctx, m, d_Q, d_counts, N, method, d_scores, d_status);
+        return phk_score_fast(ctx, m, d_Q, d_counts, d_rowsum, N, method, d_scores, d_status);
     }
 
     // exact path in batches sized to a 512 MiB distance scratch

@@ -20,6 +20,8 @@
 // streamed with LDS-DMA (global_load_lds_dwordx4: no VGPR staging, lane-linear = fragment order) into
 // a double buffer, one barrier per block.  A wave keeps its 32 queries' b_hi / b_lo fragments in 128
 // VGPRs for the whole sweep, exactly like the fp32 kernel keeps q'.
+#include <stdlib.h>
+
 #include "phk_common.h"
 #include "score_lists.h"
 #include "score_model.h"
@@ -101,8 +103,11 @@ __device__ __forceinline__ void f16_split8(const float (&x)[8], half8 &hi, half8
     }
 }
 
+// Workgroup = 4 waves = 128 queries; two workgroups per CU (one wave of each per SIMD).
+#define F16_WAVES 4
 template <int SRC>
-__global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restrict__ src, uint64_t N,
+__global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restrict__ src,
+                                                             const uint32_t *__restrict__ rowsum, uint64_t N,
                                                              const uint4 *__restrict__ Af,
                                                              const float *__restrict__ mu32,
                                                              const double *__restrict__ mu64,
@@ -115,13 +120,13 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const uint64_t q0 = ((uint64_t)blockIdx.x * 4 + wave) * 32;
+    const uint64_t q0 = ((uint64_t)blockIdx.x * F16_WAVES + wave) * 32;
     // NB: every wave of the workgroup takes part in the DMA + barriers even if its queries are padding
     const uint64_t qrow = (q0 + j < N) ? q0 + j : N - 1;
     const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
     const uint32_t seg_end0 = nblk_ref, seg_end1 = nblk_ref + nblk_pos;
 
-    // one block record -> LDS buffer `buf`: 33 pieces, piece p by wave p % 4.  The LDS-DMA is issued
+    // one block record -> LDS buffer `buf`: 33 pieces, piece p by wave p % 8.  The LDS-DMA is issued
     // from inline asm: a builtin DMA makes hipcc put s_waitcnt vmcnt(0) in front of the next ds_read
     // (it cannot tell the two LDS buffers apart), which would serialise the prefetch with the MFMAs.
     // The asm loads are invisible to hipcc's counters; they are drained by the explicit vmcnt(0) in
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     auto dma_block = [&](uint32_t blk, int buf) {
         const uint4 *g = Af + (uint64_t)blk * (F16_BLOCK_BYTES / 16) + lane;
         const uint32_t l = lds_base + (uint32_t)buf * F16_BLOCK_BYTES;
-        for (int p = wave; p < F16_PIECES; p += 4) {
+        for (int p = wave; p < F16_PIECES; p += F16_WAVES) {
             const uint4 *gp = g + p * 64;
             const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
@@ -142,13 +147,18 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     half8 bh[16], bl[16];
     if (SRC == 0) {
         const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + qrow * FAST_D + 128 * h);
-        uint32_t sum = 0;
+        uint32_t tot;
+        if (rowsum) {
+            tot = rowsum[qrow];  // the count kernel's row sums: saves a pass over the counts
+        } else {
+            uint32_t sum = 0;
 #pragma unroll
-        for (int g = 0; g < 32; ++g) {
-            const uint4 c = row[g];
-            sum += c.x + c.y + c.z + c.w;
+            for (int g = 0; g < 32; ++g) {
+                const uint4 c = row[g];
+                sum += c.x + c.y + c.z + c.w;
+            }
+            tot = sum + __shfl_xor(sum, 32);
         }
-        const uint32_t tot = sum + __shfl_xor(sum, 32);
         const float inv = (float)(1.0 / (double)tot) * F16_SCALE;
         const float4 *mp = reinterpret_cast<const float4 *>(mu32 + 128 * h);
 #pragma unroll
@@ -192,6 +202,34 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     }
     int seg = 0;
     uint32_t seg_first = 0;
+    // list flush / reset once column block `b` (the last of its segment) has been inserted
+    auto flush_if_segment_end = [&](uint32_t b) {
+        while (seg < NSEG && b + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
+            if (q0 + j < N) {
+                const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
+                cand_v[o] = make_float4(lv[0], lv[1], lv[2], lv[3]);
+                cand_i[o] = make_uint4(li[0], li[1], li[2], li[3]);
+                cand_u[o] = ldrop;
+            }
+#pragma unroll
+            for (int c = 0; c < CAND; ++c) {
+                lv[c] = -3.0e38f;
+                li[c] = 0xFFFFFFFFu;
+            }
+            ldrop = -3.0e38f;
+            ++seg;
+            seg_first = b + 1;
+        }
+    };
+
+    // Software pipeline inside the wave: while block blk's 48 MFMAs run on the matrix pipe, the VALU
+    // inserts the 16 values of block blk-1 (one branch-free insertion per k-step, i.e. per 3 MFMAs),
+    // so the epilogue costs no separate phase.  xs = values of the previous block (acc + norm term);
+    // before the first block it is -3e38, which no list accepts.
+    f32x16 xs;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xs[r] = -3.0e38f;
+    uint32_t cbase = 4u * (uint32_t)h;  // index base of the block held in xs
     for (uint32_t blk = 0; blk < total; ++blk) {
         // block blk has landed (every wave waits for its own pieces, then the barrier), and every wave
         // is done reading the other buffer, which the next DMA overwrites
@@ -211,36 +249,26 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc, 0, 0, 0);
+            list_insert(lv, li, ldrop, xs[s], cbase + (uint32_t)((s & 3) + 8 * (s >> 2)));
         }
-        // epilogue: most values no longer reach any lane's list once the lists have warmed up
+        if (blk > 0) flush_if_segment_end(blk - 1);
         // D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h'; add its norm term
-        const uint32_t cbase = 32u * (blk - seg_first) + 4u * (uint32_t)h;
+        // now (the buffer is recycled after the next barrier)
         const float4 *cn = reinterpret_cast<const float4 *>(buf + 32 * 1024) + h;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float4 c4 = cn[2 * (r >> 2)];
-            const float x = acc[r] + ((r & 3) == 0 ? c4.x : (r & 3) == 1 ? c4.y : (r & 3) == 2 ? c4.z : c4.w);
-            if (__any(x > lv[3]))
-                list_insert(lv, li, ldrop, x, cbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
-            else
-                ldrop = fmaxf(ldrop, x);
+        for (int m4 = 0; m4 < 4; ++m4) {
+            const float4 c4 = cn[2 * m4];
+            xs[4 * m4 + 0] = acc[4 * m4 + 0] + c4.x;
+            xs[4 * m4 + 1] = acc[4 * m4 + 1] + c4.y;
+            xs[4 * m4 + 2] = acc[4 * m4 + 2] + c4.z;
+            xs[4 * m4 + 3] = acc[4 * m4 + 3] + c4.w;
         }
-        while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
-            if (q0 + j < N) {
-                const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
-                cand_v[o] = make_float4(lv[0], lv[1], lv[2], lv[3]);
-                cand_i[o] = make_uint4(li[0], li[1], li[2], li[3]);
-                cand_u[o] = ldrop;
-            }
+        cbase = 32u * (blk - seg_first) + 4u * (uint32_t)h;
+    }
+    if (total) {  // the last block's values
 #pragma unroll
-            for (int c = 0; c < CAND; ++c) {
-                lv[c] = -3.0e38f;
-                li[c] = 0xFFFFFFFFu;
-            }
-            ldrop = -3.0e38f;
-            ++seg;
-            seg_first = blk + 1;
-        }
+        for (int r = 0; r < 16; ++r) list_insert(lv, li, ldrop, xs[r], cbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
+        flush_if_segment_end(total - 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch before the LDS is released
     for (; seg < NSEG; ++seg) {
@@ -253,8 +281,9 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     }
 }
 
-int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, uint64_t nb,
-                            uint32_t nref, uint32_t npos, uint32_t nneg, float4 *cv, uint4 *ci, float *cu) {
+int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
+                            const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
+                            float4 *cv, uint4 *ci, float *cu) {
     static bool attr_set = false;
     const size_t lds = 2 * F16_BLOCK_BYTES;
     if (!attr_set) {
@@ -263,15 +292,15 @@ int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, b
         attr_set = true;
     }
     const uint4 *af = (const uint4 *)m->d_Af16 + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16_BLOCK_BYTES / 16);
-    const unsigned gblocks = (unsigned)phk_div_up(nb, 128);
+    const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * F16_WAVES);
     if (src_counts) {
         PHK_LAUNCH(ctx, "phk_knn_f16_kernel",
-                   phk_knn_f16_kernel<0><<<dim3(gblocks), dim3(256), lds, ctx->stream>>>(
-                       src, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu));
+                   phk_knn_f16_kernel<0><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
+                       src, d_rowsum, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu));
     } else {
         PHK_LAUNCH(ctx, "phk_knn_f16_kernel",
-                   phk_knn_f16_kernel<1><<<dim3(gblocks), dim3(256), lds, ctx->stream>>>(
-                       src, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu));
+                   phk_knn_f16_kernel<1><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
+                       src, nullptr, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu));
     }
     return PHK_OK;
 }

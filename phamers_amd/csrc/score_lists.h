@@ -10,19 +10,30 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define NSEG 3         // train rows, positive centroids, negative centroids
 #define PAD_V (-1.0e30f)
 
-// sorted (descending) insert of (x, c) into a 4-deep list held in registers, tracking the largest
+// Sorted (descending) insert of (x, c) into a 4-deep list held in registers, tracking the largest
 // value that ever fell off the list (`drop`): every column this list does not hold has a computed
-// value <= drop.
+// value <= drop.  Written without any i1 condition on purpose: hipcc turns a chain of `?:` selects
+// into divergent branches (s_and_saveexec + register moves, ~10x the instructions).  Values move with
+// v_max / v_med3 (the list is sorted, so the new k-th value is med3(v[k-1], v[k], x)); indices move with
+// bitfield inserts under sign-replicated masks m_k = (x > v[k]) ? ~0 : 0 taken from the sign of v[k] - x.
+__device__ __forceinline__ uint32_t phk_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+
 __device__ __forceinline__ void list_insert(float (&v)[CAND], uint32_t (&ix)[CAND], float &drop, float x,
                                             uint32_t c) {
-    const bool g0 = x > v[0], g1 = x > v[1], g2 = x > v[2], g3 = x > v[3];
-    drop = fmaxf(drop, g3 ? v[3] : x);
-    v[3] = g2 ? v[2] : (g3 ? x : v[3]);
-    ix[3] = g2 ? ix[2] : (g3 ? c : ix[3]);
-    v[2] = g1 ? v[1] : (g2 ? x : v[2]);
-    ix[2] = g1 ? ix[1] : (g2 ? c : ix[2]);
-    v[1] = g0 ? v[0] : (g1 ? x : v[1]);
-    ix[1] = g0 ? ix[0] : (g1 ? c : ix[1]);
-    v[0] = g0 ? x : v[0];
-    ix[0] = g0 ? c : ix[0];
+    const uint32_t m0 = (uint32_t)(__float_as_int(v[0] - x) >> 31);
+    const uint32_t m1 = (uint32_t)(__float_as_int(v[1] - x) >> 31);
+    const uint32_t m2 = (uint32_t)(__float_as_int(v[2] - x) >> 31);
+    const uint32_t m3 = (uint32_t)(__float_as_int(v[3] - x) >> 31);
+    drop = fmaxf(drop, fminf(v[3], x));
+    ix[3] = phk_bfi(m2, ix[2], phk_bfi(m3, c, ix[3]));
+    ix[2] = phk_bfi(m1, ix[1], phk_bfi(m2, c, ix[2]));
+    ix[1] = phk_bfi(m0, ix[0], phk_bfi(m1, c, ix[1]));
+    ix[0] = phk_bfi(m0, c, ix[0]);
+    const float n3 = __builtin_amdgcn_fmed3f(v[2], v[3], x);
+    const float n2 = __builtin_amdgcn_fmed3f(v[1], v[2], x);
+    const float n1 = __builtin_amdgcn_fmed3f(v[0], v[1], x);
+    v[0] = fmaxf(v[0], x);
+    v[1] = n1;
+    v[2] = n2;
+    v[3] = n3;
 }

@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p)
 // driver
 // ------------------------------------------------------------------------------------
 int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
-                   uint64_t N, int method, double *d_scores, uint32_t *d_status) {
+                   const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status) {
     const uint64_t BATCH = 1ull << 20;  // bounds the candidate (200 B/query) and fallback (1 KiB/query) workspaces
     const uint64_t nb_max = N < BATCH ? N : BATCH;
     const uint64_t per_list = nb_max * NSEG * 2;
@@ -673,7 +673,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         }
         const unsigned rblocks = (unsigned)phk_div_up(nb, 4);
         if (use_f16) {
-            PHK_TRY(phk_launch_proposal_f16(ctx, m, src, d_counts != nullptr, nb, nref, npos, nneg, (float4 *)cv, ci, cu));
+            PHK_TRY(phk_launch_proposal_f16(ctx, m, src, d_counts != nullptr, d_rowsum ? d_rowsum + s : nullptr, nb, nref, npos,
+                                            nneg, (float4 *)cv, ci, cu));
         } else if (d_counts) {
             PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
                        phk_knn_mfma_kernel<0><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(

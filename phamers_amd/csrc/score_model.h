@@ -34,7 +34,8 @@ static inline bool phk_model_has_fast(const phk_model *m) { return m->fast; }
 // split-f16 proposal (score_f16.hip)
 int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, const double *cpos,
                         const double *cneg, const double *mu);
-int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, uint64_t nb,
-                            uint32_t nref, uint32_t npos, uint32_t nneg, float4 *cv, uint4 *ci, float *cu);
+int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
+                            const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
+                            float4 *cv, uint4 *ci, float *cu);
 int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
-                   uint64_t N, int method, double *d_scores, uint32_t *d_status);
+                   const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status);
