@@ -44,50 +44,65 @@ static void split_f16(double x, _Float16 &hi, _Float16 &lo) {
     lo = (_Float16)(x - (double)hi);
 }
 
-static void pack_segment_f16(const double *rows, uint64_t n, const double *mu, std::vector<uint8_t> &rec, uint64_t cb0) {
+// Block record for D = 256 * nchunk: nchunk chunks of 32 pieces (hi/lo of the 16 k-steps of that
+// chunk: dims 256c + 128*(lane>>5) + 8s .. +7), then one piece with the 32 norm terms.  For D = 256
+// this is the 33-piece record of the k = 4 kernel.  cn_all (one float per column slot, padding
+// included) duplicates the norm terms for the general-D kernel, which reads them from global memory.
+static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const double *mu, std::vector<uint8_t> &rec,
+                             uint64_t rec_bytes, uint64_t cb0, std::vector<float> &cn_all) {
     const uint64_t nblk = phk_div_up(n, 32);
+    const int nchunk = (int)(D / 256);
     for (uint64_t b = 0; b < nblk; ++b) {
-        uint8_t *blk = rec.data() + (cb0 + b) * F16_BLOCK_BYTES;
-        float *cn = reinterpret_cast<float *>(blk + 32 * 1024);
+        uint8_t *blk = rec.data() + (cb0 + b) * rec_bytes;
+        float *cn = reinterpret_cast<float *>(blk + (uint64_t)nchunk * 32 * 1024);
         for (int i = 0; i < 32; ++i) {
             const uint64_t r = b * 32 + i;
             if (r >= n) {  // padding column: zero operand, never selectable
                 cn[i] = PAD_V;
+                cn_all[(cb0 + b) * 32 + i] = PAD_V;
                 continue;
             }
             double nrm2 = 0.0;
-            for (int h = 0; h < 2; ++h)
-                for (int s = 0; s < 16; ++s)
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int d = 128 * h + 8 * s + jj;
-                        const double x = (rows[r * FAST_D + d] - mu[d]) * (double)F16_SCALE;
-                        _Float16 hi, lo;
-                        split_f16(x, hi, lo);
-                        const int lane = h * 32 + i;
-                        reinterpret_cast<_Float16 *>(blk + (2 * s) * 1024 + lane * 16)[jj] = hi;
-                        reinterpret_cast<_Float16 *>(blk + (2 * s + 1) * 1024 + lane * 16)[jj] = lo;
-                        const double xt = (double)hi + (double)lo;  // the column as the kernel sees it (scaled)
-                        nrm2 += xt * xt;
-                    }
+            for (int c = 0; c < nchunk; ++c)
+                for (int h = 0; h < 2; ++h)
+                    for (int s = 0; s < 16; ++s)
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const uint64_t d = 256 * c + 128 * h + 8 * s + jj;
+                            const double x = (rows[r * D + d] - mu[d]) * (double)F16_SCALE;
+                            _Float16 hi, lo;
+                            split_f16(x, hi, lo);
+                            const int lane = h * 32 + i;
+                            uint8_t *piece = blk + ((uint64_t)c * 32 + 2 * s) * 1024;
+                            reinterpret_cast<_Float16 *>(piece + lane * 16)[jj] = hi;
+                            reinterpret_cast<_Float16 *>(piece + 1024 + lane * 16)[jj] = lo;
+                            const double xt = (double)hi + (double)lo;  // the column as the kernel sees it (scaled)
+                            nrm2 += xt * xt;
+                        }
             cn[i] = (float)(-0.5 * nrm2);  // already in S^2 units
+            cn_all[(cb0 + b) * 32 + i] = cn[i];
         }
     }
 }
 
 int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, const double *cpos,
                         const double *cneg, const double *mu) {
+    const uint64_t D = m->D;
     const uint64_t nblk = (uint64_t)m->n_rblk_ref + m->n_rblk_pos + m->n_rblk_neg;
-    std::vector<uint8_t> rec((nblk + 1) * F16_BLOCK_BYTES, 0);  // + one block: the DMA prefetch runs one past the end
+    const uint64_t rec_bytes = (D / 256 * 32 + 1) * 1024;
+    std::vector<uint8_t> rec((nblk + 1) * rec_bytes, 0);  // + one block: the DMA prefetch runs one past the end
+    std::vector<float> cn_all((nblk + 1) * 32, PAD_V);
     {
-        std::vector<double> train(m->M * FAST_D);
-        std::copy(pos, pos + m->n_pos * FAST_D, train.begin());
-        std::copy(neg, neg + m->n_neg * FAST_D, train.begin() + m->n_pos * FAST_D);
-        pack_segment_f16(train.data(), m->M, mu, rec, 0);
+        std::vector<double> train(m->M * D);
+        std::copy(pos, pos + m->n_pos * D, train.begin());
+        std::copy(neg, neg + m->n_neg * D, train.begin() + m->n_pos * D);
+        pack_segment_f16(train.data(), m->M, D, mu, rec, rec_bytes, 0, cn_all);
     }
-    if (m->n_cpos) pack_segment_f16(cpos, m->n_cpos, mu, rec, m->n_rblk_ref);
-    if (m->n_cneg) pack_segment_f16(cneg, m->n_cneg, mu, rec, (uint64_t)m->n_rblk_ref + m->n_rblk_pos);
+    if (m->n_cpos) pack_segment_f16(cpos, m->n_cpos, D, mu, rec, rec_bytes, m->n_rblk_ref, cn_all);
+    if (m->n_cneg) pack_segment_f16(cneg, m->n_cneg, D, mu, rec, rec_bytes, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, cn_all);
     if (hipMalloc(&m->d_Af16, rec.size()) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMemcpy(m->d_Af16, rec.data(), rec.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    if (hipMalloc(&m->d_cn16, cn_all.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMemcpy(m->d_cn16, cn_all.data(), cn_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     return PHK_OK;
 }
 
@@ -302,5 +317,242 @@ int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, b
                    phk_knn_f16_kernel<1><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
                        src, nullptr, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu));
     }
+    return PHK_OK;
+}
+
+
+// ====================================================================================
+// General D = 256 * nchunk (k = 5: 1024, k = 6: 4096): the query operand no longer fits in
+// registers, so (i) queries are split once into fragment order in a workspace (phk_split_queries),
+// (ii) a wave keeps CT = 4 column-block accumulators and sweeps the K chunks, re-loading its 32
+// queries' chunk fragments (32 KiB, coalesced) once per (tile, chunk) = once per 192 MFMAs, while
+// the column-chunk records stream through the same LDS double buffer as above.
+// ====================================================================================
+__global__ __launch_bounds__(256) void phk_rowsum_kernel(const uint32_t *__restrict__ counts, uint64_t N, uint64_t D,
+                                                         uint32_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= N) return;
+    uint32_t s = 0;
+    for (uint64_t d = lane; d < D; d += 64) s += counts[r * D + d];
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+    if (lane == 0) out[r] = s;
+}
+
+// one wave per (query block of 32, chunk): Bq[(qb * nchunk + c) * 32 + piece][lane] (uint4)
+template <int SRC>
+__global__ __launch_bounds__(256) void phk_split_queries_kernel(const void *__restrict__ src,
+                                                                const uint32_t *__restrict__ rowsum, uint64_t N,
+                                                                uint64_t D, const float *__restrict__ mu32,
+                                                                const double *__restrict__ mu64,
+                                                                uint4 *__restrict__ Bq) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const uint64_t nchunk = D / 256;
+    const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nqb = (N + 31) / 32;
+    if (w >= nqb * nchunk) return;
+    const uint64_t qb = w / nchunk, c = w % nchunk;
+    const uint64_t qrow = (qb * 32 + j < N) ? qb * 32 + j : N - 1;
+    const uint64_t d0 = 256 * c + 128 * h;
+    uint4 *out = Bq + (w * 32) * 64 + lane;
+    float inv = 0.f;
+    if (SRC == 0) inv = (float)(1.0 / (double)rowsum[qrow]) * F16_SCALE;
+    for (int s = 0; s < 16; ++s) {
+        float x[8];
+        if (SRC == 0) {
+            const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + qrow * D + d0 + 8 * s);
+            const float4 *mp = reinterpret_cast<const float4 *>(mu32 + d0 + 8 * s);
+            const uint4 c0 = row[0], c1 = row[1];
+            const float4 m0 = mp[0], m1 = mp[1];
+            x[0] = fmaf((float)c0.x, inv, -m0.x * F16_SCALE);
+            x[1] = fmaf((float)c0.y, inv, -m0.y * F16_SCALE);
+            x[2] = fmaf((float)c0.z, inv, -m0.z * F16_SCALE);
+            x[3] = fmaf((float)c0.w, inv, -m0.w * F16_SCALE);
+            x[4] = fmaf((float)c1.x, inv, -m1.x * F16_SCALE);
+            x[5] = fmaf((float)c1.y, inv, -m1.y * F16_SCALE);
+            x[6] = fmaf((float)c1.z, inv, -m1.z * F16_SCALE);
+            x[7] = fmaf((float)c1.w, inv, -m1.w * F16_SCALE);
+        } else {
+            const double *row = static_cast<const double *>(src) + qrow * D + d0 + 8 * s;
+            const double *mp = mu64 + d0 + 8 * s;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x[t] = (float)((row[t] - mp[t]) * (double)F16_SCALE);
+        }
+        half8 hi, lo;
+        f16_split8(x, hi, lo);
+        out[(2 * s) * 64] = *reinterpret_cast<uint4 *>(&hi);
+        out[(2 * s + 1) * 64] = *reinterpret_cast<uint4 *>(&lo);
+    }
+}
+
+#define GEN_CT 4
+__global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4 *__restrict__ Bq, uint64_t N,
+                                                                     uint32_t nchunk,
+                                                                     const uint4 *__restrict__ Af,
+                                                                     uint64_t rec_u4,  // uint4 per block record
+                                                                     const float *__restrict__ cn_all,
+                                                                     uint32_t blk0,    // first block swept
+                                                                     uint32_t nblk_ref, uint32_t nblk_pos,
+                                                                     uint32_t nblk_neg,
+                                                                     float4 *__restrict__ cand_v,
+                                                                     uint4 *__restrict__ cand_i,
+                                                                     float *__restrict__ cand_u) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x 32 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const uint64_t qb = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t q0 = qb * 32;
+    const uint64_t nqb = (N + 31) / 32;
+    const uint64_t qbc = qb < nqb ? qb : nqb - 1;  // padding waves re-read the last block; nothing is written
+    const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
+    const uint32_t seg_end0 = nblk_ref, seg_end1 = nblk_ref + nblk_pos;
+    const uint32_t ntile = (total + GEN_CT - 1) / GEN_CT;
+    const uint64_t nitem = (uint64_t)ntile * nchunk * GEN_CT;
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    // item it = ((tile * nchunk) + chunk) * CT + cb  ->  32 pieces of (block, chunk)
+    auto dma_item = [&](uint64_t it, int buf) {
+        if (it >= nitem) it = nitem - 1;
+        const uint32_t cb = (uint32_t)(it % GEN_CT);
+        const uint64_t tc = it / GEN_CT;
+        const uint32_t c = (uint32_t)(tc % nchunk);
+        uint32_t blk = (uint32_t)(tc / nchunk) * GEN_CT + cb;
+        if (blk >= total) blk = total - 1;  // partial last tile: harmless re-read, result discarded
+        const uint4 *g = Af + (uint64_t)(blk0 + blk) * rec_u4 + (uint64_t)c * 32 * 64 + lane;
+        const uint32_t l = lds_base + (uint32_t)buf * 32768u;
+        for (int p = wave; p < 32; p += 4) {
+            const uint4 *gp = g + p * 64;
+            const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
+        }
+    };
+    if (nitem) dma_item(0, 0);
+
+    float lv[CAND];
+    uint32_t li[CAND];
+    float ldrop = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < CAND; ++c) {
+        lv[c] = -3.0e38f;
+        li[c] = 0xFFFFFFFFu;
+    }
+    int seg = 0;
+    uint32_t seg_first = 0;
+    uint64_t it = 0;
+    for (uint32_t t = 0; t < ntile; ++t) {
+        f32x16 acc[GEN_CT];
+#pragma unroll
+        for (int cb = 0; cb < GEN_CT; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+        for (uint32_t c = 0; c < nchunk; ++c) {
+            // this wave's query fragments of chunk c (16 x hi + 16 x lo, 1 KiB coalesced loads)
+            half8 bh[16], bl[16];
+            const uint4 *bq = Bq + ((qbc * nchunk + c) * 32) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const uint4 uh = bq[(2 * s) * 64], ul = bq[(2 * s + 1) * 64];
+                bh[s] = *reinterpret_cast<const half8 *>(&uh);
+                bl[s] = *reinterpret_cast<const half8 *>(&ul);
+            }
+#pragma unroll
+            for (int cb = 0; cb < GEN_CT; ++cb, ++it) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                dma_item(it + 1, (int)((it + 1) & 1));
+                const half8 *fr = reinterpret_cast<const half8 *>(smem + (it & 1) * 32768u) + lane;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const half8 ah = fr[(2 * s) * 64];
+                    const half8 al = fr[(2 * s + 1) * 64];
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc[cb], 0, 0, 0);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc[cb], 0, 0, 0);
+                }
+            }
+        }
+        // epilogue of the tile: norm terms from global memory, branch-free insertion, segment flushes
+#pragma unroll
+        for (int cb = 0; cb < GEN_CT; ++cb) {
+            const uint32_t blk = t * GEN_CT + cb;
+            if (blk < total) {
+                const float4 *cn = reinterpret_cast<const float4 *>(cn_all + (uint64_t)(blk0 + blk) * 32) + h;
+                const uint32_t cbase = 32u * (blk - seg_first) + 4u * (uint32_t)h;
+#pragma unroll
+                for (int m4 = 0; m4 < 4; ++m4) {
+                    const float4 c4 = cn[2 * m4];
+                    list_insert(lv, li, ldrop, acc[cb][4 * m4 + 0] + c4.x, cbase + 8u * m4 + 0u);
+                    list_insert(lv, li, ldrop, acc[cb][4 * m4 + 1] + c4.y, cbase + 8u * m4 + 1u);
+                    list_insert(lv, li, ldrop, acc[cb][4 * m4 + 2] + c4.z, cbase + 8u * m4 + 2u);
+                    list_insert(lv, li, ldrop, acc[cb][4 * m4 + 3] + c4.w, cbase + 8u * m4 + 3u);
+                }
+                while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
+                    if (qb < nqb && q0 + j < N) {
+                        const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
+                        cand_v[o] = make_float4(lv[0], lv[1], lv[2], lv[3]);
+                        cand_i[o] = make_uint4(li[0], li[1], li[2], li[3]);
+                        cand_u[o] = ldrop;
+                    }
+#pragma unroll
+                    for (int c = 0; c < CAND; ++c) {
+                        lv[c] = -3.0e38f;
+                        li[c] = 0xFFFFFFFFu;
+                    }
+                    ldrop = -3.0e38f;
+                    ++seg;
+                    seg_first = blk + 1;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (; seg < NSEG; ++seg) {
+        if (qb < nqb && q0 + j < N) {
+            const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
+            cand_v[o] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+            cand_i[o] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            cand_u[o] = -3.0e38f;
+        }
+    }
+}
+
+// proposal pass for D = 256 * nchunk > 256: row sums (if needed) -> split queries -> sweep
+int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
+                                    const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
+                                    float4 *cv, uint4 *ci, float *cu) {
+    const uint64_t D = m->D, nchunk = D / 256;
+    const uint64_t nqb = phk_div_up(nb, 32);
+    void *bq, *rs = nullptr;
+    PHK_TRY(phk_ws(ctx, WS_Q64, nqb * nchunk * 32 * 1024, &bq));
+    if (src_counts && !d_rowsum) {
+        PHK_TRY(phk_ws(ctx, WS_NWIN, nb * sizeof(uint32_t), &rs));
+        PHK_LAUNCH(ctx, "phk_rowsum_kernel",
+                   phk_rowsum_kernel<<<dim3((unsigned)phk_div_up(nb, 4)), dim3(256), 0, ctx->stream>>>(
+                       (const uint32_t *)src, nb, D, (uint32_t *)rs));
+        d_rowsum = (const uint32_t *)rs;
+    }
+    const unsigned sblocks = (unsigned)phk_div_up(nqb * nchunk, 4);
+    if (src_counts) {
+        PHK_LAUNCH(ctx, "phk_split_queries_kernel",
+                   phk_split_queries_kernel<0><<<dim3(sblocks), dim3(256), 0, ctx->stream>>>(
+                       src, d_rowsum, nb, D, m->d_mu32, m->d_mu64, (uint4 *)bq));
+    } else {
+        PHK_LAUNCH(ctx, "phk_split_queries_kernel",
+                   phk_split_queries_kernel<1><<<dim3(sblocks), dim3(256), 0, ctx->stream>>>(
+                       src, nullptr, nb, D, m->d_mu32, m->d_mu64, (uint4 *)bq));
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        attr_set = true;
+    }
+    const uint64_t rec_u4 = (nchunk * 32 + 1) * 64;
+    const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
+    PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
+               phk_knn_f16_general_kernel<<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
+                   (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, blk0, nref, npos,
+                   nneg, cv, ci, cu));
     return PHK_OK;
 }

@@ -41,6 +41,8 @@
 
 #define NG 33          // 32 k-groups + the norm group
 
+bool phk_fast_supports_dim(uint64_t D);
+
 // ------------------------------------------------------------------------------------
 // model build (host): centre, round to fp32, fragment-order, upload
 // ------------------------------------------------------------------------------------
@@ -75,16 +77,18 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
                          const double *cpos, const double *cneg) {
     (void)ctx;
     m->fast = false;
-    if (m->D != FAST_D || m->kn > CAND - 1) return PHK_OK;  // exact path serves other shapes
+    const uint64_t D = m->D;
+    // MFMA proposal paths: D a multiple of 256 up to 4096 (k = 4, 5, 6) and up to 3 neighbours
+    if (!phk_fast_supports_dim(D) || m->kn > CAND - 1) return PHK_OK;  // exact path serves other shapes
     if (m->M >= (1ull << 31)) return PHK_OK;
-    std::vector<double> mu(FAST_D, 0.0);
+    std::vector<double> mu(D, 0.0);
     for (uint64_t r = 0; r < m->n_pos; ++r)
-        for (int d = 0; d < FAST_D; ++d) mu[d] += pos[r * FAST_D + d];
+        for (uint64_t d = 0; d < D; ++d) mu[d] += pos[r * D + d];
     for (uint64_t r = 0; r < m->n_neg; ++r)
-        for (int d = 0; d < FAST_D; ++d) mu[d] += neg[r * FAST_D + d];
+        for (uint64_t d = 0; d < D; ++d) mu[d] += neg[r * D + d];
     double mu2 = 0.0;
-    std::vector<float> mu32(FAST_D);
-    for (int d = 0; d < FAST_D; ++d) {
+    std::vector<float> mu32(D);
+    for (uint64_t d = 0; d < D; ++d) {
         mu[d] /= (double)m->M;
         if (!(mu[d] == mu[d]) || std::isinf(mu[d])) return PHK_OK;  // NaN/inf train data: exact path
         mu32[d] = (float)mu[d];
@@ -95,30 +99,48 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
     m->n_rblk_pos = (uint32_t)phk_div_up(m->n_cpos, 32);
     m->n_rblk_neg = (uint32_t)phk_div_up(m->n_cneg, 32);
     const uint64_t nblk = (uint64_t)m->n_rblk_ref + m->n_rblk_pos + m->n_rblk_neg;
-    std::vector<float> bf((nblk * NG + 16) * 64 * 4, 0.0f);  // + 16 groups: the kernel's prefetch ring runs past the end
     double max_norm = 0.0;
     std::vector<double> colnorm(m->M + m->n_cpos + m->n_cneg + 1, 0.0);  // |r'| of every real column
-    // train = vstack(pos, neg): gather into one row array for packing
-    {
-        std::vector<double> train(m->M * FAST_D);
-        std::copy(pos, pos + m->n_pos * FAST_D, train.begin());
-        std::copy(neg, neg + m->n_neg * FAST_D, train.begin() + m->n_pos * FAST_D);
-        pack_segment(train.data(), m->M, mu, bf, 0, max_norm, colnorm.data());
+    if (D == FAST_D) {
+        // fp32 fragment-ordered operand of the fp32-input MFMA kernel (k = 4 only)
+        std::vector<float> bf((nblk * NG + 16) * 64 * 4, 0.0f);  // + 16 groups: the prefetch ring runs past the end
+        {
+            std::vector<double> train(m->M * FAST_D);
+            std::copy(pos, pos + m->n_pos * FAST_D, train.begin());
+            std::copy(neg, neg + m->n_neg * FAST_D, train.begin() + m->n_pos * FAST_D);
+            pack_segment(train.data(), m->M, mu, bf, 0, max_norm, colnorm.data());
+        }
+        if (m->n_cpos) pack_segment(cpos, m->n_cpos, mu, bf, m->n_rblk_ref, max_norm, colnorm.data() + m->M);
+        if (m->n_cneg)
+            pack_segment(cneg, m->n_cneg, mu, bf, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, max_norm,
+                         colnorm.data() + m->M + m->n_cpos);
+        if (hipMalloc(&m->d_Bf, bf.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
+        if (hipMemcpy(m->d_Bf, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return PHK_ERR_HIP;
+    } else {
+        auto norms = [&](const double *rows, uint64_t n, double *out) {
+            for (uint64_t r = 0; r < n; ++r) {
+                double s2 = 0.0;
+                for (uint64_t d = 0; d < D; ++d) {
+                    const double v = (double)(float)(rows[r * D + d] - mu[d]);
+                    s2 += v * v;
+                }
+                out[r] = std::sqrt(s2);
+                if (out[r] > max_norm) max_norm = out[r];
+            }
+        };
+        norms(pos, m->n_pos, colnorm.data());
+        norms(neg, m->n_neg, colnorm.data() + m->n_pos);
+        if (m->n_cpos) norms(cpos, m->n_cpos, colnorm.data() + m->M);
+        if (m->n_cneg) norms(cneg, m->n_cneg, colnorm.data() + m->M + m->n_cpos);
     }
-    if (m->n_cpos) pack_segment(cpos, m->n_cpos, mu, bf, m->n_rblk_ref, max_norm, colnorm.data() + m->M);
-    if (m->n_cneg)
-        pack_segment(cneg, m->n_cneg, mu, bf, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, max_norm,
-                     colnorm.data() + m->M + m->n_cpos);
     if (!(max_norm == max_norm) || std::isinf(max_norm)) return PHK_OK;
-    if (hipMalloc(&m->d_Bf, bf.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
-    if (hipMalloc(&m->d_mu32, FAST_D * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
-    if (hipMalloc(&m->d_mu64, FAST_D * sizeof(double)) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMalloc(&m->d_mu32, D * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMalloc(&m->d_mu64, D * sizeof(double)) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMalloc(&m->d_colnorm, colnorm.size() * sizeof(double)) != hipSuccess) return PHK_ERR_NOMEM;
-    if (hipMemcpy(m->d_colnorm, colnorm.data(), colnorm.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
-        return PHK_ERR_HIP;
-    if (hipMemcpy(m->d_Bf, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(m->d_mu32, mu32.data(), FAST_D * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(m->d_mu64, mu.data(), FAST_D * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(m->d_colnorm, colnorm.data(), colnorm.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_mu32, mu32.data(), D * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_mu64, mu.data(), D * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         return PHK_ERR_HIP;
     PHK_TRY(phk_model_build_f16(m, pos, neg, cpos, cneg, mu.data()));
     m->max_colnorm = max_norm;
@@ -132,6 +154,8 @@ void phk_model_free_fast(phk_model *m) {
     if (m->d_colnorm) (void)hipFree(m->d_colnorm);
     if (m->d_Af16) (void)hipFree(m->d_Af16);
     m->d_Af16 = nullptr;
+    if (m->d_cn16) (void)hipFree(m->d_cn16);
+    m->d_cn16 = nullptr;
     if (m->d_mu32) (void)hipFree(m->d_mu32);
     if (m->d_mu64) (void)hipFree(m->d_mu64);
     m->d_Bf = nullptr;
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
 // 2. certify / exact re-rank: one wavefront per query, lane = 4 dimensions
 // ------------------------------------------------------------------------------------
 struct RerankParams {
-    uint64_t N, M, n_cpos, n_cneg;
+    uint64_t N, M, n_cpos, n_cneg, D;
     int kn, method;
     double rmax, mu_norm;
     double vscale;          // computed values are in units of 1/vscale (split-f16 path: S^2)
@@ -304,12 +328,20 @@ __device__ __forceinline__ double wave_sum(double x) {
     return x;
 }
 
-// exact direct-difference squared distance of the wave's query (4 dims per lane) to `row`
-__device__ __forceinline__ double exact_d2(const double (&qd)[4], const double *row, int lane) {
-    const double2 a = reinterpret_cast<const double2 *>(row)[2 * lane];
-    const double2 b = reinterpret_cast<const double2 *>(row)[2 * lane + 1];
-    const double d0 = qd[0] - a.x, d1 = qd[1] - a.y, d2 = qd[2] - b.x, d3 = qd[3] - b.y;
-    return wave_sum(fma(d0, d0, fma(d1, d1, fma(d2, d2, d3 * d3))));
+// exact direct-difference squared distance of the wave's query to `row`.  D = 256 * DSUB; lane l
+// holds dimensions 256*sub + 4l .. +3 of the query for sub = 0 .. DSUB-1.
+template <int DSUB>
+__device__ __forceinline__ double exact_d2(const double (&qd)[4 * DSUB], const double *row, int lane) {
+    double acc = 0.0;
+#pragma unroll
+    for (int sub = 0; sub < DSUB; ++sub) {
+        const double2 a = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane];
+        const double2 b = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane + 1];
+        const double d0 = qd[4 * sub + 0] - a.x, d1 = qd[4 * sub + 1] - a.y;
+        const double d2 = qd[4 * sub + 2] - b.x, d3 = qd[4 * sub + 3] - b.y;
+        acc = fma(d0, d0, fma(d1, d1, fma(d2, d2, fma(d3, d3, acc))));
+    }
+    return wave_sum(acc);
 }
 
 // Rigorous bound on |computed v - true v| of the proposal pass for a column with |r'| <= R
@@ -334,8 +366,9 @@ struct ErrBound {
 //   want_d2, or when the order had to be decided by exact distances).
 // Columns with |r'| > |q'| + d_need cannot be among the `need` nearest (triangle inequality), so the
 // error bound only has to hold for columns with |r'| <= R0 = |q'| + (upper bound of d_need).
+template <int DSUB>
 __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
-                                const double (&qd)[4], double nqp2, const ErrBound &eb, const double *rows,
+                                const double (&qd)[4 * DSUB], double nqp2, const ErrBound &eb, const double *rows,
                                 const double *colnorm, bool want_d2, int lane, uint32_t (&out_idx)[3],
                                 double &out_d2) {
     // lanes 0..7 hold the 8 candidates (half = lane>>2, slot = lane&3)
@@ -384,7 +417,7 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
         if (((double)rv[need - 1] - (double)rv[need]) * vs > 2.0 * eps_m) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) out_idx[r] = ri[r];
-            if (want_d2) out_d2 = exact_d2(qd, rows + (uint64_t)ri[0] * FAST_D, lane);
+            if (want_d2) out_d2 = exact_d2<DSUB>(qd, rows + (uint64_t)ri[0] * (256 * DSUB), lane);
             return true;
         }
     }
@@ -395,7 +428,7 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
     for (int m = 0; m < 8; ++m) {
         const uint32_t c = __shfl(ix, m);
         if (c >= ncols) continue;
-        const double d2 = exact_d2(qd, rows + (uint64_t)c * FAST_D, lane);
+        const double d2 = exact_d2<DSUB>(qd, rows + (uint64_t)c * (256 * DSUB), lane);
         // insert (d2, c) ascending; ties to the lower column index
         if (d2 < best[2] || (d2 == best[2] && c < bidx[2])) {
             best[2] = d2; bidx[2] = c;
@@ -420,27 +453,46 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
     return true;
 }
 
-template <int SRC>
+template <int SRC, int DSUB>
 __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict__ src, RerankParams p) {
+    constexpr int D = 256 * DSUB;
     const int lane = threadIdx.x & 63;
     const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (q >= p.N) return;
-    // exact float64 query elements for this lane's 4 dimensions (kmer.normalize_counts arithmetic)
-    double qd[4];
+    // exact float64 query elements of this lane (kmer.normalize_counts arithmetic): dims 256*sub + 4*lane .. +3
+    double qd[4 * DSUB];
     bool nan_row = false;
     if (SRC == 0) {
-        const uint4 c = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D)[lane];
-        uint32_t s = c.x + c.y + c.z + c.w;
+        const uint32_t *row = static_cast<const uint32_t *>(src) + q * D;
+        uint4 c[DSUB];
+        uint32_t s = 0;
+#pragma unroll
+        for (int sub = 0; sub < DSUB; ++sub) {
+            c[sub] = reinterpret_cast<const uint4 *>(row + 256 * sub)[lane];
+            s += c[sub].x + c[sub].y + c[sub].z + c[sub].w;
+        }
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
         nan_row = s == 0;
         const double ds = (double)s;
-        qd[0] = (double)c.x / ds; qd[1] = (double)c.y / ds; qd[2] = (double)c.z / ds; qd[3] = (double)c.w / ds;
+#pragma unroll
+        for (int sub = 0; sub < DSUB; ++sub) {
+            qd[4 * sub + 0] = (double)c[sub].x / ds;
+            qd[4 * sub + 1] = (double)c[sub].y / ds;
+            qd[4 * sub + 2] = (double)c[sub].z / ds;
+            qd[4 * sub + 3] = (double)c[sub].w / ds;
+        }
     } else {
-        const double2 a = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D)[2 * lane];
-        const double2 b = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D)[2 * lane + 1];
-        qd[0] = a.x; qd[1] = a.y; qd[2] = b.x; qd[3] = b.y;
-        nan_row = __any(qd[0] != qd[0] || qd[1] != qd[1] || qd[2] != qd[2] || qd[3] != qd[3]);
+        const double *row = static_cast<const double *>(src) + q * D;
+        bool bad = false;
+#pragma unroll
+        for (int sub = 0; sub < DSUB; ++sub) {
+            const double2 a = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane];
+            const double2 b = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane + 1];
+            qd[4 * sub + 0] = a.x; qd[4 * sub + 1] = a.y; qd[4 * sub + 2] = b.x; qd[4 * sub + 3] = b.y;
+            bad |= a.x != a.x || a.y != a.y || b.x != b.x || b.y != b.y;
+        }
+        nan_row = __any(bad);
     }
     if (nan_row) {  // zero-count contig: the reference's normalised row is NaN
         if (lane == 0) {
@@ -449,11 +501,19 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
         }
         return;
     }
-    const double2 m0 = reinterpret_cast<const double2 *>(p.mu64)[2 * lane];
-    const double2 m1 = reinterpret_cast<const double2 *>(p.mu64)[2 * lane + 1];
-    const double c0 = qd[0] - m0.x, c1 = qd[1] - m0.y, c2 = qd[2] - m1.x, c3 = qd[3] - m1.y;
-    const double nq2 = wave_sum(fma(qd[0], qd[0], fma(qd[1], qd[1], fma(qd[2], qd[2], qd[3] * qd[3]))));
-    const double nqp2 = wave_sum(fma(c0, c0, fma(c1, c1, fma(c2, c2, c3 * c3))));
+    double aq = 0.0, ap = 0.0;
+#pragma unroll
+    for (int sub = 0; sub < DSUB; ++sub) {
+        const double2 m0 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane];
+        const double2 m1 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane + 1];
+        const double c0 = qd[4 * sub + 0] - m0.x, c1 = qd[4 * sub + 1] - m0.y;
+        const double c2 = qd[4 * sub + 2] - m1.x, c3 = qd[4 * sub + 3] - m1.y;
+        aq = fma(qd[4 * sub + 0], qd[4 * sub + 0], fma(qd[4 * sub + 1], qd[4 * sub + 1],
+                 fma(qd[4 * sub + 2], qd[4 * sub + 2], fma(qd[4 * sub + 3], qd[4 * sub + 3], aq))));
+        ap = fma(c0, c0, fma(c1, c1, fma(c2, c2, fma(c3, c3, ap))));
+    }
+    const double nq2 = wave_sum(aq);
+    const double nqp2 = wave_sum(ap);
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
@@ -464,7 +524,7 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
     uint32_t idx[3];
     double d2;
     if (p.method & PHK_METHOD_KNN) {
-        ok = resolve_segment(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, p.R64, p.colnorm, false, lane, idx, d2);
+        ok = resolve_segment<DSUB>(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, p.R64, p.colnorm, false, lane, idx, d2);
         if (ok) {
             int votes = 0;
             for (int r = 0; r < p.kn; ++r) votes += p.labels[idx[r]] ? 1 : 0;
@@ -473,9 +533,9 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
     }
     if (ok && (p.method & PHK_METHOD_KMEANS)) {
         double dp2 = 0.0, dn2 = 0.0;
-        ok = resolve_segment(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, p.C64, p.colnorm + p.M, true, lane, idx, dp2);
+        ok = resolve_segment<DSUB>(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, p.C64, p.colnorm + p.M, true, lane, idx, dp2);
         if (ok)
-            ok = resolve_segment(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, p.C64 + p.n_cpos * FAST_D,
+            ok = resolve_segment<DSUB>(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, p.C64 + p.n_cpos * D,
                                  p.colnorm + p.M + p.n_cpos, true, lane, idx, dn2);
         if (ok) {
             const double ep = sqrt(dp2), en = sqrt(dn2);
@@ -513,7 +573,8 @@ __device__ __forceinline__ bool fb_less(double da, uint64_t ia, double db, uint6
 template <int SRC>
 __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *__restrict__ src, RerankParams p) {
     extern __shared__ double fb_lds[];  // [0, 256): the query; then one chunk of distances
-    double *fb_q = fb_lds, *fb_dist = fb_lds + FAST_D;
+    const uint64_t D = p.D;
+    double *fb_q = fb_lds, *fb_dist = fb_lds + D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t count = *p.fb_count;
     const uint64_t ncols = p.M + p.n_cpos + p.n_cneg;
@@ -524,23 +585,23 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
         const uint64_t qi = it / FB_CHUNKS, ch = it % FB_CHUNKS;
         const uint64_t q = p.fb_list[qi];
         const uint64_t c0 = ch * cw, c1 = (c0 + cw < ncols) ? c0 + cw : ncols;
-        // the query row in float64 (kmer.normalize_counts arithmetic), one element per thread
+        // the query row in float64 (kmer.normalize_counts arithmetic)
         if (SRC == 0) {
-            const uint32_t *row = static_cast<const uint32_t *>(src) + q * FAST_D;
-            uint32_t s = row[lane] + row[lane + 64] + row[lane + 128] + row[lane + 192];
+            const uint32_t *row = static_cast<const uint32_t *>(src) + q * D;
+            uint32_t s = 0;
+            for (uint64_t d = lane; d < D; d += 64) s += row[d];  // every wave sums the whole row
 #pragma unroll
             for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
-            fb_q[threadIdx.x] = (double)row[threadIdx.x] / (double)s;
+            for (uint64_t d = threadIdx.x; d < D; d += 256) fb_q[d] = (double)row[d] / (double)s;
         } else {
-            fb_q[threadIdx.x] = static_cast<const double *>(src)[q * FAST_D + threadIdx.x];
+            for (uint64_t d = threadIdx.x; d < D; d += 256) fb_q[d] = static_cast<const double *>(src)[q * D + d];
         }
         __syncthreads();
         for (uint64_t c = c0 + threadIdx.x; c < c1; c += 256) {
-            const double2 *row = reinterpret_cast<const double2 *>(c < p.M ? p.R64 + c * FAST_D
-                                                                            : p.C64 + (c - p.M) * FAST_D);
+            const double2 *row = reinterpret_cast<const double2 *>(c < p.M ? p.R64 + c * D : p.C64 + (c - p.M) * D);
             double acc = 0.0;
 #pragma unroll 8
-            for (int d = 0; d < FAST_D / 2; ++d) {
+            for (uint64_t d = 0; d < D / 2; ++d) {
                 const double2 r = row[d];
                 const double d0 = fb_q[2 * d] - r.x, d1 = fb_q[2 * d + 1] - r.y;
                 acc = fma(d0, d0, acc);
@@ -631,9 +692,39 @@ __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p)
 // ------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------
+template <int SRC>
+static int launch_rerank(phk_ctx *ctx, unsigned blocks, const void *src, const RerankParams &p) {
+    switch (p.D) {
+        case 256:
+            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 1><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+            break;
+        case 512:
+            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 2><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+            break;
+        case 1024:
+            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 4><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+            break;
+        case 2048:
+            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 8><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+            break;
+        case 4096:
+            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 16><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+            break;
+        default:
+            phk_set_error("phk_score: no decision kernel for D = %llu", (unsigned long long)p.D);
+            return PHK_ERR_UNSUPPORTED;
+    }
+    return PHK_OK;
+}
+
+bool phk_fast_supports_dim(uint64_t D) { return D == 256 || D == 512 || D == 1024 || D == 2048 || D == 4096; }
+
 int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
                    const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status) {
-    const uint64_t BATCH = 1ull << 20;  // bounds the candidate (200 B/query) and fallback (1 KiB/query) workspaces
+    const uint64_t D = m->D;
+    // batch: bounds the candidate (200 B/query), fallback (1 KiB/query) and split-query (4 D B/query) workspaces
+    uint64_t BATCH = 1ull << 20;
+    while (BATCH > 4096 && BATCH * D * 4 > (2ull << 30)) BATCH >>= 1;
     const uint64_t nb_max = N < BATCH ? N : BATCH;
     const uint64_t per_list = nb_max * NSEG * 2;
     void *cv, *fb, *rec;
@@ -644,54 +735,67 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     PHK_TRY(phk_ws(ctx, WS_QF32, nb_max * FB_CHUNKS * sizeof(FbRecord), &rec));
     uint32_t *fb_count = (uint32_t *)fb, *fb_list = (uint32_t *)fb + 16;
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
-    const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + FAST_D) * sizeof(double);
-    // proposal pass: split-f16 MFMA by default; PHK_PROPOSAL=f32 selects the fp32-input MFMA kernel
+    const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + D) * sizeof(double);
+    PHK_REQUIRE(fb_lds <= 160 * 1024, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);
+    static bool attr_set = false;
+    if (!attr_set && fb_lds > 64 * 1024) {
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_fallback_partial_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_fallback_partial_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    // proposal pass: split-f16 MFMA by default; PHK_PROPOSAL=f32 selects the fp32-input MFMA kernel (k = 4 only)
     const char *prop = getenv("PHK_PROPOSAL");
-    const bool use_f16 = !(prop && prop[0] == 'f' && prop[1] == '3');
+    const bool use_f16 = D != FAST_D || !(prop && prop[0] == 'f' && prop[1] == '3');
     for (uint64_t s = 0; s < N; s += BATCH) {
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
-        const void *src = d_counts ? (const void *)(d_counts + s * FAST_D) : (const void *)(d_Q + s * FAST_D);
-        const unsigned gblocks = (unsigned)phk_div_up(nb, 128);
+        const void *src = d_counts ? (const void *)(d_counts + s * D) : (const void *)(d_Q + s * D);
+        const uint32_t *rsum = d_rowsum ? d_rowsum + s : nullptr;
         // segments the method does not need are skipped by giving them zero blocks
         const uint32_t nref = (method & PHK_METHOD_KNN) ? m->n_rblk_ref : 0;
         const uint32_t npos = (method & PHK_METHOD_KMEANS) ? m->n_rblk_pos : 0;
         const uint32_t nneg = (method & PHK_METHOD_KMEANS) ? m->n_rblk_neg : 0;
-        const float4 *bf = (const float4 *)m->d_Bf + (uint64_t)(nref ? 0 : m->n_rblk_ref) * NG * 64;
         PHK_HIP(hipMemsetAsync(fb_count, 0, 64, ctx->stream));
         RerankParams p;
-        p.N = nb; p.M = m->M; p.n_cpos = m->n_cpos; p.n_cneg = m->n_cneg;
+        p.N = nb; p.M = m->M; p.n_cpos = m->n_cpos; p.n_cneg = m->n_cneg; p.D = D;
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
         p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.colnorm = m->d_colnorm; p.labels = m->d_labels;
         p.cand_v = (const float4 *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
         p.scores = d_scores; p.status = d_status; p.fb_count = fb_count; p.fb_list = fb_list; p.q_base = s;
         if (use_f16) {
+            // 3 D product accumulations charged 2u each (+ the small input terms), subnormal quantum sqrt(D) 2^-25 / S
             p.vscale = 1.0 / (4096.0 * 4096.0);
-            p.eb_cA = 6.0; p.eb_cP = 1600.0; p.eb_cR = 6.0; p.eb_abs = 9.5367431640625e-07 / 4096.0;
+            p.eb_cA = 6.0; p.eb_cP = 6.0 * (double)D + 64.0; p.eb_cR = 6.0;
+            p.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
         } else {
             p.vscale = 1.0;
             p.eb_cA = 6.0; p.eb_cP = 264.0; p.eb_cR = 4.0; p.eb_abs = 0.0;
         }
-        const unsigned rblocks = (unsigned)phk_div_up(nb, 4);
-        if (use_f16) {
-            PHK_TRY(phk_launch_proposal_f16(ctx, m, src, d_counts != nullptr, d_rowsum ? d_rowsum + s : nullptr, nb, nref, npos,
-                                            nneg, (float4 *)cv, ci, cu));
-        } else if (d_counts) {
-            PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
-                       phk_knn_mfma_kernel<0><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
-                           src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, ci, cu));
+        if (D != FAST_D) {
+            PHK_TRY(phk_launch_proposal_f16_general(ctx, m, src, d_counts != nullptr, rsum, nb, nref, npos, nneg,
+                                                    (float4 *)cv, ci, cu));
+        } else if (use_f16) {
+            PHK_TRY(phk_launch_proposal_f16(ctx, m, src, d_counts != nullptr, rsum, nb, nref, npos, nneg, (float4 *)cv,
+                                            ci, cu));
         } else {
-            PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
-                       phk_knn_mfma_kernel<1><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
-                           src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, ci, cu));
+            const unsigned gblocks = (unsigned)phk_div_up(nb, 128);
+            const float4 *bf = (const float4 *)m->d_Bf + (uint64_t)(nref ? 0 : m->n_rblk_ref) * NG * 64;
+            if (d_counts) {
+                PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
+                           phk_knn_mfma_kernel<0><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
+                               src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, ci, cu));
+            } else {
+                PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
+                           phk_knn_mfma_kernel<1><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
+                               src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, ci, cu));
+            }
         }
+        const unsigned rblocks = (unsigned)phk_div_up(nb, 4);
         if (d_counts) {
-            PHK_LAUNCH(ctx, "phk_rerank_kernel",
-                       phk_rerank_kernel<0><<<dim3(rblocks), dim3(256), 0, ctx->stream>>>(src, p));
+            PHK_TRY(launch_rerank<0>(ctx, rblocks, src, p));
             PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
                        phk_fallback_partial_kernel<0><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, p));
         } else {
-            PHK_LAUNCH(ctx, "phk_rerank_kernel",
-                       phk_rerank_kernel<1><<<dim3(rblocks), dim3(256), 0, ctx->stream>>>(src, p));
+            PHK_TRY(launch_rerank<1>(ctx, rblocks, src, p));
             PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
                        phk_fallback_partial_kernel<1><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, p));
         }

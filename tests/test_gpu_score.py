@@ -215,3 +215,58 @@ def test_duplicate_train_rows_take_the_certified_or_fallback_route():
     # identical nearest centroids in both classes give exactly 0 for query 0-like points
     assert np.allclose(got, want, rtol=1e-6, atol=1e-12)
     model.close()
+
+
+@pytest.mark.parametrize("k,n_ref,n_q", [(5, 1500, 3000), (6, 700, 1200)])
+def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q):
+    """k = 5 / 6 (D = 1024 / 4096): the general-D split-f16 proposal path against the float64
+    brute-force path on synthetic genomes; identical votes, float scores equal to rounding; the
+    uint32-count entry point and the float64-row entry point agree."""
+    from phamers_amd import _lib, device, synth
+    from oracle import oracle
+    ctx = _lib.get_context()
+    D = 4 ** k
+
+    def device_counts(seed, n, L):
+        T = n * L
+        d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+        d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+        device.synth_packed(ctx, seed, 0, n, L, d_packed, d_off)
+        d_counts = device.DeviceArray(ctx, (n, D), np.uint32)
+        device.count(ctx, d_packed, None, T, d_off, n, k, d_counts)
+        return d_counts
+
+    ref_counts = device_counts(40 + k, n_ref, 30000).to_host().astype(np.float64)
+    # skew half of the rows so the two classes differ (uniform random genomes are all alike)
+    w = 1.0 + 0.3 * np.sin(np.arange(D) * 0.37)
+    ref_counts[: n_ref // 2] *= w
+    ref = ref_counts / ref_counts.sum(axis=1, keepdims=True)
+    pos, neg = ref[: n_ref // 2], ref[n_ref // 2:]
+    cpos = np.stack([pos[i::12].mean(axis=0) for i in range(12)])
+    cneg = np.stack([neg[i::12].mean(axis=0) for i in range(12)])
+    model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
+    d_q = device_counts(90 + k, n_q, 10000)
+    out = {}
+    for path in ("f16", "exact"):
+        monkeypatch.setenv("PHK_FORCE_EXACT", "1" if path == "exact" else "0")
+        for method in ("knn", "kmeans", "combo"):
+            d_scores = device.DeviceArray(ctx, n_q, np.float64)
+            d_status = device.DeviceArray(ctx, 1, np.uint32)
+            device.score_counts(ctx, model, d_q, n_q, method, d_scores, d_status)
+            out[(path, method)] = d_scores.to_host()
+            assert d_status.to_host()[0] == 0
+        if path == "f16":
+            n_fallback, _ = ctx.score_stats()
+            assert n_fallback < max(n_q // 20, 8)
+    assert np.array_equal(out[("f16", "knn")], out[("exact", "knn")])
+    assert helpers.rel_err(out[("f16", "kmeans")], out[("exact", "kmeans")]) < 1e-9
+    assert helpers.rel_err(out[("f16", "combo")], out[("exact", "combo")]) < 1e-9
+    # float64-row entry point on a slice, against the oracle
+    monkeypatch.setenv("PHK_FORCE_EXACT", "0")
+    qc = d_q.to_host()[:64].astype(np.int64)
+    q = oracle.normalize_counts(qc)
+    got = model.score(q, "combo")
+    want = oracle.knn_score_points(q, pos, neg, 3) + oracle.centroid_score_points_fast(q, cpos, cneg)
+    assert helpers.rel_err(got, want) < RTOL
+    assert np.array_equal(got, out[("f16", "combo")][:64]) or helpers.rel_err(got, out[("f16", "combo")][:64]) < 1e-12
+    model.close()
