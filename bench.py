@@ -208,7 +208,7 @@ def main():
         "value": world * n * L * args.steps / elapsed / 1e9,
         "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32 counts + f32-input MFMA proposal + f64 decision",
+        "vs_baseline": None, "dtype": "u32 counts + split-f16 MFMA proposal (f32 accumulate) + f64 decision",
         "data": "synthetic (seeded uniform ATGC contigs, device-generated); reference matrix: " + ref_name,
         "config": {"workload": "k=%d, %d x %d-base contigs per GPU, count+normalise+%s score, "
                                "%d reference rows + %d centroids" % (k, n, L, args.method, M, C),
