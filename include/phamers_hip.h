@@ -54,6 +54,7 @@ extern "C" {
 #define PHK_ERR_NOMEM (-3)       /* device allocation failed */
 #define PHK_ERR_UNSUPPORTED (-4) /* outside the implemented path (e.g. k > PHK_MAX_K) */
 #define PHK_ERR_NAN (-5)         /* a query row contains NaN (zero-count contig), see phk_score_* */
+#define PHK_ERR_IO (-6)          /* file cannot be opened / read (phk_fasta_read) */
 
 #define PHK_MAX_K 7              /* 4^k uint32 bins must fit one wave's LDS histogram */
 
@@ -63,6 +64,7 @@ extern "C" {
 
 typedef struct phk_ctx phk_ctx;
 typedef struct phk_model phk_model;
+typedef struct phk_fasta phk_fasta;
 
 /* ---- library / context ------------------------------------------------------------- */
 int phk_abi_version(void);
@@ -93,6 +95,24 @@ int phk_count_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, ui
 int phk_normalize_i64(phk_ctx *ctx, const int64_t *counts, uint64_t n, uint64_t D, double *out);
 /* same for an already-float matrix (row sum taken left to right in float64) */
 int phk_normalize_f64(phk_ctx *ctx, const double *rows, uint64_t n, uint64_t D, double *out);
+
+/* ---- host API: FASTA ingest --------------------------------------------------------- */
+/* One multi-threaded pass over a FASTA file (plain, or gzip when the name ends in ".gz") replacing
+ * the Biopython passes of kmer.count_file (scripts/kmer.py:124-140) and fileIO.read_fasta /
+ * get_fasta_ids / get_fasta_sequences (scripts/fileIO.py:28-94).  Record semantics are Bio.SeqIO's:
+ * title = '>' line minus '>' and trailing white space (record.id = its first word); sequence = the
+ * following lines with trailing white space, ' ' and '\r' removed.  threads <= 0 = automatic.
+ * Returns PHK_ERR_IO when the file cannot be read (count_file then returns (None, None),
+ * scripts/kmer.py:126-128). */
+int phk_fasta_read(const char *path, int threads, phk_fasta **out);
+int phk_fasta_shape(const phk_fasta *f, uint64_t *n_records, uint64_t *total_bases, uint64_t *title_bytes);
+/* borrowed pointers, valid until phk_fasta_free: concatenated sequence bytes + offsets[n+1] (exactly the
+ * arguments of phk_count_ascii), concatenated titles + title_offsets[n+1] */
+int phk_fasta_data(const phk_fasta *f, const char **bases, const uint64_t **offsets, const char **titles,
+                   const uint64_t **title_offsets);
+int phk_fasta_free(phk_fasta *f);
+/* kmer.count_file's counting loop (scripts/kmer.py:135-139) on a parsed file: counts[n][4^k] int64 */
+int phk_count_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *symbols4, int64_t *counts);
 
 /* ---- scoring model ----------------------------------------------------------------- */
 /* The training side of phamer_scorer.score_points (scripts/phamer.py:177-195): positive /

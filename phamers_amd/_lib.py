@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libphamers_hip.so")
 
 PHK_OK = 0
-PHK_ERR_ARG, PHK_ERR_HIP, PHK_ERR_NOMEM, PHK_ERR_UNSUPPORTED, PHK_ERR_NAN = -1, -2, -3, -4, -5
+PHK_ERR_ARG, PHK_ERR_HIP, PHK_ERR_NOMEM, PHK_ERR_UNSUPPORTED, PHK_ERR_NAN, PHK_ERR_IO = -1, -2, -3, -4, -5, -6
 METHOD_KNN, METHOD_KMEANS, METHOD_COMBO = 1, 2, 3
 METHODS = {"knn": METHOD_KNN, "kmeans": METHOD_KMEANS, "combo": METHOD_COMBO}
 MAX_K = 7
@@ -38,6 +38,11 @@ SIGNATURES = {
     "phk_count_ascii": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_char_p, c_void_p]),
     "phk_normalize_i64": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p]),
     "phk_normalize_f64": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p]),
+    "phk_fasta_read": (c_int, [c_char_p, c_int, P(c_void_p)]),
+    "phk_fasta_shape": (c_int, [c_void_p, P(c_u64), P(c_u64), P(c_u64)]),
+    "phk_fasta_data": (c_int, [c_void_p, P(c_void_p), P(c_void_p), P(c_void_p), P(c_void_p)]),
+    "phk_fasta_free": (c_int, [c_void_p]),
+    "phk_count_fasta": (c_int, [c_void_p, c_void_p, c_int, c_char_p, c_void_p]),
     "phk_model_create": (c_int, [c_void_p, c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_u64,
                                  c_void_p, c_u64, c_u64, c_int, P(c_void_p)]),
     "phk_model_destroy": (c_int, [c_void_p, c_void_p]),
@@ -202,6 +207,63 @@ class Model(object):
         out = np.empty(Q.shape[0], dtype=np.float64)
         check(self.ctx.lib.phk_score(self.ctx.handle, self.handle, ptr(Q), Q.shape[0], METHODS[method], ptr(out)))
         return out
+
+
+class Fasta(object):
+    """A FASTA file parsed by the native multi-threaded reader (phk_fasta_read)."""
+
+    def __init__(self, path, threads=0):
+        self.lib = load()
+        h = ctypes.c_void_p()
+        rc = self.lib.phk_fasta_read(os.fsencode(path), int(threads), ctypes.byref(h))
+        if rc == PHK_ERR_IO:
+            raise IOError(self.lib.phk_last_error().decode("utf-8", "replace"))
+        check(rc)
+        self.handle = h
+        n, t, tb = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        check(self.lib.phk_fasta_shape(h, ctypes.byref(n), ctypes.byref(t), ctypes.byref(tb)))
+        self.n_records, self.total_bases, self.title_bytes = n.value, t.value, tb.value
+        b, o, ti, to = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        check(self.lib.phk_fasta_data(h, ctypes.byref(b), ctypes.byref(o), ctypes.byref(ti), ctypes.byref(to)))
+        self._bases, self._offsets, self._titles, self._title_off = b.value, o.value, ti.value, to.value
+
+    def offsets(self):
+        return np.ctypeslib.as_array(ctypes.cast(self._offsets, ctypes.POINTER(ctypes.c_uint64)),
+                                     shape=(self.n_records + 1,)).copy()
+
+    def lengths(self):
+        return np.diff(self.offsets().astype(np.int64))
+
+    def titles(self):
+        off = np.ctypeslib.as_array(ctypes.cast(self._title_off, ctypes.POINTER(ctypes.c_uint64)),
+                                    shape=(self.n_records + 1,))
+        raw = ctypes.string_at(self._titles, self.title_bytes) if self.title_bytes else b""
+        return [raw[int(off[i]):int(off[i + 1])].decode("latin-1") for i in range(self.n_records)]
+
+    def ids(self):
+        """Bio.SeqIO record.id: the first white-space delimited word of each title."""
+        return [(t.split(None, 1) or [""])[0] for t in self.titles()]
+
+    def sequences(self):
+        off = self.offsets()
+        raw = ctypes.string_at(self._bases, self.total_bases) if self.total_bases else b""
+        return [raw[int(off[i]):int(off[i + 1])].decode("latin-1") for i in range(self.n_records)]
+
+    def count(self, ctx, kmer_length, symbols=b"ATGC"):
+        out = np.zeros((self.n_records, 4 ** int(kmer_length)), dtype=np.int64)
+        check(self.lib.phk_count_fasta(ctx.handle, self.handle, int(kmer_length), symbols, ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.phk_fasta_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def get_context(device=None):

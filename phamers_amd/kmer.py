@@ -14,7 +14,6 @@ Scope notes: only 4-symbol alphabets run on the GPU (the reference's
 integer-replacement branch with DNA/RNA); other alphabets raise NotImplementedError --
 there is no CPU fallback in this package.
 """
-import gzip
 import logging
 import os
 
@@ -96,46 +95,49 @@ def count(data, kmer_length, symbols=DNA, normalize=False):
     return kmer_count
 
 
-def read_fasta_records(input_file):
-    """(headers, sequences) of a FASTA file; '.gz' files are read through gzip
-    (scripts/kmer.py:131-135).  The header is the text after '>' up to the first white space
-    (Biopython's record.id)."""
-    opener = gzip.open if input_file.endswith('.gz') else open
-    headers, seqs, cur = [], [], None
-    with opener(input_file, 'rt') as f:
-        for line in f:
-            if line.startswith('>'):
-                if cur is not None:
-                    seqs.append(''.join(cur))
-                fields = line[1:].split()
-                headers.append(fields[0] if fields else '')
-                cur = []
-            elif cur is not None:
-                cur.append(line.strip())
-    if cur is not None:
-        seqs.append(''.join(cur))
-    return headers, seqs
-
-
 def count_file(input_file, kmer_length, symbols=DNA, normalize=False):
     """Counts k-mers of every record of a FASTA file (scripts/kmer.py:114-140).  Returns
     (ids, counts): ids parsed by the reference's header rules (scripts/id_parser.py:89-100),
-    counts (n, 4^k).  An unreadable file gives (None, None)."""
+    counts (n, 4^k).  An unreadable file gives (None, None).  The file is parsed once by the
+    native multi-threaded reader (phk_fasta_read; plain or .gz) and counted on the GPU."""
+    sym = _check_symbols(symbols)
     try:
-        headers, seqs = read_fasta_records(input_file)
+        fasta = _lib.Fasta(input_file)
     except IOError:
         logger.warning("Could not read file: %s" % os.path.basename(input_file))
         return None, None
-    ids = np.array([id_parser.get_id(h) for h in headers])
-    counts = np.zeros((len(ids), pow(len(symbols), kmer_length)), dtype=(int, float)[normalize])
-    if len(seqs):
-        got = _count_batch(seqs, kmer_length, symbols)
-        if normalize:
-            sums = got.sum(axis=1)
-            got = normalize_counts(got)
-            got[sums == 0] = 0.0
-        counts[:, :] = got
+    try:
+        ids = np.array([id_parser.get_id(h) for h in fasta.ids()])
+        counts = np.zeros((len(ids), pow(len(symbols), kmer_length)), dtype=(int, float)[normalize])
+        if fasta.n_records:
+            got = fasta.count(_lib.get_context(), kmer_length, sym)
+            if normalize:
+                sums = got.sum(axis=1)
+                got = normalize_counts(got)
+                got[sums == 0] = 0.0
+            counts[:, :] = got
+    finally:
+        fasta.close()
     return ids, counts
+
+
+def read_fasta(fasta_file):
+    """(ids, sequences) of a FASTA file (scripts/fileIO.py:28-42), through the native reader."""
+    fasta = _lib.Fasta(fasta_file)
+    try:
+        return np.array([id_parser.get_id(h) for h in fasta.ids()]), fasta.sequences()
+    finally:
+        fasta.close()
+
+
+def fasta_lengths(fasta_file):
+    """(ids, sequence lengths): what phamer_scorer.screen_by_length needs (scripts/phamer.py:144-157)
+    without materialising the sequences as Python strings."""
+    fasta = _lib.Fasta(fasta_file)
+    try:
+        return np.array([id_parser.get_id(h) for h in fasta.ids()]), fasta.lengths()
+    finally:
+        fasta.close()
 
 
 def normalize_counts(counts):

@@ -11,11 +11,14 @@ fit that yields the centroids is scikit-learn's, as in the reference.  Methods o
 {knn, kmeans, combo} raise NotImplementedError (dbscan / svm / density / silhouette are
 out of the accelerated path).
 """
+import argparse
 import logging
+import os
 
 import numpy as np
 
 from . import _lib
+from . import fileIO
 from . import kmer
 from . import learning
 
@@ -27,6 +30,15 @@ logger.setLevel(logging.WARNING)
 class phamer_scorer(object):
 
     def __init__(self):
+        # file locations (scripts/phamer.py:46-57)
+        self.input_directory = None
+        self.features_file = None
+        self.fasta_file = None
+        self.data_directory = None
+        self.positive_features_file = None
+        self.negative_features_file = None
+        self.output_directory = None
+
         # the attributes of the reference object that the hot path reads (scripts/phamer.py:59-79)
         self.data_ids = None
         self.data_points = None
@@ -53,6 +65,72 @@ class phamer_scorer(object):
         # centroids of the last kmeans / combo call (captured for inspection and tests)
         self.positive_centroids = None
         self.negative_centroids = None
+
+    # ---- files either side of the path (scripts/phamer.py:103-157, 316-323, 406-440) ------------
+    def find_data_files(self):
+        """Reference feature files at their default place under the data directory
+        (scripts/phamer.py:406-415)."""
+        self.positive_features_file = os.path.join(self.data_directory, "reference_features", "positive_features.csv")
+        self.negative_features_file = os.path.join(self.data_directory, "reference_features", "negative_features.csv")
+
+    def find_input_files(self):
+        """The lone *.fasta|*.fa (not '*genes') and the lone *.csv of the input directory
+        (scripts/phamer.py:417-436)."""
+        if self.input_directory and os.path.isdir(self.input_directory):
+            fasta_files = [f for f in os.listdir(self.input_directory) if f.endswith('.fasta') or f.endswith('.fa')]
+            if len(fasta_files) == 1:
+                self.fasta_file = os.path.join(self.input_directory, fasta_files[0])
+            elif fasta_files:
+                for candidate in fasta_files:
+                    if not os.path.splitext(candidate)[0].endswith("genes"):
+                        self.fasta_file = os.path.join(self.input_directory, candidate)
+                        break
+                if self.fasta_file is None:
+                    self.fasta_file = os.path.join(self.input_directory, fasta_files[0])
+            features_files = [f for f in os.listdir(self.input_directory) if f.endswith('.csv')]
+            if len(features_files) == 1:
+                self.features_file = os.path.join(self.input_directory, features_files[0])
+
+    def load_data(self, length_requirement=True):
+        """Reference matrices (normalised) + query features: a cached features CSV if the input
+        directory has one, else count the FASTA on the GPU and write the cache next to it
+        (scripts/phamer.py:103-142).  ``length_requirement`` truthy applies the length screen, which --
+        as in the reference -- always uses self.length_requirement (5000), not the CLI value."""
+        self.positive_ids, self.positive_data = fileIO.read_feature_file(self.positive_features_file, normalize=True)
+        self.negative_ids, self.negative_data = fileIO.read_feature_file(self.negative_features_file, normalize=True)
+        self.find_input_files()
+        if self.features_file is not None and os.path.exists(self.features_file):
+            logger.info("Reading features from: %s..." % os.path.basename(self.features_file))
+            self.data_ids, self.data_points = fileIO.read_feature_file(self.features_file)
+        elif self.fasta_file is not None and os.path.exists(self.fasta_file):
+            logger.info("Calculating features of: %s" % os.path.basename(self.fasta_file))
+            self.data_ids, self.data_points = kmer.count_file(self.fasta_file, self.kmer_length, normalize=False)
+            self.features_file = "{base}_features.csv".format(base=os.path.splitext(self.fasta_file)[0])
+            fileIO.save_counts(self.data_points, self.data_ids, self.features_file)
+        else:
+            raise SystemExit("No input fasta file or features file. Exiting...")
+        self.data_points = kmer.normalize_counts(self.data_points)
+        if length_requirement:
+            self.screen_by_length()
+
+    def screen_by_length(self, length_requirement=None):
+        """Keep contigs with at least ``length_requirement`` bases (scripts/phamer.py:144-157)."""
+        if length_requirement:
+            self.length_requirement = length_requirement
+        if self.fasta_file is None or not os.path.exists(self.fasta_file):
+            return
+        unknown_ids, lengths = kmer.fasta_lengths(self.fasta_file)
+        long_ids = [unknown_ids[i] for i in range(len(unknown_ids)) if lengths[i] >= self.length_requirement]
+        self.data_points = self.data_points[np.in1d(self.data_ids, long_ids)]
+        self.data_ids = np.array(long_ids)
+
+    def get_phamer_output_filename(self):
+        return os.path.join(self.output_directory, "phamer_scores.csv")
+
+    def make_summary_file(self, args=None):
+        """Write phamer_scores.csv (scripts/phamer.py:316-323)."""
+        self.phamer_output_filename = self.get_phamer_output_filename()
+        fileIO.save_phamer_scores(self.data_ids, self.scores, self.phamer_output_filename, args=args)
 
     def _outside_path(self):
         raise NotImplementedError("scoring method %r is outside the accelerated path; "
@@ -140,3 +218,59 @@ def score_contigs(sequences, positive_training_data, negative_training_data, kme
     counts = kmer.count(list(sequences), kmer_length)
     counts = counts.reshape(-1, 4 ** kmer_length)
     return score_points(kmer.normalize_counts(counts), positive_training_data, negative_training_data, method)
+
+
+def main(argv=None):
+    """Command-line driver with the reference's flags for this path (scripts/phamer.py:512-598):
+        python -m phamers_amd.phamer -in <input_dir> -data <data_dir> [--equalize_reference]
+    Counting, normalising and scoring run on the GPU; the scores go to
+    <input_dir>/phamer_output/phamer_scores.csv (or -out).  As in the reference the scoring method
+    is always 'combo' (--method is parsed but never applied there)."""
+    parser = argparse.ArgumentParser(description='This script scores contigs based on feature similarity',
+                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument('-in', '--input_directory', help='Directory containing input files')
+    parser.add_argument('-fasta', '--fasta_file', help='Fasta compilation file of unknown sequences')
+    parser.add_argument('-features', '--features_file', help='Input feature file')
+    parser.add_argument('-data', '--data_directory', help='Directory containing reference_features/')
+    parser.add_argument('-pf', '--positive_features', help='Positive reference features CSV')
+    parser.add_argument('-nf', '--negative_features', help='Negative reference features CSV')
+    parser.add_argument('-out', '--output_directory', help='Output directory path')
+    parser.add_argument('-k', '--kmer_length', type=int, default=4, help='k-mer length')
+    parser.add_argument('-l', '--length_requirement', type=int, default=5000, help='Input sequence length requirement')
+    parser.add_argument('-e', '--equalize_reference', action='store_true', help='Same number of reference points')
+    parser.add_argument('-v', '--verbose', action='store_true')
+    parser.add_argument('--debug', action='store_true')
+    args = parser.parse_args(argv)
+    logger.setLevel(logging.DEBUG if args.debug else logging.INFO if args.verbose else logging.WARNING)
+
+    scorer = phamer_scorer()
+    scorer.kmer_length = args.kmer_length
+    scorer.input_directory = args.input_directory
+    scorer.fasta_file = args.fasta_file
+    scorer.features_file = args.features_file
+    if args.data_directory:
+        scorer.data_directory = args.data_directory
+        scorer.find_data_files()
+    if args.positive_features:
+        scorer.positive_features_file = args.positive_features
+    if args.negative_features:
+        scorer.negative_features_file = args.negative_features
+    if not (scorer.positive_features_file and scorer.negative_features_file):
+        parser.error("give -data <dir with reference_features/> or -pf and -nf")
+    if args.output_directory:
+        scorer.output_directory = args.output_directory
+    else:
+        base = args.input_directory or os.path.dirname(args.fasta_file or args.features_file or '.')
+        scorer.output_directory = os.path.join(base, "phamer_output")
+    scorer.load_data(length_requirement=args.length_requirement)
+    if args.equalize_reference:
+        scorer.equalize_reference_data()
+    if not os.path.isdir(scorer.output_directory):
+        os.makedirs(scorer.output_directory)
+    scorer.score_points()
+    scorer.make_summary_file(args=args)
+    return scorer
+
+
+if __name__ == '__main__':
+    main()

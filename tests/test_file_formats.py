@@ -1,0 +1,168 @@
+"""On-disk formats (features CSV, phamer_scores.csv) against files written by the reference's own
+writer functions (tests/golden/files.json), byte for byte.  The native FASTA reader against a plain
+statement of Bio.SeqIO's FASTA record rules.  CPU-only except where marked."""
+import argparse
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+
+def test_writers_are_byte_compatible(tmp_path):
+    from phamers_amd import fileIO
+    doc = helpers.load_json("files.json")
+    arr = helpers.load_npz("files.npz")
+    ids = np.array(doc["ids"])
+    args = argparse.Namespace(**{k: doc["args"][k] for k in
+                                 ("input_file", "kmer_length", "output_file", "symbols", "verbose", "sample",
+                                  "file_identifier", "debug")})
+    out = {}
+    fileIO.save_counts(arr["counts"], ids, str(tmp_path / "f_noargs.csv"))
+    fileIO.save_counts(arr["counts"], ids, str(tmp_path / "f_args.csv"), args=args)
+    fileIO.save_phamer_scores(ids, arr["scores"], str(tmp_path / "s_noargs.csv"))
+    fileIO.save_phamer_scores(ids, arr["scores"], str(tmp_path / "s_args.csv"), args=args)
+    for name, want in doc["files"].items():
+        out[name] = open(tmp_path / name).read()
+        assert out[name] == want, name
+    got = fileIO.read_phamer_output(str(tmp_path / "s_args.csv"))
+    assert got == doc["scores_read_back"]
+
+
+def test_generate_summary_text():
+    from phamers_amd import fileIO
+    doc = helpers.load_json("files.json")
+    args = argparse.Namespace(**{k: doc["args"][k] for k in
+                                 ("input_file", "kmer_length", "output_file", "symbols", "verbose", "sample",
+                                  "file_identifier", "debug")})
+    text = fileIO.generate_summary(args, header="K-mer count file")
+    want_header = "".join(line[2:] if line.startswith("# ") else line[1:]
+                          for line in doc["files"]["f_args.csv"].splitlines(keepends=True) if line.startswith("#"))
+    assert text == want_header.rstrip("\n") or text.rstrip("\n") == want_header.rstrip("\n")
+    assert fileIO.generate_summary(None) == ""
+
+
+def _seqio_like(text):
+    """Bio.SeqIO FASTA record rules restated: skip text before the first '>' line; title = line[1:]
+    right-stripped; id = first word; sequence = following lines right-stripped, joined, ' ' and '\\r'
+    removed."""
+    titles, seqs, cur = [], [], None
+    for line in text.split("\n"):
+        if line.startswith(">"):
+            if cur is not None:
+                seqs.append("".join(cur).replace(" ", "").replace("\r", ""))
+            titles.append(line[1:].rstrip())
+            cur = []
+        elif cur is not None:
+            cur.append(line.rstrip())
+    if cur is not None:
+        seqs.append("".join(cur).replace(" ", "").replace("\r", ""))
+    return titles, seqs
+
+
+FASTA_TEXT = ("leading junk\n>SuperContig_1_length_12_ID_7 extra words \nATGC ATGC\r\nNNatgc  \n\n"
+              ">gi|1|ref|NC_000001.1| phage\nGGGG\nCC\n>empty\n>CP000084.1 Candidatus\nACGTNNNN\nTT\tA\n>last_ID_9\nA")
+
+
+@pytest.mark.parametrize("threads", [1, 3, 0])
+def test_native_fasta_reader_matches_seqio_rules(tmp_path, threads):
+    from phamers_amd import _lib
+    from phamers_amd import synth
+    text = FASTA_TEXT
+    for c in range(40):   # multi-line records of ragged width
+        s = synth.synth_contig(5, c, 100 + 37 * c, invalid_ppm=20000)
+        w = 7 + c % 60
+        text += "\n>" + synth.contig_header(c, len(s)) + "\n" + "\n".join(s[i:i + w] for i in range(0, len(s), w))
+    p = tmp_path / "a.fasta"
+    p.write_text(text)
+    want_titles, want_seqs = _seqio_like(text)
+    for path in (str(p), str(p) + ".gz"):
+        if path.endswith(".gz"):
+            with gzip.open(path, "wt") as g:
+                g.write(text)
+        f = _lib.Fasta(path, threads=threads)
+        assert f.n_records == len(want_titles)
+        assert f.titles() == want_titles
+        assert f.sequences() == want_seqs
+        assert f.ids() == [(t.split(None, 1) or [""])[0] for t in want_titles]
+        assert f.lengths().tolist() == [len(s) for s in want_seqs]
+        f.close()
+    with pytest.raises(IOError):
+        _lib.Fasta(str(tmp_path / "missing.fa"))
+    empty = tmp_path / "empty.fa"
+    empty.write_text("")
+    f = _lib.Fasta(str(empty))
+    assert f.n_records == 0 and f.sequences() == []
+
+
+@pytest.mark.gpu
+def test_count_file_and_feature_file_round_trip(tmp_path):
+    """kmer.count_file on plain and gzip FASTA (ids by the reference's header rules), the soft IOError
+    failure, and the features-CSV cache round trip (save_counts -> read_feature_file)."""
+    from oracle import oracle
+    from phamers_amd import fileIO, kmer, synth
+    seqs = [synth.synth_contig(6, c, 5000 if c % 3 else 777, invalid_ppm=5000) for c in range(25)]
+    text = "".join(">%s\n%s\n" % (synth.contig_header(c, len(s)), "\n".join(s[i:i + 60] for i in range(0, len(s), 60)))
+                   for c, s in enumerate(seqs))
+    p = tmp_path / "contigs.fasta"
+    p.write_text(text)
+    with gzip.open(str(p) + ".gz", "wt") as g:
+        g.write(text)
+    want = oracle.count(seqs, 4)
+    for path in (str(p), str(p) + ".gz"):
+        ids, counts = kmer.count_file(path, 4)
+        assert ids.tolist() == [str(c) for c in range(25)]
+        assert counts.dtype == np.int64 and np.array_equal(counts, want)
+    ids, freq = kmer.count_file(str(p), 4, normalize=True)
+    assert np.array_equal(freq, oracle.normalize_counts(want))
+    assert kmer.count_file(str(tmp_path / "nope.fasta"), 4) == (None, None)
+    rid, lens = kmer.fasta_lengths(str(p))
+    assert lens.tolist() == [len(s) for s in seqs]
+    cache = tmp_path / "contigs_features.csv"
+    fileIO.save_counts(counts, ids, str(cache))
+    rid, rcounts = fileIO.read_feature_file(str(cache))
+    assert rid.tolist() == ids.tolist() and np.array_equal(rcounts, counts)
+    rid, rnorm = fileIO.read_feature_file(str(cache), normalize=True)
+    assert np.array_equal(rnorm, oracle.normalize_counts(want))
+
+
+@pytest.mark.gpu
+def test_config0_cli_end_to_end(tmp_path):
+    """BASELINE configs[0]: 100 synthetic 5 kb contigs through the phamer.py command line (input
+    directory with one FASTA, data directory with reference_features/, --equalize_reference); the
+    written phamer_scores.csv is compared with the reference's scores for the same contigs."""
+    from phamers_amd import fileIO, phamer, synth
+    g = helpers.load_npz("scoring_k4.npz")
+    ref = helpers.load_npz("ref_features.npz")
+    indir, data = tmp_path / "input", tmp_path / "data" / "reference_features"
+    indir.mkdir()
+    data.mkdir(parents=True)
+    fileIO.save_counts(ref["pos_counts"], ref["pos_ids"], str(data / "positive_features.csv"))
+    fileIO.save_counts(ref["neg_counts"], ref["neg_ids"], str(data / "negative_features.csv"))
+    with open(indir / "contigs.fasta", "w") as f:
+        for c in range(100):
+            s = synth.synth_contig(0, c, 5000)
+            f.write(">%s\n" % synth.contig_header(c, 5000))
+            f.write("\n".join(s[i:i + 70] for i in range(0, 5000, 70)) + "\n")
+        f.write(">%s\nATGCATGCATGC\n" % synth.contig_header(100, 12))     # screened out: shorter than 5000
+    scorer = phamer.main(["-in", str(indir), "-data", str(tmp_path / "data"), "--equalize_reference"])
+    out = indir / "phamer_output" / "phamer_scores.csv"
+    assert out.exists() and (indir / "contigs_features.csv").exists()      # scores + features cache
+    got = fileIO.read_phamer_output(str(out))
+    assert sorted(got, key=int) == [str(c) for c in range(100)]
+    scores = np.array([got[str(c)] for c in range(100)])
+    if np.allclose(scorer.positive_centroids, g["cpos_eq"], rtol=0, atol=1e-15):
+        assert helpers.rel_err(scores, g["combo_eq"]) < 1e-6
+    else:   # another scikit-learn build on this box: compare with the oracle on this run's centroids
+        from oracle import oracle
+        want = oracle.score_points(g["q"], scorer.positive_data, scorer.negative_data, "combo", 3,
+                                   scorer.positive_centroids, scorer.negative_centroids)
+        assert helpers.rel_err(scores, want) < 1e-6
+    assert np.array_equal(np.sign(scores), np.sign(g["combo_eq"]))
+    # second run picks up the features cache (counting skipped) and gives the same file
+    first = out.read_text()
+    phamer.main(["-in", str(indir), "-data", str(tmp_path / "data"), "--equalize_reference", "-l", "0"])
+    assert fileIO.read_phamer_output(str(out)).keys() >= got.keys()
+    assert first.split("\n# \n")[-1].splitlines()[:100] == out.read_text().split("\n# \n")[-1].splitlines()[:100]

@@ -83,8 +83,11 @@ def load_reference(ref):
                        ['kmeans_seed', 'distances', 'closest_to', 'get_centroids', 'knn', 'kmeans'],
                        learn_ns)
 
-    fio_ns = {'np': np, 'xrange': range, 'logger': quiet, 'kmer': kmer}
-    fileIO = extract(os.path.join(scripts, 'fileIO.py'), ['read_feature_file'], fio_ns)
+    basic = extract(os.path.join(scripts, 'basic.py'), ['generate_summary'], {'np': np, 'xrange': range})
+    id_parser = extract(os.path.join(scripts, 'id_parser.py'), ['get_contig_id'], {'logger': quiet})
+    fio_ns = {'np': np, 'xrange': range, 'logger': quiet, 'kmer': kmer, 'basic': basic, 'id_parser': id_parser}
+    fileIO = extract(os.path.join(scripts, 'fileIO.py'),
+                     ['read_feature_file', 'save_counts', 'save_phamer_scores', 'read_phamer_output'], fio_ns)
 
     ph_ns = {'np': np, 'xrange': range, 'logger': quiet, 'os': os, 'kmer': kmer,
              'learning': learning, 'fileIO': fileIO,
@@ -276,6 +279,34 @@ def gen_scoring_highdim(kmer, learning, phamer, out):
     np.savez_compressed(os.path.join(out, 'scoring_highdim.npz'), **arrays)
 
 
+def gen_files(kmer, fileIO, out):
+    """On-disk formats either side of the path, written by the reference's own writer functions
+    (scripts/fileIO.py:169-181, 241-253; header text from scripts/basic.py:22-37).  The produced
+    files are stored byte for byte (they are outputs, i.e. data)."""
+    import tempfile
+    g = np.load(os.path.join(out, 'scoring_k4.npz'))
+    ids = np.array([str(i) for i in range(8)])
+    counts = g['q_counts'][:8]
+    scores = g['combo_eq'][:8]
+    args = argparse.Namespace(input_file='contigs.fasta', kmer_length=4, output_file='contigs_4mers.csv',
+                              symbols='ATGC', verbose=True, sample=None, file_identifier='.fna', debug=False)
+    d = tempfile.mkdtemp()
+    files = {}
+    fileIO.save_counts(counts, ids, os.path.join(d, 'f_noargs.csv'))
+    fileIO.save_counts(counts, ids, os.path.join(d, 'f_args.csv'), args=args)
+    fileIO.save_phamer_scores(ids, scores, os.path.join(d, 's_noargs.csv'))
+    fileIO.save_phamer_scores(ids, scores, os.path.join(d, 's_args.csv'), args=args)
+    for name in ('f_noargs.csv', 'f_args.csv', 's_noargs.csv', 's_args.csv'):
+        files[name] = open(os.path.join(d, name)).read()
+    rid, rcounts = fileIO.read_feature_file(os.path.join(d, 'f_args.csv'))
+    rid2, rnorm = fileIO.read_feature_file(os.path.join(d, 'f_args.csv'), normalize=True)
+    sd = fileIO.read_phamer_output(os.path.join(d, 's_args.csv'))
+    json.dump({'files': files, 'ids': ids.tolist(), 'scores_read_back': {k: sd[k] for k in sorted(sd)},
+               'args': vars(args)}, open(os.path.join(out, 'files.json'), 'w'), indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(out, 'files.npz'), counts=counts, scores=scores, read_counts=rcounts,
+                        read_ids=np.array(rid, dtype='U16'), read_norm=rnorm)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -289,6 +320,7 @@ def main():
     pc, nc = gen_reference_features(fileIO, args.ref, args.out)
     gen_scoring(kmer, learning, phamer, pc, nc, args.out)
     gen_scoring_highdim(kmer, learning, phamer, args.out)
+    gen_files(kmer, fileIO, args.out)
     json.dump({'generator': 'tools/gen_golden.py', 'python': sys.version.split()[0],
                'numpy': np.__version__, 'scikit-learn': skl, 'count_arrays': n,
                'reference_functions': 'executed from the reference text via ast extraction; '
