@@ -257,14 +257,27 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
         const half8 *fr = reinterpret_cast<const half8 *>(buf) + lane;
+        // fragments are read one k-step ahead of their MFMAs (LDS latency ~ one step of MFMA time);
+        // the issue order per step is pinned: 2 LDS reads, then MFMA / insertion-VALU interleaved
+        half8 ahn = fr[0], aln = fr[64];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const half8 ah = fr[(2 * s) * 64];
-            const half8 al = fr[(2 * s + 1) * 64];
+            const half8 ah = ahn, al = aln;
+            if (s < 15) {
+                ahn = fr[(2 * s + 2) * 64];
+                aln = fr[(2 * s + 3) * 64];
+            }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc, 0, 0, 0);
             list_insert(lv, li, ldrop, xs[s], cbase + (uint32_t)((s & 3) + 8 * (s >> 2)));
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read (next step)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // VALU (insertion)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
         }
         if (blk > 0) flush_if_segment_end(blk - 1);
         // D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h'; add its norm term

@@ -554,6 +554,229 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
 }
 
 // ------------------------------------------------------------------------------------
+// 2b. the same decision stage for D = 256 with FOUR queries per wavefront (16 lanes each, 16
+//     dimensions per lane).  The one-wave-per-query kernel above is latency bound (a chain of ~6
+//     dependent memory round trips per query); packing 4 queries into a wave quarters the number of
+//     such chains per SIMD.  Control flow is uniform per wave: a group that does not need a step
+//     runs it predicated on safe addresses.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ double group16_sum(double x) {
+    x += __shfl_xor(x, 8);
+    x += __shfl_xor(x, 4);
+    x += __shfl_xor(x, 2);
+    x += __shfl_xor(x, 1);
+    return x;
+}
+
+__device__ __forceinline__ double exact_d2_g16(const double (&qd)[16], const double *row, int t) {
+    const double2 *r = reinterpret_cast<const double2 *>(row + 16 * t);
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double2 v = r[i];
+        const double d0 = qd[2 * i] - v.x, d1 = qd[2 * i + 1] - v.y;
+        acc = fma(d0, d0, fma(d1, d1, acc));
+    }
+    return group16_sum(acc);
+}
+
+// per-group version of resolve_segment; `live` = this group still needs an answer.  Returns ok.
+__device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
+                                    const double (&qd)[16], double nqp2, const ErrBound &eb, const double *rows,
+                                    const double *colnorm, bool want_d2, bool live, int lane, uint32_t (&out_idx)[3],
+                                    double &out_d2) {
+    const int t = lane & 15, base = lane & 48;
+    float v = -3.0e38f;
+    uint32_t ix = 0xFFFFFFFFu;
+    if (t < 8) {
+        const uint64_t o = (q * NSEG + seg) * 2 + (t >> 2);
+        const float4 cv = p.cand_v[o];
+        const uint4 ci = p.cand_i[o];
+        const int s = t & 3;
+        v = s == 0 ? cv.x : s == 1 ? cv.y : s == 2 ? cv.z : cv.w;
+        ix = s == 0 ? ci.x : s == 1 ? ci.y : s == 2 ? ci.z : ci.w;
+        if (ix >= ncols) v = -3.0e38f;
+    }
+    const double vs = p.vscale;
+    const uint64_t ou = (q * NSEG + seg) * 2;
+    const double U = fmax((double)p.cand_u[ou], (double)p.cand_u[ou + 1]) * vs;
+    // rank among the group's 8 candidates, then values / indices by rank
+    int rank = 0;
+    float cvv[8];
+    uint32_t cix[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        cvv[m] = __shfl(v, base + m);
+        cix[m] = __shfl(ix, base + m);
+        rank += (t < 8 && (cvv[m] > v || (cvv[m] == v && m < t))) ? 1 : 0;
+    }
+    float rv[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    uint32_t ri[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int rm = __shfl(rank, base + m);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rv[r] = rm == r ? cvv[m] : rv[r];
+            ri[r] = rm == r ? cix[m] : ri[r];
+        }
+    }
+    const double nqp = sqrt(nqp2);
+    const double eps_g = eb(p.rmax);
+    bool certified = false;
+    if (ri[need - 1] < ncols) {
+        const double d2up = fmax(nqp2 - 2.0 * ((double)rv[need - 1] * vs - eps_g), 0.0);
+        const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
+        bool near = true;
+        for (int r = 0; r < need; ++r) near = near && colnorm[ri[r]] <= R0;
+        const double eps_m = near ? eb(R0) : eps_g;
+        certified = ((double)rv[need - 1] - (double)rv[need]) * vs > 2.0 * eps_m;
+    }
+    bool ok = certified;
+    double best[3] = {INFINITY, INFINITY, INFINITY};
+    uint32_t bidx[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const bool need_exact = live && !certified;
+    if (__any(need_exact)) {  // wave-uniform: some group must decide by exact float64 distances
+        if (need_exact && t == 0) atomicAdd(p.fb_count + 1, 1u);
+#pragma unroll 1
+        for (int m = 0; m < 8; ++m) {
+            const uint32_t c = cix[m];
+            const bool valid = need_exact && c < ncols;
+            const double d2 = exact_d2_g16(qd, rows + (uint64_t)(valid ? c : 0u) * FAST_D, t);
+            if (valid && (d2 < best[2] || (d2 == best[2] && c < bidx[2]))) {
+                best[2] = d2; bidx[2] = c;
+                if (best[2] < best[1] || (best[2] == best[1] && bidx[2] < bidx[1])) {
+                    double td = best[1]; best[1] = best[2]; best[2] = td;
+                    uint32_t ti = bidx[1]; bidx[1] = bidx[2]; bidx[2] = ti;
+                    if (best[1] < best[0] || (best[1] == best[0] && bidx[1] < bidx[0])) {
+                        td = best[0]; best[0] = best[1]; best[1] = td;
+                        ti = bidx[0]; bidx[0] = bidx[1]; bidx[1] = ti;
+                    }
+                }
+            }
+        }
+        if (need_exact) {
+            ok = false;
+            if (bidx[need - 1] != 0xFFFFFFFFu) {
+                const double R0x = fmin(p.rmax, (nqp + sqrt(best[need - 1])) * (1.0 + 1e-6));
+                const double tv = 0.5 * (nqp2 - best[need - 1]);
+                ok = tv > U + eb(R0x);
+            }
+        }
+    }
+    if (certified) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) out_idx[r] = ri[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) out_idx[r] = bidx[r];
+    }
+    if (want_d2) {  // distance to the best column (centroid segments): one exact evaluation when certified
+        const uint32_t c0 = certified ? ri[0] : 0u;
+        const double d2c = exact_d2_g16(qd, rows + (uint64_t)(c0 < ncols ? c0 : 0u) * FAST_D, t);
+        out_d2 = certified ? d2c : best[0];
+    }
+    return ok;
+}
+
+template <int SRC>
+__global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restrict__ src, RerankParams p) {
+    const int lane = threadIdx.x & 63, t = lane & 15;
+    const uint64_t qraw = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
+    if ((qraw & ~3ull) >= p.N) return;  // whole wave past the end
+    const bool inrange = qraw < p.N;
+    const uint64_t q = inrange ? qraw : p.N - 1;
+    double qd[16];
+    bool nan_row = false;
+    if (SRC == 0) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
+        uint4 c[4];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            c[i] = row[i];
+            sum += c[i].x + c[i].y + c[i].z + c[i].w;
+        }
+        sum += __shfl_xor(sum, 8);
+        sum += __shfl_xor(sum, 4);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 1);
+        nan_row = sum == 0;
+        const double ds = (double)sum;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qd[4 * i + 0] = (double)c[i].x / ds;
+            qd[4 * i + 1] = (double)c[i].y / ds;
+            qd[4 * i + 2] = (double)c[i].z / ds;
+            qd[4 * i + 3] = (double)c[i].w / ds;
+        }
+    } else {
+        const double2 *row = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D + 16 * t);
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double2 v = row[i];
+            qd[2 * i] = v.x;
+            qd[2 * i + 1] = v.y;
+            bad |= v.x != v.x || v.y != v.y;
+        }
+        // any NaN in the group's row
+        unsigned b = bad ? 1u : 0u;
+        b |= __shfl_xor(b, 8); b |= __shfl_xor(b, 4); b |= __shfl_xor(b, 2); b |= __shfl_xor(b, 1);
+        nan_row = b != 0;
+    }
+    double aq = 0.0, ap = 0.0;
+    {
+        const double2 *mp = reinterpret_cast<const double2 *>(p.mu64 + 16 * t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double2 m = mp[i];
+            const double c0 = qd[2 * i] - m.x, c1 = qd[2 * i + 1] - m.y;
+            aq = fma(qd[2 * i], qd[2 * i], fma(qd[2 * i + 1], qd[2 * i + 1], aq));
+            ap = fma(c0, c0, fma(c1, c1, ap));
+        }
+    }
+    const double nq2 = group16_sum(aq), nqp2 = group16_sum(ap);
+    ErrBound eb;
+    eb.A = sqrt(nq2) + p.mu_norm;
+    eb.P = sqrt(nqp2);
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs;
+
+    bool live = inrange && !nan_row;   // NaN rows: every comparison below is false; they are answered separately
+    bool ok = true;
+    double knn = 0.0, cen = 0.0;
+    uint32_t idx[3];
+    double d2 = 0.0;
+    if (p.method & PHK_METHOD_KNN) {
+        ok = resolve_segment_g16(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, p.R64, p.colnorm, false, live, lane, idx, d2);
+        int votes = 0;
+        for (int r = 0; r < p.kn; ++r) votes += (idx[r] < p.M && p.labels[idx[r]]) ? 1 : 0;
+        knn = (2 * votes > p.kn) ? 1.0 : -1.0;
+    }
+    if (p.method & PHK_METHOD_KMEANS) {
+        double dp2 = 0.0, dn2 = 0.0;
+        const bool ok1 = resolve_segment_g16(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, p.C64, p.colnorm + p.M, true,
+                                             live && ok, lane, idx, dp2);
+        const bool ok2 = resolve_segment_g16(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, p.C64 + p.n_cpos * FAST_D,
+                                             p.colnorm + p.M + p.n_cpos, true, live && ok && ok1, lane, idx, dn2);
+        ok = ok && ok1 && ok2;
+        const double ep = sqrt(dp2), en = sqrt(dn2);
+        cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
+    }
+    if (t == 0 && inrange) {
+        if (nan_row) {  // zero-count contig: the reference's normalised row is NaN
+            p.scores[p.q_base + q] = __builtin_nan("");
+            if (p.status) atomicAdd(p.status, 1u);
+        } else if (ok) {
+            p.scores[p.q_base + q] = knn + cen;  // scripts/phamer.py:313
+        } else {
+            const uint32_t slot = atomicAdd(p.fb_count, 1u);
+            p.fb_list[slot] = (uint32_t)q;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // 3. exact brute force for queued queries.  Work item = (queued query, column chunk): a block
 //    computes the direct-difference float64 distances of its chunk (one thread per column), then
 //    reduces them to a partial record (3 nearest train columns of the chunk + nearest positive /
@@ -696,9 +919,16 @@ __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p)
 template <int SRC>
 static int launch_rerank(phk_ctx *ctx, unsigned blocks, const void *src, const RerankParams &p) {
     switch (p.D) {
-        case 256:
-            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 1><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+        case 256: {
+            const char *rr = getenv("PHK_RERANK");
+            if (rr && rr[0] == 'w') {  // one wave per query (the general kernel), for A/B comparison
+                PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 1><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+            } else {                   // four queries per wave
+                PHK_LAUNCH(ctx, "phk_rerank16_kernel",
+                           phk_rerank16_kernel<SRC><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p));
+            }
             break;
+        }
         case 512:
             PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 2><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
             break;

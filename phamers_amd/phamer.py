@@ -121,7 +121,7 @@ class phamer_scorer(object):
             return
         unknown_ids, lengths = kmer.fasta_lengths(self.fasta_file)
         long_ids = [unknown_ids[i] for i in range(len(unknown_ids)) if lengths[i] >= self.length_requirement]
-        self.data_points = self.data_points[np.in1d(self.data_ids, long_ids)]
+        self.data_points = self.data_points[np.isin(self.data_ids, long_ids)]
         self.data_ids = np.array(long_ids)
 
     def get_phamer_output_filename(self):
