@@ -96,6 +96,12 @@ int phk_normalize_i64(phk_ctx *ctx, const int64_t *counts, uint64_t n, uint64_t 
 /* same for an already-float matrix (row sum taken left to right in float64) */
 int phk_normalize_f64(phk_ctx *ctx, const double *rows, uint64_t n, uint64_t D, double *out);
 
+/* transform_kmers.transform_kmers (scripts/transform_kmers.py:68-88): out[r][j] = rows[r][perm[j]]; the
+ * reverse / complement / reverse-complement count vectors are column permutations (perm built by the
+ * host facade). */
+int phk_permute_columns_i64(phk_ctx *ctx, const int64_t *rows, uint64_t n, uint64_t D, const uint32_t *perm,
+                            int64_t *out);
+
 /* ---- host API: FASTA ingest --------------------------------------------------------- */
 /* One multi-threaded pass over a FASTA file (plain, or gzip when the name ends in ".gz") replacing
  * the Biopython passes of kmer.count_file (scripts/kmer.py:124-140) and fileIO.read_fasta /

@@ -38,6 +38,7 @@ SIGNATURES = {
     "phk_count_ascii": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_char_p, c_void_p]),
     "phk_normalize_i64": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p]),
     "phk_normalize_f64": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p]),
+    "phk_permute_columns_i64": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p, c_void_p]),
     "phk_fasta_read": (c_int, [c_char_p, c_int, P(c_void_p)]),
     "phk_fasta_shape": (c_int, [c_void_p, P(c_u64), P(c_u64), P(c_u64)]),
     "phk_fasta_data": (c_int, [c_void_p, P(c_void_p), P(c_void_p), P(c_void_p), P(c_void_p)]),

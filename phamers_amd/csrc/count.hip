@@ -524,3 +524,27 @@ int phk_launch_normalize_f64(phk_ctx *ctx, const double *d_rows, uint64_t n, uin
                    d_rows, n, D, d_out));
     return PHK_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// column gather: out[r][j] = in[r][perm[j]]  (reverse / complement / reverse-complement count vectors,
+// scripts/transform_kmers.py:68-88)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void phk_permute_columns_kernel(const int64_t *__restrict__ in, uint64_t n, uint64_t D,
+                                                                  const uint32_t *__restrict__ perm,
+                                                                  int64_t *__restrict__ out) {
+    const uint64_t total = n * D;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / D, j = i % D;
+        out[i] = in[r * D + perm[j]];
+    }
+}
+
+int phk_launch_permute_columns(phk_ctx *ctx, const int64_t *d_in, uint64_t n, uint64_t D, const uint32_t *d_perm,
+                               int64_t *d_out) {
+    if (n == 0 || D == 0) return PHK_OK;
+    uint64_t blocks = phk_div_up(n * D, 256);
+    if (blocks > (uint64_t)ctx->num_cus * 16) blocks = (uint64_t)ctx->num_cus * 16;
+    PHK_LAUNCH(ctx, "phk_permute_columns_kernel",
+               phk_permute_columns_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(d_in, n, D, d_perm, d_out));
+    return PHK_OK;
+}

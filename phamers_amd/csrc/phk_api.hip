@@ -291,6 +291,25 @@ extern "C" int phk_normalize_f64(phk_ctx *ctx, const double *rows, uint64_t n, u
     return PHK_OK;
 }
 
+extern "C" int phk_permute_columns_i64(phk_ctx *ctx, const int64_t *rows, uint64_t n, uint64_t D, const uint32_t *perm,
+                                       int64_t *out) {
+    PHK_REQUIRE(ctx, "phk_permute_columns_i64: NULL ctx");
+    if (n == 0 || D == 0) return PHK_OK;
+    PHK_REQUIRE(rows && perm && out, "phk_permute_columns_i64: NULL pointer");
+    for (uint64_t j = 0; j < D; ++j) PHK_REQUIRE(perm[j] < D, "phk_permute_columns_i64: perm[%llu] out of range", (unsigned long long)j);
+    PHK_HIP(hipSetDevice(ctx->device));
+    void *d_in, *d_out, *d_perm;
+    PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &d_in));
+    PHK_TRY(phk_ws(ctx, WS_Q64, n * D * 8, &d_out));
+    PHK_TRY(phk_ws(ctx, WS_OFFSETS, D * 4, &d_perm));
+    PHK_HIP(hipMemcpyAsync(d_in, rows, n * D * 8, hipMemcpyHostToDevice, ctx->stream));
+    PHK_HIP(hipMemcpyAsync(d_perm, perm, D * 4, hipMemcpyHostToDevice, ctx->stream));
+    PHK_TRY(phk_launch_permute_columns(ctx, (const int64_t *)d_in, n, D, (const uint32_t *)d_perm, (int64_t *)d_out));
+    PHK_HIP(hipMemcpyAsync(out, d_out, n * D * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    return PHK_OK;
+}
+
 extern "C" int phk_score(phk_ctx *ctx, const phk_model *model, const double *Q, uint64_t N, int method,
                          double *scores) {
     PHK_REQUIRE(ctx && model, "phk_score: NULL ctx/model");

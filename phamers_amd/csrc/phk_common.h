@@ -113,6 +113,8 @@ int phk_launch_normalize_i64(phk_ctx *ctx, const int64_t *d_counts, uint64_t n, 
                              double *d_out);
 int phk_launch_normalize_f64(phk_ctx *ctx, const double *d_rows, uint64_t n, uint64_t D,
                              double *d_out);
+int phk_launch_permute_columns(phk_ctx *ctx, const int64_t *d_in, uint64_t n, uint64_t D, const uint32_t *d_perm,
+                               int64_t *d_out);
 // synth.hip
 int phk_launch_synth(phk_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, uint64_t L,
                      uint32_t invalid_ppm, uint32_t *d_packed, uint32_t *d_mask,

@@ -140,3 +140,19 @@ def test_device_synth_matches_host_generator(ctx):
         assert np.array_equal(d_packed.to_host(), want_packed), (n, L, ppm)
         assert np.array_equal(d_mask.to_host(), want_mask), (n, L, ppm)
         assert np.array_equal(d_off.to_host(), np.arange(n + 1, dtype=np.uint64) * L)
+
+
+def test_transform_kmers_identity(kmer):
+    """counts(reverse / complement / reverse-complement of s) == transform_kmers(counts(s))."""
+    from phamers_amd import synth, transform_kmers
+    comp = str.maketrans("ATGC", "TACG")
+    seqs = [synth.synth_contig(12, i, 300 + 211 * i) for i in range(6)]
+    for k in (2, 4, 5):
+        c = kmer.count(seqs, k)
+        rev = kmer.count([s[::-1] for s in seqs], k)
+        cmp_ = kmer.count([s.translate(comp) for s in seqs], k)
+        rc = kmer.count([s.translate(comp)[::-1] for s in seqs], k)
+        assert np.array_equal(transform_kmers.transform_kmers(c, reverse=True, complement=False), rev)
+        assert np.array_equal(transform_kmers.transform_kmers(c, reverse=False, complement=True), cmp_)
+        assert np.array_equal(transform_kmers.transform_kmers(c, reverse=True, complement=True), rc)
+        assert transform_kmers.transform_kmers(c, reverse=False, complement=False) is c

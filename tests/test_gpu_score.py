@@ -270,3 +270,26 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
     assert helpers.rel_err(got, want) < RTOL
     assert np.array_equal(got, out[("f16", "combo")][:64]) or helpers.rel_err(got, out[("f16", "combo")][:64]) < 1e-12
     model.close()
+
+
+def test_cross_validation_driver_matches_oracle_folds():
+    """cross_validator.cross_validate (the other caller of score_points, scripts/cross_validate.py:57-101):
+    4 folds over a 400+400-row slice of the reference matrices with a fixed seed; every fold's knn
+    scores equal the oracle's for the same fold assignment."""
+    from oracle import oracle
+    from phamers_amd import cross_validate
+    pos, neg = _ref_matrices()
+    pos, neg = pos[:400], neg[:450]
+    v = cross_validate.cross_validator()
+    v.positive_data, v.negative_data = pos, neg
+    v.N, v.method, v.seed, v.equalize_reference = 4, "knn", 3, True
+    ps, ns = v.cross_validate()
+    assert ps.shape == (400,) and ns.shape == (400,) and set(np.unique(np.concatenate((ps, ns)))) <= {-1.0, 1.0}
+    pa, na = v.positive_assignment, v.negative_assignment
+    assert sorted(np.bincount(pa).tolist()) == [100] * 4
+    for n in range(4):
+        wp, wn = pa == n, na == n
+        want = oracle.knn_score_points(np.vstack((v.positive_data[wp], v.negative_data[wn])),
+                                       v.positive_data[~wp], v.negative_data[~wn], 3)
+        assert np.array_equal(np.concatenate((ps[wp], ns[wn])), want)
+    assert ps.mean() > 0 > ns.mean()     # the classifier separates the two reference classes
