@@ -96,18 +96,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    local_dev = local_rank % max(ndev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if args.gpus > 1 or world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL over xGMI in production; PHK_BENCH_BACKEND=gloo only to rehearse the multi-rank code path
+        # with several ranks sharing one GPU (RCCL refuses duplicate devices)
+        backend = os.environ.get("PHK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
 
     from phamers_amd import _lib, device
-    ctx = _lib.Context(local_rank, stream.cuda_stream)
+    ctx = _lib.Context(local_dev, stream.cuda_stream)
     n, L, k = args.contigs, args.length, args.k
     D = 4 ** k
     T = n * L
@@ -127,7 +135,12 @@ def main():
         device.count_score(ctx, model, packed.data_ptr(), None, T, offsets.data_ptr(), n, k, args.method,
                            counts.data_ptr(), scores.data_ptr(), status.data_ptr())
         if dist:
-            dist.all_gather_into_tensor(gathered, scores)   # the only collective: final score gather
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(gathered, scores)   # the only collective: final score gather
+            else:
+                host = scores.cpu()
+                parts = [torch.empty_like(host) for _ in range(world)]
+                dist.all_gather(parts, host)
 
     for _ in range(args.warmup):
         step()
@@ -146,7 +159,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     prof = ctx.profile()
