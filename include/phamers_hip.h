@@ -133,6 +133,15 @@ int phk_model_create(phk_ctx *ctx, const double *pos, uint64_t n_pos, const doub
                      uint64_t n_cneg, uint64_t D, int kn, phk_model **out);
 int phk_model_destroy(phk_ctx *ctx, phk_model *model);
 
+/* Deterministic device k-means (opt-in alternative to the scikit-learn fit of scripts/learning.py:131-146,
+ * whose centroids depend on the scikit-learn version): k-means++ seeding driven by splitmix64(seed + j),
+ * Lloyd sweeps in float64 with index-ordered sums (bit-reproducible), empty clusters re-seeded with the
+ * farthest point; stops when no label changes or after max_iter sweeps.  X[n][D] host float64 ->
+ * centroids[k][D], labels[n] (may be NULL), number of sweeps (may be NULL).  Cluster c's centroid is the
+ * mean of the points labelled c, as learning.get_centroids computes it (scripts/learning.py:69-81). */
+int phk_kmeans(phk_ctx *ctx, const double *X, uint64_t n, uint64_t D, uint32_t k, uint64_t seed, int max_iter,
+               double *centroids, uint32_t *labels, int *n_iter);
+
 /* ---- host API: scoring ------------------------------------------------------------- */
 /* phamer.score_points / phamer_scorer.score_points (scripts/phamer.py:451-468, 177-195) for
  * method in {knn, kmeans, combo}: Q[N][D] float64 host rows -> scores[N] float64.

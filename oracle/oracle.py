@@ -240,3 +240,82 @@ def score_points(points, positive, negative, method='combo', k_neighbors=3,
         return (knn_score_points(points, positive, negative, k_neighbors)
                 + centroid_score_points(points, positive_centroids, negative_centroids))
     raise ValueError("method %r is outside the restated path" % (method,))
+
+
+# --------------------------------------------------------------------------
+# deterministic Lloyd k-means (restates phamers_amd/csrc/kmeans.hip; NOT a reference function --
+# the reference uses scikit-learn, scripts/learning.py:138)
+# --------------------------------------------------------------------------
+def _splitmix64(x):
+    m = (1 << 64) - 1
+    z = (x + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
+def kmeans_lloyd(X, k, seed=10, max_iter=300):
+    """k-means++ seeding (inverse CDF in index order, u_j = splitmix64(seed+j)/2^64 on 53 bits) + Lloyd
+    sweeps with ties to the lower index, index-ordered means, farthest-point re-seeding of empty
+    clusters.  Returns (labels, centroids, sweeps)."""
+    X = np.asarray(X, dtype=float)
+    n, D = X.shape
+    u = lambda j: float(_splitmix64(seed + j) >> 11) / 9007199254740992.0
+    centres = np.zeros((k, D))
+    c0 = min(int(u(0) * n), n - 1)
+    centres[0] = X[c0]
+    mind2 = ((X - centres[0]) ** 2).sum(axis=1)
+    for j in range(1, k):
+        # slice sums in index order (256 contiguous slices), then the inverse-CDF walk
+        per = (n + 255) // 256
+        parts = [sum(mind2[per * t: min(per * t + per, n)].tolist(), 0.0) for t in range(256)]
+        total = 0.0
+        for p in parts:
+            total += p
+        target = u(j) * total
+        run, pick, done = 0.0, n - 1, False
+        for t in range(256):
+            if done:
+                break
+            if run + parts[t] > target:
+                lo, hi = per * t, min(per * t + per, n)
+                for i in range(lo, hi):
+                    run += mind2[i]
+                    if run > target:
+                        pick, done = i, True
+                        break
+                if not done:
+                    pick, done = (hi - 1 if hi else 0), True
+            else:
+                run += parts[t]
+        centres[j] = X[pick]
+        mind2 = np.minimum(mind2, ((X - centres[j]) ** 2).sum(axis=1))
+    labels = np.full(n, -1, dtype=np.int64)
+    sweeps = 0
+    for it in range(max_iter):
+        d2 = np.stack([((X - centres[c]) ** 2).sum(axis=1) for c in range(k)], axis=1)
+        new = np.argmin(d2, axis=1)                      # first minimum = lower centre index
+        changed = int((new != labels).sum())
+        labels = new
+        own = d2[np.arange(n), labels]
+        sizes = np.bincount(labels, minlength=k)
+        for c in range(k):
+            if sizes[c]:
+                centres[c] = X[labels == c].sum(axis=0) / sizes[c]
+        for c in range(k):
+            if sizes[c] == 0:
+                ok = sizes[labels] > 1
+                if not ok.any():
+                    continue
+                cand = np.where(ok, own, -1.0)
+                far = int(np.argmax(cand))
+                sizes[labels[far]] -= 1
+                labels[far] = c
+                sizes[c] = 1
+                own[far] = 0.0
+                centres[c] = X[far]
+                changed += 1
+        sweeps = it + 1
+        if changed == 0:
+            break
+    return labels, centres, sweeps

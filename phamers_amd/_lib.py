@@ -44,6 +44,7 @@ SIGNATURES = {
     "phk_fasta_data": (c_int, [c_void_p, P(c_void_p), P(c_void_p), P(c_void_p), P(c_void_p)]),
     "phk_fasta_free": (c_int, [c_void_p]),
     "phk_count_fasta": (c_int, [c_void_p, c_void_p, c_int, c_char_p, c_void_p]),
+    "phk_kmeans": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_u32, c_u64, c_int, c_void_p, c_void_p, P(c_int)]),
     "phk_model_create": (c_int, [c_void_p, c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_u64,
                                  c_void_p, c_u64, c_u64, c_int, P(c_void_p)]),
     "phk_model_destroy": (c_int, [c_void_p, c_void_p]),

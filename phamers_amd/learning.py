@@ -41,9 +41,27 @@ def knn(queries, ref_data, ref_labels, k=3):
         model.close()
 
 
+def kmeans_gpu(data, k, seed=kmeans_seed, max_iter=300):
+    """Deterministic device k-means (phk_kmeans): (labels, centroids, sweeps).  Version independent and
+    bit-reproducible; NOT the scikit-learn result the reference's scores are pinned to."""
+    import ctypes
+    X = np.ascontiguousarray(data, dtype=np.float64)
+    n, D = X.shape
+    centroids = np.empty((k, D), dtype=np.float64)
+    labels = np.empty(n, dtype=np.uint32)
+    n_iter = ctypes.c_int()
+    ctx = _lib.get_context()
+    _lib.check(ctx.lib.phk_kmeans(ctx.handle, _lib.ptr(X), n, D, int(k), int(seed), int(max_iter), _lib.ptr(centroids),
+                                  _lib.ptr(labels), ctypes.byref(n_iter)))
+    return labels.astype(np.int64), centroids, n_iter.value
+
+
 def kmeans(data, k, verbose=False, sort_by_size=False):
-    """K-means labels through scikit-learn with the reference's seed
-    (scripts/learning.py:131-146)."""
+    """K-means labels (scripts/learning.py:131-146): scikit-learn with the reference's seed by default;
+    PHAMERS_KMEANS=gpu selects the deterministic device implementation."""
+    import os
+    if os.environ.get("PHAMERS_KMEANS", "sklearn") == "gpu":
+        return kmeans_gpu(data, k)[0]
     from sklearn.cluster import KMeans
     assignment = KMeans(n_clusters=k, random_state=kmeans_seed).fit(data).labels_
     if type(assignment) != np.ndarray:

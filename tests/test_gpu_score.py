@@ -293,3 +293,37 @@ def test_cross_validation_driver_matches_oracle_folds():
                                        v.positive_data[~wp], v.negative_data[~wn], 3)
         assert np.array_equal(np.concatenate((ps[wp], ns[wn])), want)
     assert ps.mean() > 0 > ns.mean()     # the classifier separates the two reference classes
+
+
+def test_gpu_kmeans_matches_its_restatement_and_is_usable(monkeypatch):
+    """phk_kmeans (deterministic device Lloyd k-means, opt-in) against oracle.kmeans_lloyd -- same labels,
+    centroids to rounding -- is reproducible, its inertia is in scikit-learn's range, and
+    PHAMERS_KMEANS=gpu routes phamer.score_points through it."""
+    from oracle import oracle
+    from phamers_amd import learning, phamer
+    pos, neg = _ref_matrices()
+    X = pos[:700]
+    labels, cents, sweeps = learning.kmeans_gpu(X, 12)
+    wl, wc, ws = oracle.kmeans_lloyd(X, 12)
+    assert np.array_equal(labels, wl) and sweeps == ws
+    assert np.allclose(cents, wc, rtol=1e-12, atol=1e-15)
+    l2, c2, _ = learning.kmeans_gpu(X, 12)
+    assert np.array_equal(l2, labels) and np.array_equal(c2.view(np.uint64), cents.view(np.uint64))
+    assert np.allclose(cents, learning.get_centroids(X, labels), rtol=1e-12, atol=1e-15)
+    # full positive class, the reference's k = 86: quality comparable to scikit-learn's fit
+    from sklearn.cluster import KMeans
+    lab86, c86, _ = learning.kmeans_gpu(pos, 86)
+    inertia = ((pos - c86[lab86]) ** 2).sum()
+    sk = KMeans(n_clusters=86, random_state=10).fit(pos)
+    assert len(np.unique(lab86)) == 86 and inertia < 1.15 * sk.inertia_
+    # scoring through the GPU k-means backend
+    g = helpers.load_npz("scoring_k4.npz")
+    monkeypatch.setenv("PHAMERS_KMEANS", "gpu")
+    sc = phamer.phamer_scorer()
+    sc.data_points, sc.positive_data, sc.negative_data = g["q"], pos[:600], neg[:600]
+    sc.k_clusters, sc.scoring_method = 20, "kmeans"
+    got = sc.score_points()
+    want = oracle.centroid_score_points(g["q"], sc.positive_centroids, sc.negative_centroids)
+    assert helpers.rel_err(got, want) < RTOL
+    lp, cp, _ = oracle.kmeans_lloyd(pos[:600], 20)
+    assert np.allclose(sc.positive_centroids, cp, rtol=1e-12, atol=1e-15)
