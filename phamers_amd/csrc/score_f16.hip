@@ -16,7 +16,8 @@
 // a block record is 33 pieces of 1 KiB in MFMA fragment order,
 //     piece 2s   : a_hi of step s   (lane l: row l&31, dims 128*(l>>5) + 8s .. +7, 8 halves = 16 B)
 //     piece 2s+1 : a_lo of step s
-//     piece 32   : 32 floats  -S^2 |r~'|^2 / 2  (r~' = (hi+lo)/S, the column as the kernel sees it)
+//     piece 32   : 32 floats  -S^2 |r~'|^2 / 2  (r~' = (hi+lo)/S, the column as the kernel sees it), then
+//                  32 floats  S (mu.r~' + |r~'|^2 / 2)  (bias of the count-exact kernel below)
 // streamed with LDS-DMA (global_load_lds_dwordx4: no VGPR staging, lane-linear = fragment order) into
 // a double buffer, one barrier per block.  A wave keeps its 32 queries' b_hi / b_lo fragments in 128
 // VGPRs for the whole sweep, exactly like the fp32 kernel keeps q'.
@@ -59,10 +60,11 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
             const uint64_t r = b * 32 + i;
             if (r >= n) {  // padding column: zero operand, never selectable
                 cn[i] = PAD_V;
+                cn[32 + i] = -PAD_V;
                 cn_all[(cb0 + b) * 32 + i] = PAD_V;
                 continue;
             }
-            double nrm2 = 0.0;
+            double nrm2 = 0.0, mudot = 0.0;
             for (int c = 0; c < nchunk; ++c)
                 for (int h = 0; h < 2; ++h)
                     for (int s = 0; s < 16; ++s)
@@ -77,7 +79,10 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
                             reinterpret_cast<_Float16 *>(piece + 1024 + lane * 16)[jj] = lo;
                             const double xt = (double)hi + (double)lo;  // the column as the kernel sees it (scaled)
                             nrm2 += xt * xt;
+                            mudot += mu[d] * xt;
                         }
+            // count-exact kernel: S beta = S (mu.r~' + |r~'|^2 / 2), the bias per unit of row sum
+            cn[32 + i] = (float)(mudot + 0.5 * nrm2 / (double)F16_SCALE);
             cn[i] = (float)(-0.5 * nrm2);  // already in S^2 units
             cn_all[(cb0 + b) * 32 + i] = cn[i];
         }
@@ -148,6 +153,9 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     // front of the barrier below (M0 = LDS byte address of the piece, written in the same statement).
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
     auto dma_block = [&](uint32_t blk, int buf) {
+#if defined(PHK_ABL) && (PHK_ABL == 3 || PHK_ABL == 4)
+        if (blk > 1) return;
+#endif
         const uint4 *g = Af + (uint64_t)blk * (F16_BLOCK_BYTES / 16) + lane;
         const uint32_t l = lds_base + (uint32_t)buf * F16_BLOCK_BYTES;
         for (int p = wave; p < F16_PIECES; p += F16_WAVES) {
@@ -267,11 +275,11 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
                 ahn = fr[(2 * s + 2) * 64];
                 aln = fr[(2 * s + 3) * 64];
             }
+            __builtin_amdgcn_sched_barrier(0);  // the reads stay up here, one step ahead of their MFMAs
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc, 0, 0, 0);
             list_insert(lv, li, ldrop, xs[s], cbase + (uint32_t)((s & 3) + 8 * (s >> 2)));
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS read (next step)
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // VALU (insertion)
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -329,6 +337,268 @@ int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, b
         PHK_LAUNCH(ctx, "phk_knn_f16_kernel",
                    phk_knn_f16_kernel<1><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
                        src, nullptr, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu));
+    }
+    return PHK_OK;
+}
+
+// ====================================================================================
+// Count-exact proposal kernel (k = 4, queries given as uint32 counts).
+//
+// The query operand is the count vector ITSELF: integers <= 2048 are exact in fp16, so no split and no
+// normalisation are needed on the query side and a k-step costs 2 MFMAs (c.r_hi, c.r_lo) instead of 3.
+// With T = row sum:   sum_i c_i (r_hi + r_lo)_ji = T S (q . r~'_j)   and
+//     w_j = acc_j - T * [S (mu . r~'_j + |r~'_j|^2 / 2)]  =  T S (q'. r~'_j - |r~'_j|^2 / 2)  =  T S v_j ,
+// the same ranking quantity in per-row units (the decision stage divides by T S).  A row with a count
+// above 2048 (a contig of hundreds of kb) is handed to the exact brute-force queue: its lists are written empty.
+//
+// Candidate lists without index registers in the hot loop: the low 5 mantissa bits of a value carry
+// (r << 1) | fresh, r = which of the lane's 16 rows of the block it is, fresh = inserted during this
+// block.  The sorted 5-deep value list (4 candidates + the best dropped value) is maintained with
+// v_med3 only; once per block the block number is shifted into the id list at the positions whose
+// fresh bit is set, and the bits are cleared (clearing keeps the list sorted: fresh is the lowest bit).
+// The 31-ulp perturbation is part of the decision stage's error bound.
+// ====================================================================================
+#define CX_SENT 0x03FFFFFFu
+template <int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void phk_knn_f16c_kernel(
+    const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rowsum, uint64_t N, const uint4 *__restrict__ Af,
+    uint32_t nblk_ref, uint32_t nblk_pos, uint32_t nblk_neg, float4 *__restrict__ cand_v, uint4 *__restrict__ cand_i,
+    float *__restrict__ cand_u) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x F16_BLOCK_BYTES
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const uint64_t q0 = ((uint64_t)blockIdx.x * F16_WAVES + wave) * (32 * NT);
+    const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
+    const uint32_t seg_end0 = nblk_ref, seg_end1 = nblk_ref + nblk_pos;
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    auto dma_block = [&](uint32_t blk, int buf) {
+        const uint4 *g = Af + (uint64_t)blk * (F16_BLOCK_BYTES / 16) + lane;
+        const uint32_t l = lds_base + (uint32_t)buf * F16_BLOCK_BYTES;
+        for (int p = wave; p < F16_PIECES; p += F16_WAVES) {
+            const uint4 *gp = g + p * 64;
+            const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
+        }
+    };
+    if (total) dma_block(0, 0);
+
+    // ---- prologue: counts -> fp16 (exact up to 2048), row sum, row maximum ----
+    half8 bq[NT][16];
+    float negT[NT];
+    bool big[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const uint64_t qi = q0 + 32 * t + j;
+        const uint64_t qrow = qi < N ? qi : N - 1;
+        const uint4 *row = reinterpret_cast<const uint4 *>(counts + qrow * FAST_D + 128 * h);
+        uint32_t sum = 0, mx = 0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const uint4 c0 = row[2 * s], c1 = row[2 * s + 1];
+            const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sum += c[e];
+                mx = mx > c[e] ? mx : c[e];
+                bq[t][s][e] = (_Float16)(float)(c[e] < 2048u ? c[e] : 2048u);
+            }
+        }
+        const uint32_t tot = rowsum ? rowsum[qrow] : sum + __shfl_xor(sum, 32);
+        const uint32_t mo = __shfl_xor(mx, 32);
+        big[t] = (mx > mo ? mx : mo) > 2048u;
+        negT[t] = -(float)tot;
+    }
+
+    float lv[NT][5];
+    uint32_t lb[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) lv[t][c] = -3.0e38f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lb[t][c] = CX_SENT;
+    }
+    int seg = 0;
+    uint32_t seg_first = 0;
+    const float finf = 3.3e38f;  // above every value: med3(v0, x, finf) = max(v0, x) without the canonicalising v_max pair
+
+    // after a block's 16 insertions: block number -> id list at the fresh positions, fresh bits cleared
+    auto settle = [&](uint32_t cur) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            uint32_t m[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m[c] = (uint32_t)(-(int32_t)(__float_as_uint(lv[t][c]) & 1u));
+            lb[t][3] = phk_bfi(m[0], lb[t][2], lb[t][3]);
+            lb[t][2] = phk_bfi(m[0], lb[t][1], lb[t][2]);
+            lb[t][1] = phk_bfi(m[0], lb[t][0], lb[t][1]);
+            lb[t][0] = phk_bfi(m[0], cur, lb[t][0]);
+            lb[t][3] = phk_bfi(m[1], lb[t][2], lb[t][3]);
+            lb[t][2] = phk_bfi(m[1], lb[t][1], lb[t][2]);
+            lb[t][1] = phk_bfi(m[1], cur, lb[t][1]);
+            lb[t][3] = phk_bfi(m[2], lb[t][2], lb[t][3]);
+            lb[t][2] = phk_bfi(m[2], cur, lb[t][2]);
+            lb[t][3] = phk_bfi(m[3], cur, lb[t][3]);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) lv[t][c] = __uint_as_float(__float_as_uint(lv[t][c]) & ~1u);
+        }
+    };
+    // list flush / reset once column block `b` (the last of its segment) has been inserted and settled
+    auto flush_if_segment_end = [&](uint32_t b) {
+        while (seg < NSEG && b + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint64_t qi = q0 + 32 * t + j;
+                if (qi < N) {
+                    const uint64_t o = (qi * NSEG + seg) * 2 + h;
+                    uint32_t ix[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t r = (__float_as_uint(lv[t][c]) >> 1) & 15u;
+                        ix[c] = (lb[t][c] == CX_SENT || big[t]) ? 0xFFFFFFFFu
+                                                                 : lb[t][c] * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
+                    }
+                    cand_v[o] = make_float4(lv[t][0], lv[t][1], lv[t][2], lv[t][3]);
+                    cand_i[o] = make_uint4(ix[0], ix[1], ix[2], ix[3]);
+                    cand_u[o] = big[t] ? 3.0e38f : lv[t][4];
+                }
+#pragma unroll
+                for (int c = 0; c < 5; ++c) lv[t][c] = -3.0e38f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lb[t][c] = CX_SENT;
+            }
+            ++seg;
+            seg_first = b + 1;
+        }
+    };
+
+    // Software pipeline inside the wave: while block blk's MFMAs run, the VALU inserts block blk-1's values
+    f32x16 xs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xs[t][r] = -3.0e38f;
+    for (uint32_t blk = 0; blk < total; ++blk) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        dma_block(blk + 1, (blk + 1) & 1);  // one past the end on the last block: the record array is padded
+        const uint8_t *buf = smem + (blk & 1) * F16_BLOCK_BYTES;
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        const half8 *fr = reinterpret_cast<const half8 *>(buf) + lane;
+        half8 ahn = fr[0], aln = fr[64];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const half8 ah = ahn, al = aln;
+            if (s < 15) {
+                ahn = fr[(2 * s + 2) * 64];
+                aln = fr[(2 * s + 3) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the reads stay up here, one step ahead of their MFMAs
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[t][s], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float x = __uint_as_float((__float_as_uint(xs[t][s]) & ~31u) | (uint32_t)(2 * s + 1));
+                const float n4 = __builtin_amdgcn_fmed3f(lv[t][3], lv[t][4], x);
+                const float n3 = __builtin_amdgcn_fmed3f(lv[t][2], lv[t][3], x);
+                const float n2 = __builtin_amdgcn_fmed3f(lv[t][1], lv[t][2], x);
+                const float n1 = __builtin_amdgcn_fmed3f(lv[t][0], lv[t][1], x);
+                lv[t][0] = __builtin_amdgcn_fmed3f(lv[t][0], x, finf);
+                lv[t][1] = n1;
+                lv[t][2] = n2;
+                lv[t][3] = n3;
+                lv[t][4] = n4;
+            }
+#pragma unroll
+            for (int g = 0; g < 2 * NT; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU (insertion)
+            }
+        }
+        if (blk > 0) {
+            settle(blk - 1 - seg_first);
+            flush_if_segment_end(blk - 1);
+        }
+        // D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h'; subtract T * bias now
+        // (the buffer is recycled after the next barrier)
+        const float4 *cn = reinterpret_cast<const float4 *>(buf + 32 * 1024 + 128) + h;
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {
+            const float4 c4 = cn[2 * m4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                xs[t][4 * m4 + 0] = fmaf(negT[t], c4.x, acc[t][4 * m4 + 0]);
+                xs[t][4 * m4 + 1] = fmaf(negT[t], c4.y, acc[t][4 * m4 + 1]);
+                xs[t][4 * m4 + 2] = fmaf(negT[t], c4.z, acc[t][4 * m4 + 2]);
+                xs[t][4 * m4 + 3] = fmaf(negT[t], c4.w, acc[t][4 * m4 + 3]);
+            }
+        }
+    }
+    if (total) {  // the last block's values
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float x = __uint_as_float((__float_as_uint(xs[t][s]) & ~31u) | (uint32_t)(2 * s + 1));
+                const float n4 = __builtin_amdgcn_fmed3f(lv[t][3], lv[t][4], x);
+                const float n3 = __builtin_amdgcn_fmed3f(lv[t][2], lv[t][3], x);
+                const float n2 = __builtin_amdgcn_fmed3f(lv[t][1], lv[t][2], x);
+                const float n1 = __builtin_amdgcn_fmed3f(lv[t][0], lv[t][1], x);
+                lv[t][0] = __builtin_amdgcn_fmed3f(lv[t][0], x, finf);
+                lv[t][1] = n1;
+                lv[t][2] = n2;
+                lv[t][3] = n3;
+                lv[t][4] = n4;
+            }
+        settle(total - 1 - seg_first);
+        flush_if_segment_end(total - 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch before the LDS is released
+    for (; seg < NSEG; ++seg) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint64_t qi = q0 + 32 * t + j;
+            if (qi < N) {
+                const uint64_t o = (qi * NSEG + seg) * 2 + h;
+                cand_v[o] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+                cand_i[o] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                cand_u[o] = -3.0e38f;
+            }
+        }
+    }
+}
+
+int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
+                             uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float4 *cv, uint4 *ci, float *cu) {
+    static bool attr_set = false;
+    static int nt = 2;
+    const size_t lds = 2 * F16_BLOCK_BYTES;
+    if (!attr_set) {
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const char *e = getenv("PHK_CX_TILES");
+        if (e && e[0] == '1') nt = 1;
+        attr_set = true;
+    }
+    const uint4 *af = (const uint4 *)m->d_Af16 + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16_BLOCK_BYTES / 16);
+    const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * F16_WAVES * nt);
+    if (nt == 1) {
+        PHK_LAUNCH(ctx, "phk_knn_f16c_kernel",
+                   phk_knn_f16c_kernel<1><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
+                       d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu));
+    } else {
+        PHK_LAUNCH(ctx, "phk_knn_f16c_kernel",
+                   phk_knn_f16c_kernel<2><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
+                       d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu));
     }
     return PHK_OK;
 }

@@ -309,6 +309,8 @@ struct RerankParams {
     double rmax, mu_norm;
     double vscale;          // computed values are in units of 1/vscale (split-f16 path: S^2)
     double eb_cA, eb_cP, eb_cR, eb_abs;  // error model of the proposal pass (see ErrBound)
+    double eb_cQ;           // coefficient of |q| (count-exact proposal: accumulation of uncentred products)
+    int per_row_scale;      // count-exact proposal: computed values are in units of T_q / vscale (T_q = row sum)
     const double *R64, *C64, *mu64, *colnorm;
     const uint8_t *labels;
     const float4 *cand_v;
@@ -354,10 +356,17 @@ __device__ __forceinline__ double exact_d2(const double (&qd)[4 * DSUB], const d
 //                <= 2^-22 |x| + one fp16 subnormal quantum), the dropped lo.lo term <= 2^-22 P R, and 3D/16
 //                MFMA instructions each charged 2u (|acc_in| + sum |products|) (measured model of
 //                v_mfma_f32_32x32x16_f16: wide 8-product sub-steps, round to nearest; see probe_mfma_f16).
+//   count-exact: the query operand is the integer count vector itself (exact in fp16 up to 2048), so
+//   f16 (k = 4)  the chain computes T S (q.r~' - beta~), beta = mu.r~' + |r~'|^2/2 (r~' = column as split):
+//                cA 1 (beta -> fp32), cQ 2 (2D/16 + 1) + 1 on Q = |q| (2D/16 instructions, each charged
+//                2u (|acc_in| + sum |products|) <= 2u T S |q| R), cP 4 + 1 + 62, cR 4 + 1 + 31 (r' -> r~':
+//                2^-22; the final fma: u |v|; the 5 index bits embedded in the value: 31 ulp <= 62 u |v|),
+//                c_abs as split f16.
 struct ErrBound {
     double A, P, cA, cP, cR, cabs;
+    double Q = 0.0, cQ = 0.0;
     __device__ double operator()(double R) const {
-        return 5.9604644775390625e-08 * R * (cA * A + cP * P + cR * R) + cabs * (R + P);
+        return 5.9604644775390625e-08 * R * (cA * A + cQ * Q + cP * P + cR * R) + cabs * (R + P);
     }
 };
 
@@ -369,9 +378,9 @@ struct ErrBound {
 // error bound only has to hold for columns with |r'| <= R0 = |q'| + (upper bound of d_need).
 template <int DSUB>
 __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
-                                const double (&qd)[4 * DSUB], double nqp2, const ErrBound &eb, const double *rows,
-                                const double *colnorm, bool want_d2, int lane, uint32_t (&out_idx)[3],
-                                double &out_d2) {
+                                const double (&qd)[4 * DSUB], double nqp2, const ErrBound &eb, const double vs,
+                                const double *rows, const double *colnorm, bool want_d2, int lane,
+                                uint32_t (&out_idx)[3], double &out_d2) {
     // lanes 0..7 hold the 8 candidates (half = lane>>2, slot = lane&3)
     float v = -3.0e38f;
     uint32_t ix = 0xFFFFFFFFu;
@@ -384,7 +393,7 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
         ix = s == 0 ? ci.x : s == 1 ? ci.y : s == 2 ? ci.z : ci.w;
         if (ix >= ncols) v = -3.0e38f;  // padding / empty slot
     }
-    const double vs = p.vscale;  // exact power of two: computed values -> v units
+    // vs: computed values -> v units (a power of two, divided by the row sum for the count-exact proposal)
     // every column the two half-lists dropped has a computed value <= the larger of their
     // best-dropped values (-3e38 when nothing real was dropped)
     const uint64_t ou = (q * NSEG + seg) * 2;
@@ -462,6 +471,7 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
     if (q >= p.N) return;
     // exact float64 query elements of this lane (kmer.normalize_counts arithmetic): dims 256*sub + 4*lane .. +3
     double qd[4 * DSUB];
+    double vs = p.vscale;
     bool nan_row = false;
     if (SRC == 0) {
         const uint32_t *row = static_cast<const uint32_t *>(src) + q * D;
@@ -476,6 +486,7 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
         for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
         nan_row = s == 0;
         const double ds = (double)s;
+        if (p.per_row_scale) vs = p.vscale / ds;
 #pragma unroll
         for (int sub = 0; sub < DSUB; ++sub) {
             qd[4 * sub + 0] = (double)c[sub].x / ds;
@@ -518,14 +529,15 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs;
+    eb.Q = sqrt(nq2);
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ;
 
     bool ok = true;
     double knn = 0.0, cen = 0.0;
     uint32_t idx[3];
     double d2;
     if (p.method & PHK_METHOD_KNN) {
-        ok = resolve_segment<DSUB>(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, p.R64, p.colnorm, false, lane, idx, d2);
+        ok = resolve_segment<DSUB>(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, lane, idx, d2);
         if (ok) {
             int votes = 0;
             for (int r = 0; r < p.kn; ++r) votes += p.labels[idx[r]] ? 1 : 0;
@@ -534,9 +546,9 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
     }
     if (ok && (p.method & PHK_METHOD_KMEANS)) {
         double dp2 = 0.0, dn2 = 0.0;
-        ok = resolve_segment<DSUB>(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, p.C64, p.colnorm + p.M, true, lane, idx, dp2);
+        ok = resolve_segment<DSUB>(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, vs, p.C64, p.colnorm + p.M, true, lane, idx, dp2);
         if (ok)
-            ok = resolve_segment<DSUB>(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, p.C64 + p.n_cpos * D,
+            ok = resolve_segment<DSUB>(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, vs, p.C64 + p.n_cpos * D,
                                  p.colnorm + p.M + p.n_cpos, true, lane, idx, dn2);
         if (ok) {
             const double ep = sqrt(dp2), en = sqrt(dn2);
@@ -582,9 +594,9 @@ __device__ __forceinline__ double exact_d2_g16(const double (&qd)[16], const dou
 
 // per-group version of resolve_segment; `live` = this group still needs an answer.  Returns ok.
 __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
-                                    const double (&qd)[16], double nqp2, const ErrBound &eb, const double *rows,
-                                    const double *colnorm, bool want_d2, bool live, int lane, uint32_t (&out_idx)[3],
-                                    double &out_d2) {
+                                    const double (&qd)[16], double nqp2, const ErrBound &eb, const double vs,
+                                    const double *rows, const double *colnorm, bool want_d2, bool live, int lane,
+                                    uint32_t (&out_idx)[3], double &out_d2) {
     const int t = lane & 15, base = lane & 48;
     float v = -3.0e38f;
     uint32_t ix = 0xFFFFFFFFu;
@@ -597,7 +609,6 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
         ix = s == 0 ? ci.x : s == 1 ? ci.y : s == 2 ? ci.z : ci.w;
         if (ix >= ncols) v = -3.0e38f;
     }
-    const double vs = p.vscale;
     const uint64_t ou = (q * NSEG + seg) * 2;
     const double U = fmax((double)p.cand_u[ou], (double)p.cand_u[ou + 1]) * vs;
     // rank among the group's 8 candidates, then values / indices by rank
@@ -687,6 +698,7 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     const bool inrange = qraw < p.N;
     const uint64_t q = inrange ? qraw : p.N - 1;
     double qd[16];
+    double vs = p.vscale;
     bool nan_row = false;
     if (SRC == 0) {
         const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
@@ -703,6 +715,7 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
         sum += __shfl_xor(sum, 1);
         nan_row = sum == 0;
         const double ds = (double)sum;
+        if (p.per_row_scale) vs = p.vscale / ds;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             qd[4 * i + 0] = (double)c[i].x / ds;
@@ -740,7 +753,8 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs;
+    eb.Q = sqrt(nq2);
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ;
 
     bool live = inrange && !nan_row;   // NaN rows: every comparison below is false; they are answered separately
     bool ok = true;
@@ -748,16 +762,16 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     uint32_t idx[3];
     double d2 = 0.0;
     if (p.method & PHK_METHOD_KNN) {
-        ok = resolve_segment_g16(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, p.R64, p.colnorm, false, live, lane, idx, d2);
+        ok = resolve_segment_g16(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, live, lane, idx, d2);
         int votes = 0;
         for (int r = 0; r < p.kn; ++r) votes += (idx[r] < p.M && p.labels[idx[r]]) ? 1 : 0;
         knn = (2 * votes > p.kn) ? 1.0 : -1.0;
     }
     if (p.method & PHK_METHOD_KMEANS) {
         double dp2 = 0.0, dn2 = 0.0;
-        const bool ok1 = resolve_segment_g16(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, p.C64, p.colnorm + p.M, true,
+        const bool ok1 = resolve_segment_g16(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, vs, p.C64, p.colnorm + p.M, true,
                                              live && ok, lane, idx, dp2);
-        const bool ok2 = resolve_segment_g16(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, p.C64 + p.n_cpos * FAST_D,
+        const bool ok2 = resolve_segment_g16(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, vs, p.C64 + p.n_cpos * FAST_D,
                                              p.colnorm + p.M + p.n_cpos, true, live && ok && ok1, lane, idx, dn2);
         ok = ok && ok1 && ok2;
         const double ep = sqrt(dp2), en = sqrt(dn2);
@@ -977,6 +991,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // proposal pass: split-f16 MFMA by default; PHK_PROPOSAL=f32 selects the fp32-input MFMA kernel (k = 4 only)
     const char *prop = getenv("PHK_PROPOSAL");
     const bool use_f16 = D != FAST_D || !(prop && prop[0] == 'f' && prop[1] == '3');
+    // counts at k = 4: the count-exact kernel (2 MFMAs per k-step); PHK_PROPOSAL=f16s keeps the split-query one
+    const bool use_cx = use_f16 && D == FAST_D && d_counts && !(prop && prop[0] == 'f' && prop[1] == '1');
     for (uint64_t s = 0; s < N; s += BATCH) {
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
         const void *src = d_counts ? (const void *)(d_counts + s * D) : (const void *)(d_Q + s * D);
@@ -992,7 +1008,13 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.colnorm = m->d_colnorm; p.labels = m->d_labels;
         p.cand_v = (const float4 *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
         p.scores = d_scores; p.status = d_status; p.fb_count = fb_count; p.fb_list = fb_list; p.q_base = s;
-        if (use_f16) {
+        p.eb_cQ = 0.0; p.per_row_scale = 0;
+        if (use_cx) {
+            // see ErrBound: values are T S v (per row), 2D/16 instructions on uncentred products
+            p.vscale = 1.0 / 4096.0; p.per_row_scale = 1;
+            p.eb_cA = 1.0; p.eb_cQ = 2.0 * (2.0 * (double)D / 16.0 + 1.0) + 1.0; p.eb_cP = 67.0; p.eb_cR = 36.0;
+            p.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
+        } else if (use_f16) {
             // 3D/16 MFMA instructions, each charged 2u (|acc_in| + sum |products|) <= 2u (P + dq) R -- the
             // measured accumulation model of v_mfma_f32_32x32x16_f16 (tools/probe_mfma_f16.hip,
             // profiles/r01/probe_mfma_f16.txt: two wide 8-product sub-steps with round-to-nearest, worst
@@ -1007,6 +1029,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         if (D != FAST_D) {
             PHK_TRY(phk_launch_proposal_f16_general(ctx, m, src, d_counts != nullptr, rsum, nb, nref, npos, nneg,
                                                     (float4 *)cv, ci, cu));
+        } else if (use_cx) {
+            PHK_TRY(phk_launch_proposal_f16c(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float4 *)cv, ci, cu));
         } else if (use_f16) {
             PHK_TRY(phk_launch_proposal_f16(ctx, m, src, d_counts != nullptr, rsum, nb, nref, npos, nneg, (float4 *)cv,
                                             ci, cu));

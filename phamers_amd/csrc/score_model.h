@@ -38,6 +38,8 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
 int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                             const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
                             float4 *cv, uint4 *ci, float *cu);
+int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
+                             uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float4 *cv, uint4 *ci, float *cu);
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
                                     float4 *cv, uint4 *ci, float *cu);
