@@ -370,13 +370,15 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void phk_knn_f16c_kernel(
     const int j = lane & 31, h = lane >> 5;
     const uint64_t q0 = ((uint64_t)blockIdx.x * F16_WAVES + wave) * (32 * NT);
     const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
-    const uint32_t seg_end0 = nblk_ref, seg_end1 = nblk_ref + nblk_pos;
-
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
     auto dma_block = [&](uint32_t blk, int buf) {
         const uint4 *g = Af + (uint64_t)blk * (F16_BLOCK_BYTES / 16) + lane;
         const uint32_t l = lds_base + (uint32_t)buf * F16_BLOCK_BYTES;
-        for (int p = wave; p < F16_PIECES; p += F16_WAVES) {
+        // 9 pieces per wave, no loop (a loop here splits the hot loop into basic blocks and hipcc then sinks the
+        // insertions away from the MFMAs they are meant to hide behind); piece 32 is fetched by all four waves
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int p = k < 8 ? wave + F16_WAVES * k : 32;
             const uint4 *gp = g + p * 64;
             const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
@@ -413,84 +415,70 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void phk_knn_f16c_kernel(
 
     float lv[NT][5];
     uint32_t lb[NT][4];
+    const float vempty = __uint_as_float(__float_as_uint(-3.0e38f) & ~31u);  // empty slot: fresh bit clear
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int c = 0; c < 5; ++c) lv[t][c] = -3.0e38f;
+        for (int c = 0; c < 5; ++c) lv[t][c] = vempty;
 #pragma unroll
         for (int c = 0; c < 4; ++c) lb[t][c] = CX_SENT;
     }
-    int seg = 0;
-    uint32_t seg_first = 0;
-    const float finf = 3.3e38f;  // above every value: med3(v0, x, finf) = max(v0, x) without the canonicalising v_max pair
+    const float fbig = 3.3e38f;  // above every value: med3(v0, x, fbig) = max(v0, x) without the canonicalising v_max pair
 
-    // after a block's 16 insertions: block number -> id list at the fresh positions, fresh bits cleared
+    // after a block's 16 insertions: block number -> id list at the fresh positions, fresh bits cleared.
+    // A no-op when no fresh bit is set.
     auto settle = [&](uint32_t cur) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             uint32_t m[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) m[c] = (uint32_t)(-(int32_t)(__float_as_uint(lv[t][c]) & 1u));
-            lb[t][3] = phk_bfi(m[0], lb[t][2], lb[t][3]);
-            lb[t][2] = phk_bfi(m[0], lb[t][1], lb[t][2]);
-            lb[t][1] = phk_bfi(m[0], lb[t][0], lb[t][1]);
-            lb[t][0] = phk_bfi(m[0], cur, lb[t][0]);
-            lb[t][3] = phk_bfi(m[1], lb[t][2], lb[t][3]);
-            lb[t][2] = phk_bfi(m[1], lb[t][1], lb[t][2]);
-            lb[t][1] = phk_bfi(m[1], cur, lb[t][1]);
-            lb[t][3] = phk_bfi(m[2], lb[t][2], lb[t][3]);
-            lb[t][2] = phk_bfi(m[2], cur, lb[t][2]);
-            lb[t][3] = phk_bfi(m[3], cur, lb[t][3]);
+            for (int c = 0; c < 4; ++c) asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m[c]) : "v"(lv[t][c]));  // 0 / ~0 from bit 0
+            lb[t][3] = phk_bfi_hw(m[0], lb[t][2], lb[t][3]);
+            lb[t][2] = phk_bfi_hw(m[0], lb[t][1], lb[t][2]);
+            lb[t][1] = phk_bfi_hw(m[0], lb[t][0], lb[t][1]);
+            lb[t][0] = phk_bfi_hw(m[0], cur, lb[t][0]);
+            lb[t][3] = phk_bfi_hw(m[1], lb[t][2], lb[t][3]);
+            lb[t][2] = phk_bfi_hw(m[1], lb[t][1], lb[t][2]);
+            lb[t][1] = phk_bfi_hw(m[1], cur, lb[t][1]);
+            lb[t][3] = phk_bfi_hw(m[2], lb[t][2], lb[t][3]);
+            lb[t][2] = phk_bfi_hw(m[2], cur, lb[t][2]);
+            lb[t][3] = phk_bfi_hw(m[3], cur, lb[t][3]);
 #pragma unroll
             for (int c = 0; c < 5; ++c) lv[t][c] = __uint_as_float(__float_as_uint(lv[t][c]) & ~1u);
         }
     };
-    // list flush / reset once column block `b` (the last of its segment) has been inserted and settled
-    auto flush_if_segment_end = [&](uint32_t b) {
-        while (seg < NSEG && b + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint64_t qi = q0 + 32 * t + j;
-                if (qi < N) {
-                    const uint64_t o = (qi * NSEG + seg) * 2 + h;
-                    uint32_t ix[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const uint32_t r = (__float_as_uint(lv[t][c]) >> 1) & 15u;
-                        ix[c] = (lb[t][c] == CX_SENT || big[t]) ? 0xFFFFFFFFu
-                                                                 : lb[t][c] * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
-                    }
-                    cand_v[o] = make_float4(lv[t][0], lv[t][1], lv[t][2], lv[t][3]);
-                    cand_i[o] = make_uint4(ix[0], ix[1], ix[2], ix[3]);
-                    cand_u[o] = big[t] ? 3.0e38f : lv[t][4];
-                }
-#pragma unroll
-                for (int c = 0; c < 5; ++c) lv[t][c] = -3.0e38f;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) lb[t][c] = CX_SENT;
-            }
-            ++seg;
-            seg_first = b + 1;
-        }
+    // insertion of one value: w = acc - T * bias, index bits embedded, 5 x v_med3
+    auto insert = [&](int t, float a, float bias, int r) {
+        const float w = fmaf(negT[t], bias, a);
+        const float x = __uint_as_float((__float_as_uint(w) & ~31u) | (uint32_t)(2 * r + 1));
+        const float n4 = __builtin_amdgcn_fmed3f(lv[t][3], lv[t][4], x);
+        const float n3 = __builtin_amdgcn_fmed3f(lv[t][2], lv[t][3], x);
+        const float n2 = __builtin_amdgcn_fmed3f(lv[t][1], lv[t][2], x);
+        const float n1 = __builtin_amdgcn_fmed3f(lv[t][0], lv[t][1], x);
+        lv[t][0] = __builtin_amdgcn_fmed3f(lv[t][0], x, fbig);
+        lv[t][1] = n1;
+        lv[t][2] = n2;
+        lv[t][3] = n3;
+        lv[t][4] = n4;
     };
 
-    // Software pipeline inside the wave: while block blk's MFMAs run, the VALU inserts block blk-1's values
-    f32x16 xs[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xs[t][r] = -3.0e38f;
-    for (uint32_t blk = 0; blk < total; ++blk) {
+    // Software pipeline inside the wave, per segment: while block i's MFMAs fill one accumulator set, the VALU
+    // inserts block i-1's values out of the other set (with its bias terms, held in 16 registers) and settles
+    // the ids of block i-2's insertions during the first k-step.  Nothing but the LDS reads of the next bias
+    // terms and the workgroup barrier is left outside the MFMA stream; the hot loop has no data-dependent
+    // control flow.  The pipeline drains at the end of a segment (3 times per sweep); the DMA stream does not.
+    float bias[16];
+    f32x16 accA[NT], accB[NT];
+    uint32_t g = 0;  // global block number: LDS buffer parity and DMA source
+
+    auto block_iter = [&](uint32_t settle_id, f32x16 (&cur)[NT], const f32x16 (&prev)[NT]) {
+        // block g has landed (every wave waits for its own pieces, then the barrier), and every wave is done
+        // reading the other buffer, which the next DMA overwrites
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        dma_block(blk + 1, (blk + 1) & 1);  // one past the end on the last block: the record array is padded
-        const uint8_t *buf = smem + (blk & 1) * F16_BLOCK_BYTES;
-
-        f32x16 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        dma_block(g + 1, (g + 1) & 1);  // one past the end on the last block: the record array is padded
+        const uint8_t *buf = smem + (g & 1) * F16_BLOCK_BYTES;
+        ++g;
         const half8 *fr = reinterpret_cast<const half8 *>(buf) + lane;
         half8 ahn = fr[0], aln = fr[64];
 #pragma unroll
@@ -501,80 +489,114 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void phk_knn_f16c_kernel(
                 aln = fr[(2 * s + 3) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);  // the reads stay up here, one step ahead of their MFMAs
+            if (s == 0) {
+                f32x16 z;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], acc[t], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[t][s], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], z, 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float x = __uint_as_float((__float_as_uint(xs[t][s]) & ~31u) | (uint32_t)(2 * s + 1));
-                const float n4 = __builtin_amdgcn_fmed3f(lv[t][3], lv[t][4], x);
-                const float n3 = __builtin_amdgcn_fmed3f(lv[t][2], lv[t][3], x);
-                const float n2 = __builtin_amdgcn_fmed3f(lv[t][1], lv[t][2], x);
-                const float n1 = __builtin_amdgcn_fmed3f(lv[t][0], lv[t][1], x);
-                lv[t][0] = __builtin_amdgcn_fmed3f(lv[t][0], x, finf);
-                lv[t][1] = n1;
-                lv[t][2] = n2;
-                lv[t][3] = n3;
-                lv[t][4] = n4;
+                for (int t = 0; t < NT; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], cur[t], 0, 0, 0);
             }
 #pragma unroll
-            for (int g = 0; g < 2 * NT; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU (insertion)
+            for (int t = 0; t < NT; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[t][s], cur[t], 0, 0, 0);
+            if (s == 0) settle(settle_id);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) insert(t, prev[t][s], bias[s], s);
+            if (s == 0) {
+#pragma unroll
+                for (int gi = 0; gi < 2 * NT; ++gi) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);  // VALU (settle + insertion)
+                }
+            } else {
+#pragma unroll
+                for (int gi = 0; gi < 2 * NT; ++gi) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU (insertion)
+                }
             }
         }
-        if (blk > 0) {
-            settle(blk - 1 - seg_first);
-            flush_if_segment_end(blk - 1);
-        }
-        // D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h'; subtract T * bias now
+        // D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h'; its bias terms
         // (the buffer is recycled after the next barrier)
         const float4 *cn = reinterpret_cast<const float4 *>(buf + 32 * 1024 + 128) + h;
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) {
             const float4 c4 = cn[2 * m4];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                xs[t][4 * m4 + 0] = fmaf(negT[t], c4.x, acc[t][4 * m4 + 0]);
-                xs[t][4 * m4 + 1] = fmaf(negT[t], c4.y, acc[t][4 * m4 + 1]);
-                xs[t][4 * m4 + 2] = fmaf(negT[t], c4.z, acc[t][4 * m4 + 2]);
-                xs[t][4 * m4 + 3] = fmaf(negT[t], c4.w, acc[t][4 * m4 + 3]);
-            }
+            bias[4 * m4 + 0] = c4.x;
+            bias[4 * m4 + 1] = c4.y;
+            bias[4 * m4 + 2] = c4.z;
+            bias[4 * m4 + 3] = c4.w;
         }
-    }
-    if (total) {  // the last block's values
+    };
+    // drain: the last block's values (in `last`, bias terms loaded), ids, then the segment's lists go out
+    auto finish = [&](int seg, uint32_t nb, const f32x16 (&last)[NT]) {
+        settle(nb - 2);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float x = __uint_as_float((__float_as_uint(xs[t][s]) & ~31u) | (uint32_t)(2 * s + 1));
-                const float n4 = __builtin_amdgcn_fmed3f(lv[t][3], lv[t][4], x);
-                const float n3 = __builtin_amdgcn_fmed3f(lv[t][2], lv[t][3], x);
-                const float n2 = __builtin_amdgcn_fmed3f(lv[t][1], lv[t][2], x);
-                const float n1 = __builtin_amdgcn_fmed3f(lv[t][0], lv[t][1], x);
-                lv[t][0] = __builtin_amdgcn_fmed3f(lv[t][0], x, finf);
-                lv[t][1] = n1;
-                lv[t][2] = n2;
-                lv[t][3] = n3;
-                lv[t][4] = n4;
-            }
-        settle(total - 1 - seg_first);
-        flush_if_segment_end(total - 1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch before the LDS is released
-    for (; seg < NSEG; ++seg) {
+            for (int s = 0; s < 16; ++s) insert(t, last[t][s], bias[s], s);
+        settle(nb - 1);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const uint64_t qi = q0 + 32 * t + j;
             if (qi < N) {
                 const uint64_t o = (qi * NSEG + seg) * 2 + h;
-                cand_v[o] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
-                cand_i[o] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-                cand_u[o] = -3.0e38f;
+                uint32_t ix[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t r = (__float_as_uint(lv[t][c]) >> 1) & 15u;
+                    ix[c] = (lb[t][c] == CX_SENT || big[t]) ? 0xFFFFFFFFu
+                                                             : lb[t][c] * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
+                }
+                cand_v[o] = make_float4(lv[t][0], lv[t][1], lv[t][2], lv[t][3]);
+                cand_i[o] = make_uint4(ix[0], ix[1], ix[2], ix[3]);
+                cand_u[o] = big[t] ? 3.0e38f : lv[t][4];
             }
         }
+    };
+#pragma unroll 1
+    for (int seg = 0; seg < NSEG; ++seg) {
+        const uint32_t nb = seg == 0 ? nblk_ref : seg == 1 ? nblk_pos : nblk_neg;
+        if (nb == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint64_t qi = q0 + 32 * t + j;
+                if (qi < N) {
+                    const uint64_t o = (qi * NSEG + seg) * 2 + h;
+                    cand_v[o] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+                    cand_i[o] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                    cand_u[o] = -3.0e38f;
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) lv[t][c] = vempty;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lb[t][c] = CX_SENT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[t][r] = -3.35e38f;  // "block -1": below the empty slots, never accepted
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] = 0.0f;
+        uint32_t i = 0;
+#pragma unroll 1
+        for (; i + 1 < nb; i += 2) {
+            block_iter(i - 2, accA, accB);
+            block_iter(i - 1, accB, accA);
+        }
+        if (i < nb) {
+            block_iter(i - 2, accA, accB);
+            finish(seg, nb, accA);
+        } else {
+            finish(seg, nb, accB);
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch before the LDS is released
 }
 
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,

@@ -10,6 +10,13 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define NSEG 3         // train rows, positive centroids, negative centroids
 #define PAD_V (-1.0e30f)
 
+// v_bfi_b32 proper (the C form above is turned into compare + select pairs by hipcc)
+__device__ __forceinline__ uint32_t phk_bfi_hw(uint32_t m, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+
 // Sorted (descending) insert of (x, c) into a 4-deep list held in registers, tracking the largest
 // value that ever fell off the list (`drop`): every column this list does not hold has a computed
 // value <= drop.  Written without any i1 condition on purpose: hipcc turns a chain of `?:` selects
