@@ -359,8 +359,8 @@ int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, b
 // The 31-ulp perturbation is part of the decision stage's error bound.
 // ====================================================================================
 #define CX_SENT 0x03FFFFFFu
-template <int NT>
-__global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void phk_knn_f16c_kernel(
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn_f16c_kernel(
     const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rowsum, uint64_t N, const uint4 *__restrict__ Af,
     uint32_t nblk_ref, uint32_t nblk_pos, uint32_t nblk_neg, float4 *__restrict__ cand_v, uint4 *__restrict__ cand_i,
     float *__restrict__ cand_u) {
@@ -368,17 +368,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void phk_knn_f16c_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const uint64_t q0 = ((uint64_t)blockIdx.x * F16_WAVES + wave) * (32 * NT);
+    const uint64_t q0 = ((uint64_t)blockIdx.x * NW + wave) * (32 * NT);
     const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
     auto dma_block = [&](uint32_t blk, int buf) {
         const uint4 *g = Af + (uint64_t)blk * (F16_BLOCK_BYTES / 16) + lane;
         const uint32_t l = lds_base + (uint32_t)buf * F16_BLOCK_BYTES;
-        // 9 pieces per wave, no loop (a loop here splits the hot loop into basic blocks and hipcc then sinks the
-        // insertions away from the MFMAs they are meant to hide behind); piece 32 is fetched by all four waves
+        // 32 / NW + 1 pieces per wave, no loop (a loop here splits the hot loop into basic blocks and hipcc then sinks the
+        // insertions away from the MFMAs they are meant to hide behind); piece 32 is fetched by every wave
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int p = k < 8 ? wave + F16_WAVES * k : 32;
+        for (int k = 0; k < 32 / NW + 1; ++k) {
+            const int p = k < 32 / NW ? wave + NW * k : 32;
             const uint4 *gp = g + p * 64;
             const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
@@ -602,29 +602,33 @@ __global__ __launch_bounds__(256, NT == 1 ? 2 : 1) void phk_knn_f16c_kernel(
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float4 *cv, uint4 *ci, float *cu) {
     static bool attr_set = false;
-    static int nt = 2;
+    static int nt = 2, nw = 8;
     const size_t lds = 2 * F16_BLOCK_BYTES;
     if (!attr_set) {
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const char *e = getenv("PHK_CX_TILES");
-        if (e && e[0] == '1') nt = 1;
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const char *e = getenv("PHK_CX_CFG");  // "<tiles per wave><waves per workgroup>": 14, 24, 28 (default)
+        if (e && e[0] == '1') { nt = 1; nw = 4; }
+        if (e && e[0] == '2' && e[1] == '4') nw = 4;
         attr_set = true;
     }
     const uint4 *af = (const uint4 *)m->d_Af16 + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16_BLOCK_BYTES / 16);
-    const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * F16_WAVES * nt);
+    const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * nw * nt);
+#define PHK_CX_LAUNCH(NT_, NW_)                                                                             \
+    PHK_LAUNCH(ctx, "phk_knn_f16c_kernel",                                                                  \
+               (phk_knn_f16c_kernel<NT_, NW_><<<dim3(gblocks), dim3(64 * NW_), lds, ctx->stream>>>(         \
+                   d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu)))
     if (nt == 1) {
-        PHK_LAUNCH(ctx, "phk_knn_f16c_kernel",
-                   phk_knn_f16c_kernel<1><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
-                       d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu));
+        PHK_CX_LAUNCH(1, 4);
+    } else if (nw == 4) {
+        PHK_CX_LAUNCH(2, 4);
     } else {
-        PHK_LAUNCH(ctx, "phk_knn_f16c_kernel",
-                   phk_knn_f16c_kernel<2><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
-                       d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu));
+        PHK_CX_LAUNCH(2, 8);
     }
+#undef PHK_CX_LAUNCH
     return PHK_OK;
 }
-
 
 // ====================================================================================
 // General D = 256 * nchunk (k = 5: 1024, k = 6: 4096): the query operand no longer fits in
