@@ -191,6 +191,7 @@ def main():
         "phk_count_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, n * ((L + 3) // 4 + 8 + 4 * D + 8) / 1e9),
         "phk_knn_mfma_kernel": ("mfma", "TFLOP/s", MFMA_F32_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
         "phk_knn_f16_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
+        "phk_knn_f16c_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
         "phk_dist2_f64_kernel": ("mfma", "TFLOP/s", F64_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
     }
     kernels = {}
@@ -215,13 +216,16 @@ def main():
     if dom == "phk_knn_f16_kernel":
         # the split-f16 kernel issues 3 MFMA flops per algorithmic flop (hi.hi + hi.lo + lo.hi)
         roofline["mfma_issue_frac"] = 3.0 * kernels[dom]["frac"]
+    if dom == "phk_knn_f16c_kernel":
+        # the count-exact kernel issues 2 MFMA flops per algorithmic flop (c.r_hi + c.r_lo)
+        roofline["mfma_issue_frac"] = 2.0 * kernels[dom]["frac"]
 
     out = {
         "metric": "Gbases/s k-mer-count+score, k=%d, %d kb contigs" % (k, L // 1000),
         "value": world * n * L * args.steps / elapsed / 1e9,
         "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32 counts + split-f16 MFMA proposal (f32 accumulate) + f64 decision",
+        "vs_baseline": None, "dtype": "u32 counts + f16 MFMA proposal (exact integer counts x split-f16 reference, f32 accumulate) + f64 decision",
         "data": "synthetic (seeded uniform ATGC contigs, device-generated); reference matrix: " + ref_name,
         "config": {"workload": "k=%d, %d x %d-base contigs per GPU, count+normalise+%s score, "
                                "%d reference rows + %d centroids" % (k, n, L, args.method, M, C),

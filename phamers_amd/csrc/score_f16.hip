@@ -602,17 +602,17 @@ __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float4 *cv, uint4 *ci, float *cu) {
     static bool attr_set = false;
-    static int nt = 2, nw = 8;
     const size_t lds = 2 * F16_BLOCK_BYTES;
     if (!attr_set) {
         PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const char *e = getenv("PHK_CX_CFG");  // "<tiles per wave><waves per workgroup>": 14, 24, 28 (default)
-        if (e && e[0] == '1') { nt = 1; nw = 4; }
-        if (e && e[0] == '2' && e[1] == '4') nw = 4;
         attr_set = true;
     }
+    int nt = 2, nw = 8;
+    const char *e = getenv("PHK_CX_CFG");  // "<tiles per wave><waves per workgroup>": 14, 24, 28 (default)
+    if (e && e[0] == '1') { nt = 1; nw = 4; }
+    if (e && e[0] == '2' && e[1] == '4') nw = 4;
     const uint4 *af = (const uint4 *)m->d_Af16 + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16_BLOCK_BYTES / 16);
     const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * nw * nt);
 #define PHK_CX_LAUNCH(NT_, NW_)                                                                             \

@@ -991,7 +991,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // proposal pass: split-f16 MFMA by default; PHK_PROPOSAL=f32 selects the fp32-input MFMA kernel (k = 4 only)
     const char *prop = getenv("PHK_PROPOSAL");
     const bool use_f16 = D != FAST_D || !(prop && prop[0] == 'f' && prop[1] == '3');
-    // counts at k = 4: the count-exact kernel (2 MFMAs per k-step); PHK_PROPOSAL=f16s keeps the split-query one
+    // counts at k = 4: the count-exact kernel (2 MFMAs per k-step); PHK_PROPOSAL=f16 keeps the split-query one
     const bool use_cx = use_f16 && D == FAST_D && d_counts && !(prop && prop[0] == 'f' && prop[1] == '1');
     for (uint64_t s = 0; s < N; s += BATCH) {
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;

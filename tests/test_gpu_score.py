@@ -164,10 +164,11 @@ def test_fast_and_exact_gpu_paths_agree_on_a_larger_batch(monkeypatch):
     d_nwin = device.DeviceArray(ctx, n, np.uint32)
     device.count(ctx, d_packed, None, T, d_off, n, 4, d_counts, d_nwin)
     out = {}
-    # proposal kernel: split-f16 MFMA (default) and fp32 MFMA; "exact" = float64 brute force path
-    for path in ("f16", "f32", "exact"):
+    # proposal kernel: count-exact f16 MFMA (default, "cx"), split-query f16 MFMA and fp32 MFMA;
+    # "exact" = float64 brute force path
+    for path in ("cx", "f16", "f32", "exact"):
         monkeypatch.setenv("PHK_FORCE_EXACT", "1" if path == "exact" else "0")
-        monkeypatch.setenv("PHK_PROPOSAL", "f32" if path == "f32" else "f16")
+        monkeypatch.setenv("PHK_PROPOSAL", path if path != "exact" else "cx")
         for method in ("knn", "kmeans", "combo"):
             d_scores = device.DeviceArray(ctx, n, np.float64)
             d_status = device.DeviceArray(ctx, 1, np.uint32)
@@ -177,7 +178,7 @@ def test_fast_and_exact_gpu_paths_agree_on_a_larger_batch(monkeypatch):
         if path != "exact":
             n_fallback, n_exact = ctx.score_stats()
             assert n_fallback < n // 100, (path, n_fallback)     # the proposal must certify nearly everything
-    for path in ("f16", "f32"):
+    for path in ("cx", "f16", "f32"):
         assert np.array_equal(out[(path, "knn")], out[("exact", "knn")]), path
         assert set(np.unique(out[(path, "knn")])) <= {-1.0, 1.0}
         assert helpers.rel_err(out[(path, "kmeans")], out[("exact", "kmeans")]) < 1e-9, path
@@ -327,3 +328,47 @@ def test_gpu_kmeans_matches_its_restatement_and_is_usable(monkeypatch):
     assert helpers.rel_err(got, want) < RTOL
     lp, cp, _ = oracle.kmeans_lloyd(pos[:600], 20)
     assert np.allclose(sc.positive_centroids, cp, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["28", "24", "14"])
+def test_count_exact_kernel_shapes_and_large_counts(monkeypatch, cfg):
+    """The count-exact proposal kernel (integer counts as the fp16 MFMA operand) in its three workgroup
+    shapes: batch sizes around the 32 / 64 / 512-query tile edges, rows whose counts exceed 2048 (not
+    exact in fp16: they must take the brute-force queue and still come out right), a zero row, and all
+    three methods -- against the float64 brute-force path of the same library and against the oracle."""
+    from oracle import oracle
+    from phamers_amd import _lib, device
+    monkeypatch.setenv("PHK_CX_CFG", cfg)
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    n_eq = min(pos.shape[0], neg.shape[0])
+    pos, neg = pos[:n_eq], neg[:n_eq]
+    ctx = _lib.get_context()
+    model = _lib.Model(ctx, pos, neg, g["cpos_eq"], g["cneg_eq"], 3)
+    rng = np.random.default_rng(11)
+    base = np.vstack([pos, neg])
+    for n in (1, 31, 33, 65, 511, 513, 1300):
+        rows = base[rng.integers(0, len(base), n)]
+        T = rng.integers(800, 9000, n)
+        counts = np.stack([rng.multinomial(t, r) for t, r in zip(T, rows)]).astype(np.uint32)
+        big = []
+        if n >= 31:   # long contigs: counts far above 2048, one of them concentrated on few k-mers
+            counts[3] = rng.multinomial(900000, rows[3])
+            counts[n - 2] = rng.multinomial(300000, np.r_[np.full(8, 0.1), np.full(248, 0.2 / 248)])
+            big = [3, n - 2]
+        q = oracle.normalize_counts(counts.astype(np.int64))
+        want_knn = oracle.knn_score_points(q, pos, neg, 3)
+        want_cen = oracle.centroid_score_points_fast(q, g["cpos_eq"], g["cneg_eq"])
+        d_counts = device.DeviceArray.from_host(ctx, counts)
+        d_scores = device.DeviceArray(ctx, n, np.float64)
+        d_status = device.DeviceArray.from_host(ctx, np.zeros(1, np.uint32))
+        for method, want in (("knn", want_knn), ("kmeans", want_cen), ("combo", want_knn + want_cen)):
+            monkeypatch.setenv("PHK_PROPOSAL", "cx")
+            device.score_counts(ctx, model, d_counts, n, method, d_scores, d_status)
+            got = d_scores.to_host()
+            assert d_status.to_host()[0] == 0
+            n_fallback, _ = ctx.score_stats()
+            assert n_fallback >= len(big), (n, method, n_fallback)
+            assert helpers.rel_err(got, want) < RTOL, (cfg, n, method)
+    model.close()

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_FLAT SQ_WAVES" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OUT/p$i" -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --contigs 400000 > "$OUT/p$i.log" 2>&1 || echo "pass $i failed"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OUT/p$i" -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --contigs ${PROF_CONTIGS:-393216} > "$OUT/p$i.log" 2>&1 || echo "pass $i failed"
 done
 python3 - <<'PY'
 import csv,glob,collections,os,json
