@@ -221,8 +221,13 @@ __global__ __launch_bounds__(256) void phk_count_kernel(const uint32_t *__restri
                                                         const uint64_t *__restrict__ offsets,
                                                         uint64_t n, uint64_t max_word,
                                                         uint32_t *__restrict__ counts,
-                                                        uint32_t *__restrict__ nwin) {
+                                                        uint32_t *__restrict__ nwin,
+                                                        const uint32_t *__restrict__ list,
+                                                        const uint32_t *__restrict__ list_count) {
     static_assert(COPIES >= 4 || !PACK16 || COPIES == 1, "unsupported replication");
+    // with `list`: count contigs list[0 .. *list_count) (those the lane-pair kernel handed over)
+    if (list) n = *list_count;
+    auto cid = [&](uint64_t i) { return list ? (uint64_t)list[i] : i; };
     constexpr uint32_t D = 1u << (2 * K);
     constexpr int W = (int)(PACK16 ? D / 2 : D) * COPIES;
     constexpr int SEG_ITERS = 63;  // wave iterations between flushes (PACK16 carry bound)
@@ -300,36 +305,213 @@ __global__ __launch_bounds__(256) void phk_count_kernel(const uint32_t *__restri
     };
 
     // two rings in ping-pong: while contig c is counted out of one, contig c+S streams into the other
-    uint64_t s0 = offsets[c], e0 = offsets[c + 1];
+    uint64_t s0 = offsets[cid(c)], e0 = offsets[cid(c) + 1];
     uint64_t s1 = 0, e1 = 0;
     if (c + S < n) {
-        s1 = offsets[c + S];
-        e1 = offsets[c + S + 1];
+        s1 = offsets[cid(c + S)];
+        e1 = offsets[cid(c + S) + 1];
     }
     issue(s0, e0, ra, rb);
     for (;;) {
         // --- even phase: process (s0,e0) from ra/rb, stream contig c+S into na/nb
         uint64_t s2 = 0, e2 = 0;
         if (c + 2 * S < n) {
-            s2 = offsets[c + 2 * S];
-            e2 = offsets[c + 2 * S + 1];
+            s2 = offsets[cid(c + 2 * S)];
+            e2 = offsets[cid(c + 2 * S) + 1];
         }
         if (c + S < n) issue(s1, e1, na, nb);
-        process(c, s0, e0, ra, rb);
+        process(cid(c), s0, e0, ra, rb);
         c += S;
         if (c >= n) break;
         // --- odd phase: process (s1,e1) from na/nb, stream contig c+S into ra/rb
         uint64_t s3 = 0, e3 = 0;
         if (c + 2 * S < n) {
-            s3 = offsets[c + 2 * S];
-            e3 = offsets[c + 2 * S + 1];
+            s3 = offsets[cid(c + 2 * S)];
+            e3 = offsets[cid(c + 2 * S) + 1];
         }
         if (c + S < n) issue(s2, e2, ra, rb);
-        process(c, s1, e1, na, nb);
+        process(cid(c), s1, e1, na, nb);
         c += S;
         if (c >= n) break;
         s0 = s2; e0 = e2;
         s1 = s3; e1 = e3;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Slot kernel (k = 3, 4; all bases valid): a workgroup of 4 waves counts 32 contigs at a time, 8 lanes
+// per contig, each contig in a histogram COLUMN of its own.
+//
+// The wave-per-contig kernel above is bound by LDS bank conflicts: its 64 lanes add into ONE
+// histogram, so a wave-wide ds_add lands on random banks (about 7.7 LDS cycles per instruction at the
+// best replication, profiles/r01/count_lds_study.md), and replicas have to be summed again at the
+// flush.  Here the 32 histograms in a workgroup's LDS belong to 32 DIFFERENT contigs,
+//     bins[code][slot]   (slot = lane & 31, so the LDS bank of an add is its lane's slot, whatever the code)
+// every ds_add is conflict free (2 LDS cycles per wave instruction), there is nothing to reduce at the
+// flush, and the address of a bin costs two VALU operations: ((word >> s) & (D-1) << 7) | slot * 4.
+// The input is staged through LDS so that global loads stay coalesced: per stage the workgroup loads the
+// next 128 bytes (32 words, 512 bases) of each of its 32 contigs -- 8 adjacent lanes fetch one contig's
+// line -- and each of the 8 lanes that serve a contig then counts the 64 windows starting in one 4-word
+// chunk of it.  Chunks are word aligned, so no funnel shift is needed; windows outside [start, last
+// window] only occur in a contig's first and last chunk, which take a predicated copy of the loop.
+// A workgroup runs as many stages as its longest contig needs, so contigs much longer than the batch
+// mean are not counted here: they are appended to `long_list` for the wave-per-contig kernel, which follows.
+// ------------------------------------------------------------------------------------
+#define SLOT_LINES 2                       // 128-byte lines per contig and stage
+#define SLOT_ROW (32 * SLOT_LINES + 4)     // staging row stride in words (data + 1 look-ahead + pad: conflict-free b128 reads)
+// LDS-only workgroup barrier: waits for this wave's LDS operations, NOT for its global loads (a
+// __syncthreads() would also drain the prefetch of the next stage, issued just before)
+__device__ __forceinline__ void phk_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int K>
+__global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__restrict__ packed,
+                                                             const uint64_t *__restrict__ offsets, uint64_t n,
+                                                             uint64_t max_word, uint32_t long_thr,
+                                                             uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin,
+                                                             uint32_t *__restrict__ long_list,
+                                                             uint32_t *__restrict__ long_count) {
+    constexpr uint32_t D = 1u << (2 * K);
+    constexpr int CH = 8 * SLOT_LINES;      // 4-word chunks per contig and stage
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][32] | staging [2][32][SLOT_ROW] | smax
+    uint32_t *stage = lds + D * 32;
+    uint32_t *smax_p = stage + 2 * 32 * SLOT_ROW;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int slot = lane & 31, part = 2 * wave + (lane >> 5);   // counting role: contig slot, chunk (mod 8) within the stage
+    const int lct = t >> 3, lch = t & 7;                         // loading role: contig slot, chunk within a line
+    for (uint32_t b = t * 4; b < D * 32; b += 1024) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
+    if (t == 0) *smax_p = 0;
+    __syncthreads();
+    const uint32_t colb = (uint32_t)slot * 4u;
+    const uint64_t wmax4 = max_word - 2;  // highest start of a 4-word load inside the stream (+ pad word)
+
+    // LDS byte address of the bin of the window starting at base jw of `src` (jw < 8)
+    auto bin = [&](uint32_t src, int jw) {
+        const uint32_t a = ((src >> (32 - 2 * K - 2 * jw - 7)) & ((D - 1u) << 7)) | colb;
+        return reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(lds) + a);
+    };
+
+    for (uint64_t batch = blockIdx.x; batch * 32 < n; batch += gridDim.x) {
+        // ---- counting role: this lane's contig ----
+        const uint64_t c = batch * 32 + slot;
+        const bool have = c < n;
+        const uint64_t st = have ? offsets[c] : 0, en = have ? offsets[c + 1] : 0;
+        const uint64_t len = en - st;
+        uint32_t W = len >= (uint64_t)K ? (uint32_t)((len - K + 1) < 0xFFFFFFFFull ? (len - K + 1) : 0xFFFFFFFFull) : 0;
+        const bool handed_over = W > long_thr;
+        if (handed_over) {
+            if (part == 0) long_list[atomicAdd(long_count, 1u)] = (uint32_t)c;
+            W = 0;
+        }
+        const uint64_t last = st + W - 1;                     // last window start (W > 0)
+        const uint64_t q0 = st >> 6;                          // first 4-word chunk
+        const uint32_t nchunk = W ? (uint32_t)((last >> 6) - q0 + 1) : 0;
+        const uint32_t nseg = (nchunk + CH - 1) / CH;
+        // ---- loading role: the contig whose lines this lane fetches ----
+        const uint64_t cl = batch * 32 + lct;
+        const uint64_t lw0 = cl < n ? (offsets[cl] >> 6) * 4 : 0;  // first word of its first chunk
+        // stages this batch needs
+        uint32_t m = nseg;
+#pragma unroll
+        for (int sft = 16; sft > 0; sft >>= 1) {
+            const uint32_t o = __shfl_xor(m, sft);
+            m = m > o ? m : o;
+        }
+        if (lane == 0) atomicMax(smax_p, m);
+        phk_lds_barrier();
+        const uint32_t smax = *smax_p;
+
+        auto gload = [&](uint32_t s, uint4 (&v)[SLOT_LINES], uint32_t &la) {   // stage s: 16 bytes per line (+ a look-ahead word)
+#pragma unroll
+            for (int ln = 0; ln < SLOT_LINES; ++ln) {
+                const uint64_t w = lw0 + (32ull * SLOT_LINES) * s + 32u * ln + 4u * lch;
+                if (w <= wmax4) {
+                    v[ln] = *reinterpret_cast<const uint4 *>(packed + w);
+                } else {  // the last words of the whole stream (one pad word follows it): word by word, clamped
+                    const uint64_t e = max_word + 1;
+                    v[ln] = make_uint4(packed[w < e ? w : e], packed[w + 1 < e ? w + 1 : e], packed[w + 2 < e ? w + 2 : e],
+                                       packed[w + 3 < e ? w + 3 : e]);
+                }
+            }
+            const uint64_t wl = lw0 + (32ull * SLOT_LINES) * (s + 1);  // word after the stage's lines
+            la = packed[wl <= max_word + 1 ? wl : max_word + 1];
+        };
+        auto swrite = [&](uint32_t buf, const uint4 (&v)[SLOT_LINES], uint32_t la) {
+            uint32_t *row = stage + (buf * 32 + lct) * SLOT_ROW;
+#pragma unroll
+            for (int ln = 0; ln < SLOT_LINES; ++ln) *reinterpret_cast<uint4 *>(row + 32 * ln + 4 * lch) = v[ln];
+            if (lch == 7) row[32 * SLOT_LINES] = la;
+        };
+        uint4 v[SLOT_LINES];
+        uint32_t la;
+        if (smax) {
+            gload(0, v, la);
+            swrite(0, v, la);
+            if (smax > 1) gload(1, v, la);
+        }
+        phk_lds_barrier();
+        for (uint32_t s = 0; s < smax; ++s) {
+            const uint32_t *row = stage + ((s & 1) * 32 + slot) * SLOT_ROW + 4 * part;
+            uint4 cw[SLOT_LINES];
+            uint32_t nx[SLOT_LINES];
+#pragma unroll
+            for (int ln = 0; ln < SLOT_LINES; ++ln) {
+                cw[ln] = *reinterpret_cast<const uint4 *>(row + 32 * ln);
+                nx[ln] = row[32 * ln + 4];
+            }
+            if (s + 1 < smax) {
+                swrite((s + 1) & 1, v, la);
+                if (s + 2 < smax) gload(s + 2, v, la);
+            }
+#pragma unroll
+            for (int ln = 0; ln < SLOT_LINES; ++ln) {
+                const uint64_t q = q0 + (uint64_t)CH * s + 8u * ln + part;   // this lane's chunk; bases 64 q .. 64 q + 63
+                const uint64_t fb = q << 6;
+                const bool any = W && fb + 63 >= st && fb <= last;
+                const bool all = W && fb >= st && fb + 63 <= last;
+                const uint32_t wds[5] = {cw[ln].x, cw[ln].y, cw[ln].z, cw[ln].w, nx[ln]};
+                if (!__any(any && !all)) {   // wave-uniform: no lane of the wave is at an edge of its contig
+                    if (all) {
+#pragma unroll
+                        for (int wd = 0; wd < 4; ++wd) {
+                            const uint32_t y = wds[wd], u = __builtin_amdgcn_alignbit(y, wds[wd + 1], 16);
+#pragma unroll
+                            for (int jw = 0; jw < 16; ++jw) atomicAdd(bin(jw < 8 ? y : u, jw & 7), 1u);
+                        }
+                    }
+                } else if (any) {            // some lane is: every active lane adds its validity bit instead of 1
+                    const uint32_t lo = st > fb ? (uint32_t)(st - fb) : 0u;              // first valid window of the chunk
+                    const uint32_t hi = last - fb < 63 ? (uint32_t)(last - fb) : 63u;    // last valid one
+                    const uint64_t vm = ((hi - lo == 63u) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull)) << lo;
+                    const uint32_t vlo = (uint32_t)vm, vhi = (uint32_t)(vm >> 32);
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        const uint32_t y = wds[wd], u = __builtin_amdgcn_alignbit(y, wds[wd + 1], 16);
+#pragma unroll
+                        for (int jw = 0; jw < 16; ++jw) {
+                            const int wi = 16 * wd + jw;
+                            atomicAdd(bin(jw < 8 ? y : u, jw & 7), __builtin_amdgcn_ubfe(wi < 32 ? vlo : vhi, wi & 31, 1));
+                        }
+                    }
+                }
+            }
+            phk_lds_barrier();
+        }
+        // ---- flush: thread (slot, group g) writes codes [g D/8, (g+1) D/8) of contig `slot` and clears them ----
+        {
+            const int g = part;
+            uint32_t *cellb = lds + (g * (D / 8)) * 32 + slot;
+            uint32_t *rowo = counts + c * D + g * (D / 8);
+#pragma unroll
+            for (uint32_t i = 0; i < D / 32; ++i) {
+                uint32_t *cell = cellb + 4 * i * 32;
+                const uint4 o = make_uint4(cell[0], cell[32], cell[64], cell[96]);
+                cell[0] = 0; cell[32] = 0; cell[64] = 0; cell[96] = 0;
+                if (have && !handed_over) *reinterpret_cast<uint4 *>(rowo + 4 * i) = o;
+            }
+            if (nwin && have && !handed_over && g == 0) nwin[c] = W;
+        }
+        if (t == 0) *smax_p = 0;
+        phk_lds_barrier();
     }
 }
 
@@ -342,7 +524,7 @@ template <int K> struct PhkCountCfg {
 template <int K, int COPIES, bool P16>
 static int launch_count_cfg(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
                             const uint64_t *d_offsets, uint64_t n, uint64_t max_word, uint32_t *d_counts,
-                            uint32_t *d_nwin) {
+                            uint32_t *d_nwin, const uint32_t *d_list = nullptr, const uint32_t *d_list_count = nullptr) {
     constexpr uint32_t D = 1u << (2 * K);
     constexpr size_t wave_bytes = (size_t)(P16 ? D / 2 : D) * COPIES * 4u;
     // waves per block so that a block's bins stay <= 64 KiB
@@ -357,11 +539,11 @@ static int launch_count_cfg(phk_ctx *ctx, const uint32_t *d_packed, const uint32
     if (d_mask) {
         PHK_LAUNCH(ctx, "phk_count_kernel",
                    phk_count_kernel<K, COPIES, P16, true><<<dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream>>>(
-                       d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin));
+                       d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_list, d_list_count));
     } else {
         PHK_LAUNCH(ctx, "phk_count_kernel",
                    phk_count_kernel<K, COPIES, P16, false><<<dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream>>>(
-                       d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin));
+                       d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_list, d_list_count));
     }
     return PHK_OK;
 }
@@ -404,6 +586,37 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         return PHK_OK;
     }
     const uint64_t max_word = (T - 1) >> 4;  // last word holding a base; word max_word + 1 exists (pad)
+    // k = 3, 4 without invalid bases: slot kernel (32 contigs per workgroup, conflict-free LDS adds); contigs
+    // more than 4x the batch mean go on to the wave-per-contig kernel through a device list
+    const char *lanes_env = getenv("PHK_COUNT_LANES");
+    if ((k == 3 || k == 4) && !d_mask && max_word >= 64 && n < (1ull << 32) && !(lanes_env && lanes_env[0] == '0') &&
+        !getenv("PHK_COUNT_CFG")) {
+        void *ws;
+        PHK_TRY(phk_ws(ctx, WS_LONG, (n + 16) * sizeof(uint32_t), &ws));
+        uint32_t *d_long_count = (uint32_t *)ws, *d_long_list = (uint32_t *)ws + 16;
+        PHK_HIP(hipMemsetAsync(d_long_count, 0, sizeof(uint32_t), ctx->stream));
+        const uint64_t mean_len = T / n + 1;
+        const uint64_t thr64 = 4 * mean_len + 1024;
+        const uint32_t long_thr = thr64 < 0xFFFFFFFFull ? (uint32_t)thr64 : 0xFFFFFFFFu;
+        const size_t lds = (size_t)phk_pow4(k) * 32 * 4 + 2 * 32 * SLOT_ROW * 4 + 16;
+        const unsigned fit = (unsigned)((160u * 1024u - 1024u) / lds);
+        const unsigned per_cu = fit > 8 ? 8 : fit;
+        uint64_t blocks = phk_div_up(n, 32);
+        const uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
+        if (blocks > cap) blocks = cap;
+        if (k == 4) {
+            PHK_LAUNCH(ctx, "phk_count_slots_kernel",
+                       phk_count_slots_kernel<4><<<dim3((unsigned)blocks), dim3(256), lds, ctx->stream>>>(
+                           d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count));
+            return launch_count_cfg<4, PhkCountCfg<4>::copies, PhkCountCfg<4>::pack16>(
+                ctx, d_packed, nullptr, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count);
+        }
+        PHK_LAUNCH(ctx, "phk_count_slots_kernel",
+                   phk_count_slots_kernel<3><<<dim3((unsigned)blocks), dim3(256), lds, ctx->stream>>>(
+                       d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count));
+        return launch_count_cfg<3, PhkCountCfg<3>::copies, PhkCountCfg<3>::pack16>(
+            ctx, d_packed, nullptr, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count);
+    }
     switch (k) {
         case 1: return launch_count_k<1>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin);
         case 2: return launch_count_k<2>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin);

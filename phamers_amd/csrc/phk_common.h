@@ -53,6 +53,7 @@ enum PhkSlot {
     WS_QF32,        // scoring (MFMA path): fragment-ordered fp32 queries
     WS_CAND,        // scoring (MFMA path): candidate lists
     WS_NWIN,        // row sums
+    WS_LONG,        // counting: contigs handed from the lane-pair kernel to the wave-per-contig kernel
     WS_SLOTS
 };
 

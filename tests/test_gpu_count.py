@@ -156,3 +156,47 @@ def test_transform_kmers_identity(kmer):
         assert np.array_equal(transform_kmers.transform_kmers(c, reverse=False, complement=True), cmp_)
         assert np.array_equal(transform_kmers.transform_kmers(c, reverse=True, complement=True), rc)
         assert transform_kmers.transform_kmers(c, reverse=False, complement=False) is c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [3, 4])
+def test_lane_pair_count_kernel_ragged_and_handover(ctx, k):
+    """The lane-pair kernel (32 contigs per wave, all-valid input, k = 3 / 4): ragged lengths around every
+    edge (empty, shorter than k, exactly k, 63 / 64 / 65 / 127 / 128 / 129 windows per lane pair, the last
+    contig ending on the last word of the stream), a contig count that is not a multiple of 32, and
+    contigs far above the batch mean, which it must hand to the wave-per-contig kernel -- bit-exact
+    against the oracle, with nwin = row sums; the same batch through the wave-per-contig kernel alone
+    (PHK_COUNT_LANES=0) gives identical rows."""
+    import os
+    from oracle import oracle
+    from phamers_amd import device, synth
+    rng = np.random.default_rng(3)
+    lens = [0, 1, k - 1, k, k + 1, 63 + k - 1, 64 + k - 1, 65 + k - 1, 126 + k, 127 + k, 128 + k, 129 + k, 255, 256, 257,
+            1000, 4999, 5000, 5001, 40000, 90000]
+    lens += [int(x) for x in rng.integers(0, 3000, 150)]
+    lens += [16 * 7 + 5, 16 * 3]            # the stream ends word-aligned
+    seqs = [synth.synth_contig(9, i, L) for i, L in enumerate(lens)]
+    T = sum(lens)
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    raw = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    d_raw = device.DeviceArray.from_host(ctx, raw)
+    d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    d_mask = device.DeviceArray(ctx, device.mask_words(T), np.uint32)
+    device.pack_ascii(ctx, d_raw, T, d_packed, d_mask, None)
+    d_off = device.DeviceArray.from_host(ctx, offsets)
+    want = oracle.count(seqs, k)
+    D = 4 ** k
+    rows = {}
+    for lanes in ("1", "0"):
+        os.environ["PHK_COUNT_LANES"] = lanes
+        try:
+            d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 0xABCD, np.uint32))
+            d_nwin = device.DeviceArray.from_host(ctx, np.full(len(lens), 0xABCD, np.uint32))
+            device.count(ctx, d_packed, None, T, d_off, len(lens), k, d_counts, d_nwin)
+            rows[lanes] = d_counts.to_host()
+            assert np.array_equal(rows[lanes].astype(np.int64), want), (k, lanes)
+            assert np.array_equal(d_nwin.to_host().astype(np.int64), want.sum(axis=1)), (k, lanes)
+        finally:
+            os.environ.pop("PHK_COUNT_LANES", None)
+    assert np.array_equal(rows["0"], rows["1"])

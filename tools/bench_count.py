@@ -30,8 +30,8 @@ ctx.profile_reset(); ctx.profile_enable(True)
 for _ in range(a.iters):
     device.count(ctx, packed, mask, T, off, n, k, counts)
 ctx.sync()
-ms, launches = ctx.profile()["phk_count_kernel"]
-ms /= launches
+prof = ctx.profile()
+ms = sum(prof[name][0] for name in ("phk_count_slots_kernel", "phk_count_kernel") if name in prof) / a.iters
 alg = n * ((L + 3) // 4 + 8 + 4 * D) + (n * ((L + 7) // 8) if mask else 0)
 ok = None
 if a.check:
@@ -41,6 +41,6 @@ if a.check:
     want = oracle.count(synth.synth_contigs(0, m, L, a.invalid_ppm), k).reshape(m, D)
     got = counts.to_host()[:m].astype(np.int64)
     ok = bool(np.array_equal(got, want))
-print(json.dumps({"cfg": os.environ.get("PHK_COUNT_CFG", "default"), "k": k, "contigs": n, "length": L,
+print(json.dumps({"cfg": os.environ.get("PHK_COUNT_CFG", "default"), "kernels": sorted(prof), "k": k, "contigs": n, "length": L,
                   "ms": ms, "GBps_algorithmic": alg / ms / 1e6, "Gbases_per_s": T / ms / 1e6,
                   "frac_hbm_peak": alg / ms / 1e6 / 8000.0, "bit_exact_vs_oracle": ok}))
