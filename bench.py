@@ -189,6 +189,7 @@ def main():
     # ---- roofline of the dominant kernel (algorithmic work / HIP-event time in this run) ----
     alg = {  # kernel -> (bound, unit, peak, algorithmic work per step on this rank)
         "phk_count_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, n * ((L + 3) // 4 + 8 + 4 * D + 8) / 1e9),
+        "phk_count_slots_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, n * ((L + 3) // 4 + 8 + 4 * D + 8) / 1e9),
         "phk_knn_mfma_kernel": ("mfma", "TFLOP/s", MFMA_F32_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
         "phk_knn_f16_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
         "phk_knn_f16c_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),

@@ -385,8 +385,11 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
     const uint64_t wmax4 = max_word - 2;  // highest start of a 4-word load inside the stream (+ pad word)
 
     // LDS byte address of the bin of the window starting at base jw of `src` (jw < 8)
+    // (written as the two instructions it should be: left to itself hipcc emits shift + and + add)
     auto bin = [&](uint32_t src, int jw) {
-        const uint32_t a = ((src >> (32 - 2 * K - 2 * jw - 7)) & ((D - 1u) << 7)) | colb;
+        uint32_t code, a;
+        asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(code) : "v"(src), "n"(32 - 2 * K - 2 * jw), "n"(2 * K));
+        asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(a) : "v"(code), "v"(colb));
         return reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(lds) + a);
     };
 
