@@ -195,6 +195,8 @@ def main():
         "phk_knn_f16c_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
         "phk_dist2_f64_kernel": ("mfma", "TFLOP/s", F64_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
     }
+    if "phk_count_slots_kernel" in prof:   # the wave-per-contig kernel then only serves the hand-over list
+        alg.pop("phk_count_kernel", None)
     kernels = {}
     for name, (ms, launches) in prof.items():
         kernels[name] = {"ms_per_step": ms / args.steps, "launches_per_step": launches / args.steps}

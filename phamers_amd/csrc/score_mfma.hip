@@ -596,21 +596,18 @@ __device__ __forceinline__ double exact_d2_g16(const double (&qd)[16], const dou
 __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
                                     const double (&qd)[16], double nqp2, const ErrBound &eb, const double vs,
                                     const double *rows, const double *colnorm, bool want_d2, bool live, int lane,
-                                    uint32_t (&out_idx)[3], double &out_d2) {
+                                    float v_in, uint32_t ix_in, float u_in, uint32_t (&out_idx)[3], double &out_d2) {
+    // v_in / ix_in: this lane's candidate of the segment (lanes t < 8: half t >> 2, slot t & 3), u_in: the
+    // best-dropped value of half-list t & 1 -- loaded by the caller together with the query row, so that the
+    // three segments' lists cost one memory round trip, not three
     const int t = lane & 15, base = lane & 48;
     float v = -3.0e38f;
     uint32_t ix = 0xFFFFFFFFu;
     if (t < 8) {
-        const uint64_t o = (q * NSEG + seg) * 2 + (t >> 2);
-        const float4 cv = p.cand_v[o];
-        const uint4 ci = p.cand_i[o];
-        const int s = t & 3;
-        v = s == 0 ? cv.x : s == 1 ? cv.y : s == 2 ? cv.z : cv.w;
-        ix = s == 0 ? ci.x : s == 1 ? ci.y : s == 2 ? ci.z : ci.w;
-        if (ix >= ncols) v = -3.0e38f;
+        v = ix_in >= ncols ? -3.0e38f : v_in;
+        ix = ix_in;
     }
-    const uint64_t ou = (q * NSEG + seg) * 2;
-    const double U = fmax((double)p.cand_u[ou], (double)p.cand_u[ou + 1]) * vs;
+    const double U = fmax((double)u_in, (double)__shfl_xor(u_in, 1)) * vs;
     // rank among the group's 8 candidates, then values / indices by rank
     int rank = 0;
     float cvv[8];
@@ -638,8 +635,13 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
     if (ri[need - 1] < ncols) {
         const double d2up = fmax(nqp2 - 2.0 * ((double)rv[need - 1] * vs - eps_g), 0.0);
         const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
+        double cnr[3] = {0.0, 0.0, 0.0};  // independent loads (no short-circuit chain of round trips)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            if (r < need) cnr[r] = colnorm[ri[r]];
         bool near = true;
-        for (int r = 0; r < need; ++r) near = near && colnorm[ri[r]] <= R0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) near = near && (r >= need || cnr[r] <= R0);
         const double eps_m = near ? eb(R0) : eps_g;
         certified = ((double)rv[need - 1] - (double)rv[need]) * vs > 2.0 * eps_m;
     }
@@ -683,7 +685,7 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
         for (int r = 0; r < 3; ++r) out_idx[r] = bidx[r];
     }
     if (want_d2) {  // distance to the best column (centroid segments): one exact evaluation when certified
-        const uint32_t c0 = certified ? ri[0] : 0u;
+        const uint32_t c0 = ri[0];  // speculative: the row is fetched alongside the column norms, not after the verdict
         const double d2c = exact_d2_g16(qd, rows + (uint64_t)(c0 < ncols ? c0 : 0u) * FAST_D, t);
         out_d2 = certified ? d2c : best[0];
     }
@@ -700,6 +702,17 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     double qd[16];
     double vs = p.vscale;
     bool nan_row = false;
+    // the query's six half-lists, fetched with the row
+    float lv[NSEG], lu[NSEG];
+    uint32_t lix[NSEG];
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+        const uint64_t o = (q * NSEG + sg) * 2;
+        const uint64_t e = (o + ((t >> 2) & 1)) * 4 + (t & 3);
+        lv[sg] = reinterpret_cast<const float *>(p.cand_v)[e];
+        lix[sg] = reinterpret_cast<const uint32_t *>(p.cand_i)[e];
+        lu[sg] = p.cand_u[o + (t & 1)];
+    }
     if (SRC == 0) {
         const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
         uint4 c[4];
@@ -762,7 +775,8 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     uint32_t idx[3];
     double d2 = 0.0;
     if (p.method & PHK_METHOD_KNN) {
-        ok = resolve_segment_g16(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, live, lane, idx, d2);
+        ok = resolve_segment_g16(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, live, lane, lv[0], lix[0],
+                                 lu[0], idx, d2);
         int votes = 0;
         for (int r = 0; r < p.kn; ++r) votes += (idx[r] < p.M && p.labels[idx[r]]) ? 1 : 0;
         knn = (2 * votes > p.kn) ? 1.0 : -1.0;
@@ -770,9 +784,10 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     if (p.method & PHK_METHOD_KMEANS) {
         double dp2 = 0.0, dn2 = 0.0;
         const bool ok1 = resolve_segment_g16(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, vs, p.C64, p.colnorm + p.M, true,
-                                             live && ok, lane, idx, dp2);
+                                             live && ok, lane, lv[1], lix[1], lu[1], idx, dp2);
         const bool ok2 = resolve_segment_g16(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, vs, p.C64 + p.n_cpos * FAST_D,
-                                             p.colnorm + p.M + p.n_cpos, true, live && ok && ok1, lane, idx, dn2);
+                                             p.colnorm + p.M + p.n_cpos, true, live && ok && ok1, lane, lv[2], lix[2], lu[2],
+                                             idx, dn2);
         ok = ok && ok1 && ok2;
         const double ep = sqrt(dp2), en = sqrt(dn2);
         cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
