@@ -580,23 +580,28 @@ __device__ __forceinline__ double group16_sum(double x) {
     return x;
 }
 
-__device__ __forceinline__ double exact_d2_g16(const double (&qd)[16], const double *row, int t) {
+// Exact squared distance of the group's query to `row`.  The query is held UNNORMALISED: qd = the integer
+// counts (or the float64 row with Tq = 1), Tq = their sum, and
+//     |q - r|^2 = sum_i (c_i - Tq r_i)^2 / Tq^2        (one rounding per difference, inside the fma)
+// which needs no per-element division and is at least as accurate as forming q = c / Tq first.
+__device__ __forceinline__ double exact_d2_g16(const double (&qd)[16], double Tq, double invT2, const double *row, int t) {
     const double2 *r = reinterpret_cast<const double2 *>(row + 16 * t);
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const double2 v = r[i];
-        const double d0 = qd[2 * i] - v.x, d1 = qd[2 * i + 1] - v.y;
+        const double d0 = fma(-Tq, v.x, qd[2 * i]), d1 = fma(-Tq, v.y, qd[2 * i + 1]);
         acc = fma(d0, d0, fma(d1, d1, acc));
     }
-    return group16_sum(acc);
+    return group16_sum(acc) * invT2;
 }
 
 // per-group version of resolve_segment; `live` = this group still needs an answer.  Returns ok.
 __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
-                                    const double (&qd)[16], double nqp2, const ErrBound &eb, const double vs,
-                                    const double *rows, const double *colnorm, bool want_d2, bool live, int lane,
-                                    float v_in, uint32_t ix_in, float u_in, uint32_t (&out_idx)[3], double &out_d2) {
+                                    const double (&qd)[16], double Tq, double invT2, double nqp2, const ErrBound &eb,
+                                    const double vs, const double *rows, const double *colnorm, bool want_d2, bool live,
+                                    int lane, float v_in, uint32_t ix_in, float u_in, uint32_t (&out_idx)[3],
+                                    double &out_d2) {
     // v_in / ix_in: this lane's candidate of the segment (lanes t < 8: half t >> 2, slot t & 3), u_in: the
     // best-dropped value of half-list t & 1 -- loaded by the caller together with the query row, so that the
     // three segments' lists cost one memory round trip, not three
@@ -655,7 +660,7 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
         for (int m = 0; m < 8; ++m) {
             const uint32_t c = cix[m];
             const bool valid = need_exact && c < ncols;
-            const double d2 = exact_d2_g16(qd, rows + (uint64_t)(valid ? c : 0u) * FAST_D, t);
+            const double d2 = exact_d2_g16(qd, Tq, invT2, rows + (uint64_t)(valid ? c : 0u) * FAST_D, t);
             if (valid && (d2 < best[2] || (d2 == best[2] && c < bidx[2]))) {
                 best[2] = d2; bidx[2] = c;
                 if (best[2] < best[1] || (best[2] == best[1] && bidx[2] < bidx[1])) {
@@ -686,7 +691,7 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
     }
     if (want_d2) {  // distance to the best column (centroid segments): one exact evaluation when certified
         const uint32_t c0 = ri[0];  // speculative: the row is fetched alongside the column norms, not after the verdict
-        const double d2c = exact_d2_g16(qd, rows + (uint64_t)(c0 < ncols ? c0 : 0u) * FAST_D, t);
+        const double d2c = exact_d2_g16(qd, Tq, invT2, rows + (uint64_t)(c0 < ncols ? c0 : 0u) * FAST_D, t);
         out_d2 = certified ? d2c : best[0];
     }
     return ok;
@@ -702,6 +707,7 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     double qd[16];
     double vs = p.vscale;
     bool nan_row = false;
+    double Tq = 1.0, invT2 = 1.0;  // row sum and 1 / Tq^2 (counts); 1 for float64 rows
     // the query's six half-lists, fetched with the row
     float lv[NSEG], lu[NSEG];
     uint32_t lix[NSEG];
@@ -729,12 +735,14 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
         nan_row = sum == 0;
         const double ds = (double)sum;
         if (p.per_row_scale) vs = p.vscale / ds;
+        Tq = ds;
+        invT2 = 1.0 / (ds * ds);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            qd[4 * i + 0] = (double)c[i].x / ds;
-            qd[4 * i + 1] = (double)c[i].y / ds;
-            qd[4 * i + 2] = (double)c[i].z / ds;
-            qd[4 * i + 3] = (double)c[i].w / ds;
+        for (int i = 0; i < 4; ++i) {   // the counts themselves: see exact_d2_g16
+            qd[4 * i + 0] = (double)c[i].x;
+            qd[4 * i + 1] = (double)c[i].y;
+            qd[4 * i + 2] = (double)c[i].z;
+            qd[4 * i + 3] = (double)c[i].w;
         }
     } else {
         const double2 *row = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D + 16 * t);
@@ -757,12 +765,12 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const double2 m = mp[i];
-            const double c0 = qd[2 * i] - m.x, c1 = qd[2 * i + 1] - m.y;
+            const double c0 = fma(-Tq, m.x, qd[2 * i]), c1 = fma(-Tq, m.y, qd[2 * i + 1]);
             aq = fma(qd[2 * i], qd[2 * i], fma(qd[2 * i + 1], qd[2 * i + 1], aq));
             ap = fma(c0, c0, fma(c1, c1, ap));
         }
     }
-    const double nq2 = group16_sum(aq), nqp2 = group16_sum(ap);
+    const double nq2 = group16_sum(aq) * invT2, nqp2 = group16_sum(ap) * invT2;
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
@@ -775,7 +783,7 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     uint32_t idx[3];
     double d2 = 0.0;
     if (p.method & PHK_METHOD_KNN) {
-        ok = resolve_segment_g16(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, live, lane, lv[0], lix[0],
+        ok = resolve_segment_g16(p, q, 0, (uint32_t)p.M, p.kn, qd, Tq, invT2, nqp2, eb, vs, p.R64, p.colnorm, false, live, lane, lv[0], lix[0],
                                  lu[0], idx, d2);
         int votes = 0;
         for (int r = 0; r < p.kn; ++r) votes += (idx[r] < p.M && p.labels[idx[r]]) ? 1 : 0;
@@ -783,9 +791,9 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     }
     if (p.method & PHK_METHOD_KMEANS) {
         double dp2 = 0.0, dn2 = 0.0;
-        const bool ok1 = resolve_segment_g16(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, vs, p.C64, p.colnorm + p.M, true,
+        const bool ok1 = resolve_segment_g16(p, q, 1, (uint32_t)p.n_cpos, 1, qd, Tq, invT2, nqp2, eb, vs, p.C64, p.colnorm + p.M, true,
                                              live && ok, lane, lv[1], lix[1], lu[1], idx, dp2);
-        const bool ok2 = resolve_segment_g16(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, vs, p.C64 + p.n_cpos * FAST_D,
+        const bool ok2 = resolve_segment_g16(p, q, 2, (uint32_t)p.n_cneg, 1, qd, Tq, invT2, nqp2, eb, vs, p.C64 + p.n_cpos * FAST_D,
                                              p.colnorm + p.M + p.n_cpos, true, live && ok && ok1, lane, lv[2], lix[2], lu[2],
                                              idx, dn2);
         ok = ok && ok1 && ok2;
