@@ -212,6 +212,11 @@ __device__ __forceinline__ uint32_t phk_count_word(uint32_t *mybins, uint32_t a,
     return __popc(okbits);
 }
 
+// Batch statistics for the slot kernel's stand-down rule.  A slot workgroup runs as many 1024-window stages
+// as the longest of its 32 contigs needs; stats[0] = sum over groups of 32 x that padded maximum, stats[1] =
+// windows actually counted.  Below 60 % the wave-per-contig kernel is the faster one and takes the whole batch.
+__device__ __forceinline__ bool phk_slots_apply(const unsigned long long *stats) { return stats[1] * 10ull >= stats[0] * 6ull; }
+
 // The kernel is latency-bound unless loads run ahead of the LDS work, so it is software pipelined
 // at the contig level: offsets are fetched two contigs ahead, the first PF wave-iterations of
 // packed words one contig ahead (a register ring; longer contigs refill the ring as they go).
@@ -225,8 +230,10 @@ __global__ __launch_bounds__(256) void phk_count_kernel(const uint32_t *__restri
                                                         const uint32_t *__restrict__ list,
                                                         const uint32_t *__restrict__ list_count) {
     static_assert(COPIES >= 4 || !PACK16 || COPIES == 1, "unsupported replication");
-    // with `list`: count contigs list[0 .. *list_count) (those the lane-pair kernel handed over)
-    if (list) n = *list_count;
+    // with `list`: count contigs list[0 .. *list_count) (those the slot kernel handed over) -- unless the batch
+    // statistics behind list_count say the slot kernel stood down (ragged batch): then everything is counted here
+    if (list && phk_slots_apply(reinterpret_cast<const unsigned long long *>(list_count + 2))) n = *list_count;
+    else list = nullptr;
     auto cid = [&](uint64_t i) { return list ? (uint64_t)list[i] : i; };
     constexpr uint32_t D = 1u << (2 * K);
     constexpr int W = (int)(PACK16 ? D / 2 : D) * COPIES;
@@ -338,6 +345,36 @@ __global__ __launch_bounds__(256) void phk_count_kernel(const uint32_t *__restri
     }
 }
 
+__global__ __launch_bounds__(256) void phk_count_stats_kernel(const uint64_t *__restrict__ offsets, uint64_t n, int k,
+                                                              uint32_t long_thr, unsigned long long *__restrict__ stats) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long pad = 0, used = 0;
+    if (g * 32 < n) {
+        uint64_t mx = 0;
+        uint64_t prev = offsets[g * 32];
+        for (uint64_t i = g * 32; i < g * 32 + 32 && i < n; ++i) {
+            const uint64_t nx = offsets[i + 1];
+            const uint64_t len = nx - prev;
+            prev = nx;
+            const uint64_t w = len >= (uint64_t)k ? len - k + 1 : 0;
+            if (w <= long_thr) {
+                used += w;
+                mx = w > mx ? w : mx;
+            }
+        }
+        pad = 32ull * (((mx + 1023) >> 10) << 10);
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        pad += __shfl_xor(pad, sft);
+        used += __shfl_xor(used, sft);
+    }
+    if ((threadIdx.x & 63) == 0 && pad) {
+        atomicAdd(stats, pad);
+        atomicAdd(stats + 1, used);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Slot kernel (k = 3, 4; all bases valid): a workgroup of 4 waves counts 32 contigs at a time, 8 lanes
 // per contig, each contig in a histogram COLUMN of its own.
@@ -375,6 +412,7 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][32] | staging [2][32][SLOT_ROW] | smax
     uint32_t *stage = lds + D * 32;
     uint32_t *smax_p = stage + 2 * 32 * SLOT_ROW;
+    if (!phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) return;  // ragged batch: stand down
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int slot = lane & 31, part = 2 * wave + (lane >> 5);   // counting role: contig slot, chunk (mod 8) within the stage
     const int lct = t >> 3, lch = t & 7;                         // loading role: contig slot, chunk within a line
@@ -596,11 +634,16 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         !getenv("PHK_COUNT_CFG")) {
         void *ws;
         PHK_TRY(phk_ws(ctx, WS_LONG, (n + 16) * sizeof(uint32_t), &ws));
+        // [0] hand-over count, [2..5] batch statistics (two uint64), [16..] hand-over list
         uint32_t *d_long_count = (uint32_t *)ws, *d_long_list = (uint32_t *)ws + 16;
-        PHK_HIP(hipMemsetAsync(d_long_count, 0, sizeof(uint32_t), ctx->stream));
+        PHK_HIP(hipMemsetAsync(d_long_count, 0, 64, ctx->stream));
         const uint64_t mean_len = T / n + 1;
         const uint64_t thr64 = 4 * mean_len + 1024;
         const uint32_t long_thr = thr64 < 0xFFFFFFFFull ? (uint32_t)thr64 : 0xFFFFFFFFu;
+        if (!(lanes_env && lanes_env[0] == '2'))  // PHK_COUNT_LANES=2: slot kernel whatever the batch looks like (tests)
+        PHK_LAUNCH(ctx, "phk_count_stats_kernel",
+                   phk_count_stats_kernel<<<dim3((unsigned)phk_div_up(phk_div_up(n, 32), 256)), dim3(256), 0, ctx->stream>>>(
+                       d_offsets, n, k, long_thr, (unsigned long long *)(d_long_count + 2)));
         const size_t lds = (size_t)phk_pow4(k) * 32 * 4 + 2 * 32 * SLOT_ROW * 4 + 16;
         const unsigned fit = (unsigned)((160u * 1024u - 1024u) / lds);
         const unsigned per_cu = fit > 8 ? 8 : fit;

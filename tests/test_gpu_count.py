@@ -188,7 +188,7 @@ def test_lane_pair_count_kernel_ragged_and_handover(ctx, k):
     want = oracle.count(seqs, k)
     D = 4 ** k
     rows = {}
-    for lanes in ("1", "0"):
+    for lanes in ("2", "1", "0"):   # slot kernel forced / chosen by the batch statistics / wave-per-contig kernel only
         os.environ["PHK_COUNT_LANES"] = lanes
         try:
             d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 0xABCD, np.uint32))
@@ -199,4 +199,4 @@ def test_lane_pair_count_kernel_ragged_and_handover(ctx, k):
             assert np.array_equal(d_nwin.to_host().astype(np.int64), want.sum(axis=1)), (k, lanes)
         finally:
             os.environ.pop("PHK_COUNT_LANES", None)
-    assert np.array_equal(rows["0"], rows["1"])
+    assert np.array_equal(rows["0"], rows["1"]) and np.array_equal(rows["0"], rows["2"])
