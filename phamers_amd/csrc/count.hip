@@ -399,6 +399,10 @@ __global__ __launch_bounds__(256) void phk_count_stats_kernel(const uint64_t *__
 // LDS-only workgroup barrier: waits for this wave's LDS operations, NOT for its global loads (a
 // __syncthreads() would also drain the prefetch of the next stage, issued just before)
 __device__ __forceinline__ void phk_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// The same between two counting stages: LDS operations of a wave complete in order, so once at most 15 are
+// outstanding everything older than the last 15 -- the staging writes, issued before the stage's 128 adds --
+// has been performed; the adds themselves only have to be complete at the flush (full barrier there).
+__device__ __forceinline__ void phk_stage_barrier() { asm volatile("s_waitcnt lgkmcnt(15)\n\ts_barrier" ::: "memory"); }
 
 template <int K>
 __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__restrict__ packed,
@@ -423,12 +427,16 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
     const uint64_t wmax4 = max_word - 2;  // highest start of a 4-word load inside the stream (+ pad word)
 
     // LDS byte address of the bin of the window starting at base jw of `src` (jw < 8)
-    // (written as the two instructions it should be: left to itself hipcc emits shift + and + add)
+    // The bins sit at LDS address 0 (the kernel has no static LDS), so the byte address is formed as an integer --
+    // shift, then v_and_or with the slot -- and used as an LDS pointer directly; going through `lds + index`
+    // costs a third instruction per window (the add of the array's link-time base).
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
     auto bin = [&](uint32_t src, int jw) {
-        uint32_t code, a;
-        asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(code) : "v"(src), "n"(32 - 2 * K - 2 * jw), "n"(2 * K));
-        asm("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(a) : "v"(code), "v"(colb));
-        return reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(lds) + a);
+        const uint32_t a = ((src >> (32 - 2 * K - 2 * jw - 7)) & ((D - 1u) << 7)) | colb;
+        return (lds_u32 *)(uintptr_t)a;
+    };
+    auto add1 = [&](lds_u32 *p, uint32_t val) {
+        __hip_atomic_fetch_add(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
     for (uint64_t batch = blockIdx.x; batch * 32 < n; batch += gridDim.x) {
@@ -503,6 +511,11 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
                 swrite((s + 1) & 1, v, la);
                 if (s + 2 < smax) gload(s + 2, v, la);
             }
+            // take delivery of ALL the stage's staging reads here: a read waited for after the first adds have been
+            // issued costs a full drain of the add queue (the LDS counter is in order and saturates at 15)
+#pragma unroll
+            for (int ln = 0; ln < SLOT_LINES; ++ln)
+                asm volatile("" ::"v"(cw[ln].x), "v"(cw[ln].y), "v"(cw[ln].z), "v"(cw[ln].w), "v"(nx[ln]));
 #pragma unroll
             for (int ln = 0; ln < SLOT_LINES; ++ln) {
                 const uint64_t q = q0 + (uint64_t)CH * s + 8u * ln + part;   // this lane's chunk; bases 64 q .. 64 q + 63
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
                         for (int wd = 0; wd < 4; ++wd) {
                             const uint32_t y = wds[wd], u = __builtin_amdgcn_alignbit(y, wds[wd + 1], 16);
 #pragma unroll
-                            for (int jw = 0; jw < 16; ++jw) atomicAdd(bin(jw < 8 ? y : u, jw & 7), 1u);
+                            for (int jw = 0; jw < 16; ++jw) add1(bin(jw < 8 ? y : u, jw & 7), 1u);
                         }
                     }
                 } else if (any) {            // some lane is: every active lane adds its validity bit instead of 1
@@ -530,13 +543,14 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
 #pragma unroll
                         for (int jw = 0; jw < 16; ++jw) {
                             const int wi = 16 * wd + jw;
-                            atomicAdd(bin(jw < 8 ? y : u, jw & 7), __builtin_amdgcn_ubfe(wi < 32 ? vlo : vhi, wi & 31, 1));
+                            add1(bin(jw < 8 ? y : u, jw & 7), __builtin_amdgcn_ubfe(wi < 32 ? vlo : vhi, wi & 31, 1));
                         }
                     }
                 }
             }
-            phk_lds_barrier();
+            phk_stage_barrier();
         }
+        phk_lds_barrier();  // every wave's adds have landed
         // ---- flush: thread (slot, group g) writes codes [g D/8, (g+1) D/8) of contig `slot` and clears them ----
         {
             const int g = part;
