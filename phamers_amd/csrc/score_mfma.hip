@@ -321,6 +321,7 @@ struct RerankParams {
     uint32_t *status;       // NaN-row counter (may be null)
     uint32_t *fb_count;     // fallback queue length
     uint32_t *fb_list;      // fallback queue (query indices)
+    uint32_t *slow_list;    // queries the one-lane-per-query decision kernel could not certify (fb_count[2] of them)
     uint64_t q_base;        // index of this batch's first query within the caller's arrays
 };
 
@@ -697,12 +698,20 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
     return ok;
 }
 
-template <int SRC>
+template <int SRC, bool LISTED>
 __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restrict__ src, RerankParams p) {
     const int lane = threadIdx.x & 63, t = lane & 15;
-    const uint64_t qraw = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
-    if ((qraw & ~3ull) >= p.N) return;  // whole wave past the end
-    const bool inrange = qraw < p.N;
+    uint64_t qraw = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
+    bool inrange;
+    if (LISTED) {   // only the queries phk_decide_kernel handed over
+        const uint64_t cnt = p.fb_count[2];
+        if ((qraw & ~3ull) >= cnt) return;
+        inrange = qraw < cnt;
+        qraw = p.slow_list[inrange ? qraw : cnt - 1];
+    } else {
+        if ((qraw & ~3ull) >= p.N) return;  // whole wave past the end
+        inrange = qraw < p.N;
+    }
     const uint64_t q = inrange ? qraw : p.N - 1;
     double qd[16];
     double vs = p.vscale;
@@ -810,6 +819,201 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
             const uint32_t slot = atomicAdd(p.fb_count, 1u);
             p.fb_list[slot] = (uint32_t)q;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// 2c. D = 256: the decision for the (large) majority of queries that the margin test certifies, with the
+//     per-query scalar arithmetic -- ranking of the 8 candidates of a segment, error bounds, square roots,
+//     tanh -- done by ONE lane per query instead of redundantly by the 16 lanes that share a query in
+//     phk_rerank16_kernel (that kernel is VALU-bound on exactly this redundancy: ~345 instructions per query).
+//     A 256-thread block handles 256 queries in three phases:
+//       A  lane = query : read its six half-lists, merge them, fetch column norms / labels of the leaders
+//       B  16 lanes = query, 16 queries at a time: the row itself -- |q|^2, |q'|^2 and the exact float64
+//          distances to the leading positive / negative centroid (exact_d2_g16)
+//       C  lane = query : margin tests (the conditions of resolve_segment_g16), vote, proximity metric
+//     A query some segment of which is not certified by margin goes to `slow_list`; phk_rerank16_kernel
+//     (LISTED) then treats it exactly as before (exact candidate distances, fallback queue).
+// ------------------------------------------------------------------------------------
+template <int SRC>
+__global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict__ src, RerankParams p) {
+    __shared__ uint32_t s_ix[2][256];
+    __shared__ double s_T[256], s_nq2[256], s_nqp2[256], s_dp2[256], s_dn2[256];
+    const int tid = threadIdx.x, lane = tid & 63, t = lane & 15;
+    const uint64_t qb = (uint64_t)blockIdx.x * 256;
+    const bool want_knn = (p.method & PHK_METHOD_KNN) != 0, want_cen = (p.method & PHK_METHOD_KMEANS) != 0;
+
+    // ---- phase A: one lane per query ----
+    const uint64_t qa = qb + tid;
+    const bool in_a = qa < p.N;
+    const uint64_t qc = in_a ? qa : p.N - 1;
+    float gap_hi[NSEG], gap_lo[NSEG], Useg[NSEG];   // need-th and (need+1)-th computed value, best dropped value
+    uint32_t lead[NSEG][3];
+    bool filled[NSEG];
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+        const uint32_t ncols = sg == 0 ? (uint32_t)p.M : sg == 1 ? (uint32_t)p.n_cpos : (uint32_t)p.n_cneg;
+        const int need = sg == 0 ? p.kn : 1;
+        const uint64_t o = (qc * NSEG + sg) * 2;
+        const float4 a = p.cand_v[o], b = p.cand_v[o + 1];
+        const uint4 ai = p.cand_i[o], bi = p.cand_i[o + 1];
+        Useg[sg] = fmaxf(p.cand_u[o], p.cand_u[o + 1]);
+        // the 4 best of the 8 candidates by insertion (descending; an equal value stays behind: a tie at the
+        // decisive position fails the margin test anyway); padding / empty slots never enter
+        float v[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        uint32_t ix[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        const float w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const uint32_t wx[8] = {ai.x, ai.y, ai.z, ai.w, bi.x, bi.y, bi.z, bi.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float x = wx[c] >= ncols ? -3.0e38f : w[c];
+            uint32_t xi = wx[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool up = x > v[k];
+                const float tv = v[k];
+                const uint32_t ti = ix[k];
+                v[k] = up ? x : tv;
+                ix[k] = up ? xi : ti;
+                x = up ? tv : x;
+                xi = up ? ti : xi;
+            }
+        }
+        gap_hi[sg] = need == 1 ? v[0] : need == 2 ? v[1] : v[2];
+        gap_lo[sg] = need == 1 ? v[1] : need == 2 ? v[2] : v[3];
+        filled[sg] = (need == 1 ? ix[0] : need == 2 ? ix[1] : ix[2]) < ncols;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) lead[sg][r] = ix[r];
+    }
+    s_ix[0][tid] = lead[1][0] < (uint32_t)p.n_cpos ? lead[1][0] : 0u;
+    s_ix[1][tid] = lead[2][0] < (uint32_t)p.n_cneg ? lead[2][0] : 0u;
+    // speculative gathers, consumed in phase C
+    double cn0[3];
+    uint8_t lab0[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const uint32_t c = lead[0][r] < (uint32_t)p.M ? lead[0][r] : 0u;
+        cn0[r] = p.colnorm[c];
+        lab0[r] = p.labels[c];
+    }
+    const double cnp = p.colnorm[p.M + s_ix[0][tid]], cnn = p.colnorm[p.M + p.n_cpos + s_ix[1][tid]];
+    __syncthreads();
+
+    // ---- phase B: 16 lanes per query, 16 queries per pass ----
+    {
+        double mu[16];
+        const double2 *mp = reinterpret_cast<const double2 *>(p.mu64 + 16 * t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double2 m2 = mp[i];
+            mu[2 * i] = m2.x;
+            mu[2 * i + 1] = m2.y;
+        }
+#pragma unroll 2
+        for (int pass = 0; pass < 16; ++pass) {
+            const int ql = pass * 16 + (tid >> 4);
+            const uint64_t q = qb + ql < p.N ? qb + ql : p.N - 1;
+            double qd[16], Tq = 1.0, invT2 = 1.0;
+            bool bad = false;
+            if (SRC == 0) {
+                const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
+                uint32_t sum = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 c = row[i];
+                    sum += c.x + c.y + c.z + c.w;
+                    qd[4 * i + 0] = (double)c.x;
+                    qd[4 * i + 1] = (double)c.y;
+                    qd[4 * i + 2] = (double)c.z;
+                    qd[4 * i + 3] = (double)c.w;
+                }
+                sum += __shfl_xor(sum, 8);
+                sum += __shfl_xor(sum, 4);
+                sum += __shfl_xor(sum, 2);
+                sum += __shfl_xor(sum, 1);
+                bad = sum == 0;
+                Tq = (double)sum;
+                invT2 = 1.0 / (Tq * Tq);
+            } else {
+                const double2 *row = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D + 16 * t);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const double2 v2 = row[i];
+                    qd[2 * i] = v2.x;
+                    qd[2 * i + 1] = v2.y;
+                    bad |= v2.x != v2.x || v2.y != v2.y;
+                }
+                unsigned bb = bad ? 1u : 0u;
+                bb |= __shfl_xor(bb, 8); bb |= __shfl_xor(bb, 4); bb |= __shfl_xor(bb, 2); bb |= __shfl_xor(bb, 1);
+                bad = bb != 0;
+            }
+            double aq = 0.0, ap = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double c0 = fma(-Tq, mu[i], qd[i]);
+                aq = fma(qd[i], qd[i], aq);
+                ap = fma(c0, c0, ap);
+            }
+            const double nq2 = group16_sum(aq) * invT2, nqp2 = group16_sum(ap) * invT2;
+            double dp2 = 0.0, dn2 = 0.0;
+            if (want_cen) {
+                dp2 = exact_d2_g16(qd, Tq, invT2, p.C64 + (uint64_t)s_ix[0][ql] * FAST_D, t);
+                dn2 = exact_d2_g16(qd, Tq, invT2, p.C64 + (p.n_cpos + (uint64_t)s_ix[1][ql]) * FAST_D, t);
+            }
+            if (t == 0) {
+                s_T[ql] = bad ? 0.0 : Tq;   // 0 marks a NaN row
+                s_nq2[ql] = nq2;
+                s_nqp2[ql] = nqp2;
+                s_dp2[ql] = dp2;
+                s_dn2[ql] = dn2;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: one lane per query ----
+    if (!in_a) return;
+    const double Tq = s_T[tid];
+    if (Tq == 0.0) {  // zero-count contig / NaN input: the reference's normalised row is NaN
+        p.scores[p.q_base + qa] = __builtin_nan("");
+        if (p.status) atomicAdd(p.status, 1u);
+        return;
+    }
+    const double nq2 = s_nq2[tid], nqp2 = s_nqp2[tid];
+    const double vs = p.per_row_scale ? p.vscale / Tq : p.vscale;
+    ErrBound eb;
+    eb.A = sqrt(nq2) + p.mu_norm;
+    eb.P = sqrt(nqp2);
+    eb.Q = sqrt(nq2);
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ;
+    const double nqp = eb.P;
+    const double eps_g = eb(p.rmax);
+    auto certify = [&](int sg, int need, const double *cnorms) {   // resolve_segment_g16's margin test
+        if (!filled[sg]) return false;
+        const double d2up = fmax(nqp2 - 2.0 * ((double)gap_hi[sg] * vs - eps_g), 0.0);
+        const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
+        bool near = true;
+        for (int r = 0; r < need; ++r) near = near && cnorms[r] <= R0;
+        const double eps_m = near ? eb(R0) : eps_g;
+        return ((double)gap_hi[sg] - (double)gap_lo[sg]) * vs > 2.0 * eps_m;
+    };
+    bool cert = true;
+    double knn = 0.0, cen = 0.0;
+    if (want_knn) {
+        cert = certify(0, p.kn, cn0);
+        int votes = 0;
+        for (int r = 0; r < p.kn; ++r) votes += lab0[r] ? 1 : 0;
+        knn = (2 * votes > p.kn) ? 1.0 : -1.0;
+    }
+    if (want_cen) {
+        cert = cert && certify(1, 1, &cnp) && certify(2, 1, &cnn);
+        const double ep = sqrt(s_dp2[tid]), en = sqrt(s_dn2[tid]);
+        cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
+    }
+    if (cert) {
+        p.scores[p.q_base + qa] = knn + cen;  // scripts/phamer.py:313
+    } else {
+        p.slow_list[atomicAdd(p.fb_count + 2, 1u)] = (uint32_t)qa;
     }
 }
 
@@ -960,9 +1164,14 @@ static int launch_rerank(phk_ctx *ctx, unsigned blocks, const void *src, const R
             const char *rr = getenv("PHK_RERANK");
             if (rr && rr[0] == 'w') {  // one wave per query (the general kernel), for A/B comparison
                 PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 1><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
-            } else {                   // four queries per wave
+            } else if (rr && rr[0] == 'g') {  // four queries per wave for every query (the decision kernel off)
                 PHK_LAUNCH(ctx, "phk_rerank16_kernel",
-                           phk_rerank16_kernel<SRC><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p));
+                           (phk_rerank16_kernel<SRC, false><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p)));
+            } else {   // one lane per query for what the margin test certifies, then four per wave for the rest
+                PHK_LAUNCH(ctx, "phk_decide_kernel",
+                           phk_decide_kernel<SRC><<<dim3((unsigned)phk_div_up(p.N, 256)), dim3(256), 0, ctx->stream>>>(src, p));
+                PHK_LAUNCH(ctx, "phk_rerank16_kernel",
+                           (phk_rerank16_kernel<SRC, true><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p)));
             }
             break;
         }
@@ -999,7 +1208,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     PHK_TRY(phk_ws(ctx, WS_CAND, per_list * (sizeof(float4) + sizeof(uint4) + sizeof(float)), &cv));
     uint4 *ci = (uint4 *)((char *)cv + per_list * sizeof(float4));
     float *cu = (float *)((char *)ci + per_list * sizeof(uint4));
-    PHK_TRY(phk_ws(ctx, WS_DIST, (nb_max + 16) * sizeof(uint32_t), &fb));
+    PHK_TRY(phk_ws(ctx, WS_DIST, (2 * nb_max + 16) * sizeof(uint32_t), &fb));
     PHK_TRY(phk_ws(ctx, WS_QF32, nb_max * FB_CHUNKS * sizeof(FbRecord), &rec));
     uint32_t *fb_count = (uint32_t *)fb, *fb_list = (uint32_t *)fb + 16;
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
@@ -1030,7 +1239,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
         p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.colnorm = m->d_colnorm; p.labels = m->d_labels;
         p.cand_v = (const float4 *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
-        p.scores = d_scores; p.status = d_status; p.fb_count = fb_count; p.fb_list = fb_list; p.q_base = s;
+        p.scores = d_scores; p.status = d_status; p.fb_count = fb_count; p.fb_list = fb_list; p.slow_list = fb_list + nb_max; p.q_base = s;
         p.eb_cQ = 0.0; p.per_row_scale = 0;
         if (use_cx) {
             // see ErrBound: values are T S v (per row), 2D/16 instructions on uncentred products
