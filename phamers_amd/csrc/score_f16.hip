@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
                                                              const double *__restrict__ mu64,
                                                              uint32_t nblk_ref, uint32_t nblk_pos,
                                                              uint32_t nblk_neg,
-                                                             float4 *__restrict__ cand_v,
-                                                             uint4 *__restrict__ cand_i,
+                                                             float *__restrict__ cand_v,
+                                                             uint32_t *__restrict__ cand_i,
                                                              float *__restrict__ cand_u) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x F16_BLOCK_BYTES
     const int lane = threadIdx.x & 63;
@@ -229,10 +229,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     auto flush_if_segment_end = [&](uint32_t b) {
         while (seg < NSEG && b + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
             if (q0 + j < N) {
-                const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
-                cand_v[o] = make_float4(lv[0], lv[1], lv[2], lv[3]);
-                cand_i[o] = make_uint4(li[0], li[1], li[2], li[3]);
-                cand_u[o] = ldrop;
+                cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2], li[3], ldrop);
             }
 #pragma unroll
             for (int c = 0; c < CAND; ++c) {
@@ -309,17 +306,14 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch before the LDS is released
     for (; seg < NSEG; ++seg) {
         if (q0 + j < N) {
-            const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
-            cand_v[o] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
-            cand_i[o] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            cand_u[o] = -3.0e38f;
+            cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
         }
     }
 }
 
 int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                             const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                            float4 *cv, uint4 *ci, float *cu) {
+                            float *cv, uint32_t *ci, float *cu) {
     static bool attr_set = false;
     const size_t lds = 2 * F16_BLOCK_BYTES;
     if (!attr_set) {
@@ -362,7 +356,7 @@ int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, b
 template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn_f16c_kernel(
     const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rowsum, uint64_t N, const uint4 *__restrict__ Af,
-    uint32_t nblk_ref, uint32_t nblk_pos, uint32_t nblk_neg, float4 *__restrict__ cand_v, uint4 *__restrict__ cand_i,
+    uint32_t nblk_ref, uint32_t nblk_pos, uint32_t nblk_neg, float *__restrict__ cand_v, uint32_t *__restrict__ cand_i,
     float *__restrict__ cand_u) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x F16_BLOCK_BYTES
     const int lane = threadIdx.x & 63;
@@ -542,17 +536,14 @@ __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn
         for (int t = 0; t < NT; ++t) {
             const uint64_t qi = q0 + 32 * t + j;
             if (qi < N) {
-                const uint64_t o = (qi * NSEG + seg) * 2 + h;
-                uint32_t ix[4];
+                                uint32_t ix[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const uint32_t r = (__float_as_uint(lv[t][c]) >> 1) & 15u;
                     ix[c] = (lb[t][c] == CX_SENT || big[t]) ? 0xFFFFFFFFu
                                                              : lb[t][c] * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
                 }
-                cand_v[o] = make_float4(lv[t][0], lv[t][1], lv[t][2], lv[t][3]);
-                cand_i[o] = make_uint4(ix[0], ix[1], ix[2], ix[3]);
-                cand_u[o] = big[t] ? 3.0e38f : lv[t][4];
+                cand_store(cand_v, cand_i, cand_u, seg, h, qi, N, lv[t][0], lv[t][1], lv[t][2], lv[t][3], ix[0], ix[1], ix[2], ix[3], big[t] ? 3.0e38f : lv[t][4]);
             }
         }
     };
@@ -564,10 +555,7 @@ __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn
             for (int t = 0; t < NT; ++t) {
                 const uint64_t qi = q0 + 32 * t + j;
                 if (qi < N) {
-                    const uint64_t o = (qi * NSEG + seg) * 2 + h;
-                    cand_v[o] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
-                    cand_i[o] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-                    cand_u[o] = -3.0e38f;
+                                        cand_store_empty(cand_v, cand_i, cand_u, seg, h, qi, N);
                 }
             }
             continue;
@@ -600,7 +588,7 @@ __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn
 }
 
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
-                             uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float4 *cv, uint4 *ci, float *cu) {
+                             uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu) {
     static bool attr_set = false;
     const size_t lds = 2 * F16_BLOCK_BYTES;
     if (!attr_set) {
@@ -704,8 +692,8 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
                                                                      uint32_t blk0,    // first block swept
                                                                      uint32_t nblk_ref, uint32_t nblk_pos,
                                                                      uint32_t nblk_neg,
-                                                                     float4 *__restrict__ cand_v,
-                                                                     uint4 *__restrict__ cand_i,
+                                                                     float *__restrict__ cand_v,
+                                                                     uint32_t *__restrict__ cand_i,
                                                                      float *__restrict__ cand_u) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x 32 KiB
     const int lane = threadIdx.x & 63;
@@ -799,10 +787,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
                 }
                 while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
                     if (qb < nqb && q0 + j < N) {
-                        const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
-                        cand_v[o] = make_float4(lv[0], lv[1], lv[2], lv[3]);
-                        cand_i[o] = make_uint4(li[0], li[1], li[2], li[3]);
-                        cand_u[o] = ldrop;
+                        cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2], li[3], ldrop);
                     }
 #pragma unroll
                     for (int c = 0; c < CAND; ++c) {
@@ -819,10 +804,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (; seg < NSEG; ++seg) {
         if (qb < nqb && q0 + j < N) {
-            const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
-            cand_v[o] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
-            cand_i[o] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            cand_u[o] = -3.0e38f;
+            cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
         }
     }
 }
@@ -830,7 +812,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
 // proposal pass for D = 256 * nchunk > 256: row sums (if needed) -> split queries -> sweep
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                                    float4 *cv, uint4 *ci, float *cu) {
+                                    float *cv, uint32_t *ci, float *cu) {
     const uint64_t D = m->D, nchunk = D / 256;
     const uint64_t nqb = phk_div_up(nb, 32);
     void *bq, *rs = nullptr;

@@ -10,6 +10,32 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define NSEG 3         // train rows, positive centroids, negative centroids
 #define PAD_V (-1.0e30f)
 
+// Candidate lists of a batch of N queries, structure of arrays (a wave of the proposal kernels writes, and
+// a lane-per-query reader reads, consecutive queries at consecutive addresses):
+//   value / column index of slot c of half-list h of segment seg of query q : [((seg*2 + h)*CAND + c) * N + q]
+//   best value the half-list ever dropped                                    : [(seg*2 + h) * N + q]
+__device__ __forceinline__ uint64_t cand_at(int seg, int h, int c, uint64_t q, uint64_t N) {
+    return (uint64_t)((seg * 2 + h) * CAND + c) * N + q;
+}
+__device__ __forceinline__ uint64_t candu_at(int seg, int h, uint64_t q, uint64_t N) { return (uint64_t)(seg * 2 + h) * N + q; }
+__device__ __forceinline__ void cand_store(float *cv, uint32_t *ci, float *cu, int seg, int h, uint64_t q, uint64_t N,
+                                           float v0, float v1, float v2, float v3, uint32_t i0, uint32_t i1, uint32_t i2,
+                                           uint32_t i3, float u) {
+    cv[cand_at(seg, h, 0, q, N)] = v0;
+    cv[cand_at(seg, h, 1, q, N)] = v1;
+    cv[cand_at(seg, h, 2, q, N)] = v2;
+    cv[cand_at(seg, h, 3, q, N)] = v3;
+    ci[cand_at(seg, h, 0, q, N)] = i0;
+    ci[cand_at(seg, h, 1, q, N)] = i1;
+    ci[cand_at(seg, h, 2, q, N)] = i2;
+    ci[cand_at(seg, h, 3, q, N)] = i3;
+    cu[candu_at(seg, h, q, N)] = u;
+}
+__device__ __forceinline__ void cand_store_empty(float *cv, uint32_t *ci, float *cu, int seg, int h, uint64_t q, uint64_t N) {
+    cand_store(cv, ci, cu, seg, h, q, N, -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu,
+               0xFFFFFFFFu, -3.0e38f);
+}
+
 // v_bfi_b32 proper (the C form above is turned into compare + select pairs by hipcc)
 __device__ __forceinline__ uint32_t phk_bfi_hw(uint32_t m, uint32_t a, uint32_t b) {
     uint32_t r;

@@ -176,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
                                                               const double *__restrict__ mu64,
                                                               uint32_t nblk_ref, uint32_t nblk_pos,
                                                               uint32_t nblk_neg,
-                                                              float4 *__restrict__ cand_v,
-                                                              uint4 *__restrict__ cand_i,
+                                                              float *__restrict__ cand_v,
+                                                              uint32_t *__restrict__ cand_i,
                                                               float *__restrict__ cand_u) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
@@ -274,10 +274,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
         // segment boundary: flush this (query, segment, half) list and start the next segment
         while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
             if (q0 + j < N) {
-                const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
-                cand_v[o] = make_float4(lv[0], lv[1], lv[2], lv[3]);
-                cand_i[o] = make_uint4(li[0], li[1], li[2], li[3]);
-                cand_u[o] = ldrop;
+                cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2], li[3], ldrop);
             }
 #pragma unroll
             for (int c = 0; c < CAND; ++c) {
@@ -292,10 +289,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
     // segments with no blocks at all (method without that part) still get an (empty) list
     for (; seg < NSEG; ++seg) {
         if (q0 + j < N) {
-            const uint64_t o = ((q0 + j) * NSEG + seg) * 2 + h;
-            cand_v[o] = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
-            cand_i[o] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            cand_u[o] = -3.0e38f;
+            cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
         }
     }
 }
@@ -313,8 +307,8 @@ struct RerankParams {
     int per_row_scale;      // count-exact proposal: computed values are in units of T_q / vscale (T_q = row sum)
     const double *R64, *C64, *mu64, *colnorm;
     const uint8_t *labels;
-    const float4 *cand_v;
-    const uint4 *cand_i;
+    const float *cand_v;      // candidate lists, structure of arrays (score_lists.h: cand_at / candu_at)
+    const uint32_t *cand_i;
     const float *cand_u;
     void *fb_rec;           // fallback partial records
     double *scores;
@@ -386,19 +380,15 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
     float v = -3.0e38f;
     uint32_t ix = 0xFFFFFFFFu;
     if (lane < 8) {
-        const uint64_t o = (q * NSEG + seg) * 2 + (lane >> 2);
-        const float4 cv = p.cand_v[o];
-        const uint4 ci = p.cand_i[o];
-        const int s = lane & 3;
-        v = s == 0 ? cv.x : s == 1 ? cv.y : s == 2 ? cv.z : cv.w;
-        ix = s == 0 ? ci.x : s == 1 ? ci.y : s == 2 ? ci.z : ci.w;
+        const uint64_t o = cand_at(seg, lane >> 2, lane & 3, q, p.N);
+        v = p.cand_v[o];
+        ix = p.cand_i[o];
         if (ix >= ncols) v = -3.0e38f;  // padding / empty slot
     }
     // vs: computed values -> v units (a power of two, divided by the row sum for the count-exact proposal)
     // every column the two half-lists dropped has a computed value <= the larger of their
     // best-dropped values (-3e38 when nothing real was dropped)
-    const uint64_t ou = (q * NSEG + seg) * 2;
-    const double U = fmax((double)p.cand_u[ou], (double)p.cand_u[ou + 1]) * vs;
+    const double U = fmax((double)p.cand_u[candu_at(seg, 0, q, p.N)], (double)p.cand_u[candu_at(seg, 1, q, p.N)]) * vs;
     // rank of each candidate among the 8 (descending v, ties by lane)
     int rank = 0;
 #pragma unroll
@@ -722,11 +712,10 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     uint32_t lix[NSEG];
 #pragma unroll
     for (int sg = 0; sg < NSEG; ++sg) {
-        const uint64_t o = (q * NSEG + sg) * 2;
-        const uint64_t e = (o + ((t >> 2) & 1)) * 4 + (t & 3);
-        lv[sg] = reinterpret_cast<const float *>(p.cand_v)[e];
-        lix[sg] = reinterpret_cast<const uint32_t *>(p.cand_i)[e];
-        lu[sg] = p.cand_u[o + (t & 1)];
+        const uint64_t e = cand_at(sg, (t >> 2) & 1, t & 3, q, p.N);
+        lv[sg] = p.cand_v[e];
+        lix[sg] = p.cand_i[e];
+        lu[sg] = p.cand_u[candu_at(sg, t & 1, q, p.N)];
     }
     if (SRC == 0) {
         const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
@@ -854,16 +843,18 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
     for (int sg = 0; sg < NSEG; ++sg) {
         const uint32_t ncols = sg == 0 ? (uint32_t)p.M : sg == 1 ? (uint32_t)p.n_cpos : (uint32_t)p.n_cneg;
         const int need = sg == 0 ? p.kn : 1;
-        const uint64_t o = (qc * NSEG + sg) * 2;
-        const float4 a = p.cand_v[o], b = p.cand_v[o + 1];
-        const uint4 ai = p.cand_i[o], bi = p.cand_i[o + 1];
-        Useg[sg] = fmaxf(p.cand_u[o], p.cand_u[o + 1]);
+        Useg[sg] = fmaxf(p.cand_u[candu_at(sg, 0, qc, p.N)], p.cand_u[candu_at(sg, 1, qc, p.N)]);
         // the 4 best of the 8 candidates by insertion (descending; an equal value stays behind: a tie at the
         // decisive position fails the margin test anyway); padding / empty slots never enter
         float v[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
         uint32_t ix[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        const float w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        const uint32_t wx[8] = {ai.x, ai.y, ai.z, ai.w, bi.x, bi.y, bi.z, bi.w};
+        float w[8];
+        uint32_t wx[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {   // consecutive lanes = consecutive queries: coalesced
+            w[c] = p.cand_v[cand_at(sg, c >> 2, c & 3, qc, p.N)];
+            wx[c] = p.cand_i[cand_at(sg, c >> 2, c & 3, qc, p.N)];
+        }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             float x = wx[c] >= ncols ? -3.0e38f : w[c];
@@ -1206,7 +1197,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     const uint64_t per_list = nb_max * NSEG * 2;
     void *cv, *fb, *rec;
     PHK_TRY(phk_ws(ctx, WS_CAND, per_list * (sizeof(float4) + sizeof(uint4) + sizeof(float)), &cv));
-    uint4 *ci = (uint4 *)((char *)cv + per_list * sizeof(float4));
+    uint32_t *ci = (uint32_t *)((char *)cv + per_list * sizeof(float4));
     float *cu = (float *)((char *)ci + per_list * sizeof(uint4));
     PHK_TRY(phk_ws(ctx, WS_DIST, (2 * nb_max + 16) * sizeof(uint32_t), &fb));
     PHK_TRY(phk_ws(ctx, WS_QF32, nb_max * FB_CHUNKS * sizeof(FbRecord), &rec));
@@ -1238,7 +1229,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.N = nb; p.M = m->M; p.n_cpos = m->n_cpos; p.n_cneg = m->n_cneg; p.D = D;
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
         p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.colnorm = m->d_colnorm; p.labels = m->d_labels;
-        p.cand_v = (const float4 *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
+        p.cand_v = (const float *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
         p.scores = d_scores; p.status = d_status; p.fb_count = fb_count; p.fb_list = fb_list; p.slow_list = fb_list + nb_max; p.q_base = s;
         p.eb_cQ = 0.0; p.per_row_scale = 0;
         if (use_cx) {
@@ -1260,11 +1251,11 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         }
         if (D != FAST_D) {
             PHK_TRY(phk_launch_proposal_f16_general(ctx, m, src, d_counts != nullptr, rsum, nb, nref, npos, nneg,
-                                                    (float4 *)cv, ci, cu));
+                                                    (float *)cv, ci, cu));
         } else if (use_cx) {
-            PHK_TRY(phk_launch_proposal_f16c(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float4 *)cv, ci, cu));
+            PHK_TRY(phk_launch_proposal_f16c(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu));
         } else if (use_f16) {
-            PHK_TRY(phk_launch_proposal_f16(ctx, m, src, d_counts != nullptr, rsum, nb, nref, npos, nneg, (float4 *)cv,
+            PHK_TRY(phk_launch_proposal_f16(ctx, m, src, d_counts != nullptr, rsum, nb, nref, npos, nneg, (float *)cv,
                                             ci, cu));
         } else {
             const unsigned gblocks = (unsigned)phk_div_up(nb, 128);
@@ -1272,11 +1263,11 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             if (d_counts) {
                 PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
                            phk_knn_mfma_kernel<0><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
-                               src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, ci, cu));
+                               src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float *)cv, ci, cu));
             } else {
                 PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
                            phk_knn_mfma_kernel<1><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
-                               src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float4 *)cv, ci, cu));
+                               src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float *)cv, ci, cu));
             }
         }
         const unsigned rblocks = (unsigned)phk_div_up(nb, 4);

@@ -37,11 +37,11 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
                         const double *cneg, const double *mu);
 int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                             const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                            float4 *cv, uint4 *ci, float *cu);
+                            float *cv, uint32_t *ci, float *cu);
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
-                             uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float4 *cv, uint4 *ci, float *cu);
+                             uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu);
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                                    float4 *cv, uint4 *ci, float *cu);
+                                    float *cv, uint32_t *ci, float *cu);
 int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
                    const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status);

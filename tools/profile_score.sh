@@ -25,5 +25,5 @@ for d in sorted(glob.glob(root+'/p*')):
             if 'phk' in k: res.setdefault(k,{})['ms_under_pmc']=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6; res[k]['vgpr']=r.get('VGPR_Count'); res[k]['lds']=r.get('LDS_Block_Size')
 json.dump(res,open(root+'/summary.json','w'),indent=1,sort_keys=True)
 for k in res:
-    if 'knn' in k or 'rerank' in k: print(k, json.dumps(res[k],indent=0,sort_keys=True))
+    if 'knn' in k or 'rerank' in k or 'decide' in k: print(k, json.dumps(res[k],indent=0,sort_keys=True))
 PY
