@@ -50,7 +50,7 @@ static void split_f16(double x, _Float16 &hi, _Float16 &lo) {
 // this is the 33-piece record of the k = 4 kernel.  cn_all (one float per column slot, padding
 // included) duplicates the norm terms for the general-D kernel, which reads them from global memory.
 static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const double *mu, std::vector<uint8_t> &rec,
-                             uint64_t rec_bytes, uint64_t cb0, std::vector<float> &cn_all) {
+                             uint64_t rec_bytes, uint64_t cb0, std::vector<float> &cn_all, std::vector<float> &beta_all) {
     const uint64_t nblk = phk_div_up(n, 32);
     const int nchunk = (int)(D / 256);
     for (uint64_t b = 0; b < nblk; ++b) {
@@ -62,6 +62,7 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
                 cn[i] = PAD_V;
                 cn[32 + i] = -PAD_V;
                 cn_all[(cb0 + b) * 32 + i] = PAD_V;
+                beta_all[(cb0 + b) * 32 + i] = -PAD_V;
                 continue;
             }
             double nrm2 = 0.0, mudot = 0.0;
@@ -83,6 +84,7 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
                         }
             // count-exact kernel: S beta = S (mu.r~' + |r~'|^2 / 2), the bias per unit of row sum
             cn[32 + i] = (float)(mudot + 0.5 * nrm2 / (double)F16_SCALE);
+            beta_all[(cb0 + b) * 32 + i] = cn[32 + i];
             cn[i] = (float)(-0.5 * nrm2);  // already in S^2 units
             cn_all[(cb0 + b) * 32 + i] = cn[i];
         }
@@ -95,19 +97,21 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
     const uint64_t nblk = (uint64_t)m->n_rblk_ref + m->n_rblk_pos + m->n_rblk_neg;
     const uint64_t rec_bytes = (D / 256 * 32 + 1) * 1024;
     std::vector<uint8_t> rec((nblk + 1) * rec_bytes, 0);  // + one block: the DMA prefetch runs one past the end
-    std::vector<float> cn_all((nblk + 1) * 32, PAD_V);
+    std::vector<float> cn_all((nblk + 1) * 32, PAD_V), beta_all((nblk + 1) * 32, -PAD_V);
     {
         std::vector<double> train(m->M * D);
         std::copy(pos, pos + m->n_pos * D, train.begin());
         std::copy(neg, neg + m->n_neg * D, train.begin() + m->n_pos * D);
-        pack_segment_f16(train.data(), m->M, D, mu, rec, rec_bytes, 0, cn_all);
+        pack_segment_f16(train.data(), m->M, D, mu, rec, rec_bytes, 0, cn_all, beta_all);
     }
-    if (m->n_cpos) pack_segment_f16(cpos, m->n_cpos, D, mu, rec, rec_bytes, m->n_rblk_ref, cn_all);
-    if (m->n_cneg) pack_segment_f16(cneg, m->n_cneg, D, mu, rec, rec_bytes, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, cn_all);
+    if (m->n_cpos) pack_segment_f16(cpos, m->n_cpos, D, mu, rec, rec_bytes, m->n_rblk_ref, cn_all, beta_all);
+    if (m->n_cneg) pack_segment_f16(cneg, m->n_cneg, D, mu, rec, rec_bytes, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, cn_all, beta_all);
     if (hipMalloc(&m->d_Af16, rec.size()) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMemcpy(m->d_Af16, rec.data(), rec.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     if (hipMalloc(&m->d_cn16, cn_all.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMemcpy(m->d_cn16, cn_all.data(), cn_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    if (hipMalloc(&m->d_beta16, beta_all.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMemcpy(m->d_beta16, beta_all.data(), beta_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     return PHK_OK;
 }
 
@@ -643,7 +647,10 @@ __global__ __launch_bounds__(256) void phk_split_queries_kernel(const void *__re
                                                                 const uint32_t *__restrict__ rowsum, uint64_t N,
                                                                 uint64_t D, const float *__restrict__ mu32,
                                                                 const double *__restrict__ mu64,
-                                                                uint4 *__restrict__ Bq) {
+                                                                uint4 *__restrict__ Bq, uint32_t *__restrict__ big) {
+    // SRC 0: counts -> normalised, centred, split (hi, lo);  SRC 1: float64 rows -> centred, split;
+    // SRC 2 (count-exact): counts -> fp16 as they are (hi slots only; lo slots unused), rows holding a count
+    // above 2048 are flagged in `big`
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const uint64_t nchunk = D / 256;
     const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -655,6 +662,23 @@ __global__ __launch_bounds__(256) void phk_split_queries_kernel(const void *__re
     uint4 *out = Bq + (w * 32) * 64 + lane;
     float inv = 0.f;
     if (SRC == 0) inv = (float)(1.0 / (double)rowsum[qrow]) * F16_SCALE;
+    if (SRC == 2) {
+        uint32_t mx = 0;
+        for (int s = 0; s < 16; ++s) {
+            const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + qrow * D + d0 + 8 * s);
+            const uint4 c0 = row[0], c1 = row[1];
+            const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            half8 hi;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                mx = mx > c[e] ? mx : c[e];
+                hi[e] = (_Float16)(float)(c[e] < 2048u ? c[e] : 2048u);
+            }
+            out[(2 * s) * 64] = *reinterpret_cast<uint4 *>(&hi);
+        }
+        if (mx > 2048u) atomicOr(big + qrow, 1u);
+        return;
+    }
     for (int s = 0; s < 16; ++s) {
         float x[8];
         if (SRC == 0) {
@@ -684,11 +708,17 @@ __global__ __launch_bounds__(256) void phk_split_queries_kernel(const void *__re
 }
 
 #define GEN_CT 4
+// CX (count-exact): Bq holds the fp16 counts (hi slots), 2 MFMAs per k-step, value = acc - T * bias (rowsum,
+// beta_all), rows flagged in `big` get empty lists (-> exact brute-force queue)
+template <bool CX>
 __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4 *__restrict__ Bq, uint64_t N,
                                                                      uint32_t nchunk,
                                                                      const uint4 *__restrict__ Af,
                                                                      uint64_t rec_u4,  // uint4 per block record
                                                                      const float *__restrict__ cn_all,
+                                                                     const float *__restrict__ beta_all,
+                                                                     const uint32_t *__restrict__ rowsum,
+                                                                     const uint32_t *__restrict__ big,
                                                                      uint32_t blk0,    // first block swept
                                                                      uint32_t nblk_ref, uint32_t nblk_pos,
                                                                      uint32_t nblk_neg,
@@ -735,6 +765,13 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
         lv[c] = -3.0e38f;
         li[c] = 0xFFFFFFFFu;
     }
+    float negT = 0.f;
+    bool isbig = false;
+    if (CX) {
+        const uint64_t qr = (qb < nqb && q0 + j < N) ? q0 + j : N - 1;
+        negT = -(float)rowsum[qr];
+        isbig = big[qr] != 0;
+    }
     int seg = 0;
     uint32_t seg_first = 0;
     uint64_t it = 0;
@@ -750,9 +787,12 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
             const uint4 *bq = Bq + ((qbc * nchunk + c) * 32) * 64 + lane;
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const uint4 uh = bq[(2 * s) * 64], ul = bq[(2 * s + 1) * 64];
+                const uint4 uh = bq[(2 * s) * 64];
                 bh[s] = *reinterpret_cast<const half8 *>(&uh);
-                bl[s] = *reinterpret_cast<const half8 *>(&ul);
+                if (!CX) {
+                    const uint4 ul = bq[(2 * s + 1) * 64];
+                    bl[s] = *reinterpret_cast<const half8 *>(&ul);
+                }
             }
 #pragma unroll
             for (int cb = 0; cb < GEN_CT; ++cb, ++it) {
@@ -765,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
                     const half8 ah = fr[(2 * s) * 64];
                     const half8 al = fr[(2 * s + 1) * 64];
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc[cb], 0, 0, 0);
+                    if (!CX) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc[cb], 0, 0, 0);
                     acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc[cb], 0, 0, 0);
                 }
             }
@@ -775,19 +815,25 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
         for (int cb = 0; cb < GEN_CT; ++cb) {
             const uint32_t blk = t * GEN_CT + cb;
             if (blk < total) {
-                const float4 *cn = reinterpret_cast<const float4 *>(cn_all + (uint64_t)(blk0 + blk) * 32) + h;
+                const float4 *cn = reinterpret_cast<const float4 *>((CX ? beta_all : cn_all) + (uint64_t)(blk0 + blk) * 32) + h;
                 const uint32_t cbase = 32u * (blk - seg_first) + 4u * (uint32_t)h;
+                const float mul = CX ? negT : 1.0f;   // CX: acc - T * bias;  else acc + norm term
 #pragma unroll
                 for (int m4 = 0; m4 < 4; ++m4) {
                     const float4 c4 = cn[2 * m4];
-                    list_insert(lv, li, ldrop, acc[cb][4 * m4 + 0] + c4.x, cbase + 8u * m4 + 0u);
-                    list_insert(lv, li, ldrop, acc[cb][4 * m4 + 1] + c4.y, cbase + 8u * m4 + 1u);
-                    list_insert(lv, li, ldrop, acc[cb][4 * m4 + 2] + c4.z, cbase + 8u * m4 + 2u);
-                    list_insert(lv, li, ldrop, acc[cb][4 * m4 + 3] + c4.w, cbase + 8u * m4 + 3u);
+                    list_insert(lv, li, ldrop, fmaf(mul, c4.x, acc[cb][4 * m4 + 0]), cbase + 8u * m4 + 0u);
+                    list_insert(lv, li, ldrop, fmaf(mul, c4.y, acc[cb][4 * m4 + 1]), cbase + 8u * m4 + 1u);
+                    list_insert(lv, li, ldrop, fmaf(mul, c4.z, acc[cb][4 * m4 + 2]), cbase + 8u * m4 + 2u);
+                    list_insert(lv, li, ldrop, fmaf(mul, c4.w, acc[cb][4 * m4 + 3]), cbase + 8u * m4 + 3u);
                 }
                 while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
                     if (qb < nqb && q0 + j < N) {
-                        cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2], li[3], ldrop);
+                        if (CX && isbig)
+                            cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f,
+                                       0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 3.0e38f);
+                        else
+                            cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2],
+                                       li[3], ldrop);
                     }
 #pragma unroll
                     for (int c = 0; c < CAND; ++c) {
@@ -810,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
 }
 
 // proposal pass for D = 256 * nchunk > 256: row sums (if needed) -> split queries -> sweep
-int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
+int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, bool count_exact,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
                                     float *cv, uint32_t *ci, float *cu) {
     const uint64_t D = m->D, nchunk = D / 256;
@@ -825,25 +871,42 @@ int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void
         d_rowsum = (const uint32_t *)rs;
     }
     const unsigned sblocks = (unsigned)phk_div_up(nqb * nchunk, 4);
-    if (src_counts) {
+    uint32_t *d_big = nullptr;
+    if (src_counts && count_exact) {
+        void *bg;
+        PHK_TRY(phk_ws(ctx, WS_LONG, nb * sizeof(uint32_t), &bg));
+        d_big = (uint32_t *)bg;
+        PHK_HIP(hipMemsetAsync(d_big, 0, nb * sizeof(uint32_t), ctx->stream));
+        PHK_LAUNCH(ctx, "phk_split_queries_kernel",
+                   phk_split_queries_kernel<2><<<dim3(sblocks), dim3(256), 0, ctx->stream>>>(
+                       src, d_rowsum, nb, D, m->d_mu32, m->d_mu64, (uint4 *)bq, d_big));
+    } else if (src_counts) {
         PHK_LAUNCH(ctx, "phk_split_queries_kernel",
                    phk_split_queries_kernel<0><<<dim3(sblocks), dim3(256), 0, ctx->stream>>>(
-                       src, d_rowsum, nb, D, m->d_mu32, m->d_mu64, (uint4 *)bq));
+                       src, d_rowsum, nb, D, m->d_mu32, m->d_mu64, (uint4 *)bq, nullptr));
     } else {
         PHK_LAUNCH(ctx, "phk_split_queries_kernel",
                    phk_split_queries_kernel<1><<<dim3(sblocks), dim3(256), 0, ctx->stream>>>(
-                       src, nullptr, nb, D, m->d_mu32, m->d_mu64, (uint4 *)bq));
+                       src, nullptr, nb, D, m->d_mu32, m->d_mu64, (uint4 *)bq, nullptr));
     }
     static bool attr_set = false;
     if (!attr_set) {
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         attr_set = true;
     }
     const uint64_t rec_u4 = (nchunk * 32 + 1) * 64;
     const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
-    PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
-               phk_knn_f16_general_kernel<<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
-                   (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, blk0, nref, npos,
-                   nneg, cv, ci, cu));
+    if (d_big) {
+        PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
+                   phk_knn_f16_general_kernel<true><<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
+                       (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, d_rowsum,
+                       d_big, blk0, nref, npos, nneg, cv, ci, cu));
+    } else {
+        PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
+                   phk_knn_f16_general_kernel<false><<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
+                       (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, nullptr,
+                       nullptr, blk0, nref, npos, nneg, cv, ci, cu));
+    }
     return PHK_OK;
 }

@@ -155,6 +155,7 @@ void phk_model_free_fast(phk_model *m) {
     if (m->d_Af16) (void)hipFree(m->d_Af16);
     m->d_Af16 = nullptr;
     if (m->d_cn16) (void)hipFree(m->d_cn16);
+    if (m->d_beta16) (void)hipFree(m->d_beta16);
     m->d_cn16 = nullptr;
     if (m->d_mu32) (void)hipFree(m->d_mu32);
     if (m->d_mu64) (void)hipFree(m->d_mu64);
@@ -1215,7 +1216,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     const char *prop = getenv("PHK_PROPOSAL");
     const bool use_f16 = D != FAST_D || !(prop && prop[0] == 'f' && prop[1] == '3');
     // counts at k = 4: the count-exact kernel (2 MFMAs per k-step); PHK_PROPOSAL=f16 keeps the split-query one
-    const bool use_cx = use_f16 && D == FAST_D && d_counts && !(prop && prop[0] == 'f' && prop[1] == '1');
+    const bool use_cx = use_f16 && d_counts && !(prop && prop[0] == 'f' && prop[1] == '1');
     for (uint64_t s = 0; s < N; s += BATCH) {
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
         const void *src = d_counts ? (const void *)(d_counts + s * D) : (const void *)(d_Q + s * D);
@@ -1235,7 +1236,9 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         if (use_cx) {
             // see ErrBound: values are T S v (per row), 2D/16 instructions on uncentred products
             p.vscale = 1.0 / 4096.0; p.per_row_scale = 1;
-            p.eb_cA = 1.0; p.eb_cQ = 2.0 * (2.0 * (double)D / 16.0 + 1.0) + 1.0; p.eb_cP = 67.0; p.eb_cR = 36.0;
+            // (general D keeps its indices in registers: no embedded index bits, 62 / 31 less on cP / cR)
+            p.eb_cA = 1.0; p.eb_cQ = 2.0 * (2.0 * (double)D / 16.0 + 1.0) + 1.0;
+            p.eb_cP = D == FAST_D ? 67.0 : 5.0; p.eb_cR = D == FAST_D ? 36.0 : 5.0;
             p.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
         } else if (use_f16) {
             // 3D/16 MFMA instructions, each charged 2u (|acc_in| + sum |products|) <= 2u (P + dq) R -- the
@@ -1250,7 +1253,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             p.eb_cA = 6.0; p.eb_cP = 264.0; p.eb_cR = 4.0; p.eb_abs = 0.0;
         }
         if (D != FAST_D) {
-            PHK_TRY(phk_launch_proposal_f16_general(ctx, m, src, d_counts != nullptr, rsum, nb, nref, npos, nneg,
+            PHK_TRY(phk_launch_proposal_f16_general(ctx, m, src, d_counts != nullptr, use_cx, rsum, nb, nref, npos, nneg,
                                                     (float *)cv, ci, cu));
         } else if (use_cx) {
             PHK_TRY(phk_launch_proposal_f16c(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu));

@@ -16,6 +16,7 @@ struct phk_model {
     double *d_colnorm = nullptr;  // |r'| per real column (train rows, pos centroids, neg centroids)
     void *d_Af16 = nullptr;       // split-f16 fragment-ordered block records (score_f16.hip)
     float *d_cn16 = nullptr;      // split-f16 norm terms per column slot (general-D kernel)
+    float *d_beta16 = nullptr;    // count-exact bias terms S (mu.r~' + |r~'|^2/2) per column slot (general-D kernel)
     float *d_mu32 = nullptr;      // centring vector, fp32
     double *d_mu64 = nullptr;     // centring vector, fp64
     uint32_t n_rblk_ref = 0, n_rblk_pos = 0, n_rblk_neg = 0;  // 32-column blocks per segment
@@ -40,7 +41,7 @@ int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, b
                             float *cv, uint32_t *ci, float *cu);
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu);
-int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
+int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, bool count_exact,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
                                     float *cv, uint32_t *ci, float *cu);
 int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,

@@ -86,7 +86,7 @@ print(json.dumps({
     "algorithmic_TFLOP": flops / 1e12,
     "proposal_kernel_TFLOPs_algorithmic": flops / (ms / 1e3) / 1e12 if ms else None,
     "proposal_kernel_frac_of_2.5PF_f16_peak": flops / (ms / 1e3) / 2.5e15 if ms else None,
-    "proposal_kernel_mfma_issue_frac": 3 * flops / (ms / 1e3) / 2.5e15 if ms else None,
+    "proposal_kernel_mfma_issue_frac": (3 if os.environ.get("PHK_PROPOSAL", "cx").startswith("f1") else 2) * flops / (ms / 1e3) / 2.5e15 if ms else None,
     "queries_per_s": N / wall,
     "fallback_queries": n_fallback, "orderings_decided_by_exact_distances": n_exact,
     "sample_checked": ns, "sample_knn_votes_equal": bool(np.array_equal(np.sign(got[:ns]), np.sign(want))),
