@@ -346,13 +346,14 @@ __global__ __launch_bounds__(256) void phk_count_kernel(const uint32_t *__restri
 }
 
 __global__ __launch_bounds__(256) void phk_count_stats_kernel(const uint64_t *__restrict__ offsets, uint64_t n, int k,
+                                                              uint32_t gs,  // contigs per slot workgroup
                                                               uint32_t long_thr, unsigned long long *__restrict__ stats) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long pad = 0, used = 0;
-    if (g * 32 < n) {
+    if (g * gs < n) {
         uint64_t mx = 0;
-        uint64_t prev = offsets[g * 32];
-        for (uint64_t i = g * 32; i < g * 32 + 32 && i < n; ++i) {
+        uint64_t prev = offsets[g * gs];
+        for (uint64_t i = g * gs; i < g * gs + gs && i < n; ++i) {
             const uint64_t nx = offsets[i + 1];
             const uint64_t len = nx - prev;
             prev = nx;
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void phk_count_stats_kernel(const uint64_t *__
                 mx = w > mx ? w : mx;
             }
         }
-        pad = 32ull * (((mx + 1023) >> 10) << 10);
+        pad = (unsigned long long)gs * (((mx + 1023) >> 10) << 10);
     }
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) {
@@ -404,7 +405,10 @@ __device__ __forceinline__ void phk_lds_barrier() { asm volatile("s_waitcnt lgkm
 // has been performed; the adds themselves only have to be complete at the flush (full barrier there).
 __device__ __forceinline__ void phk_stage_barrier() { asm volatile("s_waitcnt lgkmcnt(15)\n\ts_barrier" ::: "memory"); }
 
-template <int K>
+// SLOTS = contigs per workgroup: 32 (k <= 4: bank = slot, conflict free) or 16 (k = 5: a 1024-bin column set of
+// 32 contigs would not fit; bank = slot + 16 (code & 1), so the two lanes of a half-wave that share a slot
+// collide only when their codes have the same parity -- 3 LDS cycles per instruction on average instead of 2).
+template <int K, int SLOTS>
 __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__restrict__ packed,
                                                              const uint64_t *__restrict__ offsets, uint64_t n,
                                                              uint64_t max_word, uint32_t long_thr,
@@ -413,35 +417,41 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
                                                              uint32_t *__restrict__ long_count) {
     constexpr uint32_t D = 1u << (2 * K);
     constexpr int CH = 8 * SLOT_LINES;      // 4-word chunks per contig and stage
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][32] | staging [2][32][SLOT_ROW] | smax
-    uint32_t *stage = lds + D * 32;
-    uint32_t *smax_p = stage + 2 * 32 * SLOT_ROW;
+    constexpr int PARTS = 256 / SLOTS;      // lanes per contig
+    constexpr int CPL = CH / PARTS;         // chunks per lane and stage
+    constexpr int LPT = SLOTS * CH / 256;   // staging loads per thread and stage
+    constexpr int SHB = SLOTS == 32 ? 7 : 6;  // log2 of a bin row in bytes
+    static_assert(CH % PARTS == 0 && (SLOTS * CH) % 256 == 0, "stage geometry");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][SLOTS] | staging [2][SLOTS][SLOT_ROW] | smax
+    uint32_t *stage = lds + D * SLOTS;
+    uint32_t *smax_p = stage + 2 * SLOTS * SLOT_ROW;
     if (!phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) return;  // ragged batch: stand down
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int slot = lane & 31, part = 2 * wave + (lane >> 5);   // counting role: contig slot, chunk (mod 8) within the stage
-    const int lct = t >> 3, lch = t & 7;                         // loading role: contig slot, chunk within a line
-    for (uint32_t b = t * 4; b < D * 32; b += 1024) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
+    const int t = threadIdx.x, lane = t & 63;
+    const int slot = t & (SLOTS - 1), part = t / SLOTS;          // counting role: contig slot, chunk (mod PARTS) within the stage
+    for (uint32_t b = t * 4; b < D * SLOTS; b += 1024) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
     if (t == 0) *smax_p = 0;
     __syncthreads();
     const uint32_t colb = (uint32_t)slot * 4u;
     const uint64_t wmax4 = max_word - 2;  // highest start of a 4-word load inside the stream (+ pad word)
 
-    // LDS byte address of the bin of the window starting at base jw of `src` (jw < 8)
+    // LDS byte address of the bin of the window starting at base jw of `src` (jw < 8).
     // The bins sit at LDS address 0 (the kernel has no static LDS), so the byte address is formed as an integer --
     // shift, then v_and_or with the slot -- and used as an LDS pointer directly; going through `lds + index`
     // costs a third instruction per window (the add of the array's link-time base).
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
     auto bin = [&](uint32_t src, int jw) {
-        const uint32_t a = ((src >> (32 - 2 * K - 2 * jw - 7)) & ((D - 1u) << 7)) | colb;
+        constexpr uint32_t msk = (D - 1u) << SHB;
+        const int sh = 32 - 2 * K - 2 * jw - SHB;   // >= 0 for jw < 8, k <= 5
+        const uint32_t a = ((src >> sh) & msk) | colb;
         return (lds_u32 *)(uintptr_t)a;
     };
     auto add1 = [&](lds_u32 *p, uint32_t val) {
         __hip_atomic_fetch_add(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
 
-    for (uint64_t batch = blockIdx.x; batch * 32 < n; batch += gridDim.x) {
+    for (uint64_t batch = blockIdx.x; batch * SLOTS < n; batch += gridDim.x) {
         // ---- counting role: this lane's contig ----
-        const uint64_t c = batch * 32 + slot;
+        const uint64_t c = batch * SLOTS + slot;
         const bool have = c < n;
         const uint64_t st = have ? offsets[c] : 0, en = have ? offsets[c + 1] : 0;
         const uint64_t len = en - st;
@@ -455,13 +465,10 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
         const uint64_t q0 = st >> 6;                          // first 4-word chunk
         const uint32_t nchunk = W ? (uint32_t)((last >> 6) - q0 + 1) : 0;
         const uint32_t nseg = (nchunk + CH - 1) / CH;
-        // ---- loading role: the contig whose lines this lane fetches ----
-        const uint64_t cl = batch * 32 + lct;
-        const uint64_t lw0 = cl < n ? (offsets[cl] >> 6) * 4 : 0;  // first word of its first chunk
         // stages this batch needs
         uint32_t m = nseg;
 #pragma unroll
-        for (int sft = 16; sft > 0; sft >>= 1) {
+        for (int sft = 32; sft > 0; sft >>= 1) {
             const uint32_t o = __shfl_xor(m, sft);
             m = m > o ? m : o;
         }
@@ -469,29 +476,40 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
         phk_lds_barrier();
         const uint32_t smax = *smax_p;
 
-        auto gload = [&](uint32_t s, uint4 (&v)[SLOT_LINES], uint32_t &la) {   // stage s: 16 bytes per line (+ a look-ahead word)
+        // ---- loading role: staging element e = t + 256 i  ->  contig e / CH, chunk e % CH of the stage ----
+        uint64_t lw0[LPT];
 #pragma unroll
-            for (int ln = 0; ln < SLOT_LINES; ++ln) {
-                const uint64_t w = lw0 + (32ull * SLOT_LINES) * s + 32u * ln + 4u * lch;
+        for (int i = 0; i < LPT; ++i) {
+            const uint64_t cl = batch * SLOTS + (uint32_t)(t + 256 * i) / CH;
+            lw0[i] = cl < n ? (offsets[cl] >> 6) * 4 : 0;   // first word of its first chunk
+        }
+        auto gload = [&](uint32_t s, uint4 (&v)[LPT], uint32_t (&la)[LPT]) {   // 16 bytes each (+ a look-ahead word)
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) {
+                const uint32_t ch = (uint32_t)(t + 256 * i) % CH;
+                const uint64_t w = lw0[i] + (4ull * CH) * s + 4u * ch;
                 if (w <= wmax4) {
-                    v[ln] = *reinterpret_cast<const uint4 *>(packed + w);
+                    v[i] = *reinterpret_cast<const uint4 *>(packed + w);
                 } else {  // the last words of the whole stream (one pad word follows it): word by word, clamped
                     const uint64_t e = max_word + 1;
-                    v[ln] = make_uint4(packed[w < e ? w : e], packed[w + 1 < e ? w + 1 : e], packed[w + 2 < e ? w + 2 : e],
-                                       packed[w + 3 < e ? w + 3 : e]);
+                    v[i] = make_uint4(packed[w < e ? w : e], packed[w + 1 < e ? w + 1 : e], packed[w + 2 < e ? w + 2 : e],
+                                      packed[w + 3 < e ? w + 3 : e]);
                 }
+                const uint64_t wl = lw0[i] + (4ull * CH) * (s + 1);  // word after the stage's lines
+                la[i] = packed[wl <= max_word + 1 ? wl : max_word + 1];
             }
-            const uint64_t wl = lw0 + (32ull * SLOT_LINES) * (s + 1);  // word after the stage's lines
-            la = packed[wl <= max_word + 1 ? wl : max_word + 1];
         };
-        auto swrite = [&](uint32_t buf, const uint4 (&v)[SLOT_LINES], uint32_t la) {
-            uint32_t *row = stage + (buf * 32 + lct) * SLOT_ROW;
+        auto swrite = [&](uint32_t buf, const uint4 (&v)[LPT], const uint32_t (&la)[LPT]) {
 #pragma unroll
-            for (int ln = 0; ln < SLOT_LINES; ++ln) *reinterpret_cast<uint4 *>(row + 32 * ln + 4 * lch) = v[ln];
-            if (lch == 7) row[32 * SLOT_LINES] = la;
+            for (int i = 0; i < LPT; ++i) {
+                const uint32_t e = (uint32_t)(t + 256 * i);
+                uint32_t *row = stage + (buf * SLOTS + e / CH) * SLOT_ROW;
+                *reinterpret_cast<uint4 *>(row + 4 * (e % CH)) = v[i];
+                if (e % CH == CH - 1) row[4 * CH] = la[i];
+            }
         };
-        uint4 v[SLOT_LINES];
-        uint32_t la;
+        uint4 v[LPT];
+        uint32_t la[LPT];
         if (smax) {
             gload(0, v, la);
             swrite(0, v, la);
@@ -499,13 +517,13 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
         }
         phk_lds_barrier();
         for (uint32_t s = 0; s < smax; ++s) {
-            const uint32_t *row = stage + ((s & 1) * 32 + slot) * SLOT_ROW + 4 * part;
-            uint4 cw[SLOT_LINES];
-            uint32_t nx[SLOT_LINES];
+            const uint32_t *row = stage + ((s & 1) * SLOTS + slot) * SLOT_ROW + 4 * part;
+            uint4 cw[CPL];
+            uint32_t nx[CPL];
 #pragma unroll
-            for (int ln = 0; ln < SLOT_LINES; ++ln) {
-                cw[ln] = *reinterpret_cast<const uint4 *>(row + 32 * ln);
-                nx[ln] = row[32 * ln + 4];
+            for (int ln = 0; ln < CPL; ++ln) {
+                cw[ln] = *reinterpret_cast<const uint4 *>(row + 4 * PARTS * ln);
+                nx[ln] = row[4 * PARTS * ln + 4];
             }
             if (s + 1 < smax) {
                 swrite((s + 1) & 1, v, la);
@@ -514,11 +532,11 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
             // take delivery of ALL the stage's staging reads here: a read waited for after the first adds have been
             // issued costs a full drain of the add queue (the LDS counter is in order and saturates at 15)
 #pragma unroll
-            for (int ln = 0; ln < SLOT_LINES; ++ln)
+            for (int ln = 0; ln < CPL; ++ln)
                 asm volatile("" ::"v"(cw[ln].x), "v"(cw[ln].y), "v"(cw[ln].z), "v"(cw[ln].w), "v"(nx[ln]));
 #pragma unroll
-            for (int ln = 0; ln < SLOT_LINES; ++ln) {
-                const uint64_t q = q0 + (uint64_t)CH * s + 8u * ln + part;   // this lane's chunk; bases 64 q .. 64 q + 63
+            for (int ln = 0; ln < CPL; ++ln) {
+                const uint64_t q = q0 + (uint64_t)CH * s + (uint32_t)(PARTS * ln + part);   // this lane's chunk; bases 64 q .. 64 q + 63
                 const uint64_t fb = q << 6;
                 const bool any = W && fb + 63 >= st && fb <= last;
                 const bool all = W && fb >= st && fb + 63 <= last;
@@ -551,16 +569,16 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
             phk_stage_barrier();
         }
         phk_lds_barrier();  // every wave's adds have landed
-        // ---- flush: thread (slot, group g) writes codes [g D/8, (g+1) D/8) of contig `slot` and clears them ----
+        // ---- flush: thread (slot, group g) writes codes [g D/PARTS, (g+1) D/PARTS) of contig `slot` and clears them ----
         {
             const int g = part;
-            uint32_t *cellb = lds + (g * (D / 8)) * 32 + slot;
-            uint32_t *rowo = counts + c * D + g * (D / 8);
-#pragma unroll
-            for (uint32_t i = 0; i < D / 32; ++i) {
-                uint32_t *cell = cellb + 4 * i * 32;
-                const uint4 o = make_uint4(cell[0], cell[32], cell[64], cell[96]);
-                cell[0] = 0; cell[32] = 0; cell[64] = 0; cell[96] = 0;
+            uint32_t *cellb = lds + (g * (D / PARTS)) * SLOTS + slot;
+            uint32_t *rowo = counts + c * D + g * (D / PARTS);
+#pragma unroll 8
+            for (uint32_t i = 0; i < D / PARTS / 4; ++i) {
+                uint32_t *cell = cellb + 4 * i * SLOTS;
+                const uint4 o = make_uint4(cell[0], cell[SLOTS], cell[2 * SLOTS], cell[3 * SLOTS]);
+                cell[0] = 0; cell[SLOTS] = 0; cell[2 * SLOTS] = 0; cell[3 * SLOTS] = 0;
                 if (have && !handed_over) *reinterpret_cast<uint4 *>(rowo + 4 * i) = o;
             }
             if (nwin && have && !handed_over && g == 0) nwin[c] = W;
@@ -644,8 +662,9 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
     // k = 3, 4 without invalid bases: slot kernel (32 contigs per workgroup, conflict-free LDS adds); contigs
     // more than 4x the batch mean go on to the wave-per-contig kernel through a device list
     const char *lanes_env = getenv("PHK_COUNT_LANES");
-    if ((k == 3 || k == 4) && !d_mask && max_word >= 64 && n < (1ull << 32) && !(lanes_env && lanes_env[0] == '0') &&
+    if (k >= 3 && k <= 5 && !d_mask && max_word >= 64 && n < (1ull << 32) && !(lanes_env && lanes_env[0] == '0') &&
         !getenv("PHK_COUNT_CFG")) {
+        const uint32_t slots = k == 5 ? 16u : 32u;
         void *ws;
         PHK_TRY(phk_ws(ctx, WS_LONG, (n + 16) * sizeof(uint32_t), &ws));
         // [0] hand-over count, [2..5] batch statistics (two uint64), [16..] hand-over list
@@ -656,26 +675,30 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         const uint32_t long_thr = thr64 < 0xFFFFFFFFull ? (uint32_t)thr64 : 0xFFFFFFFFu;
         if (!(lanes_env && lanes_env[0] == '2'))  // PHK_COUNT_LANES=2: slot kernel whatever the batch looks like (tests)
         PHK_LAUNCH(ctx, "phk_count_stats_kernel",
-                   phk_count_stats_kernel<<<dim3((unsigned)phk_div_up(phk_div_up(n, 32), 256)), dim3(256), 0, ctx->stream>>>(
-                       d_offsets, n, k, long_thr, (unsigned long long *)(d_long_count + 2)));
-        const size_t lds = (size_t)phk_pow4(k) * 32 * 4 + 2 * 32 * SLOT_ROW * 4 + 16;
+                   phk_count_stats_kernel<<<dim3((unsigned)phk_div_up(phk_div_up(n, slots), 256)), dim3(256), 0, ctx->stream>>>(
+                       d_offsets, n, k, slots, long_thr, (unsigned long long *)(d_long_count + 2)));
+        const size_t lds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * SLOT_ROW * 4 + 16;
+        // resident blocks per CU: the LDS allocation granule keeps a block that would exactly fill the 160 KiB out
         const unsigned fit = (unsigned)((160u * 1024u - 1024u) / lds);
         const unsigned per_cu = fit > 8 ? 8 : fit;
-        uint64_t blocks = phk_div_up(n, 32);
+        uint64_t blocks = phk_div_up(n, slots);
         const uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
         if (blocks > cap) blocks = cap;
-        if (k == 4) {
-            PHK_LAUNCH(ctx, "phk_count_slots_kernel",
-                       phk_count_slots_kernel<4><<<dim3((unsigned)blocks), dim3(256), lds, ctx->stream>>>(
-                           d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count));
-            return launch_count_cfg<4, PhkCountCfg<4>::copies, PhkCountCfg<4>::pack16>(
-                ctx, d_packed, nullptr, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count);
+        static bool attr_set = false;
+        if (!attr_set) {
+            PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_set = true;
         }
-        PHK_LAUNCH(ctx, "phk_count_slots_kernel",
-                   phk_count_slots_kernel<3><<<dim3((unsigned)blocks), dim3(256), lds, ctx->stream>>>(
-                       d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count));
-        return launch_count_cfg<3, PhkCountCfg<3>::copies, PhkCountCfg<3>::pack16>(
-            ctx, d_packed, nullptr, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count);
+#define PHK_SLOTS(K_, S_)                                                                                                   \
+        PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                           \
+                   (phk_count_slots_kernel<K_, S_><<<dim3((unsigned)blocks), dim3(256), lds, ctx->stream>>>(                \
+                       d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count)));           \
+        return launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                                    \
+            ctx, d_packed, nullptr, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count)
+        if (k == 3) { PHK_SLOTS(3, 32); }
+        if (k == 4) { PHK_SLOTS(4, 32); }
+        PHK_SLOTS(5, 16);
+#undef PHK_SLOTS
     }
     switch (k) {
         case 1: return launch_count_k<1>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin);

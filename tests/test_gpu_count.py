@@ -159,9 +159,9 @@ def test_transform_kmers_identity(kmer):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k", [3, 4])
-def test_lane_pair_count_kernel_ragged_and_handover(ctx, k):
-    """The lane-pair kernel (32 contigs per wave, all-valid input, k = 3 / 4): ragged lengths around every
+@pytest.mark.parametrize("k", [3, 4, 5])
+def test_slot_count_kernel_ragged_and_handover(ctx, k):
+    """The slot kernel (32 contigs per workgroup at k = 3 / 4, 16 at k = 5; all-valid input): ragged lengths around every
     edge (empty, shorter than k, exactly k, 63 / 64 / 65 / 127 / 128 / 129 windows per lane pair, the last
     contig ending on the last word of the stream), a contig count that is not a multiple of 32, and
     contigs far above the batch mean, which it must hand to the wave-per-contig kernel -- bit-exact
