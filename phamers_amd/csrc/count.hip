@@ -408,8 +408,8 @@ __device__ __forceinline__ void phk_stage_barrier() { asm volatile("s_waitcnt lg
 // SLOTS = contigs per workgroup: 32 (k <= 4: bank = slot, conflict free) or 16 (k = 5: a 1024-bin column set of
 // 32 contigs would not fit; bank = slot + 16 (code & 1), so the two lanes of a half-wave that share a slot
 // collide only when their codes have the same parity -- 3 LDS cycles per instruction on average instead of 2).
-template <int K, int SLOTS>
-__global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__restrict__ packed,
+template <int K, int SLOTS, int NTH>
+__global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__restrict__ packed,
                                                              const uint64_t *__restrict__ offsets, uint64_t n,
                                                              uint64_t max_word, uint32_t long_thr,
                                                              uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin,
@@ -417,18 +417,18 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
                                                              uint32_t *__restrict__ long_count) {
     constexpr uint32_t D = 1u << (2 * K);
     constexpr int CH = 8 * SLOT_LINES;      // 4-word chunks per contig and stage
-    constexpr int PARTS = 256 / SLOTS;      // lanes per contig
+    constexpr int PARTS = NTH / SLOTS;      // lanes per contig
     constexpr int CPL = CH / PARTS;         // chunks per lane and stage
-    constexpr int LPT = SLOTS * CH / 256;   // staging loads per thread and stage
+    constexpr int LPT = (SLOTS * CH + NTH - 1) / NTH;   // staging loads per thread and stage (the last may be partial)
     constexpr int SHB = SLOTS == 32 ? 7 : 6;  // log2 of a bin row in bytes
-    static_assert(CH % PARTS == 0 && (SLOTS * CH) % 256 == 0, "stage geometry");
+    static_assert(CH % PARTS == 0, "stage geometry");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][SLOTS] | staging [2][SLOTS][SLOT_ROW] | smax
     uint32_t *stage = lds + D * SLOTS;
     uint32_t *smax_p = stage + 2 * SLOTS * SLOT_ROW;
     if (!phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) return;  // ragged batch: stand down
     const int t = threadIdx.x, lane = t & 63;
     const int slot = t & (SLOTS - 1), part = t / SLOTS;          // counting role: contig slot, chunk (mod PARTS) within the stage
-    for (uint32_t b = t * 4; b < D * SLOTS; b += 1024) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
+    for (uint32_t b = t * 4; b < D * SLOTS; b += 4 * NTH) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
     if (t == 0) *smax_p = 0;
     __syncthreads();
     const uint32_t colb = (uint32_t)slot * 4u;
@@ -480,13 +480,13 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
         uint64_t lw0[LPT];
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            const uint64_t cl = batch * SLOTS + (uint32_t)(t + 256 * i) / CH;
+            const uint64_t cl = batch * SLOTS + (uint32_t)(t + NTH * i) / CH;
             lw0[i] = cl < n ? (offsets[cl] >> 6) * 4 : 0;   // first word of its first chunk
         }
         auto gload = [&](uint32_t s, uint4 (&v)[LPT], uint32_t (&la)[LPT]) {   // 16 bytes each (+ a look-ahead word)
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {
-                const uint32_t ch = (uint32_t)(t + 256 * i) % CH;
+                const uint32_t ch = (uint32_t)(t + NTH * i) % CH;
                 const uint64_t w = lw0[i] + (4ull * CH) * s + 4u * ch;
                 if (w <= wmax4) {
                     v[i] = *reinterpret_cast<const uint4 *>(packed + w);
@@ -502,7 +502,8 @@ __global__ __launch_bounds__(256) void phk_count_slots_kernel(const uint32_t *__
         auto swrite = [&](uint32_t buf, const uint4 (&v)[LPT], const uint32_t (&la)[LPT]) {
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {
-                const uint32_t e = (uint32_t)(t + 256 * i);
+                const uint32_t e = (uint32_t)(t + NTH * i);
+                if (e >= (uint32_t)(SLOTS * CH)) continue;
                 uint32_t *row = stage + (buf * SLOTS + e / CH) * SLOT_ROW;
                 *reinterpret_cast<uint4 *>(row + 4 * (e % CH)) = v[i];
                 if (e % CH == CH - 1) row[4 * CH] = la[i];
@@ -686,18 +687,22 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         if (blocks > cap) blocks = cap;
         static bool attr_set = false;
         if (!attr_set) {
-            PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             attr_set = true;
         }
-#define PHK_SLOTS(K_, S_)                                                                                                   \
+#define PHK_SLOTS(K_, S_, T_)                                                                                                   \
         PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                           \
-                   (phk_count_slots_kernel<K_, S_><<<dim3((unsigned)blocks), dim3(256), lds, ctx->stream>>>(                \
+                   (phk_count_slots_kernel<K_, S_, T_><<<dim3((unsigned)blocks), dim3(T_), lds, ctx->stream>>>(                \
                        d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count)));           \
         return launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                                    \
             ctx, d_packed, nullptr, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count)
-        if (k == 3) { PHK_SLOTS(3, 32); }
-        if (k == 4) { PHK_SLOTS(4, 32); }
-        PHK_SLOTS(5, 16);
+        // 16 lanes per contig (512 threads) at k <= 4: 24 waves per CU hide the barrier and staging latencies better
+        // than 12 (0.94 vs 1.03 ms per 1M x 5 kb); PHK_SLOT_THREADS=256 for comparison
+        const char *th = getenv("PHK_SLOT_THREADS");
+        const bool t256 = th && th[0] == '2';
+        if (k == 3) { if (t256) { PHK_SLOTS(3, 32, 256); } PHK_SLOTS(3, 32, 512); }
+        if (k == 4) { if (t256) { PHK_SLOTS(4, 32, 256); } PHK_SLOTS(4, 32, 512); }
+        PHK_SLOTS(5, 16, 256);
 #undef PHK_SLOTS
     }
     switch (k) {
