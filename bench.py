@@ -28,7 +28,7 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak
 F64_PEAK_TF = 78.6             # fp64 vector / matrix peak
-MFMA_F16_PEAK_TF = 2500.0      # f16/bf16 dense MFMA peak (the split-f16 kernel issues 3 MFMA flops per algorithmic flop)
+MFMA_F16_PEAK_TF = 2500.0      # f16/bf16 dense MFMA peak (the count-exact kernel issues 2 MFMA flops per algorithmic flop, the split-query one 3)
 
 
 def load_model_inputs(D):
