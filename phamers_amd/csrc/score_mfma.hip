@@ -830,7 +830,8 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
     __shared__ uint32_t s_ix[2][256];
     __shared__ double s_T[256], s_nq2[256], s_nqp2[256], s_dp2[256], s_dn2[256];
     const int tid = threadIdx.x, lane = tid & 63, t = lane & 15;
-    const uint64_t qb = (uint64_t)blockIdx.x * 256;
+    const int QB = blockDim.x;   // queries per block (64: one wave per block, no cross-wave waiting at the phase changes)
+    const uint64_t qb = (uint64_t)blockIdx.x * QB;
     const bool want_knn = (p.method & PHK_METHOD_KNN) != 0, want_cen = (p.method & PHK_METHOD_KMEANS) != 0;
 
     // ---- phase A: one lane per query ----
@@ -901,18 +902,40 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
             mu[2 * i] = m2.x;
             mu[2 * i + 1] = m2.y;
         }
+        // the count rows are fetched two passes ahead (explicit register double buffer: hipcc does not software-
+        // pipeline the loop by itself and each pass would otherwise start with a full memory round trip)
+        auto rowptr = [&](int pass) {
+            const int ql = pass * (QB / 16) + (tid >> 4);
+            const uint64_t q = qb + ql < p.N ? qb + ql : p.N - 1;
+            return reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
+        };
+        uint4 pre[2][4];
+        if (SRC == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                pre[0][i] = rowptr(0)[i];
+                pre[1][i] = rowptr(1)[i];
+            }
+        }
 #pragma unroll 2
         for (int pass = 0; pass < 16; ++pass) {
-            const int ql = pass * 16 + (tid >> 4);
+            const int ql = pass * (QB / 16) + (tid >> 4);
             const uint64_t q = qb + ql < p.N ? qb + ql : p.N - 1;
             double qd[16], Tq = 1.0, invT2 = 1.0;
             bool bad = false;
             if (SRC == 0) {
-                const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
+                uint4 cur[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) cur[i] = pre[pass & 1][i];
+                if (pass + 2 < 16) {
+                    const uint4 *nrow = rowptr(pass + 2);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) pre[pass & 1][i] = nrow[i];
+                }
                 uint32_t sum = 0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const uint4 c = row[i];
+                    const uint4 c = cur[i];
                     sum += c.x + c.y + c.z + c.w;
                     qd[4 * i + 0] = (double)c.x;
                     qd[4 * i + 1] = (double)c.y;
@@ -1161,7 +1184,7 @@ static int launch_rerank(phk_ctx *ctx, unsigned blocks, const void *src, const R
                            (phk_rerank16_kernel<SRC, false><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p)));
             } else {   // one lane per query for what the margin test certifies, then four per wave for the rest
                 PHK_LAUNCH(ctx, "phk_decide_kernel",
-                           phk_decide_kernel<SRC><<<dim3((unsigned)phk_div_up(p.N, 256)), dim3(256), 0, ctx->stream>>>(src, p));
+                           phk_decide_kernel<SRC><<<dim3((unsigned)phk_div_up(p.N, 64)), dim3(64), 0, ctx->stream>>>(src, p));
                 PHK_LAUNCH(ctx, "phk_rerank16_kernel",
                            (phk_rerank16_kernel<SRC, true><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p)));
             }
