@@ -408,8 +408,13 @@ __device__ __forceinline__ void phk_stage_barrier() { asm volatile("s_waitcnt lg
 // SLOTS = contigs per workgroup: 32 (k <= 4: bank = slot, conflict free) or 16 (k = 5: a 1024-bin column set of
 // 32 contigs would not fit; bank = slot + 16 (code & 1), so the two lanes of a half-wave that share a slot
 // collide only when their codes have the same parity -- 3 LDS cycles per instruction on average instead of 2).
-template <int K, int SLOTS, int NTH>
+// MASK: validity bits are read straight from global memory (three words per chunk, fetched a stage ahead); a chunk
+// that is interior to its contig and all valid still takes the predicate-free loop, every other one adds the bit
+// "window starts inside the contig and its k bases are valid"; the per-contig number of counted windows goes
+// through an LDS counter.
+template <int K, int SLOTS, int NTH, bool MASK>
 __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__restrict__ packed,
+                                                             const uint32_t *__restrict__ mask,
                                                              const uint64_t *__restrict__ offsets, uint64_t n,
                                                              uint64_t max_word, uint32_t long_thr,
                                                              uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin,
@@ -425,11 +430,13 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][SLOTS] | staging [2][SLOTS][SLOT_ROW] | smax
     uint32_t *stage = lds + D * SLOTS;
     uint32_t *smax_p = stage + 2 * SLOTS * SLOT_ROW;
+    uint32_t *nwin_s = smax_p + 4;   // [SLOTS] counted windows per contig (MASK)
     if (!phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) return;  // ragged batch: stand down
     const int t = threadIdx.x, lane = t & 63;
     const int slot = t & (SLOTS - 1), part = t / SLOTS;          // counting role: contig slot, chunk (mod PARTS) within the stage
     for (uint32_t b = t * 4; b < D * SLOTS; b += 4 * NTH) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
     if (t == 0) *smax_p = 0;
+    if (MASK && t < SLOTS) nwin_s[t] = 0;
     __syncthreads();
     const uint32_t colb = (uint32_t)slot * 4u;
     const uint64_t wmax4 = max_word - 2;  // highest start of a 4-word load inside the stream (+ pad word)
@@ -516,6 +523,19 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
             swrite(0, v, la);
             if (smax > 1) gload(1, v, la);
         }
+        // MASK: validity words of this lane's chunks (word 2 q .. 2 q + 2 of the mask), one stage ahead
+        const uint64_t mmax = (max_word >> 1) + 1;   // last mask word that exists (ceil(T/32) + 1 words)
+        uint32_t mk[CPL][3], mkn[CPL][3];
+        uint32_t cnt_ok = 0;
+        auto mload = [&](uint32_t s, uint32_t (&m)[CPL][3]) {
+#pragma unroll
+            for (int ln = 0; ln < CPL; ++ln) {
+                const uint64_t mw = 2 * (q0 + (uint64_t)CH * s + (uint32_t)(PARTS * ln + part));
+#pragma unroll
+                for (int j = 0; j < 3; ++j) m[ln][j] = mask[mw + j <= mmax ? mw + j : mmax];
+            }
+        };
+        if (MASK && smax) mload(0, mkn);
         phk_lds_barrier();
         for (uint32_t s = 0; s < smax; ++s) {
             const uint32_t *row = stage + ((s & 1) * SLOTS + slot) * SLOT_ROW + 4 * part;
@@ -530,6 +550,13 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                 swrite((s + 1) & 1, v, la);
                 if (s + 2 < smax) gload(s + 2, v, la);
             }
+            if (MASK) {
+#pragma unroll
+                for (int ln = 0; ln < CPL; ++ln)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) mk[ln][j] = mkn[ln][j];
+                if (s + 1 < smax) mload(s + 1, mkn);
+            }
             // take delivery of ALL the stage's staging reads here: a read waited for after the first adds have been
             // issued costs a full drain of the add queue (the LDS counter is in order and saturates at 15)
 #pragma unroll
@@ -540,9 +567,25 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                 const uint64_t q = q0 + (uint64_t)CH * s + (uint32_t)(PARTS * ln + part);   // this lane's chunk; bases 64 q .. 64 q + 63
                 const uint64_t fb = q << 6;
                 const bool any = W && fb + 63 >= st && fb <= last;
-                const bool all = W && fb >= st && fb + 63 <= last;
+                bool all = W && fb >= st && fb + 63 <= last;
+                // bit 63 - i of wv: window i of the chunk is counted (inside the contig; MASK: its k bases valid)
+                uint64_t wv = 0;
+                if (any) {
+                    const uint32_t lo = st > fb ? (uint32_t)(st - fb) : 0u;              // first window of the chunk inside the contig
+                    const uint32_t hi = last - fb < 63 ? (uint32_t)(last - fb) : 63u;    // last one
+                    wv = ((hi - lo == 63u) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << (63 - hi)));
+                    if (MASK) {
+                        const uint64_t vb = ((uint64_t)mk[ln][0] << 32) | mk[ln][1];   // bit 63 - i: base i of the chunk valid
+                        uint64_t w = vb;
+#pragma unroll
+                        for (int j = 1; j < K; ++j) w &= (vb << j) | ((uint64_t)mk[ln][2] >> (32 - j));
+                        wv &= w;
+                        all = all && w == ~0ull;
+                        cnt_ok += (uint32_t)__popcll(wv);
+                    }
+                }
                 const uint32_t wds[5] = {cw[ln].x, cw[ln].y, cw[ln].z, cw[ln].w, nx[ln]};
-                if (!__any(any && !all)) {   // wave-uniform: no lane of the wave is at an edge of its contig
+                if (!__any(any && !all)) {   // wave-uniform: every lane's chunk is interior to its contig (and all valid) or empty
                     if (all) {
 #pragma unroll
                         for (int wd = 0; wd < 4; ++wd) {
@@ -551,24 +594,22 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                             for (int jw = 0; jw < 16; ++jw) add1(bin(jw < 8 ? y : u, jw & 7), 1u);
                         }
                     }
-                } else if (any) {            // some lane is: every active lane adds its validity bit instead of 1
-                    const uint32_t lo = st > fb ? (uint32_t)(st - fb) : 0u;              // first valid window of the chunk
-                    const uint32_t hi = last - fb < 63 ? (uint32_t)(last - fb) : 63u;    // last valid one
-                    const uint64_t vm = ((hi - lo == 63u) ? ~0ull : ((1ull << (hi - lo + 1)) - 1ull)) << lo;
-                    const uint32_t vlo = (uint32_t)vm, vhi = (uint32_t)(vm >> 32);
+                } else if (any) {            // some lane is at an edge / sees an invalid base: add the window's bit instead of 1
+                    const uint32_t vhi = (uint32_t)(wv >> 32), vlo = (uint32_t)wv;
 #pragma unroll
                     for (int wd = 0; wd < 4; ++wd) {
                         const uint32_t y = wds[wd], u = __builtin_amdgcn_alignbit(y, wds[wd + 1], 16);
 #pragma unroll
                         for (int jw = 0; jw < 16; ++jw) {
                             const int wi = 16 * wd + jw;
-                            add1(bin(jw < 8 ? y : u, jw & 7), __builtin_amdgcn_ubfe(wi < 32 ? vlo : vhi, wi & 31, 1));
+                            add1(bin(jw < 8 ? y : u, jw & 7), __builtin_amdgcn_ubfe(wi < 32 ? vhi : vlo, 31 - (wi & 31), 1));
                         }
                     }
                 }
             }
             phk_stage_barrier();
         }
+        if (MASK && cnt_ok) atomicAdd(nwin_s + slot, cnt_ok);
         phk_lds_barrier();  // every wave's adds have landed
         // ---- flush: thread (slot, group g) writes codes [g D/PARTS, (g+1) D/PARTS) of contig `slot` and clears them ----
         {
@@ -582,8 +623,10 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                 cell[0] = 0; cell[SLOTS] = 0; cell[2 * SLOTS] = 0; cell[3 * SLOTS] = 0;
                 if (have && !handed_over) *reinterpret_cast<uint4 *>(rowo + 4 * i) = o;
             }
-            if (nwin && have && !handed_over && g == 0) nwin[c] = W;
+            if (nwin && have && !handed_over && g == 0) nwin[c] = MASK ? nwin_s[slot] : W;
         }
+        phk_lds_barrier();
+        if (MASK && t < SLOTS) nwin_s[t] = 0;
         if (t == 0) *smax_p = 0;
         phk_lds_barrier();
     }
@@ -663,7 +706,7 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
     // k = 3, 4 without invalid bases: slot kernel (32 contigs per workgroup, conflict-free LDS adds); contigs
     // more than 4x the batch mean go on to the wave-per-contig kernel through a device list
     const char *lanes_env = getenv("PHK_COUNT_LANES");
-    if (k >= 3 && k <= 5 && !d_mask && max_word >= 64 && n < (1ull << 32) && !(lanes_env && lanes_env[0] == '0') &&
+    if (k >= 3 && k <= 5 && max_word >= 64 && n < (1ull << 32) && !(lanes_env && lanes_env[0] == '0') &&
         !getenv("PHK_COUNT_CFG")) {
         const uint32_t slots = k == 5 ? 16u : 32u;
         void *ws;
@@ -678,7 +721,7 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         PHK_LAUNCH(ctx, "phk_count_stats_kernel",
                    phk_count_stats_kernel<<<dim3((unsigned)phk_div_up(phk_div_up(n, slots), 256)), dim3(256), 0, ctx->stream>>>(
                        d_offsets, n, k, slots, long_thr, (unsigned long long *)(d_long_count + 2)));
-        const size_t lds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * SLOT_ROW * 4 + 16;
+        const size_t lds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * SLOT_ROW * 4 + 16 + slots * 4;
         // resident blocks per CU: the LDS allocation granule keeps a block that would exactly fill the 160 KiB out
         const unsigned fit = (unsigned)((160u * 1024u - 1024u) / lds);
         const unsigned per_cu = fit > 8 ? 8 : fit;
@@ -687,15 +730,22 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         if (blocks > cap) blocks = cap;
         static bool attr_set = false;
         if (!attr_set) {
-            PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
             attr_set = true;
         }
-#define PHK_SLOTS(K_, S_, T_)                                                                                                   \
-        PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                           \
-                   (phk_count_slots_kernel<K_, S_, T_><<<dim3((unsigned)blocks), dim3(T_), lds, ctx->stream>>>(                \
-                       d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count)));           \
+#define PHK_SLOTS(K_, S_, T_)                                                                                               \
+        if (d_mask) {                                                                                                       \
+            PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                       \
+                       (phk_count_slots_kernel<K_, S_, T_, true><<<dim3((unsigned)blocks), dim3(T_), lds, ctx->stream>>>(   \
+                           d_packed, d_mask, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count))); \
+        } else {                                                                                                            \
+            PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                       \
+                       (phk_count_slots_kernel<K_, S_, T_, false><<<dim3((unsigned)blocks), dim3(T_), lds, ctx->stream>>>(  \
+                           d_packed, nullptr, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count))); \
+        }                                                                                                                   \
         return launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                                    \
-            ctx, d_packed, nullptr, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count)
+            ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count)
         // 16 lanes per contig (512 threads) at k <= 4: 24 waves per CU hide the barrier and staging latencies better
         // than 12 (0.94 vs 1.03 ms per 1M x 5 kb); PHK_SLOT_THREADS=256 for comparison
         const char *th = getenv("PHK_SLOT_THREADS");

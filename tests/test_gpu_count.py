@@ -200,3 +200,24 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
         finally:
             os.environ.pop("PHK_COUNT_LANES", None)
     assert np.array_equal(rows["0"], rows["1"]) and np.array_equal(rows["0"], rows["2"])
+    # the same with invalid bases (validity mask): scattered single characters and long runs
+    seqs_n = [synth.synth_contig(9, i, L, invalid_ppm=(30000 if i % 3 else 0)) for i, L in enumerate(lens)]
+    seqs_n[16] = seqs_n[16][:300] + "N" * 200 + seqs_n[16][500:]
+    seqs_n[18] = "N" * 70 + seqs_n[18][70:4000] + "n" * 5 + seqs_n[18][4005:]
+    raw_n = np.frombuffer("".join(seqs_n).encode(), dtype=np.uint8)
+    assert len(raw_n) == T
+    d_raw_n = device.DeviceArray.from_host(ctx, raw_n)
+    d_flag = device.DeviceArray(ctx, 1, np.uint32)
+    device.pack_ascii(ctx, d_raw_n, T, d_packed, d_mask, d_flag)
+    assert d_flag.to_host()[0] != 0
+    want_n = oracle.count(seqs_n, k)
+    for lanes in ("2", "0"):
+        os.environ["PHK_COUNT_LANES"] = lanes
+        try:
+            d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 0xABCD, np.uint32))
+            d_nwin = device.DeviceArray.from_host(ctx, np.full(len(lens), 0xABCD, np.uint32))
+            device.count(ctx, d_packed, d_mask, T, d_off, len(lens), k, d_counts, d_nwin)
+            assert np.array_equal(d_counts.to_host().astype(np.int64), want_n), (k, lanes, "masked")
+            assert np.array_equal(d_nwin.to_host().astype(np.int64), want_n.sum(axis=1)), (k, lanes, "masked")
+        finally:
+            os.environ.pop("PHK_COUNT_LANES", None)
