@@ -221,3 +221,47 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
             assert np.array_equal(d_nwin.to_host().astype(np.int64), want_n.sum(axis=1)), (k, lanes, "masked")
         finally:
             os.environ.pop("PHK_COUNT_LANES", None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_slot_count_kernel_random_batches(ctx, seed):
+    """Randomised batches through the slot kernel (forced) and through the automatic choice: heavy-tailed
+    lengths in arbitrary order, random k in {3, 4, 5}, with and without invalid characters, batch sizes that
+    are not multiples of the workgroup's 32 / 16 contigs -- counts and window totals equal the oracle's."""
+    import os
+    from oracle import oracle
+    from phamers_amd import device, synth
+    rng = np.random.default_rng(100 + seed)
+    k = int(rng.choice([3, 4, 5]))
+    n = int(rng.integers(1, 140))
+    lens = np.minimum((rng.pareto(1.2, n) * 300).astype(np.int64), 60000)
+    lens[rng.integers(0, n, max(1, n // 10))] = 0
+    masked = bool(seed % 2)
+    seqs = [synth.synth_contig(50 + seed, i, int(L), invalid_ppm=(20000 if masked and i % 2 else 0)) for i, L in enumerate(lens)]
+    T = int(lens.sum())
+    if T < 2048:   # the slot kernel needs a stream of at least 64 words
+        seqs.append(synth.synth_contig(50 + seed, n, 4096))
+        lens = np.append(lens, 4096)
+        T = int(lens.sum())
+    offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens)
+    raw = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    d_raw = device.DeviceArray.from_host(ctx, raw)
+    d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    d_mask = device.DeviceArray(ctx, device.mask_words(T), np.uint32)
+    d_flag = device.DeviceArray(ctx, 1, np.uint32)
+    device.pack_ascii(ctx, d_raw, T, d_packed, d_mask, d_flag)
+    d_off = device.DeviceArray.from_host(ctx, offsets)
+    want = oracle.count(seqs, k)
+    D = 4 ** k
+    for lanes in ("2", "1"):
+        os.environ["PHK_COUNT_LANES"] = lanes
+        try:
+            d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 7, np.uint32))
+            d_nwin = device.DeviceArray.from_host(ctx, np.full(len(lens), 7, np.uint32))
+            device.count(ctx, d_packed, d_mask if masked else None, T, d_off, len(lens), k, d_counts, d_nwin)
+            assert np.array_equal(d_counts.to_host().astype(np.int64), want), (seed, k, lanes)
+            assert np.array_equal(d_nwin.to_host().astype(np.int64), want.sum(axis=1)), (seed, k, lanes)
+        finally:
+            os.environ.pop("PHK_COUNT_LANES", None)
