@@ -372,3 +372,54 @@ def test_count_exact_kernel_shapes_and_large_counts(monkeypatch, cfg):
             assert n_fallback >= len(big), (n, method, n_fallback)
             assert helpers.rel_err(got, want) < RTOL, (cfg, n, method)
     model.close()
+
+
+@pytest.mark.gpu
+def test_count_exact_path_adversarial_queries():
+    """Counts-in scoring (count-exact proposal + lane-per-query decision kernel) on queries built to sit ON
+    the decision boundaries: the reference genomes' own count vectors (distance 0 to a train row; counts far
+    above 2048, so the brute-force queue), the same thinned to contig-sized counts (nearest neighbour at
+    sampling-noise distance), sums of a positive and a negative genome's counts (two near-equidistant
+    neighbours with opposite labels), and single-k-mer rows -- against the oracle, for all three methods."""
+    import os
+    from oracle import oracle
+    from phamers_amd import _lib, device
+    g = helpers.load_npz("scoring_k4.npz")
+    with np.load(os.path.join(helpers.GOLDEN, "ref_features.npz")) as z:
+        pc = z["pos_counts"].astype(np.int64)
+        nc = z["neg_counts"].astype(np.int64)
+    n_eq = min(len(pc), len(nc))
+    pc, nc = pc[:n_eq], nc[:n_eq]
+    pos = pc / pc.sum(axis=1, keepdims=True)
+    neg = nc / nc.sum(axis=1, keepdims=True)
+    rng = np.random.default_rng(5)
+    ip, ineg = rng.integers(0, n_eq, 40), rng.integers(0, n_eq, 40)
+    rows = [pc[ip], nc[ineg],                                   # the genomes themselves (big counts)
+            pc[ip] // 16 + 1, nc[ineg] // 16 + 1,               # contig-sized versions of them
+            pc[ip] // 40 + nc[ineg] // 40,                      # between a positive and a negative genome
+            np.eye(256, dtype=np.int64)[rng.integers(0, 256, 8)] * 1500]   # all windows the same k-mer
+    counts = np.vstack(rows)
+    counts = np.minimum(counts, 2 ** 31 - 1).astype(np.uint32)
+    q = oracle.normalize_counts(counts.astype(np.int64))
+    want_knn = oracle.knn_score_points(q, pos, neg, 3)
+    want_cen = oracle.centroid_score_points_fast(q, g["cpos_eq"], g["cneg_eq"])
+    ctx = _lib.get_context()
+    model = _lib.Model(ctx, pos, neg, g["cpos_eq"], g["cneg_eq"], 3)
+    d_counts = device.DeviceArray.from_host(ctx, counts)
+    d_scores = device.DeviceArray(ctx, len(counts), np.float64)
+    d_status = device.DeviceArray.from_host(ctx, np.zeros(1, np.uint32))
+    for method, want in (("knn", want_knn), ("kmeans", want_cen), ("combo", want_knn + want_cen)):
+        device.score_counts(ctx, model, d_counts, len(counts), method, d_scores, d_status)
+        got = d_scores.to_host()
+        assert d_status.to_host()[0] == 0
+        # a query that IS a train row has exact ties only through duplicate genomes; compare votes where the
+        # oracle's 3rd and 4th neighbour are distinguishable, floats everywhere
+        if method == "kmeans":
+            assert helpers.rel_err(got, want) < RTOL, method
+        else:
+            d2 = ((q[:, None, :] - np.vstack([pos, neg])[None, :, :]) ** 2).sum(axis=2)
+            srt = np.sort(d2, axis=1)
+            clear = (srt[:, 3] - srt[:, 2]) > 1e-12 * np.maximum(srt[:, 3], 1e-300)
+            assert clear.sum() > len(counts) // 2
+            assert helpers.rel_err(got[clear], want[clear]) < RTOL, method
+    model.close()
