@@ -7,6 +7,7 @@ Same names, argument meaning, defaults and return shapes as the reference:
     count_string(sequence, kmer_length, symbols=DNA, normalize=False)   scripts/kmer.py:32
     count(data, kmer_length, symbols=DNA, normalize=False)              scripts/kmer.py:82
     count_file(input_file, kmer_length, symbols=DNA, normalize=False)   scripts/kmer.py:114
+    count_directory(directory, kmer_length, identifier='fna', ...)       scripts/kmer.py:143
     normalize_counts(counts)                                            scripts/kmer.py:209
     kmers(k, symbols=DNA), sequence_to_integers, get_kmer_index         scripts/kmer.py:183-251
 
@@ -16,6 +17,7 @@ there is no CPU fallback in this package.
 """
 import logging
 import os
+import random
 
 import numpy as np
 
@@ -118,6 +120,39 @@ def count_file(input_file, kmer_length, symbols=DNA, normalize=False):
             counts[:, :] = got
     finally:
         fasta.close()
+    return ids, counts
+
+
+def count_directory(directory, kmer_length, identifier='fna', symbols=DNA, sum_file=True, sample=0):
+    """Counts k-mers of all FASTA files of a directory whose base name contains `identifier`
+    (scripts/kmer.py:143-181): one row per file -- with sum_file the column sums over the file's records,
+    labelled with the id of its first record (how the reference matrix is regenerated from genome files) --
+    as a float array like the reference's.  Unreadable / empty / all-zero files are skipped with a warning;
+    `sample` > 0 shuffles the files and stops after that many rows."""
+    selected_files = [os.path.join(directory, f) for f in os.listdir(directory) if identifier in os.path.basename(f)]
+    if sample:
+        random.shuffle(selected_files)
+    ids, rows = [], []
+    for path in selected_files:
+        file_ids, file_counts = count_file(path, kmer_length, symbols=symbols)
+        if file_ids is None or len(file_ids) == 0 or np.sum(file_counts) == 0:
+            logger.warning("Could not read file: %s" % os.path.basename(path))
+            continue
+        if sum_file and len(file_counts.shape) == 2:
+            # Summing k-mer counts of all sequences within a file
+            file_counts = np.sum(file_counts, axis=0)
+        elif len(file_counts.shape) == 2 and file_counts.shape[0] == 1:
+            file_counts = file_counts[0]
+        elif len(file_counts.shape) == 2:
+            raise ValueError("count_directory(sum_file=False) needs single-record files (%s has %d records)"
+                             % (os.path.basename(path), file_counts.shape[0]))
+        ids.append(file_ids[0])
+        rows.append(file_counts)
+        if sample and len(ids) == sample:
+            break
+    counts = np.zeros((len(rows), pow(len(symbols), kmer_length)))
+    for i, r in enumerate(rows):
+        counts[i] = r
     return ids, counts
 
 

@@ -265,3 +265,26 @@ def test_slot_count_kernel_random_batches(ctx, seed):
             assert np.array_equal(d_nwin.to_host().astype(np.int64), want.sum(axis=1)), (seed, k, lanes)
         finally:
             os.environ.pop("PHK_COUNT_LANES", None)
+
+
+@pytest.mark.gpu
+def test_count_directory_sums_per_file(kmer, tmp_path):
+    """kmer.count_directory (scripts/kmer.py:143-181): one row per FASTA file = column sums over its records,
+    id of the first record; files without the identifier or without countable sequence are skipped."""
+    from oracle import oracle
+    from phamers_amd import synth
+    want = {}
+    for fi, nrec in enumerate((1, 3, 5)):
+        seqs = [synth.synth_contig(70 + fi, r, 900 + 37 * r) for r in range(nrec)]
+        with open(tmp_path / ("genome_%d.fna" % fi), "w") as fh:
+            for r, sq in enumerate(seqs):
+                fh.write(">GB%03d%02d.1 some description\n" % (fi, r))
+                for p0 in range(0, len(sq), 70):
+                    fh.write(sq[p0:p0 + 70] + "\n")
+        want["GB%03d00.1" % fi] = oracle.count(seqs, 4).reshape(nrec, 256).sum(axis=0)
+    (tmp_path / "notes.txt").write_text("not a fasta file")
+    (tmp_path / "empty.fna").write_text(">ZZ00000.1 only n\nNNNNNNNNNN\n")
+    ids, counts = kmer.count_directory(str(tmp_path), 4)
+    assert sorted(ids) == sorted(want) and counts.shape == (3, 256) and counts.dtype == np.float64
+    for i, name in enumerate(ids):
+        assert np.array_equal(counts[i], want[name].astype(np.float64)), name
