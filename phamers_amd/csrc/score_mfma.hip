@@ -834,6 +834,23 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
     const uint64_t qb = (uint64_t)blockIdx.x * QB;
     const bool want_knn = (p.method & PHK_METHOD_KNN) != 0, want_cen = (p.method & PHK_METHOD_KMEANS) != 0;
 
+    // the count rows of phase B are fetched two passes ahead (explicit register double buffer: hipcc does not
+    // software-pipeline that loop by itself and each pass would otherwise start with a full memory round trip);
+    // the first two are requested here, ahead of phase A's list reads
+    auto rowptr = [&](int pass) {
+        const int ql = pass * (QB / 16) + (tid >> 4);
+        const uint64_t q = qb + ql < p.N ? qb + ql : p.N - 1;
+        return reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
+    };
+    uint4 pre[2][4];
+    if (SRC == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pre[0][i] = rowptr(0)[i];
+            pre[1][i] = rowptr(1)[i];
+        }
+    }
+
     // ---- phase A: one lane per query ----
     const uint64_t qa = qb + tid;
     const bool in_a = qa < p.N;
@@ -901,21 +918,6 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
             const double2 m2 = mp[i];
             mu[2 * i] = m2.x;
             mu[2 * i + 1] = m2.y;
-        }
-        // the count rows are fetched two passes ahead (explicit register double buffer: hipcc does not software-
-        // pipeline the loop by itself and each pass would otherwise start with a full memory round trip)
-        auto rowptr = [&](int pass) {
-            const int ql = pass * (QB / 16) + (tid >> 4);
-            const uint64_t q = qb + ql < p.N ? qb + ql : p.N - 1;
-            return reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
-        };
-        uint4 pre[2][4];
-        if (SRC == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                pre[0][i] = rowptr(0)[i];
-                pre[1][i] = rowptr(1)[i];
-            }
         }
 #pragma unroll 2
         for (int pass = 0; pass < 16; ++pass) {
