@@ -71,5 +71,16 @@ int main() {
         }
     }
     printf("probeE random (200 tiles): max err = %.3f u*|exact result|, %.3f u*sum|terms|  (single RN rounding gives <= 1.0 u*|result|)\n", worst_rel, worst_abs);
+    // F: fp16 subnormal inputs (the lo parts of the split operands can be subnormal): kept or flushed?
+    clear();
+    hA[0] = (_Float16)9.5367431640625e-07f;   // 2^-20, subnormal in fp16 (min normal 2^-14)
+    hB[0] = (_Float16)1024.0f;
+    run();
+    printf("probeF subnormal A (2^-20) x 2^10: %.9g (kept: 0.0009765625 = 2^-10; flushed: 0)\n", hD[0]);
+    clear();
+    hA[0] = (_Float16)1024.0f;
+    hB[0] = (_Float16)5.9604644775390625e-08f;  // 2^-24, smallest fp16 subnormal
+    run();
+    printf("probeF subnormal B (2^-24) x 2^10: %.9g (kept: 6.10351562e-05 = 2^-14; flushed: 0)\n", hD[0]);
     return 0;
 }
