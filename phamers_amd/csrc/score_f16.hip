@@ -707,10 +707,11 @@ __global__ __launch_bounds__(256) void phk_split_queries_kernel(const void *__re
     }
 }
 
-#define GEN_CT 4
 // CX (count-exact): Bq holds the fp16 counts (hi slots), 2 MFMAs per k-step, value = acc - T * bias (rowsum,
 // beta_all), rows flagged in `big` get empty lists (-> exact brute-force queue)
-template <bool CX>
+// GEN_CT = column blocks per tile (accumulators per wave): a query chunk fetched from memory serves GEN_CT x 16 k-steps;
+// the count-exact flavour has no lo query fragments and spends the registers on 8 accumulators instead of 4
+template <bool CX, int GEN_CT>
 __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4 *__restrict__ Bq, uint64_t N,
                                                                      uint32_t nchunk,
                                                                      const uint4 *__restrict__ Af,
@@ -891,20 +892,20 @@ int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void
     }
     static bool attr_set = false;
     if (!attr_set) {
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         attr_set = true;
     }
     const uint64_t rec_u4 = (nchunk * 32 + 1) * 64;
     const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
     if (d_big) {
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
-                   phk_knn_f16_general_kernel<true><<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
+                   phk_knn_f16_general_kernel<true, 8><<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, d_rowsum,
                        d_big, blk0, nref, npos, nneg, cv, ci, cu));
     } else {
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
-                   phk_knn_f16_general_kernel<false><<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
+                   phk_knn_f16_general_kernel<false, 4><<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, nullptr,
                        nullptr, blk0, nref, npos, nneg, cv, ci, cu));
     }

@@ -1079,17 +1079,25 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
             for (uint64_t d = threadIdx.x; d < D; d += 256) fb_q[d] = static_cast<const double *>(src)[q * D + d];
         }
         __syncthreads();
-        for (uint64_t c = c0 + threadIdx.x; c < c1; c += 256) {
-            const double2 *row = reinterpret_cast<const double2 *>(c < p.M ? p.R64 + c * D : p.C64 + (c - p.M) * D);
+        // 16 lanes per column (contiguous 256-byte pieces of its row per load), 16 columns per pass
+        for (uint64_t cb = c0; cb < c1; cb += 16) {
+            const uint64_t c = cb + (threadIdx.x >> 4);
+            const int t16 = threadIdx.x & 15;
+            const uint64_t cc = c < c1 ? c : c1 - 1;
+            const double2 *row = reinterpret_cast<const double2 *>(cc < p.M ? p.R64 + cc * D : p.C64 + (cc - p.M) * D);
             double acc = 0.0;
-#pragma unroll 8
-            for (uint64_t d = 0; d < D / 2; ++d) {
+#pragma unroll 4
+            for (uint64_t d = t16; d < D / 2; d += 16) {
                 const double2 r = row[d];
                 const double d0 = fb_q[2 * d] - r.x, d1 = fb_q[2 * d + 1] - r.y;
                 acc = fma(d0, d0, acc);
                 acc = fma(d1, d1, acc);
             }
-            fb_dist[c - c0] = acc;
+            acc += __shfl_xor(acc, 8);
+            acc += __shfl_xor(acc, 4);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 1);
+            if (t16 == 0 && c < c1) fb_dist[c - c0] = acc;
         }
         __syncthreads();
         if (wave == 0) {
