@@ -440,6 +440,8 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
     __syncthreads();
     const uint32_t colb = (uint32_t)slot * 4u;
     const uint64_t wmax4 = max_word - 2;  // highest start of a 4-word load inside the stream (+ pad word)
+    // the integer bin addresses below assume the dynamic LDS array starts at address 0 (no static LDS in this kernel)
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0u) __builtin_trap();
 
     // LDS byte address of the bin of the window starting at base jw of `src` (jw < 8).
     // The bins sit at LDS address 0 (the kernel has no static LDS), so the byte address is formed as an integer --
