@@ -2,13 +2,13 @@
 learning.py -- drop-in for the hot-path helpers of PhaMers' scripts/learning.py.
 
     knn(queries, ref_data, ref_labels, k=3)       scripts/learning.py:118-128   -> GPU
-    kmeans(data, k, ...)                          scripts/learning.py:131-146   -> scikit-learn
+    kmeans(data, k, ...)                          scripts/learning.py:131-146   -> scikit-learn (default) / GPU
     get_centroids(data, assignment)               scripts/learning.py:69-81     -> NumPy (86 means)
 
-k-means stays on scikit-learn exactly as in the reference (a per-run fit that does not
-depend on the number of query contigs); its centroids are an explicit
-input of the GPU scorer.  A deterministic GPU Lloyd k-means is listed under "next" in
-DESIGN.md.
+k-means uses scikit-learn by default, exactly as in the reference (a per-run fit that does not
+depend on the number of query contigs; the golden scores are pinned to
+its centroids); the centroids are an explicit input of the GPU scorer.  PHAMERS_KMEANS=gpu selects
+kmeans_gpu, a deterministic device Lloyd k-means (phk_kmeans).
 """
 import logging
 
