@@ -75,6 +75,15 @@ int phk_device_count(int *count);
 int phk_create(int device_id, void *stream, phk_ctx **out);
 int phk_destroy(phk_ctx *ctx);
 int phk_sync(phk_ctx *ctx);
+/* Tuning / diagnostic knobs of a context.  Each knob takes its initial value from the environment variable
+ * PHK_<KEY upper case> ONCE, when the context is created; afterwards it changes only through this call (no
+ * launch path reads the environment).  Keys: "count_lanes" ("0" wave-per-contig count kernel only, "2" slot
+ * kernel whatever the batch looks like), "count_cfg" ("<copies>,<pack16>"), "slot_threads" ("256"),
+ * "count_sort" ("0" = no length-bucketed order for ragged batches), "force_exact" ("1" = float64 scoring
+ * path for every model), "proposal" ("f32" | "f16" | "" default), "cx_cfg" ("14" | "24" | "28"), "rerank"
+ * ("w" | "g"), "score_batch" (queries per scoring batch).  Unknown key -> PHK_ERR_ARG.  The results of every
+ * entry point are the same under every setting; the parity tests use the knobs to cross-check the paths. */
+int phk_set_option(phk_ctx *ctx, const char *key, const char *value);
 
 /* device buffers for hosts that do not bring their own allocator */
 int phk_malloc(phk_ctx *ctx, uint64_t bytes, void **dptr);
@@ -181,7 +190,7 @@ int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const uint32_t *d_
                         uint64_t n, int k, int method, uint32_t *d_counts, double *d_scores,
                         uint32_t *d_status);
 
-/* Diagnostics of the most recent scoring call on this context (synchronises the stream):
+/* Diagnostics of the most recent scoring call on this context, summed over its batches (synchronises the stream):
  * how many queries were resolved by the float64 brute-force fallback kernel and how many
  * (query, segment) orderings had to be decided by exact candidate distances rather than by
  * the certified fp32 margin.  Both are 0 on the all-float64 path. */

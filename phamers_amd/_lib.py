@@ -31,6 +31,7 @@ SIGNATURES = {
     "phk_create": (c_int, [c_int, c_void_p, P(c_void_p)]),
     "phk_destroy": (c_int, [c_void_p]),
     "phk_sync": (c_int, [c_void_p]),
+    "phk_set_option": (c_int, [c_void_p, c_char_p, c_char_p]),
     "phk_malloc": (c_int, [c_void_p, c_u64, P(c_void_p)]),
     "phk_free": (c_int, [c_void_p, c_void_p]),
     "phk_memcpy_h2d": (c_int, [c_void_p, c_void_p, c_void_p, c_u64]),
@@ -142,6 +143,25 @@ class Context(object):
     def sync(self):
         check(self.lib.phk_sync(self.handle))
 
+    def set_option(self, key, value):
+        """Tuning / diagnostic knob (phk_set_option); knobs start from PHK_<KEY> in the environment at creation."""
+        check(self.lib.phk_set_option(self.handle, key.encode(), str(value).encode()))
+
+    def options(self, **kw):
+        """Context manager: set knobs for a block, restore the given ``(value, restore)`` pairs afterwards:
+        ``with ctx.options(force_exact=("1", "0")): ...``"""
+        ctx = self
+
+        class _Scope(object):
+            def __enter__(self_):
+                for k, (v, _) in kw.items():
+                    ctx.set_option(k, v)
+
+            def __exit__(self_, *exc):
+                for k, (_, r) in kw.items():
+                    ctx.set_option(k, r)
+        return _Scope()
+
     def score_stats(self):
         """(queries sent to the float64 fallback, orderings decided by exact candidate distances)
         of the most recent scoring call."""
@@ -183,6 +203,11 @@ class Model(object):
         if positive_centroids is not None:
             cp = np.ascontiguousarray(positive_centroids, dtype=np.float64)
             cn = np.ascontiguousarray(negative_centroids, dtype=np.float64)
+        # a zero-count reference row is NaN after normalisation; the reference's scikit-learn fit raises on it
+        # (scripts/learning.py:127, 138), so no model is ever built from such data
+        for a in (pos, neg, cp, cn):
+            if a is not None and np.isnan(a).any():
+                raise ValueError("Input contains NaN.")
         self.D = pos.shape[1]
         h = ctypes.c_void_p()
         check(ctx.lib.phk_model_create(ctx.handle, ptr(pos), pos.shape[0], ptr(neg), neg.shape[0],

@@ -440,8 +440,8 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
     __syncthreads();
     const uint32_t colb = (uint32_t)slot * 4u;
     const uint64_t wmax4 = max_word - 2;  // highest start of a 4-word load inside the stream (+ pad word)
-    // the integer bin addresses below assume the dynamic LDS array starts at address 0 (no static LDS in this kernel)
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds != 0u) __builtin_trap();
+    // the integer bin addresses below assume the dynamic LDS array starts at address 0: true while the kernel has no
+    // static LDS, which phk_count_init_device verifies on the host (hipFuncGetAttributes) before this kernel is ever used
 
     // LDS byte address of the bin of the window starting at base jw of `src` (jw < 8).
     // The bins sit at LDS address 0 (the kernel has no static LDS), so the byte address is formed as an integer --
@@ -673,9 +673,9 @@ static int launch_count_k(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t
                           uint32_t *d_nwin) {
     // tuning knob for the LDS replication study: PHK_COUNT_CFG="<copies>,<pack16>", k = 4 / 5 / 6 only
     if (K == 4 || K == 5 || K == 6) {
-        const char *cfg = getenv("PHK_COUNT_CFG");
+        const char *cfg = ctx->knobs.count_cfg;
         int copies = 0, p16 = 0;
-        if (cfg && sscanf(cfg, "%d,%d", &copies, &p16) == 2) {
+        if (cfg[0] && sscanf(cfg, "%d,%d", &copies, &p16) == 2) {
 #define PHK_CFG(C, P) if (copies == C && p16 == P) return launch_count_cfg<(K == 4 || K == 5 || K == 6) ? K : 4, C, P != 0>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin)
             PHK_CFG(1, 0); PHK_CFG(2, 0); PHK_CFG(4, 0); PHK_CFG(8, 0); PHK_CFG(16, 0);
             PHK_CFG(1, 1); PHK_CFG(4, 1); PHK_CFG(8, 1); PHK_CFG(16, 1);
@@ -686,6 +686,37 @@ static int launch_count_k(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t
     }
     return launch_count_cfg<K, PhkCountCfg<K>::copies, PhkCountCfg<K>::pack16>(ctx, d_packed, d_mask, d_offsets, n,
                                                                               max_word, d_counts, d_nwin);
+}
+
+// Per-device set-up, called from phk_create with the context's device current: raise the dynamic LDS limit of the
+// k = 5 slot kernel and verify, for every slot kernel instance, that it has no static LDS -- its bin addresses are
+// formed as integers on the assumption that the dynamic array starts at LDS address 0.  If a toolchain ever lays
+// the kernel out differently the slot kernel is simply not used on this context (the wave-per-contig kernel
+// serves every k): a host-side refusal instead of a device-side abort.
+template <typename Kern>
+static int slots_instance_ok(Kern kern, bool *ok) {
+    hipFuncAttributes fa;
+    PHK_HIP(hipFuncGetAttributes(&fa, (const void *)kern));
+    if (fa.sharedSizeBytes != 0) *ok = false;
+    return PHK_OK;
+}
+
+int phk_count_init_device(phk_ctx *ctx) {
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    bool ok = true;
+    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 256, false>, &ok));
+    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 256, true>, &ok));
+    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 512, false>, &ok));
+    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 512, true>, &ok));
+    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<4, 32, 256, false>, &ok));
+    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<4, 32, 256, true>, &ok));
+    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<4, 32, 512, false>, &ok));
+    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<4, 32, 512, true>, &ok));
+    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<5, 16, 256, false>, &ok));
+    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<5, 16, 256, true>, &ok));
+    ctx->slots_lds0 = ok;
+    return PHK_OK;
 }
 
 int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t T,
@@ -707,9 +738,9 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
     const uint64_t max_word = (T - 1) >> 4;  // last word holding a base; word max_word + 1 exists (pad)
     // k = 3, 4 without invalid bases: slot kernel (32 contigs per workgroup, conflict-free LDS adds); contigs
     // more than 4x the batch mean go on to the wave-per-contig kernel through a device list
-    const char *lanes_env = getenv("PHK_COUNT_LANES");
-    if (k >= 3 && k <= 5 && max_word >= 64 && n < (1ull << 32) && !(lanes_env && lanes_env[0] == '0') &&
-        !getenv("PHK_COUNT_CFG")) {
+    const char lanes_knob = ctx->knobs.count_lanes;
+    if (k >= 3 && k <= 5 && max_word >= 64 && n < (1ull << 32) && lanes_knob != '0' && ctx->slots_lds0 &&
+        !ctx->knobs.count_cfg[0]) {
         const uint32_t slots = k == 5 ? 16u : 32u;
         void *ws;
         PHK_TRY(phk_ws(ctx, WS_LONG, (n + 16) * sizeof(uint32_t), &ws));
@@ -719,7 +750,7 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         const uint64_t mean_len = T / n + 1;
         const uint64_t thr64 = 4 * mean_len + 1024;
         const uint32_t long_thr = thr64 < 0xFFFFFFFFull ? (uint32_t)thr64 : 0xFFFFFFFFu;
-        if (!(lanes_env && lanes_env[0] == '2'))  // PHK_COUNT_LANES=2: slot kernel whatever the batch looks like (tests)
+        if (lanes_knob != '2')  // count_lanes=2: slot kernel whatever the batch looks like (tests)
         PHK_LAUNCH(ctx, "phk_count_stats_kernel",
                    phk_count_stats_kernel<<<dim3((unsigned)phk_div_up(phk_div_up(n, slots), 256)), dim3(256), 0, ctx->stream>>>(
                        d_offsets, n, k, slots, long_thr, (unsigned long long *)(d_long_count + 2)));
@@ -730,12 +761,6 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         uint64_t blocks = phk_div_up(n, slots);
         const uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
         if (blocks > cap) blocks = cap;
-        static bool attr_set = false;
-        if (!attr_set) {
-            PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-            attr_set = true;
-        }
 #define PHK_SLOTS(K_, S_, T_)                                                                                               \
         if (d_mask) {                                                                                                       \
             PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                       \
@@ -750,8 +775,7 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
             ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count)
         // 16 lanes per contig (512 threads) at k <= 4: 24 waves per CU hide the barrier and staging latencies better
         // than 12 (0.94 vs 1.03 ms per 1M x 5 kb); PHK_SLOT_THREADS=256 for comparison
-        const char *th = getenv("PHK_SLOT_THREADS");
-        const bool t256 = th && th[0] == '2';
+        const bool t256 = ctx->knobs.slot_threads == '2';
         if (k == 3) { if (t256) { PHK_SLOTS(3, 32, 256); } PHK_SLOTS(3, 32, 512); }
         if (k == 4) { if (t256) { PHK_SLOTS(4, 32, 256); } PHK_SLOTS(4, 32, 512); }
         PHK_SLOTS(5, 16, 256);

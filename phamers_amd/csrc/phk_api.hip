@@ -1,5 +1,6 @@
 // phk_api.hip -- the extern "C" surface of libphamers_hip.so (include/phamers_hip.h):
 // context / workspace / timing plumbing and the host- and device-pointer entry points.
+#include <stdlib.h>
 #include <string.h>
 
 #include "phk_common.h"
@@ -23,6 +24,43 @@ extern "C" int phk_device_count(int *count) {
     return PHK_OK;
 }
 
+// one knob by name (the part after PHK_ of its environment variable, lower case)
+static int set_knob(PhkKnobs &k, const char *key, const char *value) {
+    const char *v = value ? value : "";
+    if (!strcmp(key, "count_cfg")) snprintf(k.count_cfg, sizeof(k.count_cfg), "%s", v);
+    else if (!strcmp(key, "count_lanes")) k.count_lanes = v[0];
+    else if (!strcmp(key, "slot_threads")) k.slot_threads = v[0];
+    else if (!strcmp(key, "force_exact")) k.force_exact = v[0] == '1';
+    else if (!strcmp(key, "proposal")) snprintf(k.proposal, sizeof(k.proposal), "%s", v);
+    else if (!strcmp(key, "cx_cfg")) snprintf(k.cx_cfg, sizeof(k.cx_cfg), "%s", v);
+    else if (!strcmp(key, "rerank")) k.rerank = v[0];
+    else if (!strcmp(key, "count_sort")) k.count_sort = v[0] != '0';
+    else if (!strcmp(key, "score_batch")) k.score_batch = strtoull(v, nullptr, 10);
+    else return PHK_ERR_ARG;
+    return PHK_OK;
+}
+
+static void knobs_from_env(PhkKnobs &k) {
+    static const char *const names[][2] = {{"count_cfg", "PHK_COUNT_CFG"}, {"count_lanes", "PHK_COUNT_LANES"},
+                                           {"slot_threads", "PHK_SLOT_THREADS"}, {"force_exact", "PHK_FORCE_EXACT"},
+                                           {"proposal", "PHK_PROPOSAL"}, {"cx_cfg", "PHK_CX_CFG"},
+                                           {"rerank", "PHK_RERANK"}, {"count_sort", "PHK_COUNT_SORT"},
+                                           {"score_batch", "PHK_SCORE_BATCH"}};
+    for (auto &n : names) {
+        const char *e = getenv(n[1]);
+        if (e) (void)set_knob(k, n[0], e);
+    }
+}
+
+extern "C" int phk_set_option(phk_ctx *ctx, const char *key, const char *value) {
+    PHK_REQUIRE(ctx && key, "phk_set_option: NULL");
+    if (set_knob(ctx->knobs, key, value) != PHK_OK) {
+        phk_set_error("phk_set_option: unknown option '%s'", key);
+        return PHK_ERR_ARG;
+    }
+    return PHK_OK;
+}
+
 extern "C" int phk_create(int device_id, void *stream, phk_ctx **out) {
     PHK_REQUIRE(out, "phk_create: NULL out");
     int ndev = 0;
@@ -40,6 +78,17 @@ extern "C" int phk_create(int device_id, void *stream, phk_ctx **out) {
     phk_ctx *ctx = new phk_ctx();
     ctx->device = device_id;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    knobs_from_env(ctx->knobs);
+    // kernel attributes are per device: set them for THIS context's device now, not lazily at a first launch
+    {
+        int rc = phk_count_init_device(ctx);
+        if (rc == PHK_OK) rc = phk_score_f16_init_device(ctx);
+        if (rc == PHK_OK) rc = phk_score_mfma_init_device(ctx);
+        if (rc != PHK_OK) {
+            delete ctx;
+            return rc;
+        }
+    }
     if (stream) {
         ctx->stream = (hipStream_t)stream;
         ctx->own_stream = false;
@@ -71,7 +120,7 @@ extern "C" int phk_destroy(phk_ctx *ctx) {
 }
 
 extern "C" int phk_sync(phk_ctx *ctx) {
-    PHK_REQUIRE(ctx, "phk_sync: NULL ctx");
+    PHK_ENTER(ctx, "phk_sync");
     PHK_HIP(hipStreamSynchronize(ctx->stream));
     return PHK_OK;
 }
@@ -102,13 +151,13 @@ int phk_ws(phk_ctx *ctx, int slot, uint64_t bytes, void **out) {
 }
 
 extern "C" int phk_malloc(phk_ctx *ctx, uint64_t bytes, void **dptr) {
-    PHK_REQUIRE(ctx && dptr, "phk_malloc: NULL");
-    PHK_HIP(hipSetDevice(ctx->device));
+    PHK_ENTER(ctx, "phk_malloc");
+    PHK_REQUIRE(dptr, "phk_malloc: NULL");
     PHK_HIP(hipMalloc(dptr, bytes ? bytes : 16));
     return PHK_OK;
 }
 extern "C" int phk_free(phk_ctx *ctx, void *dptr) {
-    PHK_REQUIRE(ctx, "phk_free: NULL ctx");
+    PHK_ENTER(ctx, "phk_free");
     if (dptr) {
         PHK_HIP(hipStreamSynchronize(ctx->stream));
         PHK_HIP(hipFree(dptr));
@@ -116,7 +165,8 @@ extern "C" int phk_free(phk_ctx *ctx, void *dptr) {
     return PHK_OK;
 }
 extern "C" int phk_memcpy_h2d(phk_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
-    PHK_REQUIRE(ctx && (bytes == 0 || (dst && src)), "phk_memcpy_h2d: NULL");
+    PHK_ENTER(ctx, "phk_memcpy_h2d");
+    PHK_REQUIRE(bytes == 0 || (dst && src), "phk_memcpy_h2d: NULL");
     if (bytes) {
         PHK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
         PHK_HIP(hipStreamSynchronize(ctx->stream));
@@ -124,7 +174,8 @@ extern "C" int phk_memcpy_h2d(phk_ctx *ctx, void *dst, const void *src, uint64_t
     return PHK_OK;
 }
 extern "C" int phk_memcpy_d2h(phk_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
-    PHK_REQUIRE(ctx && (bytes == 0 || (dst && src)), "phk_memcpy_d2h: NULL");
+    PHK_ENTER(ctx, "phk_memcpy_d2h");
+    PHK_REQUIRE(bytes == 0 || (dst && src), "phk_memcpy_d2h: NULL");
     if (bytes) {
         PHK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         PHK_HIP(hipStreamSynchronize(ctx->stream));
@@ -190,7 +241,7 @@ extern "C" int phk_profile_enable(phk_ctx *ctx, int on) {
     return PHK_OK;
 }
 extern "C" int phk_profile_reset(phk_ctx *ctx) {
-    PHK_REQUIRE(ctx, "phk_profile_reset: NULL ctx");
+    PHK_ENTER(ctx, "phk_profile_reset");
     PHK_HIP(hipStreamSynchronize(ctx->stream));
     for (auto &t : ctx->timed) {
         for (auto e : t.ev) ctx->ev_pool.push_back(e);
@@ -206,7 +257,8 @@ extern "C" int phk_profile_count(phk_ctx *ctx, int *count) {
 }
 extern "C" int phk_profile_get(phk_ctx *ctx, int idx, char *name, int cap, double *total_ms,
                                uint64_t *launches) {
-    PHK_REQUIRE(ctx && idx >= 0 && idx < (int)ctx->timed.size(), "phk_profile_get: bad index");
+    PHK_ENTER(ctx, "phk_profile_get");
+    PHK_REQUIRE(idx >= 0 && idx < (int)ctx->timed.size(), "phk_profile_get: bad index");
     PhkTimed &t = ctx->timed[idx];
     PHK_TRY(fold_events(ctx, t));
     if (name && cap > 0) {
@@ -221,7 +273,7 @@ extern "C" int phk_profile_get(phk_ctx *ctx, int idx, char *name, int cap, doubl
 // ---- host API ---------------------------------------------------------------------------
 extern "C" int phk_count_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n,
                                int k, const char *symbols4, int64_t *counts) {
-    PHK_REQUIRE(ctx, "phk_count_ascii: NULL ctx");
+    PHK_ENTER(ctx, "phk_count_ascii");
     PHK_REQUIRE(k >= 1, "phk_count_ascii: k must be >= 1 (got %d)", k);
     if (k > PHK_MAX_K) {
         phk_set_error("phk_count_ascii: k=%d is above PHK_MAX_K=%d", k, PHK_MAX_K);
@@ -236,7 +288,6 @@ extern "C" int phk_count_ascii(phk_ctx *ctx, const char *bases, const uint64_t *
         PHK_REQUIRE(offsets[c + 1] >= offsets[c], "phk_count_ascii: offsets must be non-decreasing");
     const uint64_t T = offsets[n];
     PHK_REQUIRE(T == 0 || bases, "phk_count_ascii: NULL bases");
-    PHK_HIP(hipSetDevice(ctx->device));
     const uint64_t D = phk_pow4(k);
     void *d_ascii, *d_packed, *d_mask, *d_off, *d_counts, *d_wide, *d_flags;
     PHK_TRY(phk_ws(ctx, WS_ASCII, T, &d_ascii));
@@ -262,10 +313,9 @@ extern "C" int phk_count_ascii(phk_ctx *ctx, const char *bases, const uint64_t *
 }
 
 extern "C" int phk_normalize_i64(phk_ctx *ctx, const int64_t *counts, uint64_t n, uint64_t D, double *out) {
-    PHK_REQUIRE(ctx, "phk_normalize_i64: NULL ctx");
+    PHK_ENTER(ctx, "phk_normalize_i64");
     if (n == 0 || D == 0) return PHK_OK;
     PHK_REQUIRE(counts && out, "phk_normalize_i64: NULL pointer");
-    PHK_HIP(hipSetDevice(ctx->device));
     void *d_in, *d_out;
     PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &d_in));
     PHK_TRY(phk_ws(ctx, WS_Q64, n * D * 8, &d_out));
@@ -277,10 +327,9 @@ extern "C" int phk_normalize_i64(phk_ctx *ctx, const int64_t *counts, uint64_t n
 }
 
 extern "C" int phk_normalize_f64(phk_ctx *ctx, const double *rows, uint64_t n, uint64_t D, double *out) {
-    PHK_REQUIRE(ctx, "phk_normalize_f64: NULL ctx");
+    PHK_ENTER(ctx, "phk_normalize_f64");
     if (n == 0 || D == 0) return PHK_OK;
     PHK_REQUIRE(rows && out, "phk_normalize_f64: NULL pointer");
-    PHK_HIP(hipSetDevice(ctx->device));
     void *d_in, *d_out;
     PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &d_in));
     PHK_TRY(phk_ws(ctx, WS_Q64, n * D * 8, &d_out));
@@ -293,11 +342,10 @@ extern "C" int phk_normalize_f64(phk_ctx *ctx, const double *rows, uint64_t n, u
 
 extern "C" int phk_permute_columns_i64(phk_ctx *ctx, const int64_t *rows, uint64_t n, uint64_t D, const uint32_t *perm,
                                        int64_t *out) {
-    PHK_REQUIRE(ctx, "phk_permute_columns_i64: NULL ctx");
+    PHK_ENTER(ctx, "phk_permute_columns_i64");
     if (n == 0 || D == 0) return PHK_OK;
     PHK_REQUIRE(rows && perm && out, "phk_permute_columns_i64: NULL pointer");
     for (uint64_t j = 0; j < D; ++j) PHK_REQUIRE(perm[j] < D, "phk_permute_columns_i64: perm[%llu] out of range", (unsigned long long)j);
-    PHK_HIP(hipSetDevice(ctx->device));
     void *d_in, *d_out, *d_perm;
     PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &d_in));
     PHK_TRY(phk_ws(ctx, WS_Q64, n * D * 8, &d_out));
@@ -312,10 +360,10 @@ extern "C" int phk_permute_columns_i64(phk_ctx *ctx, const int64_t *rows, uint64
 
 extern "C" int phk_score(phk_ctx *ctx, const phk_model *model, const double *Q, uint64_t N, int method,
                          double *scores) {
-    PHK_REQUIRE(ctx && model, "phk_score: NULL ctx/model");
+    PHK_ENTER(ctx, "phk_score");
+    PHK_REQUIRE(model, "phk_score: NULL model");
     if (N == 0) return PHK_OK;
     PHK_REQUIRE(Q && scores, "phk_score: NULL pointer");
-    PHK_HIP(hipSetDevice(ctx->device));
     const uint64_t D = model->D;
     void *d_q, *d_s, *d_flags;
     PHK_TRY(phk_ws(ctx, WS_WIDE, N * D * 8, &d_q));
@@ -340,7 +388,7 @@ extern "C" int phk_score(phk_ctx *ctx, const phk_model *model, const double *Q, 
 extern "C" int phk_pack_ascii_dev(phk_ctx *ctx, const char *d_bases, uint64_t total_bases,
                                   const char *symbols4, uint32_t *d_packed, uint32_t *d_mask,
                                   uint32_t *d_any_invalid) {
-    PHK_REQUIRE(ctx, "phk_pack_ascii_dev: NULL ctx");
+    PHK_ENTER(ctx, "phk_pack_ascii_dev");
     const char *sym = symbols4 ? symbols4 : "ATGC";
     PHK_REQUIRE(strlen(sym) == 4, "phk_pack_ascii_dev: symbols must be exactly 4 characters");
     return phk_launch_pack(ctx, d_bases, total_bases, sym, d_packed, d_mask, d_any_invalid);
@@ -349,26 +397,29 @@ extern "C" int phk_pack_ascii_dev(phk_ctx *ctx, const char *d_bases, uint64_t to
 extern "C" int phk_count_dev(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
                              uint64_t total_bases, const uint64_t *d_offsets, uint64_t n, int k,
                              uint32_t *d_counts, uint32_t *d_nwin) {
-    PHK_REQUIRE(ctx, "phk_count_dev: NULL ctx");
+    PHK_ENTER(ctx, "phk_count_dev");
     return phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets, n, k, d_counts, d_nwin);
 }
 
 extern "C" int phk_normalize_dev(phk_ctx *ctx, const uint32_t *d_counts, uint64_t n, uint64_t D,
                                  double *d_out) {
-    PHK_REQUIRE(ctx && (n == 0 || (d_counts && d_out)), "phk_normalize_dev: NULL pointer");
+    PHK_ENTER(ctx, "phk_normalize_dev");
+    PHK_REQUIRE(n == 0 || (d_counts && d_out), "phk_normalize_dev: NULL pointer");
     return phk_launch_normalize_u32(ctx, d_counts, n, D, d_out);
 }
 
 extern "C" int phk_score_dev(phk_ctx *ctx, const phk_model *model, const double *d_Q, uint64_t N,
                              int method, double *d_scores, uint32_t *d_status) {
-    PHK_REQUIRE(ctx && model, "phk_score_dev: NULL ctx/model");
+    PHK_ENTER(ctx, "phk_score_dev");
+    PHK_REQUIRE(model, "phk_score_dev: NULL model");
     PHK_REQUIRE(N == 0 || d_Q, "phk_score_dev: NULL query pointer");
     return phk_score_rows(ctx, model, d_Q, nullptr, nullptr, N, method, d_scores, d_status);
 }
 
 extern "C" int phk_score_counts_dev(phk_ctx *ctx, const phk_model *model, const uint32_t *d_counts,
                                     uint64_t N, int method, double *d_scores, uint32_t *d_status) {
-    PHK_REQUIRE(ctx && model, "phk_score_counts_dev: NULL ctx/model");
+    PHK_ENTER(ctx, "phk_score_counts_dev");
+    PHK_REQUIRE(model, "phk_score_counts_dev: NULL model");
     PHK_REQUIRE(N == 0 || d_counts, "phk_score_counts_dev: NULL counts pointer");
     return phk_score_rows(ctx, model, nullptr, d_counts, nullptr, N, method, d_scores, d_status);
 }
@@ -377,7 +428,8 @@ extern "C" int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const u
                                    const uint32_t *d_mask, uint64_t total_bases,
                                    const uint64_t *d_offsets, uint64_t n, int k, int method,
                                    uint32_t *d_counts, double *d_scores, uint32_t *d_status) {
-    PHK_REQUIRE(ctx && model, "phk_count_score_dev: NULL ctx/model");
+    PHK_ENTER(ctx, "phk_count_score_dev");
+    PHK_REQUIRE(model, "phk_count_score_dev: NULL model");
     PHK_REQUIRE(phk_pow4(k) == model->D, "phk_count_score_dev: 4^k (k=%d) != model dimension %llu", k,
                 (unsigned long long)model->D);
     void *d_nwin;  // row sums straight from the count kernel (saves the scorer a pass over the counts)
@@ -387,10 +439,10 @@ extern "C" int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const u
 }
 
 extern "C" int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_exact_resolved) {
-    PHK_REQUIRE(ctx, "phk_score_stats: NULL ctx");
+    PHK_ENTER(ctx, "phk_score_stats");
     uint32_t c[2] = {0, 0};
-    if (ctx->last_score_fast && ctx->ws[WS_DIST].ptr) {
-        PHK_HIP(hipMemcpyAsync(c, ctx->ws[WS_DIST].ptr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->last_score_fast && ctx->ws[WS_DIST].ptr) {   // words 8, 9: totals over the call's batches
+        PHK_HIP(hipMemcpyAsync(c, (const uint32_t *)ctx->ws[WS_DIST].ptr + 8, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         PHK_HIP(hipStreamSynchronize(ctx->stream));
     }
     if (n_fallback) *n_fallback = c[0];
@@ -401,6 +453,6 @@ extern "C" int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_e
 extern "C" int phk_synth_packed_dev(phk_ctx *ctx, uint64_t seed, uint64_t first_contig, uint64_t n,
                                     uint64_t L, uint32_t invalid_ppm, uint32_t *d_packed,
                                     uint32_t *d_mask, uint64_t *d_offsets) {
-    PHK_REQUIRE(ctx, "phk_synth_packed_dev: NULL ctx");
+    PHK_ENTER(ctx, "phk_synth_packed_dev");
     return phk_launch_synth(ctx, seed, first_contig, n, L, invalid_ppm, d_packed, d_mask, d_offsets);
 }

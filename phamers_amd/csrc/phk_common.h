@@ -32,6 +32,13 @@ void phk_set_error(const char *fmt, ...);
         }                             \
     } while (0)
 
+// first statement of every extern "C" entry that takes a context: the calling thread may have another device current
+#define PHK_ENTER(ctx_, fname)                                   \
+    do {                                                         \
+        PHK_REQUIRE((ctx_) != nullptr, fname ": NULL ctx");      \
+        PHK_HIP(hipSetDevice((ctx_)->device));                   \
+    } while (0)
+
 #define PHK_TRY(call)               \
     do {                            \
         int rc__ = (call);          \
@@ -69,8 +76,24 @@ struct PhkTimed {
     uint64_t launches = 0;
 };
 
+// Tuning / diagnostic knobs.  Read ONCE from the environment when the context is created (PHK_<NAME>), changed
+// afterwards only through phk_set_option(): no launch path calls getenv.
+struct PhkKnobs {
+    char count_cfg[32] = "";   // "<copies>,<pack16>": a built variant of the wave-per-contig count kernel (LDS study)
+    char count_lanes = 0;      // '0' wave-per-contig kernel only, '2' slot kernel whatever the batch looks like
+    char slot_threads = 0;     // '2' = 256-thread slot workgroups (default 512 at k <= 4)
+    bool force_exact = false;  // every model through the float64 path
+    char proposal[8] = "";     // "f32" fp32 MFMA, "f16" split-query f16, "cx2" count-exact with 2 MFMAs per k-step
+    char cx_cfg[8] = "";       // "<tiles per wave><waves per workgroup>": 14, 24, 28
+    char rerank = 0;           // 'w' wave per query, 'g' 16 lanes per query for all
+    bool count_sort = true;    // length-bucketed contig order for the slot count kernel on ragged batches
+    uint64_t score_batch = 0;  // queries per scoring batch of the MFMA path (0 = default 2^20; tests shrink it)
+};
+
 struct phk_ctx {
     int device = 0;
+    PhkKnobs knobs;
+    bool slots_lds0 = true;        // the slot count kernel's dynamic LDS starts at address 0 (checked at creation)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 256;
@@ -101,6 +124,10 @@ static inline uint64_t phk_pow4(int k) { return 1ull << (2 * k); }
 static inline uint64_t phk_div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 // ---- internal entry points implemented across translation units ----
+// per-device kernel attributes (dynamic LDS above 64 KiB), set for the context's device at phk_create
+int phk_count_init_device(phk_ctx *ctx);       // count.hip
+int phk_score_f16_init_device(phk_ctx *ctx);   // score_f16.hip
+int phk_score_mfma_init_device(phk_ctx *ctx);  // score_mfma.hip
 // count.hip
 int phk_launch_pack(phk_ctx *ctx, const char *d_bases, uint64_t T, const char *symbols4,
                     uint32_t *d_packed, uint32_t *d_mask, uint32_t *d_any_invalid);

@@ -164,13 +164,13 @@ extern "C" int phk_model_create(phk_ctx *ctx, const double *pos, uint64_t n_pos,
                                 uint64_t n_neg, const double *cpos, uint64_t n_cpos,
                                 const double *cneg, uint64_t n_cneg, uint64_t D, int kn,
                                 phk_model **out) {
-    PHK_REQUIRE(ctx && out, "phk_model_create: NULL ctx/out");
+    PHK_ENTER(ctx, "phk_model_create");
+    PHK_REQUIRE(out, "phk_model_create: NULL out");
     PHK_REQUIRE(D >= 1 && pos && neg && n_pos + n_neg >= 1, "phk_model_create: empty reference data");
     PHK_REQUIRE(kn >= 1 && (uint64_t)kn <= n_pos + n_neg && kn <= 64,
                 "phk_model_create: k_neighbors=%d out of range (1..min(64, rows))", kn);
     PHK_REQUIRE((n_cpos == 0) == (n_cneg == 0), "phk_model_create: give both centroid sets or neither");
     PHK_REQUIRE(n_cpos == 0 || (cpos && cneg), "phk_model_create: NULL centroid pointer");
-    PHK_HIP(hipSetDevice(ctx->device));
     phk_model *m = new phk_model();
     m->D = D;
     m->n_pos = n_pos;
@@ -209,8 +209,11 @@ extern "C" int phk_model_create(phk_ctx *ctx, const double *pos, uint64_t n_pos,
 }
 
 extern "C" int phk_model_destroy(phk_ctx *ctx, phk_model *m) {
-    (void)ctx;
     if (!m) return PHK_OK;
+    if (ctx) {  // kernels that still read the model may be in flight on the context's stream
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     if (m->d_R64) (void)hipFree(m->d_R64);
     if (m->d_labels) (void)hipFree(m->d_labels);
     if (m->d_C64) (void)hipFree(m->d_C64);
@@ -272,9 +275,8 @@ int phk_score_rows(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
 
     // PHK_FORCE_EXACT=1 routes every model through the float64 path (used by the parity tests to
     // cross-check the two GPU paths against each other)
-    const char *force = getenv("PHK_FORCE_EXACT");
     ctx->last_score_fast = false;
-    if (phk_model_has_fast(m) && !(force && force[0] == '1')) {
+    if (phk_model_has_fast(m) && !ctx->knobs.force_exact) {
         ctx->last_score_fast = true;
         return phk_score_fast(ctx, m, d_Q, d_counts, d_rowsum, N, method, d_scores, d_status);
     }

@@ -318,13 +318,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
 int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                             const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
                             float *cv, uint32_t *ci, float *cu) {
-    static bool attr_set = false;
     const size_t lds = 2 * F16_BLOCK_BYTES;
-    if (!attr_set) {
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     const uint4 *af = (const uint4 *)m->d_Af16 + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16_BLOCK_BYTES / 16);
     const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * F16_WAVES);
     if (src_counts) {
@@ -593,18 +587,11 @@ __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn
 
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu) {
-    static bool attr_set = false;
     const size_t lds = 2 * F16_BLOCK_BYTES;
-    if (!attr_set) {
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     int nt = 2, nw = 8;
-    const char *e = getenv("PHK_CX_CFG");  // "<tiles per wave><waves per workgroup>": 14, 24, 28 (default)
-    if (e && e[0] == '1') { nt = 1; nw = 4; }
-    if (e && e[0] == '2' && e[1] == '4') nw = 4;
+    const char *e = ctx->knobs.cx_cfg;  // "<tiles per wave><waves per workgroup>": 14, 24, 28 (default)
+    if (e[0] == '1') { nt = 1; nw = 4; }
+    if (e[0] == '2' && e[1] == '4') nw = 4;
     const uint4 *af = (const uint4 *)m->d_Af16 + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16_BLOCK_BYTES / 16);
     const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * nw * nt);
 #define PHK_CX_LAUNCH(NT_, NW_)                                                                             \
@@ -890,12 +877,6 @@ int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void
                    phk_split_queries_kernel<1><<<dim3(sblocks), dim3(256), 0, ctx->stream>>>(
                        src, nullptr, nb, D, m->d_mu32, m->d_mu64, (uint4 *)bq, nullptr));
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        attr_set = true;
-    }
     const uint64_t rec_u4 = (nchunk * 32 + 1) * 64;
     const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
     if (d_big) {
@@ -909,5 +890,19 @@ int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, nullptr,
                        nullptr, blk0, nref, npos, nneg, cv, ci, cu));
     }
+    return PHK_OK;
+}
+
+// per-device kernel attributes (dynamic LDS above the 64 KiB default), called from phk_create
+int phk_score_f16_init_device(phk_ctx *ctx) {
+    (void)ctx;
+    const int lds = 2 * F16_BLOCK_BYTES;
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     return PHK_OK;
 }

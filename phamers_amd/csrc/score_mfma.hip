@@ -40,6 +40,8 @@
 #include "score_lists.h"
 
 #define NG 33          // 32 k-groups + the norm group
+#define FB_CHUNKS 16   // column chunks per queued query in the exact brute-force fallback
+#define FB_LDS_MAX (160u * 1024u - 1024u)   // its dynamic LDS: one chunk of distances + the query, float64
 
 bool phk_fast_supports_dim(uint64_t D);
 
@@ -81,6 +83,8 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
     // MFMA proposal paths: D a multiple of 256 up to 4096 (k = 4, 5, 6) and up to 3 neighbours
     if (!phk_fast_supports_dim(D) || m->kn > CAND - 1) return PHK_OK;  // exact path serves other shapes
     if (m->M >= (1ull << 31)) return PHK_OK;
+    // the MFMA path's last resort (phk_fallback_partial_kernel) keeps one chunk of float64 distances + the query in LDS
+    if (((m->M + m->n_cpos + m->n_cneg + FB_CHUNKS - 1) / FB_CHUNKS + D) * sizeof(double) > FB_LDS_MAX) return PHK_OK;
     std::vector<double> mu(D, 0.0);
     for (uint64_t r = 0; r < m->n_pos; ++r)
         for (uint64_t d = 0; d < D; ++d) mu[d] += pos[r * D + d];
@@ -1040,7 +1044,6 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
 //    reduces them to a partial record (3 nearest train columns of the chunk + nearest positive /
 //    negative centroid of the chunk).  A second kernel merges the FB_CHUNKS records of a query.
 // ------------------------------------------------------------------------------------
-#define FB_CHUNKS 16
 struct FbRecord {
     double d[3];
     uint32_t i[3];
@@ -1143,6 +1146,10 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
 // one thread per queued query: merge its FB_CHUNKS partial records and emit the score
 __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p) {
     const uint32_t count = *p.fb_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // statistics: this batch's counters into the call's totals
+        p.fb_count[8] += p.fb_count[0];
+        p.fb_count[9] += p.fb_count[1];
+    }
     const FbRecord *rec = static_cast<const FbRecord *>(p.fb_rec);
     for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < count;
          qi += (uint64_t)gridDim.x * blockDim.x) {
@@ -1186,10 +1193,10 @@ template <int SRC>
 static int launch_rerank(phk_ctx *ctx, unsigned blocks, const void *src, const RerankParams &p) {
     switch (p.D) {
         case 256: {
-            const char *rr = getenv("PHK_RERANK");
-            if (rr && rr[0] == 'w') {  // one wave per query (the general kernel), for A/B comparison
+            const char rr = ctx->knobs.rerank;
+            if (rr == 'w') {  // one wave per query (the general kernel), for A/B comparison
                 PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 1><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
-            } else if (rr && rr[0] == 'g') {  // four queries per wave for every query (the decision kernel off)
+            } else if (rr == 'g') {  // four queries per wave for every query (the decision kernel off)
                 PHK_LAUNCH(ctx, "phk_rerank16_kernel",
                            (phk_rerank16_kernel<SRC, false><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p)));
             } else {   // one lane per query for what the margin test certifies, then four per wave for the rest
@@ -1227,6 +1234,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // batch: bounds the candidate (200 B/query), fallback (1 KiB/query) and split-query (4 D B/query) workspaces
     uint64_t BATCH = 1ull << 20;
     while (BATCH > 4096 && BATCH * D * 4 > (2ull << 30)) BATCH >>= 1;
+    if (ctx->knobs.score_batch) BATCH = ctx->knobs.score_batch < 64 ? 64 : ctx->knobs.score_batch;
     const uint64_t nb_max = N < BATCH ? N : BATCH;
     const uint64_t per_list = nb_max * NSEG * 2;
     void *cv, *fb, *rec;
@@ -1238,18 +1246,13 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     uint32_t *fb_count = (uint32_t *)fb, *fb_list = (uint32_t *)fb + 16;
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
     const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + D) * sizeof(double);
-    PHK_REQUIRE(fb_lds <= 160 * 1024, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);
-    static bool attr_set = false;
-    if (!attr_set && fb_lds > 64 * 1024) {
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_fallback_partial_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PHK_HIP(hipFuncSetAttribute((const void *)phk_fallback_partial_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    PHK_REQUIRE(fb_lds <= FB_LDS_MAX, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);  // phk_model_build_fast keeps such models off this path
     // proposal pass: split-f16 MFMA by default; PHK_PROPOSAL=f32 selects the fp32-input MFMA kernel (k = 4 only)
-    const char *prop = getenv("PHK_PROPOSAL");
-    const bool use_f16 = D != FAST_D || !(prop && prop[0] == 'f' && prop[1] == '3');
+    const char *prop = ctx->knobs.proposal;
+    const bool use_f16 = D != FAST_D || !(prop[0] == 'f' && prop[1] == '3');
     // counts at k = 4: the count-exact kernel (2 MFMAs per k-step); PHK_PROPOSAL=f16 keeps the split-query one
-    const bool use_cx = use_f16 && d_counts && !(prop && prop[0] == 'f' && prop[1] == '1');
+    const bool use_cx = use_f16 && d_counts && !(prop[0] == 'f' && prop[1] == '1');
+    PHK_HIP(hipMemsetAsync(fb_count, 0, 64, ctx->stream));   // words 8, 9: statistics totals of this call
     for (uint64_t s = 0; s < N; s += BATCH) {
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
         const void *src = d_counts ? (const void *)(d_counts + s * D) : (const void *)(d_Q + s * D);
@@ -1258,7 +1261,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         const uint32_t nref = (method & PHK_METHOD_KNN) ? m->n_rblk_ref : 0;
         const uint32_t npos = (method & PHK_METHOD_KMEANS) ? m->n_rblk_pos : 0;
         const uint32_t nneg = (method & PHK_METHOD_KMEANS) ? m->n_rblk_neg : 0;
-        PHK_HIP(hipMemsetAsync(fb_count, 0, 64, ctx->stream));
+        PHK_HIP(hipMemsetAsync(fb_count, 0, 32, ctx->stream));
         RerankParams p;
         p.N = nb; p.M = m->M; p.n_cpos = m->n_cpos; p.n_cneg = m->n_cneg; p.D = D;
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
@@ -1319,5 +1322,13 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         PHK_LAUNCH(ctx, "phk_fallback_merge_kernel",
                    phk_fallback_merge_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(p));
     }
+    return PHK_OK;
+}
+
+// per-device kernel attributes, called from phk_create
+int phk_score_mfma_init_device(phk_ctx *ctx) {
+    (void)ctx;
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_fallback_partial_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_MAX));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_fallback_partial_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_MAX));
     return PHK_OK;
 }

@@ -50,6 +50,20 @@ def gather_variable(local, group=None):
     return torch.cat([out[r * width: r * width + sizes[r]] for r in range(world)])
 
 
+def rank_device():
+    """This rank's GPU, chosen ONCE: LOCAL_RANK (or PHAMERS_HIP_DEVICE) modulo the number of visible devices.
+    The phk context, torch's current device and the collective's tensors must all sit on it: RCCL refuses two
+    ranks on one device and hangs when a rank's tensor lives on another rank's GPU."""
+    import torch
+    from . import _lib
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise RuntimeError("no GPU visible to this rank")
+    dev = _lib.default_device() % ndev
+    torch.cuda.set_device(dev)
+    return dev
+
+
 def default_scorer(device_index=None):
     """Per-rank scorer running the GPU path: (sequences, k, method, model inputs) -> scores."""
     from . import _lib, kmer
@@ -80,10 +94,11 @@ def score_contigs_distributed(sequences, positive, negative, positive_centroids=
         raise RuntimeError("torch.distributed is not initialised (launch with torch.distributed.run)")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_bounds([len(s) for s in sequences], world)[rank]
-    scorer = scorer or default_scorer()
+    use_cuda = dist.get_backend(group) == "nccl"
+    gpu = rank_device() if (use_cuda or scorer is None) else None
+    scorer = scorer or default_scorer(device_index=gpu)
     local = np.asarray(scorer(sequences[lo:hi], kmer_length, method, positive, negative,
                               positive_centroids, negative_centroids, k_neighbors), dtype=np.float64)
-    use_cuda = dist.get_backend(group) == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if use_cuda else torch.device("cpu")
+    dev = torch.device("cuda", gpu) if use_cuda else torch.device("cpu")
     full = gather_variable(torch.from_numpy(local).to(dev), group=group)
     return full.cpu().numpy()

@@ -15,3 +15,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(REPO, "tests", "golden")
+
+
+KNOB_DEFAULTS = {"count_lanes": "", "count_cfg": "", "slot_threads": "", "count_sort": "1", "force_exact": "0",
+                 "proposal": "", "cx_cfg": "", "rerank": "", "score_batch": "0"}
+
+
+@pytest.fixture(autouse=True)
+def _reset_context_knobs():
+    """GPU tests switch library paths with Context.set_option on the shared default context: put every knob back."""
+    yield
+    mod = sys.modules.get("phamers_amd._lib")
+    if mod is None:
+        return
+    for ctx in list(getattr(mod, "_contexts", {}).values()):
+        if getattr(ctx, "handle", None):
+            for k, v in KNOB_DEFAULTS.items():
+                ctx.set_option(k, v)

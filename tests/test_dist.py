@@ -124,3 +124,21 @@ def test_shard_count_invariance_single_process():
                 qq = oracle.normalize_counts(oracle.count(seqs[lo:hi], 4).reshape(hi - lo, -1))
                 parts.append(oracle.score_points(qq, pos, neg, "combo", 3, g["cpos_full"][:6], g["cneg_full"][:6]))
         assert np.array_equal(np.concatenate(parts), want)
+
+
+def test_rank_device_follows_local_rank(monkeypatch):
+    """The phk context, torch's current device and the gather tensor of a rank all use ONE device index:
+    LOCAL_RANK modulo the visible device count (device functions mocked: no GPU here)."""
+    import torch
+    from phamers_amd import dist as pdist
+    chosen = []
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: chosen.append(d))
+    monkeypatch.delenv("PHAMERS_HIP_DEVICE", raising=False)
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    assert pdist.rank_device() == 5 and chosen == [5]
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    assert pdist.rank_device() == 1 and chosen == [5, 1]
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    with pytest.raises(RuntimeError):
+        pdist.rank_device()

@@ -166,7 +166,7 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
     contig ending on the last word of the stream), a contig count that is not a multiple of 32, and
     contigs far above the batch mean, which it must hand to the wave-per-contig kernel -- bit-exact
     against the oracle, with nwin = row sums; the same batch through the wave-per-contig kernel alone
-    (PHK_COUNT_LANES=0) gives identical rows."""
+    (option count_lanes=0) gives identical rows."""
     import os
     from oracle import oracle
     from phamers_amd import device, synth
@@ -189,7 +189,7 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
     D = 4 ** k
     rows = {}
     for lanes in ("2", "1", "0"):   # slot kernel forced / chosen by the batch statistics / wave-per-contig kernel only
-        os.environ["PHK_COUNT_LANES"] = lanes
+        ctx.set_option("count_lanes", lanes)
         try:
             d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 0xABCD, np.uint32))
             d_nwin = device.DeviceArray.from_host(ctx, np.full(len(lens), 0xABCD, np.uint32))
@@ -198,7 +198,7 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
             assert np.array_equal(rows[lanes].astype(np.int64), want), (k, lanes)
             assert np.array_equal(d_nwin.to_host().astype(np.int64), want.sum(axis=1)), (k, lanes)
         finally:
-            os.environ.pop("PHK_COUNT_LANES", None)
+            ctx.set_option("count_lanes", "")
     assert np.array_equal(rows["0"], rows["1"]) and np.array_equal(rows["0"], rows["2"])
     # the same with invalid bases (validity mask): scattered single characters and long runs
     seqs_n = [synth.synth_contig(9, i, L, invalid_ppm=(30000 if i % 3 else 0)) for i, L in enumerate(lens)]
@@ -212,7 +212,7 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
     assert d_flag.to_host()[0] != 0
     want_n = oracle.count(seqs_n, k)
     for lanes in ("2", "0"):
-        os.environ["PHK_COUNT_LANES"] = lanes
+        ctx.set_option("count_lanes", lanes)
         try:
             d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 0xABCD, np.uint32))
             d_nwin = device.DeviceArray.from_host(ctx, np.full(len(lens), 0xABCD, np.uint32))
@@ -220,7 +220,7 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
             assert np.array_equal(d_counts.to_host().astype(np.int64), want_n), (k, lanes, "masked")
             assert np.array_equal(d_nwin.to_host().astype(np.int64), want_n.sum(axis=1)), (k, lanes, "masked")
         finally:
-            os.environ.pop("PHK_COUNT_LANES", None)
+            ctx.set_option("count_lanes", "")
 
 
 @pytest.mark.gpu
@@ -256,7 +256,7 @@ def test_slot_count_kernel_random_batches(ctx, seed):
     want = oracle.count(seqs, k)
     D = 4 ** k
     for lanes in ("2", "1"):
-        os.environ["PHK_COUNT_LANES"] = lanes
+        ctx.set_option("count_lanes", lanes)
         try:
             d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 7, np.uint32))
             d_nwin = device.DeviceArray.from_host(ctx, np.full(len(lens), 7, np.uint32))
@@ -264,7 +264,7 @@ def test_slot_count_kernel_random_batches(ctx, seed):
             assert np.array_equal(d_counts.to_host().astype(np.int64), want), (seed, k, lanes)
             assert np.array_equal(d_nwin.to_host().astype(np.int64), want.sum(axis=1)), (seed, k, lanes)
         finally:
-            os.environ.pop("PHK_COUNT_LANES", None)
+            ctx.set_option("count_lanes", "")
 
 
 @pytest.mark.gpu

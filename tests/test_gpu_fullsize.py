@@ -44,9 +44,9 @@ def test_full_size_batch_properties(monkeypatch):
     counts = d_counts.to_host()
     assert np.all(d_nwin.to_host() == L - K + 1)
     assert np.all(counts.sum(axis=1, dtype=np.uint64) == L - K + 1)
-    monkeypatch.setenv("PHK_COUNT_LANES", "0")
+    ctx.set_option("count_lanes", "0")
     device.count(ctx, d_packed, None, T, d_off, N, K, d_counts, d_nwin)
-    monkeypatch.delenv("PHK_COUNT_LANES")
+    ctx.set_option("count_lanes", "")
     assert np.array_equal(d_counts.to_host(), counts)
     # linearity: the column sums of the batch are the counts of the concatenated contigs' windows that do not
     # straddle a contig boundary -- checked against the oracle on a sample instead: rows of a random sample

@@ -149,7 +149,7 @@ def test_zero_count_contig_is_nan_and_flagged():
 
 def test_fast_and_exact_gpu_paths_agree_on_a_larger_batch(monkeypatch):
     """20k synthetic contigs through both MFMA proposal kernels and through the float64 brute-force
-    path (PHK_FORCE_EXACT=1): identical votes, float scores equal to rounding."""
+    path (option force_exact=1): identical votes, float scores equal to rounding."""
     from phamers_amd import _lib, device
     g = helpers.load_npz("scoring_k4.npz")
     pos, neg = _ref_matrices()
@@ -167,8 +167,8 @@ def test_fast_and_exact_gpu_paths_agree_on_a_larger_batch(monkeypatch):
     # proposal kernel: count-exact f16 MFMA (default, "cx"), split-query f16 MFMA and fp32 MFMA;
     # "exact" = float64 brute force path
     for path in ("cx", "f16", "f32", "exact"):
-        monkeypatch.setenv("PHK_FORCE_EXACT", "1" if path == "exact" else "0")
-        monkeypatch.setenv("PHK_PROPOSAL", path if path != "exact" else "cx")
+        ctx.set_option("force_exact", "1" if path == "exact" else "0")
+        ctx.set_option("proposal", path if path != "exact" else "")
         for method in ("knn", "kmeans", "combo"):
             d_scores = device.DeviceArray(ctx, n, np.float64)
             d_status = device.DeviceArray(ctx, 1, np.uint32)
@@ -249,7 +249,7 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
     d_q = device_counts(90 + k, n_q, 10000)
     out = {}
     for path in ("f16", "exact"):
-        monkeypatch.setenv("PHK_FORCE_EXACT", "1" if path == "exact" else "0")
+        ctx.set_option("force_exact", "1" if path == "exact" else "0")
         for method in ("knn", "kmeans", "combo"):
             d_scores = device.DeviceArray(ctx, n_q, np.float64)
             d_status = device.DeviceArray(ctx, 1, np.uint32)
@@ -263,7 +263,7 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
     assert helpers.rel_err(out[("f16", "kmeans")], out[("exact", "kmeans")]) < 1e-9
     assert helpers.rel_err(out[("f16", "combo")], out[("exact", "combo")]) < 1e-9
     # float64-row entry point on a slice, against the oracle
-    monkeypatch.setenv("PHK_FORCE_EXACT", "0")
+    ctx.set_option("force_exact", "0")
     qc = d_q.to_host()[:64].astype(np.int64)
     q = oracle.normalize_counts(qc)
     got = model.score(q, "combo")
@@ -339,7 +339,8 @@ def test_count_exact_kernel_shapes_and_large_counts(monkeypatch, cfg):
     three methods -- against the float64 brute-force path of the same library and against the oracle."""
     from oracle import oracle
     from phamers_amd import _lib, device
-    monkeypatch.setenv("PHK_CX_CFG", cfg)
+    ctx = _lib.get_context()
+    ctx.set_option("cx_cfg", cfg)
     g = helpers.load_npz("scoring_k4.npz")
     pos, neg = _ref_matrices()
     n_eq = min(pos.shape[0], neg.shape[0])
@@ -364,7 +365,7 @@ def test_count_exact_kernel_shapes_and_large_counts(monkeypatch, cfg):
         d_scores = device.DeviceArray(ctx, n, np.float64)
         d_status = device.DeviceArray.from_host(ctx, np.zeros(1, np.uint32))
         for method, want in (("knn", want_knn), ("kmeans", want_cen), ("combo", want_knn + want_cen)):
-            monkeypatch.setenv("PHK_PROPOSAL", "cx")
+            ctx.set_option("proposal", "")
             device.score_counts(ctx, model, d_counts, n, method, d_scores, d_status)
             got = d_scores.to_host()
             assert d_status.to_host()[0] == 0
@@ -423,3 +424,80 @@ def test_count_exact_path_adversarial_queries():
             assert clear.sum() > len(counts) // 2
             assert helpers.rel_err(got[clear], want[clear]) < RTOL, method
     model.close()
+
+
+@pytest.mark.gpu
+def test_scoring_in_several_batches_matches_one_batch_and_exact_path():
+    """N slightly above the scoring batch (option score_batch): the per-batch offsets of queries, row sums and
+    workspaces, and the statistics summed over the batches -- against one batch and against the float64 path."""
+    from phamers_amd import _lib, device
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    ctx = _lib.get_context()
+    model = _lib.Model(ctx, pos, neg, g["cpos_full"], g["cneg_full"], 3)
+    n, L = 3 * 4096 + 100, 3000
+    T = n * L
+    d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+    device.synth_packed(ctx, 21, 0, n, L, d_packed, d_off)
+    d_counts = device.DeviceArray(ctx, (n, 256), np.uint32)
+    d_scores = device.DeviceArray(ctx, n, np.float64)
+    d_status = device.DeviceArray(ctx, 1, np.uint32)
+    out, stats = {}, {}
+    for name, opts in (("one", {}), ("four", {"score_batch": "4096"}), ("exact", {"force_exact": "1"})):
+        for k_, v_ in opts.items():
+            ctx.set_option(k_, v_)
+        # the fused entry point (row sums come from the count kernel) and the counts-only one
+        device.count_score(ctx, model, d_packed, None, T, d_off, n, 4, "combo", d_counts, d_scores, d_status)
+        out[name] = d_scores.to_host()
+        stats[name] = ctx.score_stats()
+        device.score_counts(ctx, model, d_counts, n, "combo", d_scores, d_status)
+        assert np.array_equal(d_scores.to_host(), out[name]), name
+        ctx.set_option("score_batch", "0")
+        ctx.set_option("force_exact", "0")
+    assert np.array_equal(out["one"], out["four"])
+    assert stats["one"] == stats["four"] and stats["one"][1] > 0   # totals over the four batches
+    assert np.array_equal(np.sign(out["one"]), np.sign(out["exact"]))
+    assert helpers.rel_err(out["one"], out["exact"]) < 1e-9
+    model.close()
+
+
+@pytest.mark.gpu
+def test_two_contexts_on_two_threads():
+    """include/phamers_hip.h: distinct contexts may be used from distinct threads.  Two contexts (own streams,
+    own workspaces) count + score different batches concurrently; each result equals the single-threaded one."""
+    import threading
+    from phamers_amd import _lib, device
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+
+    def job(ctx, seed, n, res, key, rounds):
+        model = _lib.Model(ctx, pos[:1500], neg[:1500], g["cpos_full"], g["cneg_full"], 3)
+        L = 2000 + 500 * seed
+        T = n * L
+        d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+        d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+        device.synth_packed(ctx, seed, 0, n, L, d_packed, d_off)
+        d_counts = device.DeviceArray(ctx, (n, 256), np.uint32)
+        d_scores = device.DeviceArray(ctx, n, np.float64)
+        d_status = device.DeviceArray(ctx, 1, np.uint32)
+        outs = []
+        for _ in range(rounds):
+            device.count_score(ctx, model, d_packed, None, T, d_off, n, 4, "combo", d_counts, d_scores, d_status)
+            outs.append((d_counts.to_host(), d_scores.to_host()))
+        res[key] = outs
+        model.close()
+
+    a, b = _lib.Context(0), _lib.Context(0)
+    ref, par = {}, {}
+    job(a, 1, 5000, ref, "a", 1)
+    job(b, 2, 7000, ref, "b", 1)
+    ta = threading.Thread(target=job, args=(a, 1, 5000, par, "a", 4))
+    tb = threading.Thread(target=job, args=(b, 2, 7000, par, "b", 4))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    for key in ("a", "b"):
+        assert len(par[key]) == 4
+        for counts, scores in par[key]:
+            assert np.array_equal(counts, ref[key][0][0]) and np.array_equal(scores, ref[key][0][1]), key
+    a.close()
+    b.close()

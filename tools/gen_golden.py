@@ -31,7 +31,18 @@ sys.path.insert(0, REPO)
 from phamers_amd import synth  # noqa: E402  (seeded input generator, ours)
 
 
-def extract(path, names, namespace):
+class _Py2Division(ast.NodeTransformer):
+    """The reference is Python 2: ``/`` between integers is floor division there.  Applied (only where asked
+    for) to functions whose arithmetic relies on it, so that they run with the semantics they were written for."""
+
+    def visit_BinOp(self, node):
+        self.generic_visit(node)
+        if isinstance(node.op, ast.Div):
+            node.op = ast.FloorDiv()
+        return node
+
+
+def extract(path, names, namespace, py2_division=False):
     """exec the top-level defs / assignments called ``names`` from ``path``."""
     text = open(path).read()
     try:
@@ -59,7 +70,10 @@ def extract(path, names, namespace):
     missing = set(names) - found
     if missing:
         raise RuntimeError("not found in %s: %s" % (path, sorted(missing)))
-    exec(compile(ast.Module(body=body, type_ignores=[]), path, 'exec'), namespace)
+    module = ast.Module(body=body, type_ignores=[])
+    if py2_division:
+        module = ast.fix_missing_locations(_Py2Division().visit(module))
+    exec(compile(module, path, 'exec'), namespace)
     return types.SimpleNamespace(**{n: namespace[n] for n in names})
 
 
@@ -307,6 +321,102 @@ def gen_files(kmer, fileIO, out):
                         read_ids=np.array(rid, dtype='U16'), read_norm=rnorm)
 
 
+def gen_transform(ref, out):
+    """transform_kmers and its index tables (scripts/transform_kmers.py:21-88), executed with Python 2 integer
+    division.  The tables are what the reference really computes -- they are NOT permutations (decompose() yields
+    k+1 digits of which the first k are used, and the multipliers are k**i ascending): the fixture pins the
+    drop-in to that behaviour, including the IndexError for k >= 5."""
+    import math
+    np_shim = types.ModuleType('np_shim')
+    np_shim.__dict__.update(np.__dict__)
+    np_shim.math = math           # the reference calls np.math.log (removed from NumPy 2)
+    quiet = logging.getLogger('reference')
+    tk = extract(os.path.join(ref, 'scripts', 'transform_kmers.py'),
+                 ['DNA', 'get_transformed_indicies', 'get_reverse_complement_indicies', 'get_reverse_indicies',
+                  'get_DNA_complement_indicies', 'transform_kmers'],
+                 {'np': np_shim, 'xrange': range, 'logger': quiet}, py2_division=True)
+    arrays = {}
+    rng = np.random.default_rng(21)
+    for k in (2, 3, 4):
+        arrays['rev_idx_k%d' % k] = np.asarray(tk.get_reverse_indicies(k)).astype(np.int64)
+        arrays['comp_idx_k%d' % k] = np.asarray(tk.get_DNA_complement_indicies(k)).astype(np.int64)
+        arrays['revcomp_idx_k%d' % k] = np.asarray(tk.get_reverse_complement_indicies(k)).astype(np.int64)
+        counts = rng.integers(0, 900, size=(6, 4 ** k)).astype(np.int64)
+        arrays['in_k%d' % k] = counts
+        arrays['rev_k%d' % k] = tk.transform_kmers(counts, reverse=True, complement=False)
+        arrays['comp_k%d' % k] = tk.transform_kmers(counts, reverse=False, complement=True)
+        arrays['revcomp_k%d' % k] = tk.transform_kmers(counts, reverse=True, complement=True)
+        arrays['none_k%d' % k] = tk.transform_kmers(counts, reverse=False, complement=False)
+    errors = {}
+    for k in (5, 6):
+        try:
+            tk.transform_kmers(np.zeros((2, 4 ** k), dtype=np.int64), reverse=True, complement=True)
+            errors[str(k)] = None
+        except Exception as e:   # noqa: BLE001 -- the type is the fixture
+            errors[str(k)] = type(e).__name__
+    np.savez_compressed(os.path.join(out, 'transform.npz'), **arrays)
+    json.dump({'errors_by_k': errors}, open(os.path.join(out, 'transform.json'), 'w'), indent=1, sort_keys=True)
+
+
+ID_HEADERS = [
+    'SuperContig_12_length_5000_ID_12', 'SuperContig_7_length_9000_ID_77-circular', '>SuperContig_3_ID_5',
+    'x_ID_abc_ID_def', 'ID_9_ID_10', 'contig_ID_', 'a_ID_b-circular-circular', '  pad_ID_4  ',
+    'gi|526245011|ref|NC_021865.1|', 'gi|1|gb|KC821634.1|', '>gi|2|ref|NC_000001.9|', 'a|b|c|d|', '||||',
+    'NC_000913.3', 'CP009273.1', 'AE014075.1', 'NZ_CP011113.2', '>NC_1.1', 'X.1', '1.5', '12', 'abc', 'a.bc', '.1',
+    'plain_contig_name', 'NC_000913.3|extra', 'a|b|c|d', 'a|b|c|d|e|f', 'scaffold_ID', 'IDX_ID_y_z', '',
+]
+
+
+def gen_ids(ref, out):
+    """id_parser.get_id (scripts/id_parser.py:18-100) on the header shapes count_file meets: what comes out, or
+    the exception type the reference raises."""
+    quiet = logging.getLogger('reference')
+    basic = extract(os.path.join(ref, 'scripts', 'basic.py'), ['represents_float'], {})
+    idp = extract(os.path.join(ref, 'scripts', 'id_parser.py'),
+                  ['get_contig_id', 'get_bacteria_id', 'get_phage_id', 'is_genbank_id', 'get_id'],
+                  {'logger': quiet, 'basic': basic, 'os': os})
+    cases = []
+    for h in ID_HEADERS:
+        try:
+            cases.append({'header': h, 'id': idp.get_id(h), 'error': None})
+        except Exception as e:   # noqa: BLE001
+            cases.append({'header': h, 'id': None, 'error': type(e).__name__})
+    json.dump({'cases': cases}, open(os.path.join(out, 'ids.json'), 'w'), indent=1, sort_keys=True)
+
+
+def gen_cross_validation(ref, phamer, pc, nc, kmer, out):
+    """cross_validator.cross_validate (scripts/cross_validate.py:57-101) with the reference's scoring function
+    (phamer.score_points, as scripts/cross_validate.py:275 wires it), the real reference matrix equalised,
+    N = 20, method 'combo'.  The reference shuffles with the global NumPy RNG, unseeded; the generator seeds it
+    (np.random.seed) right before the call so that the fold assignment can be replayed by the test."""
+    quiet = logging.getLogger('reference')
+    cv = extract(os.path.join(ref, 'scripts', 'cross_validate.py'), ['cross_validator'],
+                 {'np': np, 'xrange': range, 'logger': quiet})
+    arrays = {}
+    for tag, seed, N, method in (('n20_combo', 5, 20, 'combo'), ('n7_knn', 9, 7, 'knn')):
+        v = cv.cross_validator()
+        v.positive_data = kmer.normalize_counts(pc)
+        v.negative_data = kmer.normalize_counts(nc)
+        v.positive_ids = np.arange(pc.shape[0])
+        v.negative_ids = np.arange(nc.shape[0])
+        v.equalize_reference = True
+        v.N = N
+        v.method = method
+        v.scoring_function = phamer.score_points
+        np.random.seed(seed)
+        ps, ns = v.cross_validate()
+        # the fold assignment, replayed (same seed, same draw order as scripts/cross_validate.py:71-75)
+        np.random.seed(seed)
+        pa = np.arange(v.num_positive) % N
+        na = np.arange(v.num_negative) % N
+        np.random.shuffle(pa)
+        np.random.shuffle(na)
+        arrays['pos_scores_' + tag], arrays['neg_scores_' + tag] = ps, ns
+        arrays['pos_asmt_' + tag], arrays['neg_asmt_' + tag] = pa.astype(np.int16), na.astype(np.int16)
+        arrays['meta_' + tag] = np.array([seed, N, v.num_positive, v.num_negative])
+    np.savez_compressed(os.path.join(out, 'cross_validation.npz'), **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -321,6 +431,9 @@ def main():
     gen_scoring(kmer, learning, phamer, pc, nc, args.out)
     gen_scoring_highdim(kmer, learning, phamer, args.out)
     gen_files(kmer, fileIO, args.out)
+    gen_transform(args.ref, args.out)
+    gen_ids(args.ref, args.out)
+    gen_cross_validation(args.ref, phamer, pc, nc, kmer, args.out)
     json.dump({'generator': 'tools/gen_golden.py', 'python': sys.version.split()[0],
                'numpy': np.__version__, 'scikit-learn': skl, 'count_arrays': n,
                'reference_functions': 'executed from the reference text via ast extraction; '
