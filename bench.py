@@ -5,15 +5,22 @@ bench.py -- Gbases/s of the k-mer count + phage-score hot path on MI355X.
 A "step" is one pass of the whole device-resident path over one synthetic batch:
 2-bit packed contigs in HBM -> per-contig 4^k counts (materialised, uint32) -> normalise ->
 3-NN vote + nearest-centroid proximity metric ("combo") -> float64 scores in HBM.
-Workload at N=1 = BASELINE.json configs[1]: k=4, 1M x 5 kb contigs on one MI355X; for N>1
-every rank processes its own 1M-contig shard (weak scaling, no data-path collective) and the
-step ends with one RCCL all-gather of the score vectors.
+
+Workload (--config, phamers_amd/workloads.py; BASELINE.json `configs`):
+  1 (default, the configuration the metric is quoted on)  k=4, 1M x 5 kb contigs per GPU, real PhaMers matrix
+  2  k=5, 10M x 10 kb contigs per GPU, 2255+2255 synthetic reference genomes
+  3  k=4, 100M x 5 kb contigs split over the ranks (12.5M per GPU at 8), real PhaMers matrix
+  4  k=6, 131072 x 10 kb queries per GPU against 50 000 synthetic reference genomes (replicated on every rank)
+For N>1 every rank processes its own shard of contigs / queries against a replicated reference (no data-path
+collective) and the step ends with one RCCL all-gather of the score vectors.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
 "roofline" (dominant kernel, algorithmic work / HIP-event time measured in this run) and
-"cpu_baseline" (the CPU oracle timed on this box's host cores on a bounded sample).
+"cpu_baseline" (the CPU oracle timed on this box's host cores on a bounded sample; 1 core, with the
+all-core vectorised variant beside it under "all_cores").
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -28,54 +35,132 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak
 F64_PEAK_TF = 78.6             # fp64 vector / matrix peak
-MFMA_F16_PEAK_TF = 2500.0      # f16/bf16 dense MFMA peak (the count-exact kernel issues 2 MFMA flops per algorithmic flop, the split-query one 3)
+MFMA_F16_PEAK_TF = 2500.0      # f16/bf16 dense MFMA peak
 
 
-def load_model_inputs(D):
-    """Reference matrix + centroids: the real PhaMers 4-mer matrix (equalised, 2255 + 2255 rows)
-    with the golden k-means centroids when the fixtures are present, else a seeded synthetic
-    matrix of the same shape."""
-    ref = os.path.join(REPO, "tests", "golden", "ref_features.npz")
-    sco = os.path.join(REPO, "tests", "golden", "scoring_k4.npz")
-    if D == 256 and os.path.exists(ref) and os.path.exists(sco):
-        with np.load(ref) as z:
-            pos = z["pos_counts"].astype(np.float64)
-            neg = z["neg_counts"].astype(np.float64)
-        pos /= pos.sum(axis=1, keepdims=True)
-        neg /= neg.sum(axis=1, keepdims=True)
-        n = min(len(pos), len(neg))
-        with np.load(sco) as z:
-            return pos[:n], neg[:n], z["cpos_eq"], z["cneg_eq"], "PhaMers reference_features (equalised)"
-    rng = np.random.default_rng(1)
-    pos = rng.gamma(2.0, 1.0, (2255, D))
-    neg = rng.gamma(2.0, 1.0, (2255, D)) * np.linspace(0.7, 1.3, D)
-    pos /= pos.sum(axis=1, keepdims=True)
-    neg /= neg.sum(axis=1, keepdims=True)
-    cpos = np.stack([pos[i::86].mean(axis=0) for i in range(86)])
-    cneg = np.stack([neg[i::86].mean(axis=0) for i in range(86)])
-    return pos, neg, cpos, cneg, "synthetic gamma rows"
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(k, L, pos, neg, cpos, cneg, budget_s=12.0):
-    """The oracle's literal window loop + NumPy normalise + brute k-NN + centroid loop on ONE host
-    core, on a bounded sample of the same synthetic workload."""
+_G = {}   # per-process state of the all-core baseline's pool workers
+
+
+def _pool_setup(args):
+    """Runs once in every worker (one task per worker, the barrier keeps a fast worker from taking two)."""
+    seqs, k, pos, neg, cpos, cneg, barrier_s = args
+    _G.update(seqs=seqs, k=k, score=_make_scorer(pos, neg, cpos, cneg))
+    _pool_worker_init()   # again, now that scikit-learn's OpenMP runtime is loaded in this process
+    time.sleep(barrier_s)
+    return os.getpid()
+
+
+def _make_scorer(pos, neg, cpos, cneg):
+    """The reference's own scoring route on the host: scikit-learn brute 3-NN (scripts/learning.py:127-128) + the
+    nearest-centroid proximity metric; fitted once."""
+    from oracle import oracle
+    try:
+        from sklearn.neighbors import KNeighborsClassifier
+        clf = KNeighborsClassifier(n_neighbors=3, algorithm="brute").fit(
+            np.vstack((pos, neg)), np.append(np.ones(len(pos)), np.zeros(len(neg))))
+        knn = lambda q: 2 * (clf.predict(q) - 0.5)   # noqa: E731
+    except ImportError:
+        knn = lambda q: oracle.knn_score_points(q, pos, neg, 3)   # noqa: E731
+    return lambda q: knn(q) + oracle.centroid_score_points_fast(q, cpos, cneg)
+
+
+def _pool_worker_init():
+    try:   # one BLAS / OpenMP thread per worker process: the pool is the parallelism
+        from threadpoolctl import threadpool_limits
+        _G["limits"] = threadpool_limits(limits=1)
+    except ImportError:
+        pass
+
+
+def _pool_task(_):
+    """One unit of the all-core baseline, entirely inside one worker: vectorised count of the shared sample ->
+    normalise -> score."""
+    from oracle import oracle
+    seqs, k = _G["seqs"], _G["k"]
+    q = oracle.normalize_counts(oracle.count(list(seqs), k).reshape(len(seqs), -1))
+    return float(np.sum(_G["score"](q)))
+
+
+def cpu_baseline(k, L, pos, neg, cpos, cneg, budget_s=12.0, pool=None):
+    """(i) 1 core: the oracle's literal window loop (scripts/kmer.py:47-50 restated) + normalise + brute 3-NN +
+    centroid metric; (ii) all cores: a process per core, each running the oracle's vectorised counter + the same
+    scoring on its share.  Both on bounded samples of the run's synthetic contigs."""
     from oracle import oracle
     from phamers_amd import synth
-    t0 = time.perf_counter()
-    n = 0
-    rows = []
-    while True:
-        rows.append(oracle.count_string_literal(synth.synth_contig(0, n, L), k))
-        n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 4096:
-            break
-    counts = np.array(rows)
-    q = oracle.normalize_counts(counts)
-    oracle.score_points(q, pos, neg, "combo", 3, cpos, cneg)
-    dt = time.perf_counter() - t0
-    return {"value": n * L / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
-            "sample": "%d of the run's synthetic %d-base contigs: oracle literal window loop (kmer.py:47-50 "
-                      "restated) + normalise + brute 3-NN + centroid loop, %.1f s" % (n, L, dt)}
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        import contextlib
+        threadpool_limits = lambda limits: contextlib.nullcontext()   # noqa: E731
+    cores = os.cpu_count() or 1
+    score = _make_scorer(pos, neg, cpos, cneg)
+    nmax = max(64, int(4096 * 5000 / L))
+    seqs = synth.synth_contigs(0, nmax, L)           # sample preparation is not timed
+    with threadpool_limits(limits=1):
+        t0 = time.perf_counter()
+        rows = []
+        for s in seqs:
+            rows.append(oracle.count_string_literal(s, k))
+            if time.perf_counter() - t0 > budget_s * 0.8:
+                break
+        n = len(rows)
+        score(oracle.normalize_counts(np.array(rows)))
+        dt = time.perf_counter() - t0
+    out = {"value": n * L / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
+           "sample": "%d of the run's synthetic %d-base contigs: oracle literal window loop (kmer.py:47-50 restated) "
+                     "+ normalise + scikit-learn brute 3-NN + centroid metric, %.1f s" % (n, L, dt),
+           "cpu": cpu_model_name(), "host_cores": cores}
+    # (ii) every core.  The pool was forked BEFORE this process touched the GPU (its workers hold no device state);
+    # the sample and the model inputs travel to the workers by message.
+    if pool is None:
+        return out
+    try:
+        per_task = max(8, min(256, nmax))
+        if (pos.nbytes + neg.nbytes) > (256 << 20):
+            raise RuntimeError("reference matrix too large to ship to %d worker processes" % cores)
+        _G.update(seqs=seqs[:per_task], k=k, score=score)
+        with threadpool_limits(limits=1):
+            t1 = time.perf_counter()
+            _pool_task(0)
+            one = time.perf_counter() - t1
+        ntasks = max(cores, int(budget_s / max(one, 1e-3)) * cores)
+        pids = pool.map(_pool_setup, [(seqs[:per_task], k, pos, neg, cpos, cneg, 1.0)] * cores, chunksize=1)
+        pool.map(_pool_task, range(cores), chunksize=1)          # first-call costs outside the timed region
+        t1 = time.perf_counter()
+        pool.map(_pool_task, range(ntasks), chunksize=1)
+        dta = time.perf_counter() - t1
+        out["all_cores"] = {"value": ntasks * per_task * L / dta / 1e9, "unit": "Gbases/s", "cores": len(set(pids)),
+                            "kind": "port",
+                            "sample": "%d contigs (%d tasks of %d) on a %d-process pool, each process single-threaded: "
+                                      "oracle vectorised counter + normalise + scikit-learn brute 3-NN + centroid "
+                                      "metric, %.1f s" % (ntasks * per_task, ntasks, per_task, cores, dta)}
+    except Exception as e:   # noqa: BLE001 -- the 1-core baseline is the contract; this one is best effort
+        out["all_cores"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def latest_traffic(kernel):
+    """HBM bytes per contig of `kernel` from the newest profiles/r*/traffic.json that has it (PMC measurement of
+    this same command, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, corrected as MI355X_MICROARCH.md
+    prescribes)."""
+    for tfile in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            tk = json.load(open(tfile)).get("kernels", {}).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if tk:
+            return tk["hbm_bytes_per_contig"], os.path.relpath(tfile, REPO)
+    return None, None
 
 
 def main():
@@ -83,13 +168,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--contigs", type=int, default=1000000, help="contigs per GPU")
-    ap.add_argument("--length", type=int, default=5000)
-    ap.add_argument("--k", type=int, default=4)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE.json workload (see module doc)")
+    ap.add_argument("--contigs", type=int, default=None, help="contigs per GPU (overrides the configuration)")
+    ap.add_argument("--length", type=int, default=None)
+    ap.add_argument("--k", type=int, default=None)
+    ap.add_argument("--refs", type=int, default=None, help="synthetic reference genomes (configs 2, 4)")
     ap.add_argument("--method", default="combo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parity-contigs", type=int, default=256)
+    ap.add_argument("--parity-contigs", type=int, default=None)
+    ap.add_argument("--min-seconds", type=float, default=0.0,
+                    help="keep stepping (in multiples of --steps) until the timed region is at least this long")
     args = ap.parse_args()
+
+    # worker processes of the all-core CPU baseline: forked now, before anything initialises the GPU in this process
+    pool = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        import multiprocessing as mp
+        pool = mp.get_context("fork").Pool(os.cpu_count() or 1, initializer=_pool_worker_init)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -114,12 +209,23 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
 
-    from phamers_amd import _lib, device
+    from phamers_amd import _lib, device, workloads
     ctx = _lib.Context(local_dev, stream.cuda_stream)
-    n, L, k = args.contigs, args.length, args.k
+    cfg = dict(workloads.CONFIGS[args.config])
+    if args.k is not None and args.k != cfg["k"]:
+        cfg.update(k=args.k, reference="synthetic", refs=args.refs or 4510, ref_length=50000)
+    k = cfg["k"]
+    L = args.length or cfg["length"]
+    if args.contigs is not None:
+        n = args.contigs
+    elif "contigs_total" in cfg:
+        n = cfg["contigs_total"] // world          # config 3: a fixed total, split over the ranks
+    else:
+        n = cfg["contigs"]
+    scaling = "strong" if ("contigs_total" in cfg and args.contigs is None) else "weak"
     D = 4 ** k
     T = n * L
-    pos, neg, cpos, cneg, ref_name = load_model_inputs(D)
+    pos, neg, cpos, cneg, ref_name = workloads.reference_for(ctx, cfg, args.refs)
     model = _lib.Model(ctx, pos, neg, cpos, cneg, k_neighbors=3)
     M, C = pos.shape[0] + neg.shape[0], cpos.shape[0] + cneg.shape[0]
 
@@ -129,7 +235,8 @@ def main():
     scores = torch.empty(n, dtype=torch.float64, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     gathered = torch.empty(world * n, dtype=torch.float64, device=dev) if dist else None
-    device.synth_packed(ctx, 0, rank * n, n, L, packed.data_ptr(), offsets.data_ptr())
+    first = rank * n
+    device.synth_packed(ctx, 0, first, n, L, packed.data_ptr(), offsets.data_ptr())
 
     def step():
         device.count_score(ctx, model, packed.data_ptr(), None, T, offsets.data_ptr(), n, k, args.method,
@@ -149,9 +256,25 @@ def main():
         dist.barrier()
     ctx.profile_reset()
     ctx.profile_enable(True)
+    steps = args.steps
+    if args.min_seconds > 0:
+        # sustained run: size the timed region from one probe step so that every rank times the same number of steps
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        one = time.perf_counter() - t0
+        if dist:
+            tmax = torch.tensor([one], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            one = float(tmax.item())
+        steps = max(steps, int(args.min_seconds / max(one, 1e-6)) + 1)
+        ctx.profile_reset()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     if dist:
@@ -173,8 +296,9 @@ def main():
     # ---- parity spot check against the oracle (outside the timed region) ----
     from oracle import oracle
     from phamers_amd import synth
-    npar = min(args.parity_contigs, n)
-    seqs = synth.synth_contigs(0, npar, L)
+    npar = args.parity_contigs if args.parity_contigs is not None else (256 if D * M <= 256 * 5000 else 24)
+    npar = min(npar, n)
+    seqs = synth.synth_contigs(0, npar, L, start=first)
     want_counts = oracle.count(seqs, k).reshape(npar, D)
     got_counts = counts[:npar].cpu().numpy().view(np.uint32).astype(np.int64)
     q = oracle.normalize_counts(want_counts)
@@ -187,59 +311,63 @@ def main():
               "orderings_decided_by_exact_distances": n_exact}
 
     # ---- roofline of the dominant kernel (algorithmic work / HIP-event time in this run) ----
+    count_bytes = n * ((L + 3) // 4 + 8 + 4 * D + 8) / 1e9        # packed + offset + counts + score
+    score_tflop = n * 2.0 * D * (M + C) / 1e12                     # 2 D (M + C) per contig
     alg = {  # kernel -> (bound, unit, peak, algorithmic work per step on this rank)
-        "phk_count_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, n * ((L + 3) // 4 + 8 + 4 * D + 8) / 1e9),
-        "phk_count_slots_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, n * ((L + 3) // 4 + 8 + 4 * D + 8) / 1e9),
-        "phk_knn_mfma_kernel": ("mfma", "TFLOP/s", MFMA_F32_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
-        "phk_knn_f16_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
-        "phk_knn_f16c_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
-        "phk_dist2_f64_kernel": ("mfma", "TFLOP/s", F64_PEAK_TF, n * 2.0 * D * (M + C) / 1e12),
+        "phk_count_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
+        "phk_count_slots_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
+        "phk_count_pairs_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
+        "phk_knn_mfma_kernel": ("mfma", "TFLOP/s", MFMA_F32_PEAK_TF, score_tflop),
+        "phk_knn_f16_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
+        "phk_knn_f16c_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
+        "phk_knn_f16h_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
+        "phk_knn_f16_general_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
+        "phk_dist2_f64_kernel": ("mfma", "TFLOP/s", F64_PEAK_TF, score_tflop),
     }
-    if "phk_count_slots_kernel" in prof:   # the wave-per-contig kernel then only serves the hand-over list
-        alg.pop("phk_count_kernel", None)
+    if "phk_count_slots_kernel" in prof or "phk_count_pairs_kernel" in prof:
+        alg.pop("phk_count_kernel", None)   # the wave-per-contig kernel then only serves the hand-over list
     kernels = {}
     for name, (ms, launches) in prof.items():
-        kernels[name] = {"ms_per_step": ms / args.steps, "launches_per_step": launches / args.steps}
+        kernels[name] = {"ms_per_step": ms / steps, "launches_per_step": launches / steps}
         if name in alg and ms > 0:
             bound, unit, peak, work = alg[name]
-            ach = work * args.steps / (ms / 1e3)
+            ach = work * steps / (ms / 1e3)
             kernels[name].update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
     dom = max((kname for kname in kernels if kname in alg), key=lambda kname: kernels[kname]["ms_per_step"])
-    # HBM traffic of the dominant kernel: PMC measurement of this same command (FETCH_SIZE / WRITE_SIZE
-    # in separate rocprofv3 passes, corrected as MI355X_MICROARCH.md prescribes), stored per contig
-    traffic = None
-    tfile = os.path.join(REPO, "profiles", "r01", "traffic.json")
-    if os.path.exists(tfile):
-        tk = json.load(open(tfile)).get("kernels", {}).get(dom)
-        if tk:
-            traffic = tk["hbm_bytes_per_contig"] * n
+    per_contig, tsrc = latest_traffic(dom) if args.config == 1 else (None, None)
     roofline = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
                 "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
-                "traffic": traffic}
-    if dom == "phk_knn_f16_kernel":
-        # the split-f16 kernel issues 3 MFMA flops per algorithmic flop (hi.hi + hi.lo + lo.hi)
-        roofline["mfma_issue_frac"] = 3.0 * kernels[dom]["frac"]
-    if dom == "phk_knn_f16c_kernel":
-        # the count-exact kernel issues 2 MFMA flops per algorithmic flop (c.r_hi + c.r_lo)
-        roofline["mfma_issue_frac"] = 2.0 * kernels[dom]["frac"]
+                "traffic": per_contig * n if per_contig else None}
+    if tsrc:
+        roofline["traffic_source"] = tsrc
+    # MFMA flops ISSUED per algorithmic flop: 3 (split-query f16: hi.hi + hi.lo + lo.hi), 2 (count-exact: c.r_hi +
+    # c.r_lo), 1 (count-exact, high parts only: the low parts are applied to the few candidates by the decision stage)
+    issue = {"phk_knn_f16_kernel": 3.0, "phk_knn_f16c_kernel": 2.0, "phk_knn_f16h_kernel": 1.0,
+             "phk_knn_f16_general_kernel": 2.0}.get(dom)
+    if issue:
+        roofline["mfma_issue_frac"] = issue * kernels[dom]["frac"]
 
     out = {
         "metric": "Gbases/s k-mer-count+score, k=%d, %d kb contigs" % (k, L // 1000),
-        "value": world * n * L * args.steps / elapsed / 1e9,
-        "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": world * n * L * steps / elapsed / 1e9,
+        "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "u32 counts + f16 MFMA proposal (exact integer counts x split-f16 reference, f32 accumulate) + f64 decision",
         "data": "synthetic (seeded uniform ATGC contigs, device-generated); reference matrix: " + ref_name,
-        "config": {"workload": "k=%d, %d x %d-base contigs per GPU, count+normalise+%s score, "
-                               "%d reference rows + %d centroids" % (k, n, L, args.method, M, C),
+        "config": {"workload": "BASELINE configs[%d]: k=%d, %d x %d-base contigs per GPU, count+normalise+%s score, "
+                               "%d reference rows + %d centroids" % (args.config, k, n, L, args.method, M, C),
                    "contigs_per_gpu": n, "contig_length": L, "k": k, "method": args.method,
-                   "parallelism": "contig shards, %d rank(s), final all-gather of scores" % world},
+                   "parallelism": "contig shards, %d rank(s), replicated reference, final all-gather of scores" % world},
         "roofline": roofline,
         "kernels": kernels,
         "parity": parity,
+        "timed_region_s": elapsed,
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(k, L, pos, neg, cpos, cneg)
+        out["cpu_baseline"] = cpu_baseline(k, L, pos, neg, cpos, cneg, pool=pool)
+    if pool is not None:
+        pool.close()
+        pool.join()
     print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

@@ -126,6 +126,20 @@ int phk_fasta_shape(const phk_fasta *f, uint64_t *n_records, uint64_t *total_bas
 int phk_fasta_data(const phk_fasta *f, const char **bases, const uint64_t **offsets, const char **titles,
                    const uint64_t **title_offsets);
 int phk_fasta_free(phk_fasta *f);
+
+/* FASTA header -> PhaMers id (id_parser.get_id, scripts/id_parser.py:89-100, with get_contig_id :18-30,
+ * get_phage_id :71-77, get_bacteria_id :57-68, is_genbank_id :80-86).  *status says what the reference does with
+ * the header: PHK_ID_OK (the id is written to id_out, *id_len bytes, no terminator), PHK_ID_INDEX_ERROR (the
+ * reference raises IndexError: a header that matches none of its three shapes), PHK_ID_NONE (it returns None). */
+#define PHK_ID_OK 0
+#define PHK_ID_INDEX_ERROR 1
+#define PHK_ID_NONE 2
+int phk_parse_id(const char *header, uint64_t header_len, char *id_out, uint64_t cap, uint64_t *id_len, int *status);
+/* the ids of a parsed file, computed by the reader's threads from each record.id (what fileIO.get_fasta_ids
+ * returns, scripts/fileIO.py:62-77): concatenated ids + id_offsets[n+1] + id_status[n]; borrowed pointers */
+int phk_fasta_ids(const phk_fasta *f, const char **ids, const uint64_t **id_offsets, const uint8_t **id_status);
+/* the same as a [n][width] zero-padded byte matrix (a NumPy 'S<width>' array) in caller memory */
+int phk_fasta_ids_fixed(const phk_fasta *f, uint64_t width, char *out);
 /* kmer.count_file's counting loop (scripts/kmer.py:135-139) on a parsed file: counts[n][4^k] int64 */
 int phk_count_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *symbols4, int64_t *counts);
 
@@ -189,6 +203,14 @@ int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const uint32_t *d_
                         const uint32_t *d_mask, uint64_t total_bases, const uint64_t *d_offsets,
                         uint64_t n, int k, int method, uint32_t *d_counts, double *d_scores,
                         uint32_t *d_status);
+
+/* Verification on the device (a full-size batch of counts is tens of GB and is never brought to the host to be
+ * checked): d_result[0] = number of rows of d_counts[n][D] whose sum differs from expected_rowsum (not evaluated when
+ * expected_rowsum is UINT64_MAX), d_result[1] = number of words in which d_counts differs from d_other (not evaluated
+ * when d_other is NULL).  d_result: two uint64 on the device.  A contig of L valid bases has L - k + 1 windows
+ * (scripts/kmer.py:47), which is what the full-size tests pass as expected_rowsum. */
+int phk_check_counts_dev(phk_ctx *ctx, const uint32_t *d_counts, const uint32_t *d_other, uint64_t n, uint64_t D,
+                         uint64_t expected_rowsum, uint64_t *d_result);
 
 /* Diagnostics of the most recent scoring call on this context, summed over its batches (synchronises the stream):
  * how many queries were resolved by the float64 brute-force fallback kernel and how many

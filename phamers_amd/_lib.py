@@ -44,6 +44,9 @@ SIGNATURES = {
     "phk_fasta_shape": (c_int, [c_void_p, P(c_u64), P(c_u64), P(c_u64)]),
     "phk_fasta_data": (c_int, [c_void_p, P(c_void_p), P(c_void_p), P(c_void_p), P(c_void_p)]),
     "phk_fasta_free": (c_int, [c_void_p]),
+    "phk_parse_id": (c_int, [c_char_p, c_u64, c_char_p, c_u64, P(c_u64), P(c_int)]),
+    "phk_fasta_ids": (c_int, [c_void_p, P(c_void_p), P(c_void_p), P(c_void_p)]),
+    "phk_fasta_ids_fixed": (c_int, [c_void_p, c_u64, c_void_p]),
     "phk_count_fasta": (c_int, [c_void_p, c_void_p, c_int, c_char_p, c_void_p]),
     "phk_kmeans": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_u32, c_u64, c_int, c_void_p, c_void_p, P(c_int)]),
     "phk_model_create": (c_int, [c_void_p, c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_u64,
@@ -58,6 +61,7 @@ SIGNATURES = {
     "phk_score_counts_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_void_p, c_void_p]),
     "phk_count_score_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_void_p, c_u64,
                                     c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "phk_check_counts_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_u64, c_u64, c_void_p]),
     "phk_score_stats": (c_int, [c_void_p, P(c_u64), P(c_u64)]),
     "phk_synth_packed_dev": (c_int, [c_void_p, c_u64, c_u64, c_u64, c_u64, c_u32, c_void_p,
                                      c_void_p, c_void_p]),
@@ -270,6 +274,34 @@ class Fasta(object):
     def ids(self):
         """Bio.SeqIO record.id: the first white-space delimited word of each title."""
         return [(t.split(None, 1) or [""])[0] for t in self.titles()]
+
+    def phamers_ids(self):
+        """What fileIO.get_fasta_ids returns (scripts/fileIO.py:62-77): id_parser.get_id of every record.id,
+        parsed by the native reader.  Raises IndexError where the reference does (a header that matches none of
+        its three shapes); a header for which the reference returns None gives None (object array)."""
+        n = self.n_records
+        ids, off, st = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        check(self.lib.phk_fasta_ids(self.handle, ctypes.byref(ids), ctypes.byref(off), ctypes.byref(st)))
+        if n == 0:
+            return np.array([])
+        status = np.ctypeslib.as_array(ctypes.cast(st.value, ctypes.POINTER(ctypes.c_uint8)), shape=(n,))
+        if (status == 1).any():
+            bad = int(np.argmax(status == 1))
+            raise IndexError("list index out of range (FASTA header %r has none of the id shapes)" % self.titles_at(bad))
+        offs = np.ctypeslib.as_array(ctypes.cast(off.value, ctypes.POINTER(ctypes.c_uint64)), shape=(n + 1,))
+        width = max(int(np.diff(offs.astype(np.int64)).max()), 1)
+        fixed = np.zeros(n, dtype="S%d" % width)
+        check(self.lib.phk_fasta_ids_fixed(self.handle, width, ptr(fixed)))
+        out = np.char.decode(fixed, "latin-1")
+        if (status == 2).any():
+            out = out.astype(object)
+            out[status == 2] = None
+        return out
+
+    def titles_at(self, i):
+        off = np.ctypeslib.as_array(ctypes.cast(self._title_off, ctypes.POINTER(ctypes.c_uint64)),
+                                    shape=(self.n_records + 1,))
+        return ctypes.string_at(self._titles + int(off[i]), int(off[i + 1] - off[i])).decode("latin-1")
 
     def sequences(self):
         off = self.offsets()

@@ -925,3 +925,48 @@ int phk_launch_permute_columns(phk_ctx *ctx, const int64_t *d_in, uint64_t n, ui
                phk_permute_columns_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(d_in, n, D, d_perm, d_out));
     return PHK_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// verification helper: row sums against an expected value and word-wise comparison of two count matrices,
+// both on the device (full-size batches are tens of GB: they are never brought to the host to be checked)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void phk_check_counts_kernel(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                               uint64_t n, uint64_t D, unsigned long long expect,
+                                                               unsigned long long *__restrict__ result) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t total = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long bad_rows = 0, bad_words = 0;
+    for (uint64_t r = wave; r < n; r += total) {
+        unsigned long long s = 0, diff = 0;
+        for (uint64_t j = lane; j < D; j += 64) {
+            const uint32_t x = a[r * D + j];
+            s += x;
+            if (b) diff += x != b[r * D + j];
+        }
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) {
+            s += __shfl_xor(s, sh);
+            diff += __shfl_xor(diff, sh);
+        }
+        bad_rows += (expect != ~0ull && s != expect) ? 1 : 0;
+        bad_words += diff;
+    }
+    if (lane == 0) {
+        if (bad_rows) atomicAdd(result, bad_rows);
+        if (bad_words) atomicAdd(result + 1, bad_words);
+    }
+}
+
+int phk_launch_check_counts(phk_ctx *ctx, const uint32_t *d_counts, const uint32_t *d_other, uint64_t n, uint64_t D,
+                            uint64_t expected_rowsum, uint64_t *d_result) {
+    PHK_REQUIRE(d_result && (n == 0 || d_counts), "phk_check_counts_dev: NULL pointer");
+    PHK_HIP(hipMemsetAsync(d_result, 0, 2 * sizeof(uint64_t), ctx->stream));
+    if (n == 0 || D == 0) return PHK_OK;
+    uint64_t blocks = phk_div_up(n, 4);
+    if (blocks > (uint64_t)ctx->num_cus * 16) blocks = (uint64_t)ctx->num_cus * 16;
+    PHK_LAUNCH(ctx, "phk_check_counts_kernel",
+               phk_check_counts_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(
+                   d_counts, d_other, n, D, (unsigned long long)expected_rowsum, (unsigned long long *)d_result));
+    return PHK_OK;
+}

@@ -17,6 +17,7 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <stdlib.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -26,12 +27,136 @@
 
 #include "phk_common.h"
 
+static inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
 struct phk_fasta {
     std::vector<char> bases;          // all sequences, concatenated
     std::vector<uint64_t> offsets;    // n + 1
     std::vector<char> titles;         // all titles, concatenated (no terminators)
     std::vector<uint64_t> title_off;  // n + 1
+    std::vector<char> ids;            // PhaMers ids (phk_parse_id of each record.id), concatenated
+    std::vector<uint64_t> id_off;     // n + 1
+    std::vector<uint8_t> id_status;   // n: PHK_ID_OK / PHK_ID_INDEX_ERROR / PHK_ID_NONE
 };
+
+// ------------------------------------------------------------------------------------------------
+// FASTA header -> PhaMers id (scripts/id_parser.py:18-100), restated as a small field scanner.
+//   header holding "_ID_"      : contig   -- the '_'-field after the first field that is exactly "ID", taken from
+//                                 the header stripped of outer white space and of every '>', minus every "-circular"
+//   exactly four '|'           : phage    -- the fourth '|'-field, minus every '>'
+//   anything else              : bacteria -- the text before the first ' ' if it looks like a GenBank accession
+//                                 (not a number, '.' second to last), else the second TAB-field (minus '>') under the
+//                                 same test; without a TAB the reference indexes past the end of a list.
+// ------------------------------------------------------------------------------------------------
+static bool py_float_parses(const char *s, size_t n) {
+    // what Python's float() accepts, for the strings that occur as FASTA words: optional outer white space, then a
+    // decimal float / inf / infinity / nan in any case.  strtod also takes hex floats and "nan(...)": excluded.
+    while (n && is_space(s[0])) { ++s; --n; }
+    while (n && is_space(s[n - 1])) --n;
+    if (n == 0 || n > 400) return false;
+    for (size_t i = 0; i < n; ++i)
+        if (s[i] == 'x' || s[i] == 'X' || s[i] == '(' || s[i] == '_' || s[i] == '\0') return false;
+    char tmp[408];
+    memcpy(tmp, s, n);
+    tmp[n] = 0;
+    char *end = nullptr;
+    (void)strtod(tmp, &end);
+    return end == tmp + n;
+}
+
+// 1 accession-like, 0 not, -1 the reference's test indexes out of range (string shorter than 2, not a number)
+static int looks_like_accession(const char *s, size_t n) {
+    if (py_float_parses(s, n)) return 0;
+    if (n < 2) return -1;
+    return s[n - 2] == '.' ? 1 : 0;
+}
+
+static void append_without(std::string &out, const char *s, size_t n, const char *drop) {
+    const size_t dl = strlen(drop);
+    for (size_t i = 0; i < n;) {
+        if (dl && i + dl <= n && memcmp(s + i, drop, dl) == 0) i += dl;
+        else out.push_back(s[i++]);
+    }
+}
+
+static int parse_id(const char *h, size_t n, std::string &out) {
+    out.clear();
+    static const char tag[4] = {'_', 'I', 'D', '_'};
+    const bool contig = n >= 4 && std::search(h, h + n, tag, tag + 4) != h + n;
+    if (contig) {
+        // strip(), then drop every '>'
+        size_t a = 0, b = n;
+        while (a < b && is_space(h[a])) ++a;
+        while (b > a && is_space(h[b - 1])) --b;
+        std::string t;
+        append_without(t, h + a, b - a, ">");
+        // walk the '_'-fields: the one after the first field equal to "ID"
+        size_t f0 = 0;
+        bool take_next = false;
+        for (size_t i = 0; i <= t.size(); ++i) {
+            if (i == t.size() || t[i] == '_') {
+                if (take_next) {
+                    append_without(out, t.data() + f0, i - f0, "-circular");
+                    return PHK_ID_OK;
+                }
+                take_next = (i - f0 == 2 && t[f0] == 'I' && t[f0 + 1] == 'D');
+                f0 = i + 1;
+            }
+        }
+        return PHK_ID_INDEX_ERROR;  // "ID" was the last field: nothing follows it
+    }
+    size_t bars = 0;
+    for (size_t i = 0; i < n; ++i) bars += h[i] == '|';
+    if (bars == 4) {
+        size_t f0 = 0, field = 0;
+        for (size_t i = 0; i <= n; ++i)
+            if (i == n || h[i] == '|') {
+                if (field == 3) {
+                    append_without(out, h + f0, i - f0, ">");
+                    return PHK_ID_OK;
+                }
+                ++field;
+                f0 = i + 1;
+            }
+        return PHK_ID_INDEX_ERROR;  // unreachable with four bars
+    }
+    // bacteria rule
+    const char *sp = (const char *)memchr(h, ' ', n);
+    const size_t w = sp ? (size_t)(sp - h) : n;
+    int acc = looks_like_accession(h, w);
+    if (acc < 0) return PHK_ID_INDEX_ERROR;
+    if (acc == 1) {
+        out.assign(h, w);
+        return PHK_ID_OK;
+    }
+    const char *t1 = (const char *)memchr(h, '\t', n);
+    if (!t1) return PHK_ID_INDEX_ERROR;  // split('\t')[1] of a header without a TAB
+    const char *f = t1 + 1;
+    const char *t2 = (const char *)memchr(f, '\t', (size_t)(h + n - f));
+    std::string second;
+    append_without(second, f, (size_t)((t2 ? t2 : h + n) - f), ">");
+    acc = looks_like_accession(second.data(), second.size());
+    if (acc < 0) return PHK_ID_INDEX_ERROR;
+    if (acc == 1) {
+        out = second;
+        return PHK_ID_OK;
+    }
+    return PHK_ID_NONE;
+}
+
+extern "C" int phk_parse_id(const char *header, uint64_t header_len, char *id_out, uint64_t cap, uint64_t *id_len,
+                            int *status) {
+    PHK_REQUIRE(header || header_len == 0, "phk_parse_id: NULL header");
+    PHK_REQUIRE(status && id_len, "phk_parse_id: NULL output");
+    std::string out;
+    *status = parse_id(header ? header : "", header_len, out);
+    *id_len = out.size();
+    if (*status == PHK_ID_OK && id_out) {
+        PHK_REQUIRE(cap >= out.size(), "phk_parse_id: id needs %llu bytes", (unsigned long long)out.size());
+        memcpy(id_out, out.data(), out.size());
+    }
+    return PHK_OK;
+}
 
 static int read_whole_file(const char *path, std::vector<char> &buf) {
     const size_t plen = strlen(path);
@@ -78,8 +203,6 @@ static int read_whole_file(const char *path, std::vector<char> &buf) {
     buf.resize(used);
     return PHK_OK;
 }
-
-static inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
 
 // One record = [begin, end) of the file buffer, begin pointing at its '>'.  Pass 0 measures, pass 1
 // writes at the given cursors.
@@ -175,7 +298,65 @@ extern "C" int phk_fasta_read(const char *path, int threads, phk_fasta **out) {
     f->bases.resize(f->offsets[nrec] + 64);  // slack: the device packer reads whole 16-byte groups
     f->titles.resize(f->title_off[nrec] + 1);
     run(1);
+    // ids: the PhaMers id of every record.id (first white-space delimited word of the title), in parallel
+    {
+        std::vector<std::string> chunk((size_t)threads);
+        std::vector<std::vector<uint32_t>> lens((size_t)threads);
+        f->id_status.assign(nrec, PHK_ID_OK);
+        f->id_off.assign(nrec + 1, 0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t)
+            pool.emplace_back([&, t]() {
+                const size_t lo = nrec * (size_t)t / (size_t)threads, hi = nrec * (size_t)(t + 1) / (size_t)threads;
+                std::string id;
+                lens[t].reserve(hi - lo);
+                for (size_t r = lo; r < hi; ++r) {
+                    const char *tt = f->titles.data() + f->title_off[r];
+                    const size_t tl = f->title_off[r + 1] - f->title_off[r];
+                    size_t w = 0;
+                    while (w < tl && !is_space(tt[w])) ++w;
+                    f->id_status[r] = (uint8_t)parse_id(tt, w, id);
+                    if (f->id_status[r] != PHK_ID_OK) id.clear();
+                    chunk[t] += id;
+                    lens[t].push_back((uint32_t)id.size());
+                }
+            });
+        for (auto &th : pool) th.join();
+        size_t r = 0;
+        for (int t = 0; t < threads; ++t)
+            for (uint32_t l : lens[t]) {
+                f->id_off[r + 1] = f->id_off[r] + l;
+                ++r;
+            }
+        f->ids.resize(f->id_off[nrec] + 1);
+        size_t at = 0;
+        for (int t = 0; t < threads; ++t) {
+            memcpy(f->ids.data() + at, chunk[t].data(), chunk[t].size());
+            at += chunk[t].size();
+        }
+    }
     *out = f;
+    return PHK_OK;
+}
+
+extern "C" int phk_fasta_ids(const phk_fasta *f, const char **ids, const uint64_t **id_offsets, const uint8_t **id_status) {
+    PHK_REQUIRE(f, "phk_fasta_ids: NULL");
+    if (ids) *ids = f->ids.data();
+    if (id_offsets) *id_offsets = f->id_off.data();
+    if (id_status) *id_status = f->id_status.data();
+    return PHK_OK;
+}
+
+extern "C" int phk_fasta_ids_fixed(const phk_fasta *f, uint64_t width, char *out) {
+    PHK_REQUIRE(f && out, "phk_fasta_ids_fixed: NULL");
+    const size_t nrec = f->id_off.size() - 1;
+    for (size_t r = 0; r < nrec; ++r) {
+        const size_t l = f->id_off[r + 1] - f->id_off[r];
+        PHK_REQUIRE(l <= width, "phk_fasta_ids_fixed: id %llu is %llu bytes, width %llu", (unsigned long long)r,
+                    (unsigned long long)l, (unsigned long long)width);
+        memcpy(out + r * width, f->ids.data() + f->id_off[r], l);
+        memset(out + r * width + l, 0, width - l);
+    }
     return PHK_OK;
 }
 

@@ -438,6 +438,12 @@ extern "C" int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const u
     return phk_score_rows(ctx, model, nullptr, d_counts, (const uint32_t *)d_nwin, n, method, d_scores, d_status);
 }
 
+extern "C" int phk_check_counts_dev(phk_ctx *ctx, const uint32_t *d_counts, const uint32_t *d_other, uint64_t n, uint64_t D,
+                                    uint64_t expected_rowsum, uint64_t *d_result) {
+    PHK_ENTER(ctx, "phk_check_counts_dev");
+    return phk_launch_check_counts(ctx, d_counts, d_other, n, D, expected_rowsum, d_result);
+}
+
 extern "C" int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_exact_resolved) {
     PHK_ENTER(ctx, "phk_score_stats");
     uint32_t c[2] = {0, 0};

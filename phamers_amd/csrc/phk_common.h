@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/phamers_hip.h"
@@ -120,6 +121,24 @@ int phk_prof_end(phk_ctx *ctx, int slot);
         if ((ctx)->profile) PHK_TRY(phk_prof_end((ctx), ps__)); \
     } while (0)
 
+// host-side parallel loop for the model builders (independent iterations, disjoint outputs)
+template <typename F>
+static inline void phk_parallel_for(uint64_t n, F fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+    if (n < 2 * (uint64_t)nt) nt = 1;
+    if (nt == 1) {
+        for (uint64_t i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; ++t)
+        pool.emplace_back([=]() {
+            for (uint64_t i = n * t / nt; i < n * (t + 1) / nt; ++i) fn(i);
+        });
+    for (auto &th : pool) th.join();
+}
+
 static inline uint64_t phk_pow4(int k) { return 1ull << (2 * k); }
 static inline uint64_t phk_div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
@@ -143,6 +162,8 @@ int phk_launch_normalize_f64(phk_ctx *ctx, const double *d_rows, uint64_t n, uin
                              double *d_out);
 int phk_launch_permute_columns(phk_ctx *ctx, const int64_t *d_in, uint64_t n, uint64_t D, const uint32_t *d_perm,
                                int64_t *d_out);
+int phk_launch_check_counts(phk_ctx *ctx, const uint32_t *d_counts, const uint32_t *d_other, uint64_t n, uint64_t D,
+                            uint64_t expected_rowsum, uint64_t *d_result);
 // synth.hip
 int phk_launch_synth(phk_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, uint64_t L,
                      uint32_t invalid_ppm, uint32_t *d_packed, uint32_t *d_mask,

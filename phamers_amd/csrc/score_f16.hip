@@ -53,7 +53,7 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
                              uint64_t rec_bytes, uint64_t cb0, std::vector<float> &cn_all, std::vector<float> &beta_all) {
     const uint64_t nblk = phk_div_up(n, 32);
     const int nchunk = (int)(D / 256);
-    for (uint64_t b = 0; b < nblk; ++b) {
+    phk_parallel_for(nblk, [&, nchunk](uint64_t b) {
         uint8_t *blk = rec.data() + (cb0 + b) * rec_bytes;
         float *cn = reinterpret_cast<float *>(blk + (uint64_t)nchunk * 32 * 1024);
         for (int i = 0; i < 32; ++i) {
@@ -88,7 +88,7 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
             cn[i] = (float)(-0.5 * nrm2);  // already in S^2 units
             cn_all[(cb0 + b) * 32 + i] = cn[i];
         }
-    }
+    });
 }
 
 int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, const double *cpos,
@@ -245,6 +245,13 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
             seg_first = b + 1;
         }
     };
+
+    // leading segments without columns (method 'kmeans' sweeps no train rows): empty lists; the flush rule above
+    // only fires at the end of a block
+    while (seg < NSEG && (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total) == 0) {
+        if (q0 + j < N) cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
+        ++seg;
+    }
 
     // Software pipeline inside the wave: while block blk's 48 MFMAs run on the matrix pipe, the VALU
     // inserts the 16 values of block blk-1 (one branch-free insertion per k-step, i.e. per 3 MFMAs),
@@ -763,6 +770,12 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
     int seg = 0;
     uint32_t seg_first = 0;
     uint64_t it = 0;
+    // leading segments without columns (method 'kmeans': no train rows are swept): their lists are empty, and the
+    // flush rule below -- "block b closes segment seg when b + 1 is its end" -- would never fire for them
+    while (seg < NSEG && (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total) == 0) {
+        if (qb < nqb && q0 + j < N) cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
+        ++seg;
+    }
     for (uint32_t t = 0; t < ntile; ++t) {
         f32x16 acc[GEN_CT];
 #pragma unroll

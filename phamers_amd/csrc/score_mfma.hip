@@ -123,15 +123,16 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
             return PHK_ERR_HIP;
     } else {
         auto norms = [&](const double *rows, uint64_t n, double *out) {
-            for (uint64_t r = 0; r < n; ++r) {
+            phk_parallel_for(n, [&](uint64_t r) {
                 double s2 = 0.0;
                 for (uint64_t d = 0; d < D; ++d) {
                     const double v = (double)(float)(rows[r * D + d] - mu[d]);
                     s2 += v * v;
                 }
                 out[r] = std::sqrt(s2);
+            });
+            for (uint64_t r = 0; r < n; ++r)
                 if (out[r] > max_norm) max_norm = out[r];
-            }
         };
         norms(pos, m->n_pos, colnorm.data());
         norms(neg, m->n_neg, colnorm.data() + m->n_pos);
@@ -245,6 +246,11 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
     }
     int seg = 0;
     uint32_t seg_first = 0;  // first block of the current segment
+    // leading segments without columns (method 'kmeans' sweeps no train rows): empty lists
+    while (seg < NSEG && (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total) == 0) {
+        if (q0 + j < N) cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
+        ++seg;
+    }
     for (uint32_t blk = 0; blk < total; ++blk, bp += NG * 64) {
         f32x16 acc;
 #pragma unroll

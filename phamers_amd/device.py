@@ -79,6 +79,28 @@ def count(ctx, packed, mask, total_bases, offsets, n, k, counts, nwin=None):
                                      int(k), _p(counts), _p(nwin)))
 
 
+def check_counts(ctx, counts, other, n, D, expected_rowsum=None):
+    """(rows whose sum differs from expected_rowsum, words differing from `other`), evaluated on the device."""
+    res = DeviceArray(ctx, 2, np.uint64)
+    _lib.check(ctx.lib.phk_check_counts_dev(ctx.handle, _p(counts), _p(other), int(n), int(D),
+                                            0xFFFFFFFFFFFFFFFF if expected_rowsum is None else int(expected_rowsum),
+                                            _p(res)))
+    out = res.to_host()
+    res.free()
+    return int(out[0]), int(out[1])
+
+
+def read_rows(ctx, matrix, rows, D, dtype=np.uint32):
+    """Rows `rows` of a device-resident [n][D] matrix, fetched one by one (sampling a batch too large to download)."""
+    out = np.empty((len(rows), D), dtype=dtype)
+    base = matrix.ptr if isinstance(matrix, DeviceArray) else int(matrix)
+    item = np.dtype(dtype).itemsize
+    for i, r in enumerate(rows):
+        _lib.check(ctx.lib.phk_memcpy_d2h(ctx.handle, ctypes.c_void_p(out[i].ctypes.data),
+                                          ctypes.c_void_p(base + int(r) * D * item), D * item))
+    return out
+
+
 def normalize(ctx, counts, n, D, out):
     _lib.check(ctx.lib.phk_normalize_dev(ctx.handle, _p(counts), int(n), int(D), _p(out)))
 

@@ -22,7 +22,6 @@ import random
 import numpy as np
 
 from . import _lib
-from . import id_parser
 
 logging.basicConfig(format='[%(asctime)s][%(levelname)s][%(funcName)s] - %(message)s')
 logger = logging.getLogger(__name__)
@@ -109,7 +108,7 @@ def count_file(input_file, kmer_length, symbols=DNA, normalize=False):
         logger.warning("Could not read file: %s" % os.path.basename(input_file))
         return None, None
     try:
-        ids = np.array([id_parser.get_id(h) for h in fasta.ids()])
+        ids = fasta.phamers_ids()
         counts = np.zeros((len(ids), pow(len(symbols), kmer_length)), dtype=(int, float)[normalize])
         if fasta.n_records:
             got = fasta.count(_lib.get_context(), kmer_length, sym)
@@ -160,7 +159,7 @@ def read_fasta(fasta_file):
     """(ids, sequences) of a FASTA file (scripts/fileIO.py:28-42), through the native reader."""
     fasta = _lib.Fasta(fasta_file)
     try:
-        return np.array([id_parser.get_id(h) for h in fasta.ids()]), fasta.sequences()
+        return fasta.phamers_ids(), fasta.sequences()
     finally:
         fasta.close()
 
@@ -170,7 +169,7 @@ def fasta_lengths(fasta_file):
     without materialising the sequences as Python strings."""
     fasta = _lib.Fasta(fasta_file)
     try:
-        return np.array([id_parser.get_id(h) for h in fasta.ids()]), fasta.lengths()
+        return fasta.phamers_ids(), fasta.lengths()
     finally:
         fasta.close()
 

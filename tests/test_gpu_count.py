@@ -143,19 +143,38 @@ def test_device_synth_matches_host_generator(ctx):
 
 
 def test_transform_kmers_identity(kmer):
-    """counts(reverse / complement / reverse-complement of s) == transform_kmers(counts(s))."""
+    """exact=True: counts(reverse / complement / reverse-complement of s) == transform_kmers(counts(s))."""
     from phamers_amd import synth, transform_kmers
     comp = str.maketrans("ATGC", "TACG")
-    seqs = [synth.synth_contig(12, i, 300 + 211 * i) for i in range(6)]
-    for k in (2, 4, 5):
+    for k in (2, 3, 4, 5):
+        seqs = [synth.synth_contig(4, i, 600 + 50 * i) for i in range(5)]
         c = kmer.count(seqs, k)
         rev = kmer.count([s[::-1] for s in seqs], k)
         cmp_ = kmer.count([s.translate(comp) for s in seqs], k)
         rc = kmer.count([s.translate(comp)[::-1] for s in seqs], k)
-        assert np.array_equal(transform_kmers.transform_kmers(c, reverse=True, complement=False), rev)
-        assert np.array_equal(transform_kmers.transform_kmers(c, reverse=False, complement=True), cmp_)
-        assert np.array_equal(transform_kmers.transform_kmers(c, reverse=True, complement=True), rc)
+        assert np.array_equal(transform_kmers.transform_kmers(c, reverse=True, complement=False, exact=True), rev)
+        assert np.array_equal(transform_kmers.transform_kmers(c, reverse=False, complement=True, exact=True), cmp_)
+        assert np.array_equal(transform_kmers.transform_kmers(c, reverse=True, complement=True, exact=True), rc)
         assert transform_kmers.transform_kmers(c, reverse=False, complement=False) is c
+
+
+@pytest.mark.gpu
+def test_transform_kmers_matches_the_reference_outputs():
+    """Default mode = the reference's own index tables (tests/golden/transform.npz: outputs of
+    scripts/transform_kmers.py:68-88 run with Python 2 division), including its IndexError for k >= 5."""
+    from phamers_amd import transform_kmers
+    z = helpers.load_npz("transform.npz")
+    errors = helpers.load_json("transform.json")["errors_by_k"]
+    for k in (2, 3, 4):
+        x = z["in_k%d" % k]
+        assert np.array_equal(transform_kmers.transform_kmers(x, reverse=True, complement=False), z["rev_k%d" % k])
+        assert np.array_equal(transform_kmers.transform_kmers(x, reverse=False, complement=True), z["comp_k%d" % k])
+        assert np.array_equal(transform_kmers.transform_kmers(x, reverse=True, complement=True), z["revcomp_k%d" % k])
+        assert np.array_equal(transform_kmers.transform_kmers(x, reverse=False, complement=False), z["none_k%d" % k])
+    for k in (5, 6):
+        assert errors[str(k)] == "IndexError"
+        with pytest.raises(IndexError):
+            transform_kmers.transform_kmers(np.zeros((2, 4 ** k), dtype=np.int64), reverse=True, complement=True)
 
 
 @pytest.mark.gpu

@@ -78,3 +78,110 @@ def test_full_size_batch_properties(monkeypatch):
     device.score_counts(ctx, model, d_sub, len(perm), "combo", d_sub_scores, d_status)
     assert np.array_equal(d_sub_scores.to_host(), out["combo"][perm])
     model.close()
+
+
+def test_config2_k5_10M_x_10kb_counting_and_scoring():
+    """BASELINE configs[2] at full size: k = 5 (1024 bins), 10 M x 10 kb contigs on one GPU (100 Gbases; 25 GB packed,
+    41 GB of counts per copy).  Every row sums to L - k + 1, the slot kernel and the wave-per-contig kernel agree bit
+    for bit (both checked on the device), 96 sampled rows equal the oracle's counts, and a 262 144-row slice scored
+    against 2255 + 2255 synthetic reference genomes matches the oracle on a sample."""
+    from oracle import oracle
+    from phamers_amd import _lib, device, synth, workloads
+    cfg = workloads.CONFIGS[2]
+    n, L2, k = cfg["contigs"], cfg["length"], cfg["k"]
+    D = 4 ** k
+    T = n * L2
+    ctx = _lib.get_context()
+    packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    offsets = device.DeviceArray(ctx, n + 1, np.uint64)
+    counts = device.DeviceArray(ctx, (n, D), np.uint32)
+    counts_w = device.DeviceArray(ctx, (n, D), np.uint32)
+    nwin = device.DeviceArray(ctx, n, np.uint32)
+    device.synth_packed(ctx, 0, 0, n, L2, packed, offsets)
+    device.count(ctx, packed, None, T, offsets, n, k, counts, nwin)
+    ctx.set_option("count_lanes", "0")
+    device.count(ctx, packed, None, T, offsets, n, k, counts_w, None)
+    ctx.set_option("count_lanes", "")
+    ctx.sync()
+    assert np.all(nwin.to_host() == L2 - k + 1)
+    assert nwin.to_host().shape == (10000000,) and counts.nbytes == 10000000 * 1024 * 4
+    bad_rows, bad_words = device.check_counts(ctx, counts, counts_w, n, D, L2 - k + 1)
+    assert bad_rows == 0 and bad_words == 0
+    counts_w.free()
+    rng = np.random.default_rng(2)
+    sample = np.sort(rng.choice(n, 96, replace=False))
+    got = device.read_rows(ctx, counts, sample, D).astype(np.int64)
+    want = oracle.count([synth.synth_contig(0, int(c), L2) for c in sample], k)
+    assert np.array_equal(got, want)
+
+    # scoring a slice of the batch (general-D count-exact MFMA path), sample against the oracle
+    pos, neg, cpos, cneg = workloads.synthetic_reference(ctx, k, cfg["refs"], cfg["ref_length"])
+    model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
+    ns = 262144
+    scores = device.DeviceArray(ctx, ns, np.float64)
+    status = device.DeviceArray(ctx, 1, np.uint32)
+    device.score_counts(ctx, model, counts, ns, "combo", scores, status)
+    assert status.to_host()[0] == 0
+    n_fallback, _ = ctx.score_stats()
+    assert n_fallback < ns // 100
+    pick = np.sort(rng.choice(ns, 48, replace=False))
+    q = oracle.normalize_counts(device.read_rows(ctx, counts, pick, D).astype(np.int64))
+    want_s = oracle.knn_score_points(q, pos, neg, 3) + oracle.centroid_score_points_fast(q, cpos, cneg)
+    assert helpers.rel_err(scores.to_host()[pick], want_s) < 1e-6
+    model.close()
+    for a in (packed, offsets, counts, nwin, scores, status):
+        a.free()
+
+
+def test_config4_k6_50k_row_reference_131072_queries():
+    """BASELINE configs[4] at full size on one GPU: k = 6 (D = 4096), 50 000-row reference matrix, 131 072 queries of
+    10 kb, counted and scored on the device.  Sampled queries against oracle.score_points (float64 direct-difference
+    brute force over all 50 000 rows), the brute-force fallback share bounded, combo = knn + kmeans, and scores
+    independent of a query's position in the batch."""
+    from oracle import oracle
+    from phamers_amd import _lib, device, synth, workloads
+    cfg = workloads.CONFIGS[4]
+    n, L4, k = cfg["contigs"], cfg["length"], cfg["k"]
+    D = 4 ** k
+    T = n * L4
+    ctx = _lib.get_context()
+    pos, neg, cpos, cneg = workloads.synthetic_reference(ctx, k, cfg["refs"], cfg["ref_length"])
+    assert pos.shape == (25000, D) and neg.shape == (25000, D)
+    model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
+    packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    offsets = device.DeviceArray(ctx, n + 1, np.uint64)
+    counts = device.DeviceArray(ctx, (n, D), np.uint32)
+    scores = device.DeviceArray(ctx, n, np.float64)
+    status = device.DeviceArray(ctx, 1, np.uint32)
+    device.synth_packed(ctx, 0, 0, n, L4, packed, offsets)
+    out = {}
+    for method in ("combo", "knn", "kmeans"):
+        if method == "combo":   # the whole path: count -> normalise -> score
+            device.count_score(ctx, model, packed, None, T, offsets, n, k, method, counts, scores, status)
+        else:
+            device.score_counts(ctx, model, counts, n, method, scores, status)
+        out[method] = scores.to_host()
+        assert status.to_host()[0] == 0
+        n_fallback, _ = ctx.score_stats()
+        assert n_fallback < n // 200, (method, n_fallback)
+    assert set(np.unique(out["knn"])) <= {-1.0, 1.0}
+    assert np.allclose(out["combo"], out["knn"] + out["kmeans"], rtol=0, atol=1e-15)
+    assert device.check_counts(ctx, counts, None, n, D, L4 - k + 1) == (0, 0)
+    # the oracle on a sample: counts bit-exact, scores within 1e-6 relative
+    rng = np.random.default_rng(4)
+    pick = np.sort(rng.choice(n, 24, replace=False))
+    want_counts = oracle.count([synth.synth_contig(0, int(c), L4) for c in pick], k)
+    host_counts = counts.to_host()
+    assert np.array_equal(host_counts[pick].astype(np.int64), want_counts)
+    q = oracle.normalize_counts(want_counts)
+    want = oracle.knn_score_points(q, pos, neg, 3) + oracle.centroid_score_points_fast(q, cpos, cneg, chunk=8)
+    assert helpers.rel_err(out["combo"][pick], want) < 1e-6
+    # position independence: a permuted sub-batch of another size (other tiles, workgroups, batch split)
+    perm = rng.permutation(n)[:40001]
+    sub = device.DeviceArray.from_host(ctx, host_counts[perm])
+    sub_scores = device.DeviceArray(ctx, len(perm), np.float64)
+    device.score_counts(ctx, model, sub, len(perm), "combo", sub_scores, status)
+    assert np.array_equal(sub_scores.to_host(), out["combo"][perm])
+    model.close()
+    for a in (packed, offsets, counts, scores, status, sub, sub_scores):
+        a.free()
