@@ -65,6 +65,7 @@ extern "C" {
 typedef struct phk_ctx phk_ctx;
 typedef struct phk_model phk_model;
 typedef struct phk_fasta phk_fasta;
+typedef struct phk_batch phk_batch;
 
 /* ---- library / context ------------------------------------------------------------- */
 int phk_abi_version(void);
@@ -142,6 +143,30 @@ int phk_fasta_ids(const phk_fasta *f, const char **ids, const uint64_t **id_offs
 int phk_fasta_ids_fixed(const phk_fasta *f, uint64_t width, char *out);
 /* kmer.count_file's counting loop (scripts/kmer.py:135-139) on a parsed file: counts[n][4^k] int64 */
 int phk_count_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *symbols4, int64_t *counts);
+
+/* ---- device-resident contig batches (the facade's data path) ------------------------- */
+/* What a PhaMers user calls on a FASTA input -- phamer_scorer.load_data + score_points (scripts/phamer.py:131, 139,
+ * 579), kmer.count_file (scripts/kmer.py:114-140) -- with every intermediate kept on the device.  A batch is built
+ * from host sequence bytes (uploaded once: pinned in place, chunked, copies overlapped with the packer) and owns
+ * counts[n][4^k] uint32 + row sums in HBM; counts come back only when asked for (the features cache,
+ * scripts/phamer.py:132-134), scores are the only per-call download. */
+int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n, int k,
+                         const char *symbols4, phk_batch **out);
+int phk_batch_from_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *symbols4, phk_batch **out);
+int phk_batch_shape(const phk_batch *b, uint64_t *n, uint64_t *D, uint64_t *total_bases, int *any_invalid);
+/* borrowed device pointers (valid until phk_batch_free): counts[n][D] uint32, row sums[n] uint32 */
+int phk_batch_device_ptrs(const phk_batch *b, const uint32_t **d_counts, const uint32_t **d_rowsums);
+/* kmer.count_file's count matrix as the reference returns it (int64, scripts/kmer.py:130-139) */
+int phk_batch_counts_i64(phk_ctx *ctx, const phk_batch *b, int64_t *counts);
+/* kmer.normalize_counts of the batch (scripts/kmer.py:209-221; zero row -> NaN), float64 [n][D] to the host */
+int phk_batch_normalized(phk_ctx *ctx, const phk_batch *b, double *rows);
+/* rows[0..m) of a batch as a new batch: the row filter of phamer_scorer.screen_by_length (scripts/phamer.py:
+ * 144-157) as a device gather */
+int phk_batch_select(phk_ctx *ctx, const phk_batch *b, const uint64_t *rows, uint64_t m, phk_batch **out);
+/* phamer_scorer.score_points (scripts/phamer.py:177-195) on a batch: scores[n] float64 to the host.  PHK_ERR_NAN
+ * when a row has no counted window (the reference's NaN row makes scikit-learn raise). */
+int phk_batch_score(phk_ctx *ctx, const phk_model *model, const phk_batch *b, int method, double *scores);
+int phk_batch_free(phk_ctx *ctx, phk_batch *b);
 
 /* ---- scoring model ----------------------------------------------------------------- */
 /* The training side of phamer_scorer.score_points (scripts/phamer.py:177-195): positive /

@@ -48,6 +48,15 @@ SIGNATURES = {
     "phk_fasta_ids": (c_int, [c_void_p, P(c_void_p), P(c_void_p), P(c_void_p)]),
     "phk_fasta_ids_fixed": (c_int, [c_void_p, c_u64, c_void_p]),
     "phk_count_fasta": (c_int, [c_void_p, c_void_p, c_int, c_char_p, c_void_p]),
+    "phk_batch_from_ascii": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_char_p, P(c_void_p)]),
+    "phk_batch_from_fasta": (c_int, [c_void_p, c_void_p, c_int, c_char_p, P(c_void_p)]),
+    "phk_batch_shape": (c_int, [c_void_p, P(c_u64), P(c_u64), P(c_u64), P(c_int)]),
+    "phk_batch_device_ptrs": (c_int, [c_void_p, P(c_void_p), P(c_void_p)]),
+    "phk_batch_counts_i64": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "phk_batch_normalized": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "phk_batch_select": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, P(c_void_p)]),
+    "phk_batch_score": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "phk_batch_free": (c_int, [c_void_p, c_void_p]),
     "phk_kmeans": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_u32, c_u64, c_int, c_void_p, c_void_p, P(c_int)]),
     "phk_model_create": (c_int, [c_void_p, c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_u64,
                                  c_void_p, c_u64, c_u64, c_int, P(c_void_p)]),
@@ -238,6 +247,71 @@ class Model(object):
         out = np.empty(Q.shape[0], dtype=np.float64)
         check(self.ctx.lib.phk_score(self.ctx.handle, self.handle, ptr(Q), Q.shape[0], METHODS[method], ptr(out)))
         return out
+
+
+class Batch(object):
+    """Device-resident contig batch (phk_batch): counts + row sums in HBM; see include/phamers_hip.h."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.handle = handle
+        n, D, T, inv = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
+        check(ctx.lib.phk_batch_shape(handle, ctypes.byref(n), ctypes.byref(D), ctypes.byref(T), ctypes.byref(inv)))
+        self.n, self.D, self.total_bases, self.any_invalid = n.value, D.value, T.value, bool(inv.value)
+
+    @classmethod
+    def from_fasta(cls, ctx, fasta, kmer_length, symbols=b"ATGC"):
+        h = ctypes.c_void_p()
+        check(ctx.lib.phk_batch_from_fasta(ctx.handle, fasta.handle, int(kmer_length), symbols, ctypes.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_sequences(cls, ctx, sequences, kmer_length, symbols=b"ATGC"):
+        raw = [s.encode("latin-1", "replace") for s in sequences]
+        offsets = np.zeros(len(raw) + 1, dtype=np.uint64)
+        if raw:
+            offsets[1:] = np.cumsum([len(r) for r in raw], dtype=np.uint64)
+        bases = np.frombuffer(b"".join(raw) or b"\0", dtype=np.uint8)
+        h = ctypes.c_void_p()
+        check(ctx.lib.phk_batch_from_ascii(ctx.handle, ptr(np.ascontiguousarray(bases)), ptr(offsets), len(raw),
+                                           int(kmer_length), symbols, ctypes.byref(h)))
+        return cls(ctx, h)
+
+    def counts(self):
+        """int64 (n, 4^k) on the host: what kmer.count_file returns (one download, widened on the device)."""
+        out = np.zeros((self.n, self.D), dtype=np.int64)
+        check(self.ctx.lib.phk_batch_counts_i64(self.ctx.handle, self.handle, ptr(out)))
+        return out
+
+    def normalized(self):
+        out = np.empty((self.n, self.D), dtype=np.float64)
+        check(self.ctx.lib.phk_batch_normalized(self.ctx.handle, self.handle, ptr(out)))
+        return out
+
+    def select(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        h = ctypes.c_void_p()
+        check(self.ctx.lib.phk_batch_select(self.ctx.handle, self.handle, ptr(rows), rows.shape[0], ctypes.byref(h)))
+        return Batch(self.ctx, h)
+
+    def score(self, model, method="combo"):
+        out = np.empty(self.n, dtype=np.float64)
+        rc = self.ctx.lib.phk_batch_score(self.ctx.handle, model.handle, self.handle, METHODS[method], ptr(out))
+        if rc == PHK_ERR_NAN:
+            raise ValueError("Input contains NaN.")   # what scikit-learn raises for the reference
+        check(rc)
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.phk_batch_free(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Fasta(object):

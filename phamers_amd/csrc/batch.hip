@@ -1,0 +1,273 @@
+// batch.hip -- device-resident contig batches: the drop-in facade's data path.
+//
+// What a PhaMers user calls -- phamer_scorer.load_data + score_points on a FASTA input (scripts/phamer.py:131,139,
+// 579), kmer.count_file (scripts/kmer.py:114-140) -- used to bounce every intermediate through host memory (ASCII
+// up, int64 counts down, float64 rows up again, scores down).  A phk_batch keeps the path on the device: the
+// sequence bytes go up ONCE (pinned in place, chunked, the copies overlapped with the packer on a second stream),
+// counts and row sums stay in HBM, the length screen is a device row gather, and only what the caller asks for comes
+// back: the scores, and the counts once for the features cache.
+#include <string.h>
+
+#include <vector>
+
+#include "phk_common.h"
+#include "score_model.h"
+
+struct phk_batch {
+    uint64_t n = 0, D = 0, T = 0;
+    int k = 0;
+    uint32_t *d_counts = nullptr;   // [n][D]
+    uint32_t *d_nwin = nullptr;     // [n] row sums (= counted windows)
+    bool any_invalid = false;
+};
+
+#define BATCH_CHUNK (256ull << 20)   // bases per upload chunk (a multiple of 32: chunks pack independently)
+
+static void batch_release(phk_batch *b) {
+    if (!b) return;
+    if (b->d_counts) (void)hipFree(b->d_counts);
+    if (b->d_nwin) (void)hipFree(b->d_nwin);
+    delete b;
+}
+
+extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n, int k,
+                                    const char *symbols4, phk_batch **out) {
+    PHK_ENTER(ctx, "phk_batch_from_ascii");
+    PHK_REQUIRE(out, "phk_batch_from_ascii: NULL out");
+    PHK_REQUIRE(k >= 1, "phk_batch_from_ascii: k must be >= 1 (got %d)", k);
+    if (k > PHK_MAX_K) {
+        phk_set_error("phk_batch_from_ascii: k=%d is above PHK_MAX_K=%d", k, PHK_MAX_K);
+        return PHK_ERR_UNSUPPORTED;
+    }
+    PHK_REQUIRE(n == 0 || offsets, "phk_batch_from_ascii: NULL offsets");
+    const char *sym = symbols4 ? symbols4 : "ATGC";
+    PHK_REQUIRE(strlen(sym) == 4, "phk_batch_from_ascii: symbols must be exactly 4 characters");
+    if (n) {
+        PHK_REQUIRE(offsets[0] == 0, "phk_batch_from_ascii: offsets[0] must be 0");
+        for (uint64_t c = 0; c < n; ++c)
+            PHK_REQUIRE(offsets[c + 1] >= offsets[c], "phk_batch_from_ascii: offsets must be non-decreasing");
+    }
+    const uint64_t T = n ? offsets[n] : 0;
+    PHK_REQUIRE(T == 0 || bases, "phk_batch_from_ascii: NULL bases");
+    phk_batch *b = new phk_batch();
+    b->n = n;
+    b->k = k;
+    b->D = phk_pow4(k);
+    b->T = T;
+    if (n == 0) {
+        *out = b;
+        return PHK_OK;
+    }
+    int rc = PHK_OK;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copied[2] = {nullptr, nullptr}, packed_ev[2] = {nullptr, nullptr};
+    bool registered = false;
+    void *d_chunk[2] = {nullptr, nullptr};
+    auto body = [&]() -> int {
+        if (hipMalloc(&b->d_counts, n * b->D * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc(&b->d_nwin, n * sizeof(uint32_t)) != hipSuccess) {
+            phk_set_error("phk_batch: cannot allocate %llu x %llu counts on the device", (unsigned long long)n,
+                          (unsigned long long)b->D);
+            return PHK_ERR_NOMEM;
+        }
+        void *d_packed, *d_mask, *d_off, *d_flags;
+        PHK_TRY(phk_ws(ctx, WS_PACKED, (phk_div_up(T, 16) + 1) * 4, &d_packed));
+        PHK_TRY(phk_ws(ctx, WS_MASK, (phk_div_up(T, 32) + 1) * 4, &d_mask));
+        PHK_TRY(phk_ws(ctx, WS_OFFSETS, (n + 1) * 8, &d_off));
+        const uint64_t nchunks = T ? phk_div_up(T, BATCH_CHUNK) : 0;
+        PHK_TRY(phk_ws(ctx, WS_FLAGS, (nchunks + 16) * 4, &d_flags));
+        PHK_HIP(hipMemcpyAsync(d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (T) {
+            const uint64_t chunk_bytes = T < BATCH_CHUNK ? ((T + 63) & ~63ull) : BATCH_CHUNK;
+            for (int i = 0; i < (nchunks > 1 ? 2 : 1); ++i)
+                if (hipMalloc(&d_chunk[i], chunk_bytes) != hipSuccess) return PHK_ERR_NOMEM;
+            // pin the caller's buffer in place so that the uploads are true asynchronous DMA (pageable copies are staged
+            // by the runtime and serialise with everything); if that is refused the copies below still work, just slower
+            if (nchunks > 1) registered = hipHostRegister((void *)bases, T, hipHostRegisterDefault) == hipSuccess;
+            if (!registered) (void)hipGetLastError();
+            PHK_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                PHK_HIP(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
+                PHK_HIP(hipEventCreateWithFlags(&packed_ev[i], hipEventDisableTiming));
+            }
+            for (uint64_t c = 0; c < nchunks; ++c) {
+                const int s = (int)(c & 1);
+                const uint64_t o = c * BATCH_CHUNK, len = T - o < BATCH_CHUNK ? T - o : BATCH_CHUNK;
+                if (c >= 2) PHK_HIP(hipStreamWaitEvent(copy_stream, packed_ev[s], 0));   // the packer is done with this buffer
+                PHK_HIP(hipMemcpyAsync(d_chunk[s], bases + o, len, hipMemcpyHostToDevice, copy_stream));
+                PHK_HIP(hipEventRecord(copied[s], copy_stream));
+                PHK_HIP(hipStreamWaitEvent(ctx->stream, copied[s], 0));
+                PHK_TRY(phk_launch_pack(ctx, (const char *)d_chunk[s], len, sym, (uint32_t *)d_packed + o / 16,
+                                        (uint32_t *)d_mask + o / 32, (uint32_t *)d_flags + c));
+                PHK_HIP(hipEventRecord(packed_ev[s], ctx->stream));
+            }
+        }
+        std::vector<uint32_t> flags(nchunks, 0);
+        if (nchunks) PHK_HIP(hipMemcpyAsync(flags.data(), d_flags, nchunks * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+        for (uint32_t f : flags) b->any_invalid = b->any_invalid || f != 0;
+        PHK_TRY(phk_launch_count(ctx, (const uint32_t *)d_packed, b->any_invalid ? (const uint32_t *)d_mask : nullptr, T,
+                                 (const uint64_t *)d_off, n, k, b->d_counts, b->d_nwin));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+        return PHK_OK;
+    };
+    rc = body();
+    if (copy_stream) {
+        (void)hipStreamSynchronize(copy_stream);
+        (void)hipStreamDestroy(copy_stream);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (copied[i]) (void)hipEventDestroy(copied[i]);
+        if (packed_ev[i]) (void)hipEventDestroy(packed_ev[i]);
+        if (d_chunk[i]) (void)hipFree(d_chunk[i]);
+    }
+    if (registered) (void)hipHostUnregister((void *)bases);
+    if (rc != PHK_OK) {
+        batch_release(b);
+        return rc;
+    }
+    *out = b;
+    return PHK_OK;
+}
+
+extern "C" int phk_batch_shape(const phk_batch *b, uint64_t *n, uint64_t *D, uint64_t *total_bases, int *any_invalid) {
+    PHK_REQUIRE(b, "phk_batch_shape: NULL");
+    if (n) *n = b->n;
+    if (D) *D = b->D;
+    if (total_bases) *total_bases = b->T;
+    if (any_invalid) *any_invalid = b->any_invalid ? 1 : 0;
+    return PHK_OK;
+}
+
+extern "C" int phk_batch_device_ptrs(const phk_batch *b, const uint32_t **d_counts, const uint32_t **d_rowsums) {
+    PHK_REQUIRE(b, "phk_batch_device_ptrs: NULL");
+    if (d_counts) *d_counts = b->d_counts;
+    if (d_rowsums) *d_rowsums = b->d_nwin;
+    return PHK_OK;
+}
+
+extern "C" int phk_batch_counts_i64(phk_ctx *ctx, const phk_batch *b, int64_t *counts) {
+    PHK_ENTER(ctx, "phk_batch_counts_i64");
+    PHK_REQUIRE(b && (b->n == 0 || counts), "phk_batch_counts_i64: NULL");
+    // widen on the device in slices so that the staging buffer stays small
+    const uint64_t rows_per = b->D ? ((64ull << 20) / (b->D * 8) > 0 ? (64ull << 20) / (b->D * 8) : 1) : 1;
+    void *d_wide;
+    PHK_TRY(phk_ws(ctx, WS_WIDE, (rows_per < b->n ? rows_per : b->n) * b->D * 8, &d_wide));
+    for (uint64_t r = 0; r < b->n; r += rows_per) {
+        const uint64_t m = b->n - r < rows_per ? b->n - r : rows_per;
+        PHK_TRY(phk_launch_widen(ctx, b->d_counts + r * b->D, m * b->D, (int64_t *)d_wide));
+        PHK_HIP(hipMemcpyAsync(counts + r * b->D, d_wide, m * b->D * 8, hipMemcpyDeviceToHost, ctx->stream));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PHK_OK;
+}
+
+extern "C" int phk_batch_normalized(phk_ctx *ctx, const phk_batch *b, double *rows) {
+    PHK_ENTER(ctx, "phk_batch_normalized");
+    PHK_REQUIRE(b && (b->n == 0 || rows), "phk_batch_normalized: NULL");
+    const uint64_t rows_per = b->D ? ((64ull << 20) / (b->D * 8) > 0 ? (64ull << 20) / (b->D * 8) : 1) : 1;
+    void *d_q;
+    PHK_TRY(phk_ws(ctx, WS_Q64, (rows_per < b->n ? rows_per : b->n) * b->D * 8, &d_q));
+    for (uint64_t r = 0; r < b->n; r += rows_per) {
+        const uint64_t m = b->n - r < rows_per ? b->n - r : rows_per;
+        PHK_TRY(phk_launch_normalize_u32(ctx, b->d_counts + r * b->D, m, b->D, (double *)d_q));
+        PHK_HIP(hipMemcpyAsync(rows + r * b->D, d_q, m * b->D * 8, hipMemcpyDeviceToHost, ctx->stream));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PHK_OK;
+}
+
+__global__ __launch_bounds__(256) void phk_gather_rows_kernel(const uint32_t *__restrict__ counts,
+                                                              const uint32_t *__restrict__ nwin,
+                                                              const uint64_t *__restrict__ rows, uint64_t m, uint64_t D,
+                                                              uint32_t *__restrict__ out_counts,
+                                                              uint32_t *__restrict__ out_nwin) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t total = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < m; i += total) {
+        const uint64_t r = rows[i];
+        const uint4 *src = reinterpret_cast<const uint4 *>(counts + r * D);
+        uint4 *dst = reinterpret_cast<uint4 *>(out_counts + i * D);
+        for (uint64_t j = lane; j < D / 4; j += 64) dst[j] = src[j];
+        for (uint64_t j = (D / 4) * 4 + lane; j < D; j += 64) out_counts[i * D + j] = counts[r * D + j];
+        if (lane == 0) out_nwin[i] = nwin[r];
+    }
+}
+
+// the rows `rows[0..m)` of a batch as a new batch (phamer_scorer.screen_by_length's row filter, scripts/phamer.py:
+// 144-157, on the device)
+extern "C" int phk_batch_select(phk_ctx *ctx, const phk_batch *b, const uint64_t *rows, uint64_t m, phk_batch **out) {
+    PHK_ENTER(ctx, "phk_batch_select");
+    PHK_REQUIRE(b && out && (m == 0 || rows), "phk_batch_select: NULL");
+    for (uint64_t i = 0; i < m; ++i) PHK_REQUIRE(rows[i] < b->n, "phk_batch_select: row %llu out of range", (unsigned long long)rows[i]);
+    phk_batch *s = new phk_batch();
+    s->n = m;
+    s->k = b->k;
+    s->D = b->D;
+    s->any_invalid = b->any_invalid;
+    if (m == 0) {
+        *out = s;
+        return PHK_OK;
+    }
+    void *d_rows;
+    int rc = phk_ws(ctx, WS_OFFSETS, m * 8, &d_rows);
+    if (rc == PHK_OK && (hipMalloc(&s->d_counts, m * s->D * sizeof(uint32_t)) != hipSuccess ||
+                         hipMalloc(&s->d_nwin, m * sizeof(uint32_t)) != hipSuccess))
+        rc = PHK_ERR_NOMEM;
+    if (rc != PHK_OK) {
+        batch_release(s);
+        return rc;
+    }
+    auto body = [&]() -> int {
+        PHK_HIP(hipMemcpyAsync(d_rows, rows, m * 8, hipMemcpyHostToDevice, ctx->stream));
+        uint64_t blocks = phk_div_up(m, 4);
+        if (blocks > (uint64_t)ctx->num_cus * 16) blocks = (uint64_t)ctx->num_cus * 16;
+        PHK_LAUNCH(ctx, "phk_gather_rows_kernel",
+                   phk_gather_rows_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(
+                       b->d_counts, b->d_nwin, (const uint64_t *)d_rows, m, b->D, s->d_counts, s->d_nwin));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+        return PHK_OK;
+    };
+    rc = body();
+    if (rc != PHK_OK) {
+        batch_release(s);
+        return rc;
+    }
+    *out = s;
+    return PHK_OK;
+}
+
+// phamer_scorer.score_points on a device-resident batch (scripts/phamer.py:177-195): scores[n] to the host.
+// A zero-count row (the reference's NaN row) makes the call fail with PHK_ERR_NAN, as phk_score does.
+extern "C" int phk_batch_score(phk_ctx *ctx, const phk_model *model, const phk_batch *b, int method, double *scores) {
+    PHK_ENTER(ctx, "phk_batch_score");
+    PHK_REQUIRE(model && b, "phk_batch_score: NULL model/batch");
+    PHK_REQUIRE(b->D == model->D, "phk_batch_score: batch has %llu columns, model %llu", (unsigned long long)b->D,
+                (unsigned long long)model->D);
+    if (b->n == 0) return PHK_OK;
+    PHK_REQUIRE(scores, "phk_batch_score: NULL scores");
+    void *d_s, *d_flags;
+    PHK_TRY(phk_ws(ctx, WS_OUT, b->n * 8 + 64, &d_s));
+    PHK_TRY(phk_ws(ctx, WS_FLAGS, 64, &d_flags));
+    PHK_TRY(phk_score_rows(ctx, model, nullptr, b->d_counts, b->d_nwin, b->n, method, (double *)d_s, (uint32_t *)d_flags));
+    uint32_t nan_rows = 0;
+    PHK_HIP(hipMemcpyAsync(&nan_rows, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipMemcpyAsync(scores, d_s, b->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    if (nan_rows) {
+        phk_set_error("phk_batch_score: %u row(s) have no counted window (NaN after normalisation)", nan_rows);
+        return PHK_ERR_NAN;
+    }
+    return PHK_OK;
+}
+
+extern "C" int phk_batch_free(phk_ctx *ctx, phk_batch *b) {
+    if (!b) return PHK_OK;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    batch_release(b);
+    return PHK_OK;
+}

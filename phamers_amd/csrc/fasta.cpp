@@ -383,6 +383,14 @@ extern "C" int phk_fasta_free(phk_fasta *f) {
     return PHK_OK;
 }
 
+extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n, int k,
+                                    const char *symbols4, phk_batch **out);
+
+extern "C" int phk_batch_from_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *symbols4, phk_batch **out) {
+    PHK_REQUIRE(ctx && f, "phk_batch_from_fasta: NULL");
+    return phk_batch_from_ascii(ctx, f->bases.data(), f->offsets.data(), f->offsets.size() - 1, k, symbols4, out);
+}
+
 extern "C" int phk_count_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *symbols4, int64_t *counts) {
     PHK_REQUIRE(ctx && f, "phk_count_fasta: NULL");
     return phk_count_ascii(ctx, f->bases.data(), f->offsets.data(), f->offsets.size() - 1, k, symbols4, counts);

@@ -62,6 +62,7 @@ enum PhkSlot {
     WS_CAND,        // scoring (MFMA path): candidate lists
     WS_NWIN,        // row sums
     WS_LONG,        // counting: contigs handed from the lane-pair kernel to the wave-per-contig kernel
+    WS_OUT,         // batch API: scores on their way to the host
     WS_SLOTS
 };
 

@@ -65,20 +65,22 @@ def rank_device():
 
 
 def default_scorer(device_index=None):
-    """Per-rank scorer running the GPU path: (sequences, k, method, model inputs) -> scores."""
-    from . import _lib, kmer
+    """Per-rank scorer on the GPU path, device resident: (sequences, k, method, model inputs) -> scores.  The shard's
+    bases go up once, counts and row sums stay in HBM (_lib.Batch), only the scores come back."""
+    from . import _lib
 
     def score(sequences, kmer_length, method, positive, negative, cpos, cneg, k_neighbors):
         if len(sequences) == 0:
             return np.zeros(0)
-        counts = kmer.count(list(sequences), kmer_length).reshape(len(sequences), -1)
-        q = kmer.normalize_counts(counts)
-        model = _lib.Model(_lib.get_context(device_index), positive, negative,
-                           cpos if method != "knn" else None, cneg if method != "knn" else None, k_neighbors)
+        ctx = _lib.get_context(device_index)
+        batch = _lib.Batch.from_sequences(ctx, list(sequences), kmer_length)
+        model = _lib.Model(ctx, positive, negative, cpos if method != "knn" else None,
+                           cneg if method != "knn" else None, k_neighbors)
         try:
-            return model.score(q, method)
+            return batch.score(model, method)
         finally:
             model.close()
+            batch.close()
     return score
 
 

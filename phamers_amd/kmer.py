@@ -111,11 +111,16 @@ def count_file(input_file, kmer_length, symbols=DNA, normalize=False):
         ids = fasta.phamers_ids()
         counts = np.zeros((len(ids), pow(len(symbols), kmer_length)), dtype=(int, float)[normalize])
         if fasta.n_records:
-            got = fasta.count(_lib.get_context(), kmer_length, sym)
-            if normalize:
-                sums = got.sum(axis=1)
-                got = normalize_counts(got)
-                got[sums == 0] = 0.0
+            # bases up once, counts down once (device-resident batch)
+            batch = _lib.Batch.from_fasta(_lib.get_context(), fasta, kmer_length, sym)
+            try:
+                got = batch.counts()
+                if normalize:
+                    sums = got.sum(axis=1)
+                    got = batch.normalized()
+                    got[sums == 0] = 0.0
+            finally:
+                batch.close()
             counts[:, :] = got
     finally:
         fasta.close()

@@ -1,15 +1,23 @@
 """
-phamer.py -- drop-in for the scoring entry points of PhaMers' scripts/phamer.py.
+phamer.py -- drop-in for the scoring entry points of PhaMers' scripts/phamer.py, device resident.
 
-    phamer_scorer (attributes + score_points / knn_ / kmeans_ / combo_score_points,
-                   equalize_reference_data)                     scripts/phamer.py:42-313
-    score_points(scoring_data, positive_training_data,
-                 negative_training_data, method=None)           scripts/phamer.py:451-468
+    phamer_scorer            attribute surface + load_data / screen_by_length / equalize_reference_data /
+                             score_points / knn_ / kmeans_ / combo_score_points      scripts/phamer.py:42-313
+    score_points(scoring_data, positive_training_data, negative_training_data, method=None)
+                                                                                    scripts/phamer.py:451-468
+    main()                   `python -m phamers_amd.phamer -in <dir> -data <dir> [-e]`  scripts/phamer.py:512-598
 
-The distance / vote / proximity arithmetic runs on the GPU (libphamers_hip.so); the k-means
-fit that yields the centroids is scikit-learn's, as in the reference.  Methods outside
-{knn, kmeans, combo} raise NotImplementedError (dbscan / svm / density / silhouette are
-out of the accelerated path).
+Data path.  A FASTA input is parsed once by the native reader, its bases are uploaded once, and from there the
+contigs live on the GPU as a `_lib.Batch` (uint32 counts + row sums in HBM): the length screen is a device row
+gather, scoring runs on the resident counts, and the host sees the scores -- plus the count matrix once, for the
+features cache the reference writes next to the FASTA (scripts/phamer.py:132-134).  ``data_points`` keeps its
+reference meaning (the normalised float64 matrix) but is materialised from the device only if somebody reads it;
+assigning it (as phamer.score_points and the cross-validation do) switches the object to host rows, which are
+scored through the float64-row entry point.
+
+The k-means fit that yields the centroids is scikit-learn's, as in the reference (learning.kmeans).  Methods
+outside {knn, kmeans, combo} raise NotImplementedError: dbscan / svm / density / silhouette are outside the
+accelerated path.
 """
 import argparse
 import logging
@@ -19,254 +27,278 @@ import numpy as np
 
 from . import _lib
 from . import fileIO
-from . import kmer
 from . import learning
 
 logging.basicConfig(format='[%(asctime)s][%(levelname)s][%(funcName)s] - %(message)s')
 logger = logging.getLogger(__name__)
 logger.setLevel(logging.WARNING)
 
+_GPU_METHODS = ('knn', 'kmeans', 'combo')
+_OTHER_METHODS = ('dbscan', 'svm', 'density', 'silhouette')
+
+
+def _lone(directory, suffixes, avoid_stem_suffix=None):
+    """The file of `directory` the reference would pick (scripts/phamer.py:417-436): the only one with one of
+    `suffixes`; among several, the first whose stem does not end in `avoid_stem_suffix`, else the first."""
+    if not directory or not os.path.isdir(directory):
+        return None
+    names = [f for f in os.listdir(directory) if f.endswith(suffixes)]
+    if not names:
+        return None
+    if len(names) > 1 and avoid_stem_suffix is None:
+        return None
+    for name in names:
+        if len(names) == 1 or not os.path.splitext(name)[0].endswith(avoid_stem_suffix):
+            return os.path.join(directory, name)
+    return os.path.join(directory, names[0])
+
 
 class phamer_scorer(object):
 
     def __init__(self):
-        # file locations (scripts/phamer.py:46-57)
-        self.input_directory = None
-        self.features_file = None
-        self.fasta_file = None
-        self.data_directory = None
-        self.positive_features_file = None
-        self.negative_features_file = None
+        # where things are (scripts/phamer.py:46-57)
+        self.input_directory = self.fasta_file = self.features_file = None
+        self.data_directory = self.positive_features_file = self.negative_features_file = None
         self.output_directory = None
-
-        # the attributes of the reference object that the hot path reads (scripts/phamer.py:59-79)
+        # what the hot path reads (scripts/phamer.py:59-79)
         self.data_ids = None
-        self.data_points = None
-        self.positive_ids = None
-        self.positive_data = None
-        self.negative_ids = None
-        self.negative_data = None
-
+        self.positive_ids = self.positive_data = None
+        self.negative_ids = self.negative_data = None
         self.length_requirement = 5000
-
         self.scoring_method = 'combo'
         self.all_scoring_methods = ['dbscan', 'kmeans', 'knn', 'svm', 'density', 'silhouette', 'combo']
-        self.method_function_map = {
-            'kmeans': self.kmeans_score_points, 'knn': self.knn_score_points,
-            'combo': self.combo_score_points,
-            'dbscan': self._outside_path, 'svm': self._outside_path,
-            'density': self._outside_path, 'silhouette': self._outside_path,
-        }
-
+        self.method_function_map = dict(
+            [(m, getattr(self, m + '_score_points')) for m in _GPU_METHODS] + [(m, self._outside_path) for m in _OTHER_METHODS])
         self.kmer_length = 4
         self.k_clusters = 86
         self.k_neighbors = 3
+        # centroids of the last kmeans / combo call (inspection, tests)
+        self.positive_centroids = self.negative_centroids = None
+        self.scores = None
+        # query side: device-resident batch and / or host rows
+        self._batch = None
+        self._rows = None
 
-        # centroids of the last kmeans / combo call (captured for inspection and tests)
-        self.positive_centroids = None
-        self.negative_centroids = None
+    # ---- data_points: the reference's attribute, lazily backed by the device batch --------------------
+    @property
+    def data_points(self):
+        if self._rows is None and self._batch is not None:
+            self._rows = self._batch.normalized()
+        return self._rows
 
-    # ---- files either side of the path (scripts/phamer.py:103-157, 316-323, 406-440) ------------
+    @data_points.setter
+    def data_points(self, rows):
+        self._rows = rows
+        self._drop_batch()
+
+    def _drop_batch(self):
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None
+
+    # ---- files either side of the path ------------------------------------------------------------------
     def find_data_files(self):
-        """Reference feature files at their default place under the data directory
-        (scripts/phamer.py:406-415)."""
-        self.positive_features_file = os.path.join(self.data_directory, "reference_features", "positive_features.csv")
-        self.negative_features_file = os.path.join(self.data_directory, "reference_features", "negative_features.csv")
+        """Default reference files under the data directory (scripts/phamer.py:406-415)."""
+        ref = os.path.join(self.data_directory, "reference_features")
+        self.positive_features_file = os.path.join(ref, "positive_features.csv")
+        self.negative_features_file = os.path.join(ref, "negative_features.csv")
 
     def find_input_files(self):
-        """The lone *.fasta|*.fa (not '*genes') and the lone *.csv of the input directory
-        (scripts/phamer.py:417-436)."""
-        if self.input_directory and os.path.isdir(self.input_directory):
-            fasta_files = [f for f in os.listdir(self.input_directory) if f.endswith('.fasta') or f.endswith('.fa')]
-            if len(fasta_files) == 1:
-                self.fasta_file = os.path.join(self.input_directory, fasta_files[0])
-            elif fasta_files:
-                for candidate in fasta_files:
-                    if not os.path.splitext(candidate)[0].endswith("genes"):
-                        self.fasta_file = os.path.join(self.input_directory, candidate)
-                        break
-                if self.fasta_file is None:
-                    self.fasta_file = os.path.join(self.input_directory, fasta_files[0])
-            features_files = [f for f in os.listdir(self.input_directory) if f.endswith('.csv')]
-            if len(features_files) == 1:
-                self.features_file = os.path.join(self.input_directory, features_files[0])
+        """scripts/phamer.py:417-436: the FASTA (not the '*genes' one) and the lone features CSV of the input directory."""
+        self.fasta_file = _lone(self.input_directory, ('.fasta', '.fa'), avoid_stem_suffix="genes") or self.fasta_file
+        self.features_file = _lone(self.input_directory, ('.csv',)) or self.features_file
 
     def load_data(self, length_requirement=True):
-        """Reference matrices (normalised) + query features: a cached features CSV if the input
-        directory has one, else count the FASTA on the GPU and write the cache next to it
-        (scripts/phamer.py:103-142).  ``length_requirement`` truthy applies the length screen, which --
-        as in the reference -- always uses self.length_requirement (5000), not the CLI value."""
+        """Reference matrices (normalised) and the query contigs (scripts/phamer.py:103-142).  Queries come from the
+        cached features CSV when the input directory has one; otherwise the FASTA is counted on the GPU, the counts are
+        written through to ``<fasta>_features.csv`` and stay on the device for scoring.  A truthy
+        ``length_requirement`` applies the length screen -- always with self.length_requirement (5000), as in the
+        reference, whose CLI value is never forwarded."""
         self.positive_ids, self.positive_data = fileIO.read_feature_file(self.positive_features_file, normalize=True)
         self.negative_ids, self.negative_data = fileIO.read_feature_file(self.negative_features_file, normalize=True)
         self.find_input_files()
-        if self.features_file is not None and os.path.exists(self.features_file):
+        lengths = None
+        if self.features_file and os.path.exists(self.features_file):
             logger.info("Reading features from: %s..." % os.path.basename(self.features_file))
-            self.data_ids, self.data_points = fileIO.read_feature_file(self.features_file)
-        elif self.fasta_file is not None and os.path.exists(self.fasta_file):
+            from . import kmer
+            self.data_ids, counts = fileIO.read_feature_file(self.features_file)
+            self.data_points = kmer.normalize_counts(counts)
+        elif self.fasta_file and os.path.exists(self.fasta_file):
             logger.info("Calculating features of: %s" % os.path.basename(self.fasta_file))
-            self.data_ids, self.data_points = kmer.count_file(self.fasta_file, self.kmer_length, normalize=False)
-            self.features_file = "{base}_features.csv".format(base=os.path.splitext(self.fasta_file)[0])
-            fileIO.save_counts(self.data_points, self.data_ids, self.features_file)
+            lengths = self._count_fasta_on_device()
         else:
             raise SystemExit("No input fasta file or features file. Exiting...")
-        self.data_points = kmer.normalize_counts(self.data_points)
         if length_requirement:
-            self.screen_by_length()
+            self.screen_by_length(_lengths=lengths)
 
-    def screen_by_length(self, length_requirement=None):
-        """Keep contigs with at least ``length_requirement`` bases (scripts/phamer.py:144-157)."""
+    def _count_fasta_on_device(self):
+        ctx = _lib.get_context()
+        fasta = _lib.Fasta(self.fasta_file)
+        try:
+            self.data_ids = fasta.phamers_ids()
+            lengths = fasta.lengths()
+            self._drop_batch()
+            self._rows = None
+            self._batch = _lib.Batch.from_fasta(ctx, fasta, self.kmer_length)
+        finally:
+            fasta.close()
+        self.features_file = "{base}_features.csv".format(base=os.path.splitext(self.fasta_file)[0])
+        fileIO.save_counts(self._batch.counts(), self.data_ids, self.features_file)
+        return lengths
+
+    def screen_by_length(self, length_requirement=None, _lengths=None):
+        """Keep contigs of at least ``length_requirement`` bases (scripts/phamer.py:144-157): ids filtered on the host,
+        rows by a device gather when the contigs are resident."""
         if length_requirement:
             self.length_requirement = length_requirement
-        if self.fasta_file is None or not os.path.exists(self.fasta_file):
-            return
-        unknown_ids, lengths = kmer.fasta_lengths(self.fasta_file)
-        long_ids = [unknown_ids[i] for i in range(len(unknown_ids)) if lengths[i] >= self.length_requirement]
-        self.data_points = self.data_points[np.isin(self.data_ids, long_ids)]
+        if _lengths is None:
+            if not self.fasta_file or not os.path.exists(self.fasta_file):
+                return
+            from . import kmer
+            fasta_ids, _lengths = kmer.fasta_lengths(self.fasta_file)
+        else:
+            fasta_ids = self.data_ids
+        long_ids = np.asarray(fasta_ids)[np.asarray(_lengths) >= self.length_requirement]
+        keep = np.isin(self.data_ids, long_ids)
+        if self._batch is not None:
+            old, self._batch = self._batch, self._batch.select(np.flatnonzero(keep))
+            old.close()
+            self._rows = None if self._rows is None else self._rows[keep]
+        elif self._rows is not None:
+            self._rows = self._rows[keep]
         self.data_ids = np.array(long_ids)
 
     def get_phamer_output_filename(self):
         return os.path.join(self.output_directory, "phamer_scores.csv")
 
     def make_summary_file(self, args=None):
-        """Write phamer_scores.csv (scripts/phamer.py:316-323)."""
+        """phamer_scores.csv (scripts/phamer.py:316-323)."""
         self.phamer_output_filename = self.get_phamer_output_filename()
         fileIO.save_phamer_scores(self.data_ids, self.scores, self.phamer_output_filename, args=args)
 
-    def _outside_path(self):
-        raise NotImplementedError("scoring method %r is outside the accelerated path; "
-                                  "knn / kmeans / combo are available" % (self.scoring_method,))
-
+    # ---- scoring ------------------------------------------------------------------------------------------
     def equalize_reference_data(self):
-        """Same number of positive and negative rows: the FIRST min(n+, n-) rows of each
-        (scripts/phamer.py:159-175)."""
-        num_positive = self.positive_data.shape[0]
-        num_negative = self.negative_data.shape[0]
-        if num_negative == num_positive:
-            return
-        num_ref = min(num_positive, num_negative)
-        logger.debug("Equalizing reference data to: %d data points" % num_ref)
-        self.positive_data = self.positive_data[:num_ref]
-        self.negative_data = self.negative_data[:num_ref]
-        if self.positive_ids is not None:
-            self.positive_ids = self.positive_ids[:num_ref]
-        if self.negative_ids is not None:
-            self.negative_ids = self.negative_ids[:num_ref]
-        self.num_positive = num_ref
-        self.num_negative = num_ref
+        """The FIRST min(n+, n-) rows of each class (scripts/phamer.py:159-175)."""
+        m = min(self.positive_data.shape[0], self.negative_data.shape[0])
+        if self.positive_data.shape[0] != self.negative_data.shape[0]:
+            logger.debug("Equalizing reference data to: %d data points" % m)
+            self.positive_data, self.negative_data = self.positive_data[:m], self.negative_data[:m]
+            self.positive_ids = None if self.positive_ids is None else self.positive_ids[:m]
+            self.negative_ids = None if self.negative_ids is None else self.negative_ids[:m]
+            self.num_positive = self.num_negative = m
 
     def score_points(self):
-        """Scores ``data_points`` against ``positive_data`` / ``negative_data`` with
-        ``scoring_method`` (scripts/phamer.py:177-195)."""
-        self.num_points = self.data_points.shape[0]
-        self.num_positive = self.positive_data.shape[0]
-        self.num_negative = self.negative_data.shape[0]
-        scoring_function = self.method_function_map[self.scoring_method]
-        logger.debug("Scoring %d points. Method: %s..." % (self.data_points.shape[0], self.scoring_method))
-        self.scores = np.array(scoring_function())
+        """Scores the query contigs against ``positive_data`` / ``negative_data`` with ``scoring_method``
+        (scripts/phamer.py:177-195)."""
+        self.num_points = self._batch.n if self._batch is not None else self.data_points.shape[0]
+        self.num_positive, self.num_negative = self.positive_data.shape[0], self.negative_data.shape[0]
+        logger.debug("Scoring %d points. Method: %s..." % (self.num_points, self.scoring_method))
+        self.scores = np.array(self.method_function_map[self.scoring_method]())
         return self.scores
 
+    def _outside_path(self):
+        raise NotImplementedError("scoring method %r is outside the accelerated path; knn / kmeans / combo are "
+                                  "available" % (self.scoring_method,))
+
     def _fit_centroids(self):
-        """scripts/phamer.py:245-248: k-means with k_clusters on each class, then centroids."""
-        pa = learning.kmeans(self.positive_data, self.k_clusters)
-        na = learning.kmeans(self.negative_data, self.k_clusters)
-        self.positive_centroids = learning.get_centroids(self.positive_data, pa)
-        self.negative_centroids = learning.get_centroids(self.negative_data, na)
+        """k-means with k_clusters on each class, then the cluster means (scripts/phamer.py:245-248)."""
+        self.positive_centroids, self.negative_centroids = (
+            learning.get_centroids(d, learning.kmeans(d, self.k_clusters)) for d in (self.positive_data, self.negative_data))
 
     def _gpu_score(self, method):
-        q = np.asarray(self.data_points, dtype=np.float64)
-        if np.isnan(q).any():
-            # the reference reaches scikit-learn, which raises on NaN input (zero-count contig)
-            raise ValueError("Input contains NaN.")
-        centroids = (self.positive_centroids, self.negative_centroids) if method != 'knn' else (None, None)
+        with_centroids = method != 'knn'
+        if with_centroids:
+            self._fit_centroids()
         model = _lib.Model(_lib.get_context(), self.positive_data, self.negative_data,
-                           centroids[0], centroids[1], k_neighbors=self.k_neighbors)
+                           self.positive_centroids if with_centroids else None,
+                           self.negative_centroids if with_centroids else None, k_neighbors=self.k_neighbors)
         try:
+            if self._batch is not None:
+                return self._batch.score(model, method)          # resident counts; NaN rows raise ValueError
+            q = np.asarray(self._rows, dtype=np.float64)
+            if np.isnan(q).any():
+                raise ValueError("Input contains NaN.")           # what scikit-learn raises for the reference
             return model.score(q, method)
         finally:
             model.close()
-
-    def kmeans_score_points(self):
-        """scripts/phamer.py:240-256: tanh proximity metric to the nearest centroid of each class."""
-        self._fit_centroids()
-        return self._gpu_score('kmeans')
 
     def knn_score_points(self):
         """scripts/phamer.py:268-273."""
         return self._gpu_score('knn')
 
+    def kmeans_score_points(self):
+        """scripts/phamer.py:240-256: tanh proximity metric to the nearest centroid of each class."""
+        return self._gpu_score('kmeans')
+
     def combo_score_points(self):
         """scripts/phamer.py:303-313: knn score + kmeans score (one fused GPU pass)."""
-        self._fit_centroids()
         return self._gpu_score('combo')
 
 
 def score_points(scoring_data, positive_training_data, negative_training_data, method=None):
-    """Functional form of phamer_scorer.score_points (scripts/phamer.py:451-468), used by the
+    """Functional form of phamer_scorer.score_points (scripts/phamer.py:451-468), the scoring function of the
     reference's cross-validation (scripts/cross_validate.py:95)."""
     scorer = phamer_scorer()
-    if method is not None:
-        scorer.scoring_method = method
+    scorer.scoring_method = method or scorer.scoring_method
     scorer.data_points = scoring_data
-    scorer.positive_data = positive_training_data
-    scorer.negative_data = negative_training_data
+    scorer.positive_data, scorer.negative_data = positive_training_data, negative_training_data
     return scorer.score_points()
 
 
 def score_contigs(sequences, positive_training_data, negative_training_data, kmer_length=4, method='combo'):
-    """Convenience: count -> normalise -> score a list of contig strings (what phamer.py's
-    load_data + score_points do for a FASTA input, scripts/phamer.py:131,139,579)."""
-    counts = kmer.count(list(sequences), kmer_length)
-    counts = counts.reshape(-1, 4 ** kmer_length)
-    return score_points(kmer.normalize_counts(counts), positive_training_data, negative_training_data, method)
+    """Count -> normalise -> score a list of contig strings, device resident (what load_data + score_points do for a
+    FASTA input, scripts/phamer.py:131,139,579)."""
+    scorer = phamer_scorer()
+    scorer.scoring_method = method
+    scorer.kmer_length = kmer_length
+    scorer._batch = _lib.Batch.from_sequences(_lib.get_context(), list(sequences), kmer_length)
+    scorer.positive_data, scorer.negative_data = positive_training_data, negative_training_data
+    try:
+        return scorer.score_points()
+    finally:
+        scorer._drop_batch()
 
 
 def main(argv=None):
-    """Command-line driver with the reference's flags for this path (scripts/phamer.py:512-598):
+    """The reference's command line for this path (scripts/phamer.py:512-598), cut to what the path uses:
         python -m phamers_amd.phamer -in <input_dir> -data <data_dir> [--equalize_reference]
-    Counting, normalising and scoring run on the GPU; the scores go to
-    <input_dir>/phamer_output/phamer_scores.csv (or -out).  As in the reference the scoring method
-    is always 'combo' (--method is parsed but never applied there)."""
-    parser = argparse.ArgumentParser(description='This script scores contigs based on feature similarity',
-                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument('-in', '--input_directory', help='Directory containing input files')
-    parser.add_argument('-fasta', '--fasta_file', help='Fasta compilation file of unknown sequences')
-    parser.add_argument('-features', '--features_file', help='Input feature file')
-    parser.add_argument('-data', '--data_directory', help='Directory containing reference_features/')
-    parser.add_argument('-pf', '--positive_features', help='Positive reference features CSV')
-    parser.add_argument('-nf', '--negative_features', help='Negative reference features CSV')
-    parser.add_argument('-out', '--output_directory', help='Output directory path')
-    parser.add_argument('-k', '--kmer_length', type=int, default=4, help='k-mer length')
-    parser.add_argument('-l', '--length_requirement', type=int, default=5000, help='Input sequence length requirement')
-    parser.add_argument('-e', '--equalize_reference', action='store_true', help='Same number of reference points')
-    parser.add_argument('-v', '--verbose', action='store_true')
-    parser.add_argument('--debug', action='store_true')
-    args = parser.parse_args(argv)
+    Scores go to <input_dir>/phamer_output/phamer_scores.csv (or -out).  As in the reference the method is always
+    'combo' (its --method is parsed and never applied)."""
+    ap = argparse.ArgumentParser(description='This script scores contigs based on feature similarity',
+                                 formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    for flags, kw in (
+            (('-in', '--input_directory'), dict(help='Directory containing input files')),
+            (('-fasta', '--fasta_file'), dict(help='Fasta compilation file of unknown sequences')),
+            (('-features', '--features_file'), dict(help='Input feature file')),
+            (('-data', '--data_directory'), dict(help='Directory containing reference_features/')),
+            (('-pf', '--positive_features'), dict(help='Positive reference features CSV')),
+            (('-nf', '--negative_features'), dict(help='Negative reference features CSV')),
+            (('-out', '--output_directory'), dict(help='Output directory path')),
+            (('-k', '--kmer_length'), dict(type=int, default=4, help='k-mer length')),
+            (('-l', '--length_requirement'), dict(type=int, default=5000, help='Input sequence length requirement')),
+            (('-e', '--equalize_reference'), dict(action='store_true', help='Same number of reference points')),
+            (('-v', '--verbose'), dict(action='store_true')),
+            (('--debug',), dict(action='store_true'))):
+        ap.add_argument(*flags, **kw)
+    args = ap.parse_args(argv)
     logger.setLevel(logging.DEBUG if args.debug else logging.INFO if args.verbose else logging.WARNING)
 
     scorer = phamer_scorer()
     scorer.kmer_length = args.kmer_length
-    scorer.input_directory = args.input_directory
-    scorer.fasta_file = args.fasta_file
-    scorer.features_file = args.features_file
+    scorer.input_directory, scorer.fasta_file, scorer.features_file = args.input_directory, args.fasta_file, args.features_file
     if args.data_directory:
         scorer.data_directory = args.data_directory
         scorer.find_data_files()
-    if args.positive_features:
-        scorer.positive_features_file = args.positive_features
-    if args.negative_features:
-        scorer.negative_features_file = args.negative_features
+    scorer.positive_features_file = args.positive_features or scorer.positive_features_file
+    scorer.negative_features_file = args.negative_features or scorer.negative_features_file
     if not (scorer.positive_features_file and scorer.negative_features_file):
-        parser.error("give -data <dir with reference_features/> or -pf and -nf")
-    if args.output_directory:
-        scorer.output_directory = args.output_directory
-    else:
-        base = args.input_directory or os.path.dirname(args.fasta_file or args.features_file or '.')
-        scorer.output_directory = os.path.join(base, "phamer_output")
+        ap.error("give -data <dir with reference_features/> or -pf and -nf")
+    scorer.output_directory = args.output_directory or os.path.join(
+        args.input_directory or os.path.dirname(args.fasta_file or args.features_file or '.'), "phamer_output")
     scorer.load_data(length_requirement=args.length_requirement)
     if args.equalize_reference:
         scorer.equalize_reference_data()
-    if not os.path.isdir(scorer.output_directory):
-        os.makedirs(scorer.output_directory)
+    os.makedirs(scorer.output_directory, exist_ok=True)
     scorer.score_points()
     scorer.make_summary_file(args=args)
     return scorer

@@ -150,6 +150,11 @@ def test_config0_cli_end_to_end(tmp_path):
     scorer = phamer.main(["-in", str(indir), "-data", str(tmp_path / "data"), "--equalize_reference"])
     out = indir / "phamer_output" / "phamer_scores.csv"
     assert out.exists() and (indir / "contigs_features.csv").exists()      # scores + features cache
+    # the run was device resident: the contigs were scored from the counts in HBM (100 of 101 after the length
+    # screen) and the normalised float64 matrix was never brought to the host ...
+    assert scorer._batch is not None and scorer._batch.n == 100 and scorer._rows is None
+    # ... until somebody reads the reference's attribute
+    assert scorer.data_points.shape == (100, 256) and np.array_equal(scorer.data_points, g["q"])
     got = fileIO.read_phamer_output(str(out))
     assert sorted(got, key=int) == [str(c) for c in range(100)]
     scores = np.array([got[str(c)] for c in range(100)])
@@ -165,4 +170,8 @@ def test_config0_cli_end_to_end(tmp_path):
     first = out.read_text()
     phamer.main(["-in", str(indir), "-data", str(tmp_path / "data"), "--equalize_reference", "-l", "0"])
     assert fileIO.read_phamer_output(str(out)).keys() >= got.keys()
-    assert first.split("\n# \n")[-1].splitlines()[:100] == out.read_text().split("\n# \n")[-1].splitlines()[:100]
+    # (the first run scored the resident integer counts, this one the cached float64 rows: two float64 forms of the
+    # same distances, equal to rounding)
+    again = fileIO.read_phamer_output(str(out))
+    assert helpers.rel_err(np.array([again[str(c)] for c in range(100)]), scores) < 1e-12
+    assert first.count("\n") == out.read_text().count("\n") - 1    # the 12-base contig is scored without the screen

@@ -501,3 +501,45 @@ def test_two_contexts_on_two_threads():
             assert np.array_equal(counts, ref[key][0][0]) and np.array_equal(scores, ref[key][0][1]), key
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+def test_device_resident_batch_facade():
+    """_lib.Batch (phk_batch_*): sequences up once, counts / row sums resident; counts(), normalized(), select() and
+    score() against the host-pointer entry points and the golden scores; a zero-count row raises like scikit-learn."""
+    from phamers_amd import _lib, kmer, phamer, synth
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    ctx = _lib.get_context()
+    seqs = synth.synth_contigs(0, 100, 5000)
+    batch = _lib.Batch.from_sequences(ctx, seqs, 4)
+    assert (batch.n, batch.D, batch.total_bases, batch.any_invalid) == (100, 256, 500000, False)
+    assert np.array_equal(batch.counts(), g["q_counts"])
+    assert np.array_equal(batch.normalized(), g["q"])
+    model = _lib.Model(ctx, pos, neg, g["cpos_full"], g["cneg_full"], 3)
+    assert helpers.rel_err(batch.score(model, "combo"), g["combo_full"]) < RTOL
+    assert np.array_equal(batch.score(model, "knn"), g["knn_full"])
+    rows = np.array([99, 3, 3, 40])
+    sub = batch.select(rows)
+    assert np.array_equal(sub.counts(), g["q_counts"][rows])
+    assert helpers.rel_err(sub.score(model, "kmeans"), g["kmeans_full"][rows]) < RTOL
+    sub.close()
+    batch.close()
+    # invalid characters + an all-N contig: mask path, NaN row
+    mixed = [seqs[0], "N" * 300, seqs[1][:2000] + "nnnn" + seqs[1][2004:], ""]
+    b2 = _lib.Batch.from_sequences(ctx, mixed, 4)
+    assert b2.any_invalid
+    assert np.array_equal(b2.counts(), kmer.count(mixed, 4))
+    with pytest.raises(ValueError):
+        b2.score(model, "combo")
+    ok = b2.select([0, 2])
+    from oracle import oracle
+    q = oracle.normalize_counts(oracle.count([mixed[0], mixed[2]], 4))
+    want = oracle.score_points(q, pos, neg, "combo", 3, g["cpos_full"], g["cneg_full"])
+    assert helpers.rel_err(ok.score(model, "combo"), want) < RTOL
+    ok.close()
+    b2.close()
+    model.close()
+    # the string-list convenience of the facade runs on the same path
+    got = phamer.score_contigs(seqs, pos, neg, 4, "knn")
+    assert np.array_equal(got, g["knn_full"])
