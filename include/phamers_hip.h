@@ -144,6 +144,19 @@ int phk_fasta_ids_fixed(const phk_fasta *f, uint64_t width, char *out);
 /* kmer.count_file's counting loop (scripts/kmer.py:135-139) on a parsed file: counts[n][4^k] int64 */
 int phk_count_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *symbols4, int64_t *counts);
 
+/* ---- on-disk formats either side of the path (host only) ------------------------------- */
+/* fileIO.save_counts (scripts/fileIO.py:169-181): `prefix` (the '# ' header block, NUL-terminated, may be NULL) then
+ * one "id,c0,c1,...\n" line per row; counts are uint32 (elem_bytes 4) or int64 (8), [n][D].  ids: concatenated bytes
+ * + id_offsets[n+1].  Formatted on all cores; byte-identical to the reference's np.savetxt output. */
+int phk_write_counts_csv(const char *path, const char *prefix, const char *ids, const uint64_t *id_offsets,
+                         const void *counts, int elem_bytes, uint64_t n, uint64_t D);
+/* fileIO.save_phamer_scores (scripts/fileIO.py:241-253): "id, score\n" lines, the score written as
+ * str(numpy.float64) writes it (shortest round-trip digits, Python's positional / scientific rule). */
+int phk_write_scores_csv(const char *path, const char *prefix, const char *ids, const uint64_t *id_offsets,
+                         const double *scores, uint64_t n);
+/* one float64 in that notation (NUL-terminated) */
+int phk_format_float(double v, char *out, int cap);
+
 /* ---- device-resident contig batches (the facade's data path) ------------------------- */
 /* What a PhaMers user calls on a FASTA input -- phamer_scorer.load_data + score_points (scripts/phamer.py:131, 139,
  * 579), kmer.count_file (scripts/kmer.py:114-140) -- with every intermediate kept on the device.  A batch is built
@@ -158,6 +171,8 @@ int phk_batch_shape(const phk_batch *b, uint64_t *n, uint64_t *D, uint64_t *tota
 int phk_batch_device_ptrs(const phk_batch *b, const uint32_t **d_counts, const uint32_t **d_rowsums);
 /* kmer.count_file's count matrix as the reference returns it (int64, scripts/kmer.py:130-139) */
 int phk_batch_counts_i64(phk_ctx *ctx, const phk_batch *b, int64_t *counts);
+/* the same as the device holds it (uint32; half the download, what the features-cache writer takes) */
+int phk_batch_counts_u32(phk_ctx *ctx, const phk_batch *b, uint32_t *counts);
 /* kmer.normalize_counts of the batch (scripts/kmer.py:209-221; zero row -> NaN), float64 [n][D] to the host */
 int phk_batch_normalized(phk_ctx *ctx, const phk_batch *b, double *rows);
 /* rows[0..m) of a batch as a new batch: the row filter of phamer_scorer.screen_by_length (scripts/phamer.py:

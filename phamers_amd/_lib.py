@@ -53,6 +53,10 @@ SIGNATURES = {
     "phk_batch_shape": (c_int, [c_void_p, P(c_u64), P(c_u64), P(c_u64), P(c_int)]),
     "phk_batch_device_ptrs": (c_int, [c_void_p, P(c_void_p), P(c_void_p)]),
     "phk_batch_counts_i64": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "phk_batch_counts_u32": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "phk_write_counts_csv": (c_int, [c_char_p, c_char_p, c_void_p, c_void_p, c_void_p, c_int, c_u64, c_u64]),
+    "phk_write_scores_csv": (c_int, [c_char_p, c_char_p, c_void_p, c_void_p, c_void_p, c_u64]),
+    "phk_format_float": (c_int, [c_double, c_char_p, c_int]),
     "phk_batch_normalized": (c_int, [c_void_p, c_void_p, c_void_p]),
     "phk_batch_select": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, P(c_void_p)]),
     "phk_batch_score": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -281,6 +285,12 @@ class Batch(object):
         """int64 (n, 4^k) on the host: what kmer.count_file returns (one download, widened on the device)."""
         out = np.zeros((self.n, self.D), dtype=np.int64)
         check(self.ctx.lib.phk_batch_counts_i64(self.ctx.handle, self.handle, ptr(out)))
+        return out
+
+    def counts_u32(self):
+        """uint32 (n, 4^k) on the host, as the device holds them (what the features-cache writer takes)."""
+        out = np.zeros((self.n, self.D), dtype=np.uint32)
+        check(self.ctx.lib.phk_batch_counts_u32(self.ctx.handle, self.handle, ptr(out)))
         return out
 
     def normalized(self):

@@ -162,6 +162,15 @@ extern "C" int phk_batch_counts_i64(phk_ctx *ctx, const phk_batch *b, int64_t *c
     return PHK_OK;
 }
 
+extern "C" int phk_batch_counts_u32(phk_ctx *ctx, const phk_batch *b, uint32_t *counts) {
+    PHK_ENTER(ctx, "phk_batch_counts_u32");
+    PHK_REQUIRE(b && (b->n == 0 || counts), "phk_batch_counts_u32: NULL");
+    if (b->n == 0) return PHK_OK;
+    PHK_HIP(hipMemcpyAsync(counts, b->d_counts, b->n * b->D * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    return PHK_OK;
+}
+
 extern "C" int phk_batch_normalized(phk_ctx *ctx, const phk_batch *b, double *rows) {
     PHK_ENTER(ctx, "phk_batch_normalized");
     PHK_REQUIRE(b && (b->n == 0 || rows), "phk_batch_normalized: NULL");

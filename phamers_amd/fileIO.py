@@ -8,60 +8,88 @@ scripts/fileIO.py (host I/O):
     read_phamer_output(filename)                                    scripts/fileIO.py:256-272
     generate_summary(args, line_start='', header='')                scripts/basic.py:22-37
 
-tests/test_file_formats.py checks the written bytes against files produced by the reference's own
-writer functions (tests/golden/files.json).
+The writers are native (csrc/csvio.cpp: rows formatted on all cores -- the features cache of a 1 M-contig FASTA is
+~0.7 GB of text); what they must reproduce is the output of the reference's np.savetxt calls, and
+tests/test_file_formats.py compares the bytes with files written by the reference's own functions
+(tests/golden/files.json).
 """
 import numpy as np
 
-from . import kmer
+from . import _lib
 
 
 def generate_summary(args, line_start='', header=''):
-    """The '#'-header text PhaMers stamps into its output files: the argparse Namespace's repr,
-    one 'name:<TAB>value' per line under a title line (scripts/basic.py:22-37)."""
+    """The text PhaMers stamps into its output files (scripts/basic.py:22-37): `header` on the first line, then one
+    'name:<TAB>value' line per field of the argparse Namespace, derived from its repr."""
     if args is None:
         return ""
-    text = str(args).replace('Namespace(', line_start).replace(')', '')
-    text = text.replace(', ', '\n' + line_start).replace('=', ':\t') + '\n'
-    return line_start + header + '\n' + text
+    fields = str(args)
+    for old, new in (('Namespace(', line_start), (')', ''), (', ', '\n' + line_start), ('=', ':\t')):
+        fields = fields.replace(old, new)
+    return line_start + header + '\n' + fields + '\n'
+
+
+def _comment_block(header, comments='# '):
+    """What np.savetxt writes for header=...: every line of it behind `comments`, then a newline."""
+    return (comments + header.replace('\n', '\n' + comments) + '\n').encode('latin-1')
+
+
+def _id_table(ids):
+    """ids (any sequence) -> (concatenated bytes, offsets[n+1]) for the native writers."""
+    raw = [str(i).encode('latin-1', 'replace') for i in np.asarray(ids).tolist()]
+    offsets = np.zeros(len(raw) + 1, dtype=np.uint64)
+    if raw:
+        offsets[1:] = np.cumsum([len(r) for r in raw], dtype=np.uint64)
+    return np.frombuffer(b''.join(raw) or b'\0', dtype=np.uint8), offsets
 
 
 def read_feature_file(feature_file, normalize=False, id=None):
     """'id,c0,c1,...' rows ('#' comment lines skipped) -> (ids, int features), optionally row
     normalised on the GPU (kmer.normalize_counts); ``id`` selects one row's features."""
-    data = np.loadtxt(feature_file, delimiter=',', dtype=str)
-    if data.ndim == 1:
-        data = np.array([data])
-    ids = np.array(list(data[:, 0].transpose()))
+    data = np.atleast_2d(np.loadtxt(feature_file, delimiter=',', dtype=str))
+    ids = np.array(list(data[:, 0]))
     features = data[:, 1:].astype(int)
     if normalize:
+        from . import kmer
         features = kmer.normalize_counts(features)
-    if id:
-        return features[ids == id]
-    return ids, features
+    return features[ids == id] if id else (ids, features)
 
 
 def save_counts(counts, ids, file_name, args=None, header='K-mer count file'):
-    """One 'id,count,count,...' line per sequence under a '# ' header."""
+    """One 'id,count,count,...' line per sequence under a '# ' header block.  ``counts``: any integer (or
+    integer-valued) matrix; uint32 / int64 go to the writer as they are."""
     if args is not None:
         header = generate_summary(args, header=header)
-    table = np.hstack((np.array([ids]).transpose(), np.asarray(counts).astype(int).astype(str)))
-    np.savetxt(file_name, table, fmt='%s', delimiter=',', header=header)
+    counts = np.asarray(counts)
+    if counts.ndim == 1:
+        counts = counts[None, :]
+    if counts.dtype not in (np.dtype(np.uint32), np.dtype(np.int64)):
+        counts = counts.astype(np.int64)
+    counts = np.ascontiguousarray(counts)
+    idb, ido = _id_table(ids)
+    if len(ido) - 1 != counts.shape[0]:
+        raise ValueError("%d ids for %d rows" % (len(ido) - 1, counts.shape[0]))
+    lib = _lib.load()
+    _lib.check(lib.phk_write_counts_csv(str(file_name).encode(), _comment_block(header), _lib.ptr(idb), _lib.ptr(ido),
+                                        _lib.ptr(counts), counts.dtype.itemsize, counts.shape[0], counts.shape[1]))
 
 
 def save_phamer_scores(ids, scores, file_name, args=None):
-    """'id, score' lines under a '# ' header (phamer_output/phamer_scores.csv)."""
+    """'id, score' lines under a '# ' header block (phamer_output/phamer_scores.csv); scores in str(float64) notation."""
     header = "PhaMers score file"
     if args is not None:
         header = generate_summary(args, header=header)
-    table = np.vstack((np.asarray(ids).astype(str), np.asarray(scores).astype(str))).transpose()
-    np.savetxt(file_name, table, delimiter=', ', header=header, comments="# ", fmt="%s")
+    scores = np.ascontiguousarray(scores, dtype=np.float64)
+    idb, ido = _id_table(ids)
+    if len(ido) - 1 != scores.shape[0]:
+        raise ValueError("%d ids for %d scores" % (len(ido) - 1, scores.shape[0]))
+    lib = _lib.load()
+    _lib.check(lib.phk_write_scores_csv(str(file_name).encode(), _comment_block(header), _lib.ptr(idb), _lib.ptr(ido),
+                                        _lib.ptr(scores), scores.shape[0]))
 
 
 def read_phamer_output(filename):
     """{contig id: score} of a PhaMers score file."""
-    out = {}
-    for line in open(filename, 'r').readlines():
-        if '#' not in line:
-            out[line.split(',')[0]] = float(line.split()[1])
-    return out
+    with open(filename, 'r') as f:
+        pairs = (line.split(',', 1) for line in f if '#' not in line and ',' in line)
+        return {cid: float(val.split()[0]) for cid, val in pairs}

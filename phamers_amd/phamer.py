@@ -143,7 +143,7 @@ class phamer_scorer(object):
         finally:
             fasta.close()
         self.features_file = "{base}_features.csv".format(base=os.path.splitext(self.fasta_file)[0])
-        fileIO.save_counts(self._batch.counts(), self.data_ids, self.features_file)
+        fileIO.save_counts(self._batch.counts_u32(), self.data_ids, self.features_file)
         return lengths
 
     def screen_by_length(self, length_requirement=None, _lengths=None):

@@ -31,6 +31,22 @@ def test_writers_are_byte_compatible(tmp_path):
     assert got == doc["scores_read_back"]
 
 
+def test_native_float_notation_is_numpys():
+    """phk_write_scores_csv writes a score as str(numpy.float64) does (what the reference's astype(str) yields)."""
+    import ctypes
+    from phamers_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.standard_normal(5000), np.tanh(rng.standard_normal(5000)) + rng.choice([-1.0, 1.0], 5000),
+                           10.0 ** rng.uniform(-12, 20, 5000) * rng.choice([-1, 1], 5000),
+                           [0.0, -0.0, 1.0, 1e-4, 1e-5, 123456.0, 1e16, 9.999e15, np.nan, np.inf, -np.inf, 5e-324,
+                            1.7976931348623157e308, 0.1, 100.0, 0.00012345]])
+    buf = ctypes.create_string_buffer(64)
+    for v in vals:
+        _lib.check(lib.phk_format_float(float(v), buf, 64))
+        assert buf.value.decode() == str(np.float64(v)), repr(v)
+
+
 def test_generate_summary_text():
     from phamers_amd import fileIO
     doc = helpers.load_json("files.json")
