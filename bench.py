@@ -181,6 +181,10 @@ def main():
     ap.add_argument("--method", default="combo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-contigs", type=int, default=None)
+    ap.add_argument("--workload", default="uniform", choices=["uniform", "ragged"],
+                    help="uniform: the BASELINE configuration (fixed-length, uniform i.i.d. contigs; the headline). "
+                         "ragged: heavy-tailed lengths 5-500 kb in arbitrary order, per-contig GC 0.3-0.7, 0.1 %% N -- "
+                         "a second, separately labelled workload; --contigs defaults to 200000 there")
     ap.add_argument("--min-seconds", type=float, default=0.0,
                     help="keep stepping (in multiples of --steps) until the timed region is at least this long")
     args = ap.parse_args()
@@ -226,15 +230,24 @@ def main():
         cfg.update(k=args.k, reference="synthetic", refs=args.refs or 4510, ref_length=50000)
     k = cfg["k"]
     L = args.length or cfg["length"]
+    ragged = args.workload == "ragged"
     if args.contigs is not None:
         n = args.contigs
+    elif ragged:
+        n = 200000
     elif "contigs_total" in cfg:
         n = cfg["contigs_total"] // world          # config 3: a fixed total, split over the ranks
     else:
         n = cfg["contigs"]
     scaling = "strong" if ("contigs_total" in cfg and args.contigs is None) else "weak"
     D = 4 ** k
-    T = n * L
+    lengths = None
+    if ragged:
+        from phamers_amd import synth as _synth
+        lengths = _synth.ragged_lengths(1000 + rank, n)
+        T = int(lengths.sum())
+    else:
+        T = n * L
     pos, neg, cpos, cneg, ref_name = workloads.reference_for(ctx, cfg, args.refs)
     model = _lib.Model(ctx, pos, neg, cpos, cneg, k_neighbors=3)
     M, C = pos.shape[0] + neg.shape[0], cpos.shape[0] + cneg.shape[0]
@@ -246,10 +259,21 @@ def main():
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     gathered = torch.empty(world * n, dtype=torch.float64, device=dev) if dist else None
     first = rank * n
-    device.synth_packed(ctx, 0, first, n, L, packed.data_ptr(), offsets.data_ptr())
+    mask = None
+    if ragged:
+        offs = np.zeros(n + 1, dtype=np.int64)
+        offs[1:] = np.cumsum(lengths)
+        offsets.copy_(torch.from_numpy(offs))
+        mask = torch.empty(device.mask_words(T), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        device.synth_ragged(ctx, 0, first, n, offsets.data_ptr(), T, packed.data_ptr(), mask.data_ptr(),
+                            gc_spread_permille=400, invalid_ppm=1000)
+    else:
+        device.synth_packed(ctx, 0, first, n, L, packed.data_ptr(), offsets.data_ptr())
+    mask_ptr = mask.data_ptr() if mask is not None else None
 
     def step():
-        device.count_score(ctx, model, packed.data_ptr(), None, T, offsets.data_ptr(), n, k, args.method,
+        device.count_score(ctx, model, packed.data_ptr(), mask_ptr, T, offsets.data_ptr(), n, k, args.method,
                            counts.data_ptr(), scores.data_ptr(), status.data_ptr())
         if dist:
             if dist.get_backend() == "nccl":
@@ -308,7 +332,11 @@ def main():
     from phamers_amd import synth
     npar = args.parity_contigs if args.parity_contigs is not None else (256 if D * M <= 256 * 5000 else 24)
     npar = min(npar, n)
-    seqs = synth.synth_contigs(0, npar, L, start=first)
+    if ragged:
+        npar = min(npar, 64)
+        seqs = [synth.synth_ragged_contig(0, first + c, int(lengths[c]), 400, 1000) for c in range(npar)]
+    else:
+        seqs = synth.synth_contigs(0, npar, L, start=first)
     want_counts = oracle.count(seqs, k).reshape(npar, D)
     got_counts = counts[:npar].cpu().numpy().view(np.uint32).astype(np.int64)
     q = oracle.normalize_counts(want_counts)
@@ -321,7 +349,8 @@ def main():
               "orderings_decided_by_exact_distances": n_exact}
 
     # ---- roofline of the dominant kernel (algorithmic work / HIP-event time in this run) ----
-    count_bytes = n * ((L + 3) // 4 + 8 + 4 * D + 8) / 1e9        # packed + offset + counts + score
+    # packed + offset + counts + score (+ the validity mask when one is supplied)
+    count_bytes = ((T + 3) // 4 + (T // 8 if ragged else 0) + n * (8 + 4 * D + 8)) / 1e9
     score_tflop = n * 2.0 * D * (M + C) / 1e12                     # 2 D (M + C) per contig
     alg = {  # kernel -> (bound, unit, peak, algorithmic work per step on this rank)
         "phk_count_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
@@ -358,13 +387,19 @@ def main():
         roofline["mfma_issue_frac"] = issue * kernels[dom]["frac"]
 
     out = {
-        "metric": "Gbases/s k-mer-count+score, k=%d, %d kb contigs" % (k, L // 1000),
-        "value": world * n * L * steps / elapsed / 1e9,
+        "metric": ("Gbases/s k-mer-count+score, k=%d, ragged 5-500 kb contigs" % k) if ragged else
+                  "Gbases/s k-mer-count+score, k=%d, %d kb contigs" % (k, L // 1000),
+        "value": world * T * steps / elapsed / 1e9,
         "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "u32 counts + f16 MFMA proposal (exact integer counts x split-f16 reference, f32 accumulate) + f64 decision",
-        "data": "synthetic (seeded uniform ATGC contigs, device-generated); reference matrix: " + ref_name,
-        "config": {"workload": "BASELINE configs[%d]: k=%d, %d x %d-base contigs per GPU, count+normalise+%s score, "
+        "data": ("synthetic (seeded, device-generated: heavy-tailed lengths 5-500 kb in arbitrary order, per-contig GC "
+                 "0.3-0.7, 0.1 % invalid bases); reference matrix: " if ragged else
+                 "synthetic (seeded uniform ATGC contigs, device-generated); reference matrix: ") + ref_name,
+        "config": {"workload": ("RAGGED (not the BASELINE configuration): k=%d, %d contigs per GPU, %.2f Gbases, mean %d / max %d "
+                                "bases, validity mask, count+normalise+%s score, %d reference rows + %d centroids"
+                                % (k, n, T / 1e9, T // n, int(lengths.max()), args.method, M, C)) if ragged else
+                               "BASELINE configs[%d]: k=%d, %d x %d-base contigs per GPU, count+normalise+%s score, "
                                "%d reference rows + %d centroids" % (args.config, k, n, L, args.method, M, C),
                    "contigs_per_gpu": n, "contig_length": L, "k": k, "method": args.method,
                    "parallelism": "contig shards, %d rank(s), replicated reference, final all-gather of scores" % world},
@@ -374,7 +409,7 @@ def main():
         "timed_region_s": elapsed,
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(k, L, pos, neg, cpos, cneg, pool=pool)
+        out["cpu_baseline"] = cpu_baseline(k, L if not ragged else int(T // n), pos, neg, cpos, cneg, pool=pool)
     if pool is not None:
         pool.close()
         pool.join()

@@ -265,6 +265,13 @@ int phk_synth_packed_dev(phk_ctx *ctx, uint64_t seed, uint64_t first_contig, uin
                          uint64_t L, uint32_t invalid_ppm, uint32_t *d_packed, uint32_t *d_mask,
                          uint64_t *d_offsets);
 
+/* the ragged, composition-skewed variant (second bench workload): contig boundaries d_offsets[n+1] (device, any
+ * lengths, d_offsets[n] = total_bases) are the caller's; every contig draws its own GC fraction
+ * 1/2 +- gc_spread_permille / 2000 and bases from one hash per base (phamers_amd/synth.py: synth_ragged_codes). */
+int phk_synth_ragged_dev(phk_ctx *ctx, uint64_t seed, uint64_t first_contig, uint64_t n, const uint64_t *d_offsets,
+                         uint64_t total_bases, uint32_t gc_spread_permille, uint32_t invalid_ppm, uint32_t *d_packed,
+                         uint32_t *d_mask);
+
 /* ---- in-library kernel timing (HIP events on the context's stream) ------------------ */
 int phk_profile_enable(phk_ctx *ctx, int on);
 int phk_profile_reset(phk_ctx *ctx);

@@ -78,6 +78,7 @@ SIGNATURES = {
     "phk_score_stats": (c_int, [c_void_p, P(c_u64), P(c_u64)]),
     "phk_synth_packed_dev": (c_int, [c_void_p, c_u64, c_u64, c_u64, c_u64, c_u32, c_void_p,
                                      c_void_p, c_void_p]),
+    "phk_synth_ragged_dev": (c_int, [c_void_p, c_u64, c_u64, c_u64, c_void_p, c_u64, c_u32, c_u32, c_void_p, c_void_p]),
     "phk_profile_enable": (c_int, [c_void_p, c_int]),
     "phk_profile_reset": (c_int, [c_void_p]),
     "phk_profile_count": (c_int, [c_void_p, P(c_int)]),

@@ -462,3 +462,12 @@ extern "C" int phk_synth_packed_dev(phk_ctx *ctx, uint64_t seed, uint64_t first_
     PHK_ENTER(ctx, "phk_synth_packed_dev");
     return phk_launch_synth(ctx, seed, first_contig, n, L, invalid_ppm, d_packed, d_mask, d_offsets);
 }
+
+extern "C" int phk_synth_ragged_dev(phk_ctx *ctx, uint64_t seed, uint64_t first_contig, uint64_t n, const uint64_t *d_offsets,
+                                    uint64_t total_bases, uint32_t gc_spread_permille, uint32_t invalid_ppm,
+                                    uint32_t *d_packed, uint32_t *d_mask) {
+    PHK_ENTER(ctx, "phk_synth_ragged_dev");
+    if (n == 0) return PHK_OK;
+    return phk_launch_synth_ragged(ctx, seed, first_contig, n, d_offsets, total_bases, gc_spread_permille, invalid_ppm,
+                                   d_packed, d_mask);
+}

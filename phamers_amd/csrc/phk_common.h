@@ -169,6 +169,9 @@ int phk_launch_check_counts(phk_ctx *ctx, const uint32_t *d_counts, const uint32
 int phk_launch_synth(phk_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, uint64_t L,
                      uint32_t invalid_ppm, uint32_t *d_packed, uint32_t *d_mask,
                      uint64_t *d_offsets);
+int phk_launch_synth_ragged(phk_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, const uint64_t *d_offsets,
+                            uint64_t total_bases, uint32_t gc_spread_permille, uint32_t invalid_ppm, uint32_t *d_packed,
+                            uint32_t *d_mask);
 // score.hip
 struct phk_model;
 int phk_score_rows(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,

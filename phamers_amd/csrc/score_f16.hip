@@ -139,14 +139,26 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
                                                              uint32_t nblk_neg,
                                                              float *__restrict__ cand_v,
                                                              uint32_t *__restrict__ cand_i,
-                                                             float *__restrict__ cand_u) {
+                                                             float *__restrict__ cand_u,
+                                                             const uint32_t *__restrict__ qmap,
+                                                             const uint32_t *__restrict__ qcount) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x F16_BLOCK_BYTES
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const uint64_t q0 = ((uint64_t)blockIdx.x * F16_WAVES + wave) * 32;
+    // "second chance" launches (phk_score_fast): the queries are rows qmap[0 .. *qcount) of `src`, the lists are
+    // written at the dense positions 0 .. *qcount (list stride N = the capacity of the second list set); the grid is
+    // sized for N, so workgroups wholly past the device-side count leave at once (before any DMA / barrier)
+    const uint64_t Nlist = N;
+    if (qmap) {
+        const uint64_t cnt = *qcount;
+        N = cnt < PHK_SECOND_MIN ? 0 : (cnt < N ? cnt : N);   // a handful of rows: left to the brute force
+        if ((uint64_t)blockIdx.x * F16_WAVES * 32 >= N) return;
+    }
     // NB: every wave of the workgroup takes part in the DMA + barriers even if its queries are padding
-    const uint64_t qrow = (q0 + j < N) ? q0 + j : N - 1;
+    const uint64_t qpos = (q0 + j < N) ? q0 + j : N - 1;
+    const uint64_t qrow = qmap ? (uint64_t)qmap[qpos] : qpos;
     const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
     const uint32_t seg_end0 = nblk_ref, seg_end1 = nblk_ref + nblk_pos;
 
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     auto flush_if_segment_end = [&](uint32_t b) {
         while (seg < NSEG && b + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
             if (q0 + j < N) {
-                cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2], li[3], ldrop);
+                cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, Nlist, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2], li[3], ldrop);
             }
 #pragma unroll
             for (int c = 0; c < CAND; ++c) {
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     // leading segments without columns (method 'kmeans' sweeps no train rows): empty lists; the flush rule above
     // only fires at the end of a block
     while (seg < NSEG && (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total) == 0) {
-        if (q0 + j < N) cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
+        if (q0 + j < N) cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, Nlist);
         ++seg;
     }
 
@@ -317,25 +329,25 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch before the LDS is released
     for (; seg < NSEG; ++seg) {
         if (q0 + j < N) {
-            cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
+            cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, Nlist);
         }
     }
 }
 
 int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                             const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                            float *cv, uint32_t *ci, float *cu) {
+                            float *cv, uint32_t *ci, float *cu, const uint32_t *qmap, const uint32_t *qcount) {
     const size_t lds = 2 * F16_BLOCK_BYTES;
     const uint4 *af = (const uint4 *)m->d_Af16 + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16_BLOCK_BYTES / 16);
     const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * F16_WAVES);
     if (src_counts) {
         PHK_LAUNCH(ctx, "phk_knn_f16_kernel",
                    phk_knn_f16_kernel<0><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
-                       src, d_rowsum, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu));
+                       src, d_rowsum, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu, qmap, qcount));
     } else {
         PHK_LAUNCH(ctx, "phk_knn_f16_kernel",
                    phk_knn_f16_kernel<1><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
-                       src, nullptr, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu));
+                       src, nullptr, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu, qmap, qcount));
     }
     return PHK_OK;
 }

@@ -328,6 +328,12 @@ struct RerankParams {
     uint32_t *fb_list;      // fallback queue (query indices)
     uint32_t *slow_list;    // queries the one-lane-per-query decision kernel could not certify (fb_count[2] of them)
     uint64_t q_base;        // index of this batch's first query within the caller's arrays
+    // "second chance" pass (phk_rerank16_kernel MODE 2): the queries are rows map[0 .. *map_count) of the batch, their
+    // candidate lists sit at the dense positions 0 .. min(*map_count, N) of a second list set of capacity N
+    const uint32_t *map = nullptr;
+    const uint32_t *map_count = nullptr;
+    uint32_t *stat_total = nullptr;         // [0] += fallback queue length, [1] += orderings decided by exact distances
+    const uint32_t *exact_extra = nullptr;  // exact-distance decisions of an earlier pass of the same batch
 };
 
 __device__ __forceinline__ double wave_sum(double x) {
@@ -699,21 +705,37 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
     return ok;
 }
 
-template <int SRC, bool LISTED>
+// MODE 0: every query of the batch; 1: the queries phk_decide_kernel handed over (slow_list); 2: second chance -- rows
+// map[0 .. *map_count) with their lists at dense positions (see RerankParams)
+template <int SRC, int MODE>
 __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restrict__ src, RerankParams p) {
     const int lane = threadIdx.x & 63, t = lane & 15;
     uint64_t qraw = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
     bool inrange;
-    if (LISTED) {   // only the queries phk_decide_kernel handed over
+    uint64_t q, ql;   // the query's row in src / scores; the position of its candidate lists
+    if (MODE == 1) {
         const uint64_t cnt = p.fb_count[2];
         if ((qraw & ~3ull) >= cnt) return;
         inrange = qraw < cnt;
-        qraw = p.slow_list[inrange ? qraw : cnt - 1];
+        q = ql = p.slow_list[inrange ? qraw : cnt - 1];
+    } else if (MODE == 2) {
+        const uint64_t cnt_all = *p.map_count;
+        // a handful of rows is cheaper to brute-force than to sweep (one workgroup's sweep is ~0.2 ms of latency):
+        // the second proposal pass stands down below PHK_SECOND_MIN rows (score_model.h) and so does this kernel
+        const uint64_t cnt = cnt_all < PHK_SECOND_MIN ? 0 : (cnt_all < p.N ? cnt_all : p.N);
+        // rows without a second list set (beyond its capacity, or all of them when the pass stood down) go straight to
+        // the brute-force queue
+        for (uint64_t i = cnt + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt_all; i += (uint64_t)gridDim.x * blockDim.x)
+            p.fb_list[atomicAdd(p.fb_count, 1u)] = p.map[i];
+        if ((qraw & ~3ull) >= cnt) return;
+        inrange = qraw < cnt;
+        ql = inrange ? qraw : cnt - 1;
+        q = p.map[ql];
     } else {
         if ((qraw & ~3ull) >= p.N) return;  // whole wave past the end
         inrange = qraw < p.N;
+        q = ql = inrange ? qraw : p.N - 1;
     }
-    const uint64_t q = inrange ? qraw : p.N - 1;
     double qd[16];
     double vs = p.vscale;
     bool nan_row = false;
@@ -723,10 +745,10 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     uint32_t lix[NSEG];
 #pragma unroll
     for (int sg = 0; sg < NSEG; ++sg) {
-        const uint64_t e = cand_at(sg, (t >> 2) & 1, t & 3, q, p.N);
+        const uint64_t e = cand_at(sg, (t >> 2) & 1, t & 3, ql, p.N);
         lv[sg] = p.cand_v[e];
         lix[sg] = p.cand_i[e];
-        lu[sg] = p.cand_u[candu_at(sg, t & 1, q, p.N)];
+        lu[sg] = p.cand_u[candu_at(sg, t & 1, ql, p.N)];
     }
     if (SRC == 0) {
         const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
@@ -1152,9 +1174,9 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
 // one thread per queued query: merge its FB_CHUNKS partial records and emit the score
 __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p) {
     const uint32_t count = *p.fb_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {   // statistics: this batch's counters into the call's totals
-        p.fb_count[8] += p.fb_count[0];
-        p.fb_count[9] += p.fb_count[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.stat_total) {   // statistics: this batch's counters into the call's totals
+        p.stat_total[0] += p.fb_count[0];
+        p.stat_total[1] += p.fb_count[1] + (p.exact_extra ? *p.exact_extra : 0u);
     }
     const FbRecord *rec = static_cast<const FbRecord *>(p.fb_rec);
     for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < count;
@@ -1204,12 +1226,12 @@ static int launch_rerank(phk_ctx *ctx, unsigned blocks, const void *src, const R
                 PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 1><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
             } else if (rr == 'g') {  // four queries per wave for every query (the decision kernel off)
                 PHK_LAUNCH(ctx, "phk_rerank16_kernel",
-                           (phk_rerank16_kernel<SRC, false><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p)));
+                           (phk_rerank16_kernel<SRC, 0><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p)));
             } else {   // one lane per query for what the margin test certifies, then four per wave for the rest
                 PHK_LAUNCH(ctx, "phk_decide_kernel",
                            phk_decide_kernel<SRC><<<dim3((unsigned)phk_div_up(p.N, 64)), dim3(64), 0, ctx->stream>>>(src, p));
                 PHK_LAUNCH(ctx, "phk_rerank16_kernel",
-                           (phk_rerank16_kernel<SRC, true><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p)));
+                           (phk_rerank16_kernel<SRC, 1><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p)));
             }
             break;
         }
@@ -1242,23 +1264,36 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     while (BATCH > 4096 && BATCH * D * 4 > (2ull << 30)) BATCH >>= 1;
     if (ctx->knobs.score_batch) BATCH = ctx->knobs.score_batch < 64 ? 64 : ctx->knobs.score_batch;
     const uint64_t nb_max = N < BATCH ? N : BATCH;
-    const uint64_t per_list = nb_max * NSEG * 2;
+    // proposal pass: split-f16 MFMA by default; proposal=f32 selects the fp32-input MFMA kernel (k = 4 only)
+    const char *prop = ctx->knobs.proposal;
+    const bool use_f16 = D != FAST_D || !(prop[0] == 'f' && prop[1] == '3');
+    // counts at k = 4: the count-exact kernel (2 MFMAs per k-step); proposal=f16 keeps the split-query one
+    const bool use_cx = use_f16 && d_counts && !(prop[0] == 'f' && prop[1] == '1');
+    // Second chance (k = 4, count-exact first pass): what the first pass cannot decide -- rows holding a count above
+    // 2048, which the fp16 count operand cannot carry (long or low-complexity contigs), and the rare query whose
+    // candidate lists fail certification -- is NOT sent to the float64 brute force at once.  Those rows go through the
+    // split-query MFMA kernel (any magnitude: the counts are normalised, centred and split on the fly) addressed through
+    // the first pass's queue, with their own list set; only what that pass cannot certify either is brute-forced.
+    const bool second = use_cx && D == FAST_D;
+    const uint64_t cap2 = second ? (nb_max / 8 > 4096 ? nb_max / 8 : (nb_max < 4096 ? nb_max : 4096)) : 0;
+    const uint64_t per_list = nb_max * NSEG * 2, per_list2 = cap2 * NSEG * 2;
+    const uint64_t list_bytes = sizeof(float4) + sizeof(uint4) + sizeof(float);
     void *cv, *fb, *rec;
-    PHK_TRY(phk_ws(ctx, WS_CAND, per_list * (sizeof(float4) + sizeof(uint4) + sizeof(float)), &cv));
+    PHK_TRY(phk_ws(ctx, WS_CAND, (per_list + per_list2) * list_bytes, &cv));
     uint32_t *ci = (uint32_t *)((char *)cv + per_list * sizeof(float4));
     float *cu = (float *)((char *)ci + per_list * sizeof(uint4));
-    PHK_TRY(phk_ws(ctx, WS_DIST, (2 * nb_max + 16) * sizeof(uint32_t), &fb));
+    float *cv2 = (float *)((char *)cv + per_list * list_bytes);
+    uint32_t *ci2 = (uint32_t *)((char *)cv2 + per_list2 * sizeof(float4));
+    float *cu2 = (float *)((char *)ci2 + per_list2 * sizeof(uint4));
+    PHK_TRY(phk_ws(ctx, WS_DIST, (3 * nb_max + 16) * sizeof(uint32_t), &fb));
     PHK_TRY(phk_ws(ctx, WS_QF32, nb_max * FB_CHUNKS * sizeof(FbRecord), &rec));
-    uint32_t *fb_count = (uint32_t *)fb, *fb_list = (uint32_t *)fb + 16;
+    // counter words: [0] first-pass queue length, [1] exact-distance decisions, [2] decide kernel's hand-over count,
+    // [3] brute-force queue length after the second chance, [4] its exact-distance decisions, [8], [9] totals of the call
+    uint32_t *fbc = (uint32_t *)fb, *fb_list = fbc + 16, *slow_list = fb_list + nb_max, *fb2_list = slow_list + nb_max;
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
     const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + D) * sizeof(double);
     PHK_REQUIRE(fb_lds <= FB_LDS_MAX, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);  // phk_model_build_fast keeps such models off this path
-    // proposal pass: split-f16 MFMA by default; PHK_PROPOSAL=f32 selects the fp32-input MFMA kernel (k = 4 only)
-    const char *prop = ctx->knobs.proposal;
-    const bool use_f16 = D != FAST_D || !(prop[0] == 'f' && prop[1] == '3');
-    // counts at k = 4: the count-exact kernel (2 MFMAs per k-step); PHK_PROPOSAL=f16 keeps the split-query one
-    const bool use_cx = use_f16 && d_counts && !(prop[0] == 'f' && prop[1] == '1');
-    PHK_HIP(hipMemsetAsync(fb_count, 0, 64, ctx->stream));   // words 8, 9: statistics totals of this call
+    PHK_HIP(hipMemsetAsync(fbc, 0, 64, ctx->stream));   // words 8, 9: statistics totals of this call
     for (uint64_t s = 0; s < N; s += BATCH) {
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
         const void *src = d_counts ? (const void *)(d_counts + s * D) : (const void *)(d_Q + s * D);
@@ -1267,14 +1302,25 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         const uint32_t nref = (method & PHK_METHOD_KNN) ? m->n_rblk_ref : 0;
         const uint32_t npos = (method & PHK_METHOD_KMEANS) ? m->n_rblk_pos : 0;
         const uint32_t nneg = (method & PHK_METHOD_KMEANS) ? m->n_rblk_neg : 0;
-        PHK_HIP(hipMemsetAsync(fb_count, 0, 32, ctx->stream));
+        PHK_HIP(hipMemsetAsync(fbc, 0, 32, ctx->stream));
         RerankParams p;
         p.N = nb; p.M = m->M; p.n_cpos = m->n_cpos; p.n_cneg = m->n_cneg; p.D = D;
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
         p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.colnorm = m->d_colnorm; p.labels = m->d_labels;
         p.cand_v = (const float *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
-        p.scores = d_scores; p.status = d_status; p.fb_count = fb_count; p.fb_list = fb_list; p.slow_list = fb_list + nb_max; p.q_base = s;
+        p.scores = d_scores; p.status = d_status; p.fb_count = fbc; p.fb_list = fb_list; p.slow_list = slow_list; p.q_base = s;
+        p.stat_total = fbc + 8;
         p.eb_cQ = 0.0; p.per_row_scale = 0;
+        auto split_f16_bound = [&](RerankParams &r) {
+            // 3D/16 MFMA instructions, each charged 2u (|acc_in| + sum |products|) <= 2u (P + dq) R -- the
+            // measured accumulation model of v_mfma_f32_32x32x16_f16 (tools/probe_mfma_f16.hip,
+            // profiles/r01/probe_mfma_f16.txt: two wide 8-product sub-steps with round-to-nearest, worst
+            // observed 1.27u) -- plus the input terms (3 * 2^-22 / u = 12); subnormal quantum sqrt(D) 2^-25 / S
+            r.vscale = 1.0 / (4096.0 * 4096.0);
+            r.per_row_scale = 0; r.eb_cQ = 0.0;
+            r.eb_cA = 6.0; r.eb_cP = 0.375 * (double)D + 24.0; r.eb_cR = 6.0;
+            r.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
+        };
         if (use_cx) {
             // see ErrBound: values are T S v (per row), 2D/16 instructions on uncentred products
             p.vscale = 1.0 / 4096.0; p.per_row_scale = 1;
@@ -1283,13 +1329,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             p.eb_cP = D == FAST_D ? 67.0 : 5.0; p.eb_cR = D == FAST_D ? 36.0 : 5.0;
             p.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
         } else if (use_f16) {
-            // 3D/16 MFMA instructions, each charged 2u (|acc_in| + sum |products|) <= 2u (P + dq) R -- the
-            // measured accumulation model of v_mfma_f32_32x32x16_f16 (tools/probe_mfma_f16.hip,
-            // profiles/r01/probe_mfma_f16.txt: two wide 8-product sub-steps with round-to-nearest, worst
-            // observed 1.27u) -- plus the input terms (3 * 2^-22 / u = 12); subnormal quantum sqrt(D) 2^-25 / S
-            p.vscale = 1.0 / (4096.0 * 4096.0);
-            p.eb_cA = 6.0; p.eb_cP = 0.375 * (double)D + 24.0; p.eb_cR = 6.0;
-            p.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
+            split_f16_bound(p);
         } else {
             p.vscale = 1.0;
             p.eb_cA = 6.0; p.eb_cP = 264.0; p.eb_cR = 4.0; p.eb_abs = 0.0;
@@ -1316,17 +1356,33 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             }
         }
         const unsigned rblocks = (unsigned)phk_div_up(nb, 4);
+        if (d_counts) PHK_TRY(launch_rerank<0>(ctx, rblocks, src, p));
+        else PHK_TRY(launch_rerank<1>(ctx, rblocks, src, p));
+        RerankParams pf = p;   // what the brute force works from
+        if (second) {
+            const uint64_t cap = nb < cap2 ? nb : cap2;
+            PHK_TRY(phk_launch_proposal_f16(ctx, m, src, true, rsum, cap, nref, npos, nneg, cv2, ci2, cu2, fb_list, fbc));
+            RerankParams p2 = p;
+            split_f16_bound(p2);
+            p2.N = cap;
+            p2.cand_v = cv2; p2.cand_i = ci2; p2.cand_u = cu2;
+            p2.map = fb_list; p2.map_count = fbc;
+            p2.fb_count = fbc + 3; p2.fb_list = fb2_list;
+            p2.exact_extra = fbc + 1;
+            PHK_LAUNCH(ctx, "phk_rerank16_kernel",
+                       (phk_rerank16_kernel<0, 2><<<dim3((unsigned)phk_div_up(cap, 16)), dim3(256), 0, ctx->stream>>>(src, p2)));
+            pf = p2;
+            pf.N = nb;
+        }
         if (d_counts) {
-            PHK_TRY(launch_rerank<0>(ctx, rblocks, src, p));
             PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
-                       phk_fallback_partial_kernel<0><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, p));
+                       phk_fallback_partial_kernel<0><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, pf));
         } else {
-            PHK_TRY(launch_rerank<1>(ctx, rblocks, src, p));
             PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
-                       phk_fallback_partial_kernel<1><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, p));
+                       phk_fallback_partial_kernel<1><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, pf));
         }
         PHK_LAUNCH(ctx, "phk_fallback_merge_kernel",
-                   phk_fallback_merge_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(p));
+                   phk_fallback_merge_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(pf));
     }
     return PHK_OK;
 }

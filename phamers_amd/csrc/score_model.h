@@ -24,6 +24,9 @@ struct phk_model {
     double mu_norm = 0.0;         // ||mu||
 };
 
+// second-chance pass of phk_score_fast: below this many queued rows the float64 brute force is the cheaper last resort
+#define PHK_SECOND_MIN 24
+
 // exact float64 batch scorer (score.hip)
 int phk_score_exact_batch(phk_ctx *ctx, const phk_model *m, const double *d_Q, uint64_t nq, int method,
                           double *d_knn, double *d_cen, uint32_t *d_status);
@@ -38,7 +41,8 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
                         const double *cneg, const double *mu);
 int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                             const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                            float *cv, uint32_t *ci, float *cu);
+                            float *cv, uint32_t *ci, float *cu, const uint32_t *qmap = nullptr,
+                            const uint32_t *qcount = nullptr);
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu);
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, bool count_exact,

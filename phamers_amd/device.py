@@ -69,6 +69,14 @@ def synth_packed(ctx, seed, first_contig, n, L, packed, offsets, mask=None, inva
                                             int(invalid_ppm), _p(packed), _p(mask), _p(offsets)))
 
 
+def synth_ragged(ctx, seed, first_contig, n, offsets, total_bases, packed, mask=None, gc_spread_permille=400,
+                 invalid_ppm=0):
+    """Ragged, composition-skewed seeded batch over the caller's contig boundaries (synth.synth_ragged_codes)."""
+    _lib.check(ctx.lib.phk_synth_ragged_dev(ctx.handle, int(seed), int(first_contig), int(n), _p(offsets),
+                                            int(total_bases), int(gc_spread_permille), int(invalid_ppm), _p(packed),
+                                            _p(mask)))
+
+
 def pack_ascii(ctx, bases, total_bases, packed, mask, any_invalid=None, symbols="ATGC"):
     _lib.check(ctx.lib.phk_pack_ascii_dev(ctx.handle, _p(bases), int(total_bases), symbols.encode("latin-1"),
                                           _p(packed), _p(mask), _p(any_invalid)))

@@ -55,6 +55,40 @@ def synth_codes(seed, c, L, invalid_ppm=0):
     return codes
 
 
+_GOLD2 = _U(0xD1B54A32D192ED03)
+
+
+def synth_ragged_codes(seed, c, L, gc_spread_permille=400, invalid_ppm=0):
+    """Codes of contig ``c`` of the ragged, composition-skewed batch: one hash per base, G/C with the contig's own
+    probability, the hash's low bit picks within the pair; -1 where the base is invalid."""
+    L = int(L)
+    key = contig_key(seed, c)
+    i = np.arange(L, dtype=_U)
+    with np.errstate(over='ignore'):
+        h = splitmix64(key + _GOLD2 + i)
+    # the device computes the deviation with a signed division that truncates toward zero
+    k48 = int(key) >> 48
+    num = (k48 - 32768) * int(gc_spread_permille) * 65536
+    dev = abs(num) // 1000 * (1 if num >= 0 else -1)
+    thr = _U((2147483648 + dev) & 0xFFFFFFFF)
+    codes = (np.where((h >> _U(32)) < thr, 2, 0) | (h & _U(1)).astype(np.int64)).astype(np.int8)
+    if invalid_ppm:
+        with np.errstate(over='ignore'):
+            hv = splitmix64((key ^ _INV_SALT) + i)
+        codes[(hv >> _U(32)) < _U(invalid_threshold(invalid_ppm))] = -1
+    return codes
+
+
+def synth_ragged_contig(seed, c, L, gc_spread_permille=400, invalid_ppm=0):
+    return codes_to_str(synth_ragged_codes(seed, c, L, gc_spread_permille, invalid_ppm))
+
+
+def ragged_lengths(seed, n, lo=5000, hi=500000, shape=1.1):
+    """Heavy-tailed contig lengths in [lo, hi]: lo * Pareto(shape), clipped (NumPy generator seeded with `seed`)."""
+    rng = np.random.default_rng(int(seed))
+    return np.minimum(lo * (1.0 + rng.pareto(shape, int(n))), hi).astype(np.int64)
+
+
 def codes_to_str(codes):
     out = _ATGC[np.where(codes < 0, 0, codes)].copy()
     out[codes < 0] = ord('N')

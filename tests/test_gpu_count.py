@@ -307,3 +307,29 @@ def test_count_directory_sums_per_file(kmer, tmp_path):
     assert sorted(ids) == sorted(want) and counts.shape == (3, 256) and counts.dtype == np.float64
     for i, name in enumerate(ids):
         assert np.array_equal(counts[i], want[name].astype(np.float64)), name
+
+
+@pytest.mark.gpu
+def test_ragged_skewed_generator_matches_its_host_statement(ctx):
+    """phk_synth_ragged_dev (heavy-tailed lengths, per-contig GC, invalid bases) against synth.synth_ragged_contig:
+    the device batch is what the host re-derives, checked through the counts of every contig (k = 4 and 5, mask)."""
+    from oracle import oracle
+    from phamers_amd import device, synth
+    n = 150
+    lens = synth.ragged_lengths(7, n, lo=400, hi=30000)
+    lens[5] = 0
+    lens[9] = 3
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    T = int(offs[-1])
+    d_off = device.DeviceArray.from_host(ctx, offs)
+    d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    d_mask = device.DeviceArray(ctx, device.mask_words(T), np.uint32)
+    device.synth_ragged(ctx, 3, 17, n, d_off, T, d_packed, d_mask, gc_spread_permille=700, invalid_ppm=5000)
+    seqs = [synth.synth_ragged_contig(3, 17 + c, int(lens[c]), 700, 5000) for c in range(n)]
+    gc = [(s.count("G") + s.count("C")) / max(len(s), 1) for s in seqs if len(s) > 1000]
+    assert len(gc) > 20 and max(gc) - min(gc) > 0.3  # the composition really is skewed per contig
+    for k in (4, 5):
+        d_counts = device.DeviceArray(ctx, (n, 4 ** k), np.uint32)
+        device.count(ctx, d_packed, d_mask, T, d_off, n, k, d_counts)
+        assert np.array_equal(d_counts.to_host().astype(np.int64), oracle.count(seqs, k).reshape(n, -1)), k
