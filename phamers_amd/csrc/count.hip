@@ -96,8 +96,10 @@ int phk_launch_pack(phk_ctx *ctx, const char *d_bases, uint64_t T, const char *s
 //   PACK16 = true  (k >= 5): rows[4^K/2][COPIES] uint32, row r = bins 2r (low half) and 2r+1 (high
 //     half); at most 63 wave iterations (64512 windows) go between flushes, so no half can carry.
 // A flush sums the copies with 16-byte LDS reads, clears them, and stores / accumulates uint32.
+// atomic: the row receives the partial histograms of several pieces of one long contig (global atomic adds onto a
+// zeroed row) instead of being stored
 template <int K, int COPIES, bool PACK16>
-__device__ __forceinline__ void phk_flush_bins(uint32_t *bins, uint32_t *row_out, bool first, int lane) {
+__device__ __forceinline__ void phk_flush_bins(uint32_t *bins, uint32_t *row_out, bool first, int lane, bool atomic = false) {
     constexpr int D = 1 << (2 * K);
     constexpr int ROWS = PACK16 ? D / 2 : D;
     constexpr int W = ROWS * COPIES;        // dwords per wave
@@ -116,7 +118,14 @@ __device__ __forceinline__ void phk_flush_bins(uint32_t *bins, uint32_t *row_out
             const int row = i4 / COPIES;
             if (i4 < W && (lane % (COPIES >= 4 ? COPIES / 4 : 1)) == 0) {
                 uint32_t *dst = row_out + PER * row;
-                if (PACK16) {
+                if (atomic) {   // consecutive lanes hold consecutive rows: one wave instruction adds a contiguous run
+                    if (PACK16) {
+                        if (sum & 0xFFFFu) atomicAdd(dst, sum & 0xFFFFu);
+                        if (sum >> 16) atomicAdd(dst + 1, sum >> 16);
+                    } else if (sum) {
+                        atomicAdd(dst, sum);
+                    }
+                } else if (PACK16) {
                     uint2 o = make_uint2(sum & 0xFFFFu, sum >> 16);
                     if (!first) {
                         const uint2 old = *reinterpret_cast<uint2 *>(dst);
@@ -129,7 +138,17 @@ __device__ __forceinline__ void phk_flush_bins(uint32_t *bins, uint32_t *row_out
                 }
             }
         } else if (!PACK16) {  // COPIES 1 or 2, plain uint32 bins: 4 or 2 bins per lane
-            if (i4 < W) {
+            if (i4 < W && atomic) {
+                if (COPIES == 1) {
+                    const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (vv[e]) atomicAdd(row_out + i4 + e, vv[e]);
+                } else {
+                    if (v.x + v.y) atomicAdd(row_out + i4 / 2, v.x + v.y);
+                    if (v.z + v.w) atomicAdd(row_out + i4 / 2 + 1, v.z + v.w);
+                }
+            } else if (i4 < W) {
                 if (COPIES == 1) {
                     uint4 *dst = reinterpret_cast<uint4 *>(row_out + i4);
                     if (!first) {
@@ -148,7 +167,14 @@ __device__ __forceinline__ void phk_flush_bins(uint32_t *bins, uint32_t *row_out
                 }
             }
         } else {  // COPIES == 1 (k = 7, PACK16): four rows per lane -> bins 2*i4 .. 2*i4+7
-            if (i4 < W) {
+            if (i4 < W && atomic) {
+                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (vv[e] & 0xFFFFu) atomicAdd(row_out + 2 * (i4 + e), vv[e] & 0xFFFFu);
+                    if (vv[e] >> 16) atomicAdd(row_out + 2 * (i4 + e) + 1, vv[e] >> 16);
+                }
+            } else if (i4 < W) {
                 uint4 o0 = make_uint4(v.x & 0xFFFFu, v.x >> 16, v.y & 0xFFFFu, v.y >> 16);
                 uint4 o1 = make_uint4(v.z & 0xFFFFu, v.z >> 16, v.w & 0xFFFFu, v.w >> 16);
                 uint4 *dst = reinterpret_cast<uint4 *>(row_out + 2 * i4);
@@ -227,14 +253,29 @@ __global__ __launch_bounds__(256) void phk_count_kernel(const uint32_t *__restri
                                                         uint64_t n, uint64_t max_word,
                                                         uint32_t *__restrict__ counts,
                                                         uint32_t *__restrict__ nwin,
-                                                        const uint32_t *__restrict__ list,
-                                                        const uint32_t *__restrict__ list_count) {
+                                                        const uint2 *__restrict__ list,
+                                                        const uint32_t *__restrict__ list_count,
+                                                        uint32_t piece_w) {
     static_assert(COPIES >= 4 || !PACK16 || COPIES == 1, "unsupported replication");
-    // with `list`: count contigs list[0 .. *list_count) (those the slot kernel handed over) -- unless the batch
-    // statistics behind list_count say the slot kernel stood down (ragged batch): then everything is counted here
-    if (list && phk_slots_apply(reinterpret_cast<const unsigned long long *>(list_count + 2))) n = *list_count;
+    // with `list`: count the work items list[0 .. *list_count) the slot kernel handed over, item = (contig, piece):
+    // the windows [piece * piece_w, (piece + 1) * piece_w) of the contig, added atomically onto its zeroed row
+    // (piece_w == 0: whole contigs, stored).  Legacy stand-down (count_sort off): when the batch statistics behind
+    // list_count say the slot kernel stood down (ragged batch), everything is counted here instead.
+    const bool pieces = list && piece_w != 0;
+    if (list && (pieces || phk_slots_apply(reinterpret_cast<const unsigned long long *>(list_count + 2)))) n = *list_count;
     else list = nullptr;
-    auto cid = [&](uint64_t i) { return list ? (uint64_t)list[i] : i; };
+    auto cid = [&](uint64_t i) { return list ? (uint64_t)list[i].x : i; };
+    // stream range [s, e) whose windows item i counts (a window is identified by its first base)
+    auto bounds = [&](uint64_t i, uint64_t &s, uint64_t &e) {
+        const uint64_t c = cid(i);
+        s = offsets[c];
+        e = offsets[c + 1];
+        if (pieces) {
+            s += (uint64_t)list[i].y * piece_w;
+            const uint64_t pe = s + piece_w + (K - 1);
+            e = pe < e ? pe : e;
+        }
+    };
     constexpr uint32_t D = 1u << (2 * K);
     constexpr int W = (int)(PACK16 ? D / 2 : D) * COPIES;
     constexpr int SEG_ITERS = 63;  // wave iterations between flushes (PACK16 carry bound)
@@ -297,45 +338,40 @@ __global__ __launch_bounds__(256) void phk_count_kernel(const uint32_t *__restri
                 }
                 cnt += phk_count_word<K, COPIES, PACK16, MASK>(mybins, a, b, active, wc, start, last, mask);
                 if (++since_flush == SEG_ITERS && t + 1 < niter) {  // keep 16-bit halves from carrying
-                    phk_flush_bins<K, COPIES, PACK16>(bins, row_out, first, lane);
+                    phk_flush_bins<K, COPIES, PACK16>(bins, row_out, first, lane, pieces);
                     first = false;
                     since_flush = 0;
                 }
             }
         }
-        phk_flush_bins<K, COPIES, PACK16>(bins, row_out, first, lane);
+        phk_flush_bins<K, COPIES, PACK16>(bins, row_out, first, lane, pieces);
         if (nwin) {
 #pragma unroll
             for (int s = 32; s > 0; s >>= 1) cnt += __shfl_xor(cnt, s);
-            if (lane == 0) nwin[cc] = cnt;
+            if (lane == 0) {
+                if (pieces) { if (cnt) atomicAdd(nwin + cc, cnt); }
+                else nwin[cc] = cnt;
+            }
         }
     };
 
-    // two rings in ping-pong: while contig c is counted out of one, contig c+S streams into the other
-    uint64_t s0 = offsets[cid(c)], e0 = offsets[cid(c) + 1];
+    // two rings in ping-pong: while item c is counted out of one, item c+S streams into the other
+    uint64_t s0, e0;
+    bounds(c, s0, e0);
     uint64_t s1 = 0, e1 = 0;
-    if (c + S < n) {
-        s1 = offsets[cid(c + S)];
-        e1 = offsets[cid(c + S) + 1];
-    }
+    if (c + S < n) bounds(c + S, s1, e1);
     issue(s0, e0, ra, rb);
     for (;;) {
-        // --- even phase: process (s0,e0) from ra/rb, stream contig c+S into na/nb
+        // --- even phase: process (s0,e0) from ra/rb, stream item c+S into na/nb
         uint64_t s2 = 0, e2 = 0;
-        if (c + 2 * S < n) {
-            s2 = offsets[cid(c + 2 * S)];
-            e2 = offsets[cid(c + 2 * S) + 1];
-        }
+        if (c + 2 * S < n) bounds(c + 2 * S, s2, e2);
         if (c + S < n) issue(s1, e1, na, nb);
         process(cid(c), s0, e0, ra, rb);
         c += S;
         if (c >= n) break;
-        // --- odd phase: process (s1,e1) from na/nb, stream contig c+S into ra/rb
+        // --- odd phase: process (s1,e1) from na/nb, stream item c+S into ra/rb
         uint64_t s3 = 0, e3 = 0;
-        if (c + 2 * S < n) {
-            s3 = offsets[cid(c + 2 * S)];
-            e3 = offsets[cid(c + 2 * S) + 1];
-        }
+        if (c + 2 * S < n) bounds(c + 2 * S, s3, e3);
         if (c + S < n) issue(s2, e2, ra, rb);
         process(cid(c), s1, e1, na, nb);
         c += S;
@@ -374,6 +410,75 @@ __global__ __launch_bounds__(256) void phk_count_stats_kernel(const uint64_t *__
         atomicAdd(stats, pad);
         atomicAdd(stats + 1, used);
     }
+}
+
+// ------------------------------------------------------------------------------------
+// Length-bucketed contig order for ragged batches.  The slot kernel pads every group of SLOTS contigs to its longest
+// member, so a batch of mixed lengths in arbitrary order wastes most of its stages.  A counting sort by the number of
+// 1024-window stages (descending: the longest groups start first, the short tail fills the machine at the end) makes
+// every group homogeneous.  Three small kernels, all gated ON THE DEVICE by the batch statistics: for a batch that is
+// not ragged they return at once (no host round trip decides this).
+//   key(c) = min(ceil(W_c / 1024), SORT_KEYS - 1), 0 for contigs handed over (they do no work in the slot kernel)
+// ------------------------------------------------------------------------------------
+#define SORT_KEYS 2048
+__device__ __forceinline__ uint32_t phk_sort_key(const uint64_t *offsets, uint64_t c, int k, uint32_t long_thr) {
+    const uint64_t len = offsets[c + 1] - offsets[c];
+    const uint64_t w = len >= (uint64_t)k ? len - k + 1 : 0;
+    if (w > long_thr) return 0;
+    const uint64_t key = (w + 1023) >> 10;
+    return (uint32_t)(key < SORT_KEYS - 1 ? key : SORT_KEYS - 1);
+}
+
+__global__ __launch_bounds__(256) void phk_sort_hist_kernel(const uint64_t *__restrict__ offsets, uint64_t n, int k,
+                                                            uint32_t long_thr, const unsigned long long *__restrict__ stats,
+                                                            uint32_t *__restrict__ hist) {
+    if (phk_slots_apply(stats)) return;
+    __shared__ uint32_t h[SORT_KEYS];
+    for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&h[phk_sort_key(offsets, c, k, long_thr)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x)
+        if (h[i]) atomicAdd(hist + i, h[i]);
+}
+
+// cursor[key] = number of contigs with a LARGER key (descending order); one block
+__global__ __launch_bounds__(1024) void phk_sort_scan_kernel(const unsigned long long *__restrict__ stats,
+                                                             uint32_t *__restrict__ hist /* in: counts, out: cursors */) {
+    if (phk_slots_apply(stats)) return;
+    __shared__ uint32_t v[SORT_KEYS];
+    for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x) v[i] = hist[SORT_KEYS - 1 - i];   // descending keys
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < SORT_KEYS; ++i) {
+            const uint32_t cnt = v[i];
+            v[i] = run;
+            run += cnt;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x) hist[SORT_KEYS - 1 - i] = v[i];
+}
+
+// every block reserves, per key, a range for its contigs with one global atomic, then places them
+__global__ __launch_bounds__(256) void phk_sort_scatter_kernel(const uint64_t *__restrict__ offsets, uint64_t n, int k,
+                                                               uint32_t long_thr, const unsigned long long *__restrict__ stats,
+                                                               uint32_t *__restrict__ cursor, uint32_t *__restrict__ order) {
+    if (phk_slots_apply(stats)) return;
+    __shared__ uint32_t h[SORT_KEYS];   // per-block count, then the block's base position, per key
+    const uint64_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = per_block * blockIdx.x, hi = lo + per_block < n ? lo + per_block : n;
+    for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    for (uint64_t c = lo + threadIdx.x; c < hi; c += blockDim.x) atomicAdd(&h[phk_sort_key(offsets, c, k, long_thr)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x)
+        if (h[i]) h[i] = atomicAdd(cursor + i, h[i]);
+    __syncthreads();
+    for (uint64_t c = lo + threadIdx.x; c < hi; c += blockDim.x)
+        order[atomicAdd(&h[phk_sort_key(offsets, c, k, long_thr)], 1u)] = (uint32_t)c;
 }
 
 // ------------------------------------------------------------------------------------
@@ -418,8 +523,10 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                                                              const uint64_t *__restrict__ offsets, uint64_t n,
                                                              uint64_t max_word, uint32_t long_thr,
                                                              uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin,
-                                                             uint32_t *__restrict__ long_list,
-                                                             uint32_t *__restrict__ long_count) {
+                                                             uint2 *__restrict__ long_list,
+                                                             uint32_t *__restrict__ long_count,
+                                                             const uint32_t *__restrict__ order,   // length-bucketed contig order (ragged batches), or NULL
+                                                             uint32_t piece_w) {                    // windows per hand-over piece (0: whole contigs)
     constexpr uint32_t D = 1u << (2 * K);
     constexpr int CH = 8 * SLOT_LINES;      // 4-word chunks per contig and stage
     constexpr int PARTS = NTH / SLOTS;      // lanes per contig
@@ -431,7 +538,10 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
     uint32_t *stage = lds + D * SLOTS;
     uint32_t *smax_p = stage + 2 * SLOTS * SLOT_ROW;
     uint32_t *nwin_s = smax_p + 4;   // [SLOTS] counted windows per contig (MASK)
-    if (!phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) return;  // ragged batch: stand down
+    // a batch in arbitrary order whose groups of SLOTS contigs are ragged is walked in the length-bucketed order the
+    // sort kernels prepared; without one (count_sort off) the kernel stands down and the wave-per-contig kernel counts
+    if (phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) order = nullptr;
+    else if (!order) return;
     const int t = threadIdx.x, lane = t & 63;
     const int slot = t & (SLOTS - 1), part = t / SLOTS;          // counting role: contig slot, chunk (mod PARTS) within the stage
     for (uint32_t b = t * 4; b < D * SLOTS; b += 4 * NTH) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
@@ -460,14 +570,19 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
 
     for (uint64_t batch = blockIdx.x; batch * SLOTS < n; batch += gridDim.x) {
         // ---- counting role: this lane's contig ----
-        const uint64_t c = batch * SLOTS + slot;
-        const bool have = c < n;
+        const uint64_t ci = batch * SLOTS + slot;
+        const bool have = ci < n;
+        const uint64_t c = have ? (order ? (uint64_t)order[ci] : ci) : 0;
         const uint64_t st = have ? offsets[c] : 0, en = have ? offsets[c + 1] : 0;
         const uint64_t len = en - st;
         uint32_t W = len >= (uint64_t)K ? (uint32_t)((len - K + 1) < 0xFFFFFFFFull ? (len - K + 1) : 0xFFFFFFFFull) : 0;
         const bool handed_over = W > long_thr;
         if (handed_over) {
-            if (part == 0) long_list[atomicAdd(long_count, 1u)] = (uint32_t)c;
+            if (part == 0) {   // as pieces of piece_w windows (each its own work item of the wave-per-contig kernel) or whole
+                const uint32_t np = piece_w ? (W + piece_w - 1) / piece_w : 1u;
+                const uint32_t base = atomicAdd(long_count, np);
+                for (uint32_t pc = 0; pc < np; ++pc) long_list[base + pc] = make_uint2((uint32_t)c, pc);
+            }
             W = 0;
         }
         const uint64_t last = st + W - 1;                     // last window start (W > 0)
@@ -490,7 +605,7 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const uint64_t cl = batch * SLOTS + (uint32_t)(t + NTH * i) / CH;
-            lw0[i] = cl < n ? (offsets[cl] >> 6) * 4 : 0;   // first word of its first chunk
+            lw0[i] = cl < n ? (offsets[order ? (uint64_t)order[cl] : cl] >> 6) * 4 : 0;   // first word of its first chunk
         }
         auto gload = [&](uint32_t s, uint4 (&v)[LPT], uint32_t (&la)[LPT]) {   // 16 bytes each (+ a look-ahead word)
 #pragma unroll
@@ -623,9 +738,10 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                 uint32_t *cell = cellb + 4 * i * SLOTS;
                 const uint4 o = make_uint4(cell[0], cell[SLOTS], cell[2 * SLOTS], cell[3 * SLOTS]);
                 cell[0] = 0; cell[SLOTS] = 0; cell[2 * SLOTS] = 0; cell[3 * SLOTS] = 0;
-                if (have && !handed_over) *reinterpret_cast<uint4 *>(rowo + 4 * i) = o;
+                // (a contig handed over in pieces gets its zero row here: the pieces are added onto it atomically)
+                if (have && (!handed_over || piece_w)) *reinterpret_cast<uint4 *>(rowo + 4 * i) = o;
             }
-            if (nwin && have && !handed_over && g == 0) nwin[c] = MASK ? nwin_s[slot] : W;
+            if (nwin && have && (!handed_over || piece_w) && g == 0) nwin[c] = MASK ? nwin_s[slot] : W;
         }
         phk_lds_barrier();
         if (MASK && t < SLOTS) nwin_s[t] = 0;
@@ -643,7 +759,8 @@ template <int K> struct PhkCountCfg {
 template <int K, int COPIES, bool P16>
 static int launch_count_cfg(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
                             const uint64_t *d_offsets, uint64_t n, uint64_t max_word, uint32_t *d_counts,
-                            uint32_t *d_nwin, const uint32_t *d_list = nullptr, const uint32_t *d_list_count = nullptr) {
+                            uint32_t *d_nwin, const uint2 *d_list = nullptr, const uint32_t *d_list_count = nullptr,
+                            uint32_t piece_w = 0) {
     constexpr uint32_t D = 1u << (2 * K);
     constexpr size_t wave_bytes = (size_t)(P16 ? D / 2 : D) * COPIES * 4u;
     // waves per block so that a block's bins stay <= 64 KiB
@@ -658,11 +775,11 @@ static int launch_count_cfg(phk_ctx *ctx, const uint32_t *d_packed, const uint32
     if (d_mask) {
         PHK_LAUNCH(ctx, "phk_count_kernel",
                    phk_count_kernel<K, COPIES, P16, true><<<dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream>>>(
-                       d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_list, d_list_count));
+                       d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_list, d_list_count, piece_w));
     } else {
         PHK_LAUNCH(ctx, "phk_count_kernel",
                    phk_count_kernel<K, COPIES, P16, false><<<dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream>>>(
-                       d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_list, d_list_count));
+                       d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_list, d_list_count, piece_w));
     }
     return PHK_OK;
 }
@@ -742,18 +859,40 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
     if (k >= 3 && k <= 5 && max_word >= 64 && n < (1ull << 32) && lanes_knob != '0' && ctx->slots_lds0 &&
         !ctx->knobs.count_cfg[0]) {
         const uint32_t slots = k == 5 ? 16u : 32u;
-        void *ws;
-        PHK_TRY(phk_ws(ctx, WS_LONG, (n + 16) * sizeof(uint32_t), &ws));
-        // [0] hand-over count, [2..5] batch statistics (two uint64), [16..] hand-over list
-        uint32_t *d_long_count = (uint32_t *)ws, *d_long_list = (uint32_t *)ws + 16;
-        PHK_HIP(hipMemsetAsync(d_long_count, 0, 64, ctx->stream));
+        const bool sorted = ctx->knobs.count_sort && lanes_knob != '2';
+        // contigs much longer than the batch mean leave the slot kernel (a workgroup runs as many stages as its longest
+        // contig): with count_sort they go to the wave-per-contig kernel as PIECES of 32768 windows, each its own work
+        // item adding onto the zeroed row, so that one 500 kb contig is shared by 15 waves instead of pinning one
+        const uint32_t piece_w = sorted ? 32768u : 0u;
         const uint64_t mean_len = T / n + 1;
-        const uint64_t thr64 = 4 * mean_len + 1024;
+        uint64_t thr64 = 4 * mean_len + 1024;
+        if (sorted && thr64 < 2ull * piece_w) thr64 = 2ull * piece_w;
         const uint32_t long_thr = thr64 < 0xFFFFFFFFull ? (uint32_t)thr64 : 0xFFFFFFFFu;
+        // workspace: [0] hand-over item count, [2..5] batch statistics (two uint64), [16 ..] hand-over items (contig,
+        // piece), then the sort's key cursors and the contig order
+        const uint64_t max_items = n + (piece_w ? T / piece_w : 0) + 16;
+        void *ws;
+        PHK_TRY(phk_ws(ctx, WS_LONG, (16 + 2 * max_items + SORT_KEYS + n + 16) * sizeof(uint32_t), &ws));
+        uint32_t *d_long_count = (uint32_t *)ws;
+        uint2 *d_long_list = (uint2 *)((uint32_t *)ws + 16);
+        uint32_t *d_cursor = (uint32_t *)ws + 16 + 2 * max_items, *d_order = d_cursor + SORT_KEYS;
+        PHK_HIP(hipMemsetAsync(d_long_count, 0, 64, ctx->stream));
         if (lanes_knob != '2')  // count_lanes=2: slot kernel whatever the batch looks like (tests)
         PHK_LAUNCH(ctx, "phk_count_stats_kernel",
                    phk_count_stats_kernel<<<dim3((unsigned)phk_div_up(phk_div_up(n, slots), 256)), dim3(256), 0, ctx->stream>>>(
                        d_offsets, n, k, slots, long_thr, (unsigned long long *)(d_long_count + 2)));
+        if (sorted) {   // all three return at once on the device unless the statistics call the batch ragged
+            const unsigned long long *st = (const unsigned long long *)(d_long_count + 2);
+            PHK_HIP(hipMemsetAsync(d_cursor, 0, SORT_KEYS * sizeof(uint32_t), ctx->stream));
+            uint64_t sb = phk_div_up(n, 2048);
+            sb = sb > 1024 ? 1024 : (sb < 1 ? 1 : sb);
+            PHK_LAUNCH(ctx, "phk_sort_hist_kernel",
+                       phk_sort_hist_kernel<<<dim3((unsigned)sb), dim3(256), 0, ctx->stream>>>(d_offsets, n, k, long_thr, st, d_cursor));
+            PHK_LAUNCH(ctx, "phk_sort_scan_kernel", phk_sort_scan_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(st, d_cursor));
+            PHK_LAUNCH(ctx, "phk_sort_scatter_kernel",
+                       phk_sort_scatter_kernel<<<dim3((unsigned)sb), dim3(256), 0, ctx->stream>>>(d_offsets, n, k, long_thr, st, d_cursor, d_order));
+        }
+        const uint32_t *d_ord = sorted ? d_order : nullptr;
         const size_t lds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * SLOT_ROW * 4 + 16 + slots * 4;
         // resident blocks per CU: the LDS allocation granule keeps a block that would exactly fill the 160 KiB out
         const unsigned fit = (unsigned)((160u * 1024u - 1024u) / lds);
@@ -765,14 +904,14 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         if (d_mask) {                                                                                                       \
             PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                       \
                        (phk_count_slots_kernel<K_, S_, T_, true><<<dim3((unsigned)blocks), dim3(T_), lds, ctx->stream>>>(   \
-                           d_packed, d_mask, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count))); \
+                           d_packed, d_mask, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w))); \
         } else {                                                                                                            \
             PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                       \
                        (phk_count_slots_kernel<K_, S_, T_, false><<<dim3((unsigned)blocks), dim3(T_), lds, ctx->stream>>>(  \
-                           d_packed, nullptr, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count))); \
+                           d_packed, nullptr, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w))); \
         }                                                                                                                   \
         return launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                                    \
-            ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count)
+            ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count, piece_w)
         // 16 lanes per contig (512 threads) at k <= 4: 24 waves per CU hide the barrier and staging latencies better
         // than 12 (0.94 vs 1.03 ms per 1M x 5 kb); PHK_SLOT_THREADS=256 for comparison
         const bool t256 = ctx->knobs.slot_threads == '2';

@@ -333,3 +333,47 @@ def test_ragged_skewed_generator_matches_its_host_statement(ctx):
         d_counts = device.DeviceArray(ctx, (n, 4 ** k), np.uint32)
         device.count(ctx, d_packed, d_mask, T, d_off, n, k, d_counts)
         assert np.array_equal(d_counts.to_host().astype(np.int64), oracle.count(seqs, k).reshape(n, -1)), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,masked", [(4, False), (4, True), (5, True), (3, False)])
+def test_ragged_batch_sorted_slots_and_pieces(ctx, k, masked):
+    """A heavy-tailed batch in arbitrary order: the slot kernel walks it in length-bucketed order and contigs far
+    above the mean are counted in 32768-window pieces by several waves (atomic adds onto the zeroed row).  Counts and
+    window totals equal the oracle's; the legacy stand-down path (count_sort off) and the wave-per-contig kernel
+    agree bit for bit."""
+    from oracle import oracle
+    from phamers_amd import device, synth
+    n = 700
+    lens = synth.ragged_lengths(11 + k, n, lo=300, hi=400000, shape=0.9)
+    lens[3] = 0
+    lens[10] = k - 1
+    lens[11] = k
+    lens[20] = 399999
+    lens[30], lens[40] = 150000, 98304 + k - 1        # three pieces exactly
+    lens[50], lens[51] = 65536 + k, 65536 + k - 1     # just above / exactly at the hand-over threshold (in windows)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    T = int(offs[-1])
+    d_off = device.DeviceArray.from_host(ctx, offs)
+    d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    d_mask = device.DeviceArray(ctx, device.mask_words(T), np.uint32)
+    ppm = 3000 if masked else 0
+    device.synth_ragged(ctx, 5, 0, n, d_off, T, d_packed, d_mask, gc_spread_permille=600, invalid_ppm=ppm)
+    seqs = [synth.synth_ragged_contig(5, c, int(lens[c]), 600, ppm) for c in range(n)]
+    want = oracle.count(seqs, k).reshape(n, -1)
+    assert (lens > 70000).sum() >= 4          # some contigs really are cut into pieces
+    D = 4 ** k
+    got = {}
+    for name, opts in (("sorted", {}), ("standdown", {"count_sort": "0"}), ("wave", {"count_lanes": "0"})):
+        for key, val in opts.items():
+            ctx.set_option(key, val)
+        d_counts = device.DeviceArray.from_host(ctx, np.full((n, D), 0xABCD, np.uint32))
+        d_nwin = device.DeviceArray.from_host(ctx, np.full(n, 0xABCD, np.uint32))
+        device.count(ctx, d_packed, d_mask if masked else None, T, d_off, n, k, d_counts, d_nwin)
+        got[name] = d_counts.to_host()
+        assert np.array_equal(got[name].astype(np.int64), want), (name, k, masked)
+        assert np.array_equal(d_nwin.to_host().astype(np.int64), want.sum(axis=1)), (name, k, masked)
+        ctx.set_option("count_sort", "1")
+        ctx.set_option("count_lanes", "")
+    assert np.array_equal(got["sorted"], got["wave"]) and np.array_equal(got["sorted"], got["standdown"])
