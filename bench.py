@@ -321,6 +321,7 @@ def main():
         elapsed = float(tmax.item())
     prof = ctx.profile()
     n_fallback, n_exact = ctx.score_stats()
+    stats_ex = ctx.score_stats_ex()
 
     if rank != 0:
         if dist:
@@ -346,7 +347,7 @@ def main():
     parity = {"contigs_checked": npar, "counts_bit_exact": bool(np.array_equal(got_counts, want_counts)),
               "max_rel_score_err": float(np.max(np.abs(got - want) / np.abs(want))),
               "nan_rows": int(status.item()), "fallback_queries": n_fallback,
-              "orderings_decided_by_exact_distances": n_exact}
+              "orderings_decided_by_exact_distances": n_exact, "decision_stats": stats_ex}
 
     # ---- roofline of the dominant kernel (algorithmic work / HIP-event time in this run) ----
     # packed + offset + counts + score (+ the validity mask when one is supplied)

@@ -257,6 +257,11 @@ int phk_check_counts_dev(phk_ctx *ctx, const uint32_t *d_counts, const uint32_t 
  * (query, segment) orderings had to be decided by exact candidate distances rather than by
  * the certified fp32 margin.  Both are 0 on the all-float64 path. */
 int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_exact_resolved);
+/* the same and more, out[0 .. n_out): [0] brute-forced queries, [1] orderings decided by exact distances, [2] queries
+ * that took the second chance (split-query MFMA pass), [3..6] why the high-parts-only decision stage passed them on:
+ * window wider than the refined candidates, window reaching past the lists, refined values too close, centroid
+ * leader not certified */
+int phk_score_stats_ex(phk_ctx *ctx, uint64_t *out, int n_out);
 
 /* seeded synthetic batch generated on the device (phamers_amd/synth.py defines the hash):
  * n contigs of L bases, contig ids first_contig..first_contig+n-1; writes the packed stream,

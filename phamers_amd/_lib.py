@@ -76,6 +76,7 @@ SIGNATURES = {
                                     c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "phk_check_counts_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_u64, c_u64, c_void_p]),
     "phk_score_stats": (c_int, [c_void_p, P(c_u64), P(c_u64)]),
+    "phk_score_stats_ex": (c_int, [c_void_p, c_void_p, c_int]),
     "phk_synth_packed_dev": (c_int, [c_void_p, c_u64, c_u64, c_u64, c_u64, c_u32, c_void_p,
                                      c_void_p, c_void_p]),
     "phk_synth_ragged_dev": (c_int, [c_void_p, c_u64, c_u64, c_u64, c_void_p, c_u64, c_u32, c_u32, c_void_p, c_void_p]),
@@ -186,6 +187,14 @@ class Context(object):
         a, b = ctypes.c_uint64(), ctypes.c_uint64()
         check(self.lib.phk_score_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def score_stats_ex(self):
+        """Diagnostics of the most recent scoring call (phk_score_stats_ex) as a dict."""
+        out = np.zeros(7, dtype=np.uint64)
+        check(self.lib.phk_score_stats_ex(self.handle, ptr(out), 7))
+        names = ("brute_forced", "exact_distance_decisions", "second_chance", "window_wider_than_refined",
+                 "window_past_lists", "refined_values_too_close", "centroid_leader_uncertified")
+        return {k: int(v) for k, v in zip(names, out)}
 
     # ---- timing ----
     def profile_enable(self, on=True):

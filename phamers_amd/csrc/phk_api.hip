@@ -447,12 +447,24 @@ extern "C" int phk_check_counts_dev(phk_ctx *ctx, const uint32_t *d_counts, cons
 extern "C" int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_exact_resolved) {
     PHK_ENTER(ctx, "phk_score_stats");
     uint32_t c[2] = {0, 0};
-    if (ctx->last_score_fast && ctx->ws[WS_DIST].ptr) {   // words 8, 9: totals over the call's batches
-        PHK_HIP(hipMemcpyAsync(c, (const uint32_t *)ctx->ws[WS_DIST].ptr + 8, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->last_score_fast && ctx->ws[WS_DIST].ptr) {   // words 16 ..: totals over the call's batches
+        PHK_HIP(hipMemcpyAsync(c, (const uint32_t *)ctx->ws[WS_DIST].ptr + 16, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         PHK_HIP(hipStreamSynchronize(ctx->stream));
     }
     if (n_fallback) *n_fallback = c[0];
     if (n_exact_resolved) *n_exact_resolved = c[1];
+    return PHK_OK;
+}
+
+extern "C" int phk_score_stats_ex(phk_ctx *ctx, uint64_t *out, int n_out) {
+    PHK_ENTER(ctx, "phk_score_stats_ex");
+    PHK_REQUIRE(out && n_out >= 0, "phk_score_stats_ex: NULL");
+    uint32_t c[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (ctx->last_score_fast && ctx->ws[WS_DIST].ptr) {
+        PHK_HIP(hipMemcpyAsync(c, (const uint32_t *)ctx->ws[WS_DIST].ptr + 16, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    for (int i = 0; i < n_out; ++i) out[i] = i < 7 ? c[i] : 0;
     return PHK_OK;
 }
 

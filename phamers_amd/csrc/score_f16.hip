@@ -22,6 +22,7 @@
 // a double buffer, one barrier per block.  A wave keeps its 32 queries' b_hi / b_lo fragments in 128
 // VGPRs for the whole sweep, exactly like the fp32 kernel keeps q'.
 #include <stdlib.h>
+#include <string.h>
 
 #include "phk_common.h"
 #include "score_lists.h"
@@ -49,8 +50,18 @@ static void split_f16(double x, _Float16 &hi, _Float16 &lo) {
 // chunk: dims 256c + 128*(lane>>5) + 8s .. +7), then one piece with the 32 norm terms.  For D = 256
 // this is the 33-piece record of the k = 4 kernel.  cn_all (one float per column slot, padding
 // included) duplicates the norm terms for the general-D kernel, which reads them from global memory.
+// hi-only extras (D = 256 models): betah_all = S mu.hi + S |r~'|^2 / 2 per column slot, lo_rows = the low parts row-major
+// per REAL column (col0 + r), lonorm = |lo| / S per real column
+struct HiOnlyOut {
+    std::vector<float> *betah_all = nullptr;
+    std::vector<_Float16> *lo_rows = nullptr;
+    std::vector<double> *lonorm = nullptr;
+    uint64_t col0 = 0;
+};
+
 static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const double *mu, std::vector<uint8_t> &rec,
-                             uint64_t rec_bytes, uint64_t cb0, std::vector<float> &cn_all, std::vector<float> &beta_all) {
+                             uint64_t rec_bytes, uint64_t cb0, std::vector<float> &cn_all, std::vector<float> &beta_all,
+                             HiOnlyOut ho = HiOnlyOut()) {
     const uint64_t nblk = phk_div_up(n, 32);
     const int nchunk = (int)(D / 256);
     phk_parallel_for(nblk, [&, nchunk](uint64_t b) {
@@ -63,9 +74,10 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
                 cn[32 + i] = -PAD_V;
                 cn_all[(cb0 + b) * 32 + i] = PAD_V;
                 beta_all[(cb0 + b) * 32 + i] = -PAD_V;
+                if (ho.betah_all) (*ho.betah_all)[(cb0 + b) * 32 + i] = -PAD_V;
                 continue;
             }
-            double nrm2 = 0.0, mudot = 0.0;
+            double nrm2 = 0.0, mudot = 0.0, mulo = 0.0, lo2 = 0.0;
             for (int c = 0; c < nchunk; ++c)
                 for (int h = 0; h < 2; ++h)
                     for (int s = 0; s < 16; ++s)
@@ -81,7 +93,12 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
                             const double xt = (double)hi + (double)lo;  // the column as the kernel sees it (scaled)
                             nrm2 += xt * xt;
                             mudot += mu[d] * xt;
+                            mulo += mu[d] * (double)lo;
+                            lo2 += (double)lo * (double)lo;
+                            if (ho.lo_rows) (*ho.lo_rows)[(ho.col0 + r) * D + d] = lo;
                         }
+            if (ho.betah_all) (*ho.betah_all)[(cb0 + b) * 32 + i] = (float)(mudot - mulo + 0.5 * nrm2 / (double)F16_SCALE);
+            if (ho.lonorm) (*ho.lonorm)[ho.col0 + r] = std::sqrt(lo2) / (double)F16_SCALE;
             // count-exact kernel: S beta = S (mu.r~' + |r~'|^2 / 2), the bias per unit of row sum
             cn[32 + i] = (float)(mudot + 0.5 * nrm2 / (double)F16_SCALE);
             beta_all[(cb0 + b) * 32 + i] = cn[32 + i];
@@ -91,27 +108,75 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
     });
 }
 
+#define F16H_PIECES 17
+#define F16H_BLOCK_BYTES (F16H_PIECES * 1024)
+
 int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, const double *cpos,
-                        const double *cneg, const double *mu) {
+                        const double *cneg, const double *mu, const double *colnorm) {
     const uint64_t D = m->D;
     const uint64_t nblk = (uint64_t)m->n_rblk_ref + m->n_rblk_pos + m->n_rblk_neg;
     const uint64_t rec_bytes = (D / 256 * 32 + 1) * 1024;
+    const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
+    const bool hi_only = D == FAST_D;   // the high-parts-only proposal exists for k = 4
     std::vector<uint8_t> rec((nblk + 1) * rec_bytes, 0);  // + one block: the DMA prefetch runs one past the end
-    std::vector<float> cn_all((nblk + 1) * 32, PAD_V), beta_all((nblk + 1) * 32, -PAD_V);
+    std::vector<float> cn_all((nblk + 1) * 32, PAD_V), beta_all((nblk + 1) * 32, -PAD_V), betah_all;
+    std::vector<_Float16> lo_rows;
+    std::vector<double> lonorm;
+    HiOnlyOut ho;
+    if (hi_only) {
+        betah_all.assign((nblk + 1) * 32, -PAD_V);
+        lo_rows.assign(ncols * D, (_Float16)0.0f);
+        lonorm.assign(ncols, 0.0);
+        ho.betah_all = &betah_all;
+        ho.lo_rows = &lo_rows;
+        ho.lonorm = &lonorm;
+    }
     {
         std::vector<double> train(m->M * D);
         std::copy(pos, pos + m->n_pos * D, train.begin());
         std::copy(neg, neg + m->n_neg * D, train.begin() + m->n_pos * D);
-        pack_segment_f16(train.data(), m->M, D, mu, rec, rec_bytes, 0, cn_all, beta_all);
+        ho.col0 = 0;
+        pack_segment_f16(train.data(), m->M, D, mu, rec, rec_bytes, 0, cn_all, beta_all, ho);
     }
-    if (m->n_cpos) pack_segment_f16(cpos, m->n_cpos, D, mu, rec, rec_bytes, m->n_rblk_ref, cn_all, beta_all);
-    if (m->n_cneg) pack_segment_f16(cneg, m->n_cneg, D, mu, rec, rec_bytes, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, cn_all, beta_all);
+    ho.col0 = m->M;
+    if (m->n_cpos) pack_segment_f16(cpos, m->n_cpos, D, mu, rec, rec_bytes, m->n_rblk_ref, cn_all, beta_all, ho);
+    ho.col0 = m->M + m->n_cpos;
+    if (m->n_cneg) pack_segment_f16(cneg, m->n_cneg, D, mu, rec, rec_bytes, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, cn_all, beta_all, ho);
     if (hipMalloc(&m->d_Af16, rec.size()) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMemcpy(m->d_Af16, rec.data(), rec.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     if (hipMalloc(&m->d_cn16, cn_all.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMemcpy(m->d_cn16, cn_all.data(), cn_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     if (hipMalloc(&m->d_beta16, beta_all.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMemcpy(m->d_beta16, beta_all.data(), beta_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    if (hi_only) {
+        // 17-piece records: the 16 hi fragments of the full record + one piece of bias terms
+        std::vector<uint8_t> rech((nblk + 1) * F16H_BLOCK_BYTES, 0);
+        for (uint64_t b = 0; b < nblk; ++b) {
+            for (int st = 0; st < 16; ++st)
+                memcpy(rech.data() + b * F16H_BLOCK_BYTES + st * 1024, rec.data() + b * rec_bytes + (2 * st) * 1024, 1024);
+            memcpy(rech.data() + b * F16H_BLOCK_BYTES + 16 * 1024, betah_all.data() + b * 32, 32 * sizeof(float));
+        }
+        if (hipMalloc(&m->d_Af16h, rech.size()) != hipSuccess) return PHK_ERR_NOMEM;
+        if (hipMemcpy(m->d_Af16h, rech.data(), rech.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+        if (hipMalloc((void **)&m->d_lo16, lo_rows.size() * sizeof(_Float16)) != hipSuccess) return PHK_ERR_NOMEM;
+        if (hipMemcpy(m->d_lo16, lo_rows.data(), lo_rows.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+        // lam_tab: the largest |lo_j| / S among the columns within a radius, on a 64-step grid of radii
+        double rmin = 1e300, rmax = 0.0;
+        for (uint64_t c = 0; c < ncols; ++c) {
+            rmin = colnorm[c] < rmin ? colnorm[c] : rmin;
+            rmax = colnorm[c] > rmax ? colnorm[c] : rmax;
+        }
+        m->lam_r0 = rmin;
+        m->lam_step = rmax > rmin ? (rmax - rmin) / 64.0 : 1.0;
+        for (int i = 0; i <= 64; ++i) m->lam_tab[i] = 0.0;
+        for (uint64_t c = 0; c < ncols; ++c) {
+            int i = (int)std::ceil((colnorm[c] - rmin) / m->lam_step - 1e-12);
+            i = i < 0 ? 0 : (i > 64 ? 64 : i);
+            if (lonorm[c] > m->lam_tab[i]) m->lam_tab[i] = lonorm[c];
+        }
+        for (int i = 1; i <= 64; ++i)
+            if (m->lam_tab[i - 1] > m->lam_tab[i]) m->lam_tab[i] = m->lam_tab[i - 1];
+    }
     return PHK_OK;
 }
 
@@ -604,6 +669,249 @@ __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch before the LDS is released
 }
 
+// ====================================================================================
+// High-parts-only proposal kernel (k = 4, uint32 counts; the default first pass).
+//
+// The count-exact kernel above spends 2 MFMAs per k-step because the reference column is split in two fp16 numbers
+// (r' S = hi + lo).  The lo product only carries the last 11 of 22 bits; it matters for a handful of columns per query
+// -- those whose value lies within the error of the hi product of the decisive (need-th) value.  This kernel runs the
+// hi product ALONE (1 MFMA per k-step, block records of 16 hi fragments + one piece of bias terms) and the decision
+// stage (phk_decide_h_kernel) adds the lo product, sum_i (c_i - T mu_i) lo_ji in float64, to just those candidates:
+//     w^h_j = sum_i c_i hi_ji - T [S mu.hi_j + S |r~'_j|^2 / 2]      (this kernel),
+//     w_j   = w^h_j + sum_i (c_i - T mu_i) lo_ji                     (= the count-exact kernel's value, refined later).
+// |w_j - w^h_j| <= T S |q'| |lo_j| / S by Cauchy-Schwarz: that is the window the decision stage refines inside.
+// List maintenance, index bits in the value, the two-tile ping-pong and the segment pipeline are those of the
+// count-exact kernel; with one MFMA per value the loop is bound by the VALU issue of the insertions (~7 per value).
+// ====================================================================================
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn_f16h_kernel(
+    const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rowsum, uint64_t N, const uint4 *__restrict__ Af,
+    uint32_t nblk_ref, uint32_t nblk_pos, uint32_t nblk_neg, float *__restrict__ cand_v, uint32_t *__restrict__ cand_i,
+    float *__restrict__ cand_u) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x F16H_BLOCK_BYTES
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const uint64_t q0 = ((uint64_t)blockIdx.x * NW + wave) * (32 * NT);
+    const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+    auto dma_block = [&](uint32_t blk, int buf) {
+        const uint4 *g = Af + (uint64_t)blk * (F16H_BLOCK_BYTES / 16) + lane;
+        const uint32_t l = lds_base + (uint32_t)buf * F16H_BLOCK_BYTES;
+        // 16 / NW + 1 pieces per wave, no loop (a loop here splits the hot loop into basic blocks and hipcc then sinks the
+        // insertions away from the MFMAs they are meant to hide behind); the bias piece is fetched by every wave
+#pragma unroll
+        for (int k = 0; k < 16 / NW + 1; ++k) {
+            const int p = k < 16 / NW ? wave + NW * k : 16;
+            const uint4 *gp = g + p * 64;
+            const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
+        }
+    };
+    if (total) dma_block(0, 0);
+
+    // ---- prologue: counts -> fp16 (exact up to 2048), row sum, row maximum ----
+    half8 bq[NT][16];
+    float negT[NT];
+    bool big[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const uint64_t qi = q0 + 32 * t + j;
+        const uint64_t qrow = qi < N ? qi : N - 1;
+        const uint4 *row = reinterpret_cast<const uint4 *>(counts + qrow * FAST_D + 128 * h);
+        uint32_t sum = 0, mx = 0;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const uint4 c0 = row[2 * s], c1 = row[2 * s + 1];
+            const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sum += c[e];
+                mx = mx > c[e] ? mx : c[e];
+                bq[t][s][e] = (_Float16)(float)(c[e] < 2048u ? c[e] : 2048u);
+            }
+        }
+        const uint32_t tot = rowsum ? rowsum[qrow] : sum + __shfl_xor(sum, 32);
+        const uint32_t mo = __shfl_xor(mx, 32);
+        big[t] = (mx > mo ? mx : mo) > 2048u;
+        negT[t] = -(float)tot;
+    }
+
+    float lv[NT][5];
+    uint32_t lb[NT][4];
+    const float vempty = __uint_as_float(__float_as_uint(-3.0e38f) & ~31u);  // empty slot: fresh bit clear
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) lv[t][c] = vempty;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lb[t][c] = CX_SENT;
+    }
+    const float fbig = 3.3e38f;  // above every value: med3(v0, x, fbig) = max(v0, x) without the canonicalising v_max pair
+
+    // after a block's 16 insertions: block number -> id list at the fresh positions, fresh bits cleared.
+    // A no-op when no fresh bit is set.
+    auto settle = [&](uint32_t cur) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            uint32_t m[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m[c]) : "v"(lv[t][c]));  // 0 / ~0 from bit 0
+            lb[t][3] = phk_bfi_hw(m[0], lb[t][2], lb[t][3]);
+            lb[t][2] = phk_bfi_hw(m[0], lb[t][1], lb[t][2]);
+            lb[t][1] = phk_bfi_hw(m[0], lb[t][0], lb[t][1]);
+            lb[t][0] = phk_bfi_hw(m[0], cur, lb[t][0]);
+            lb[t][3] = phk_bfi_hw(m[1], lb[t][2], lb[t][3]);
+            lb[t][2] = phk_bfi_hw(m[1], lb[t][1], lb[t][2]);
+            lb[t][1] = phk_bfi_hw(m[1], cur, lb[t][1]);
+            lb[t][3] = phk_bfi_hw(m[2], lb[t][2], lb[t][3]);
+            lb[t][2] = phk_bfi_hw(m[2], cur, lb[t][2]);
+            lb[t][3] = phk_bfi_hw(m[3], cur, lb[t][3]);
+#pragma unroll
+            for (int c = 0; c < 5; ++c) lv[t][c] = __uint_as_float(__float_as_uint(lv[t][c]) & ~1u);
+        }
+    };
+    // insertion of one value: w = acc - T * bias, index bits embedded, 5 x v_med3
+    auto insert = [&](int t, float a, float bias, int r) {
+        const float w = fmaf(negT[t], bias, a);
+        const float x = __uint_as_float((__float_as_uint(w) & ~31u) | (uint32_t)(2 * r + 1));
+        const float n4 = __builtin_amdgcn_fmed3f(lv[t][3], lv[t][4], x);
+        const float n3 = __builtin_amdgcn_fmed3f(lv[t][2], lv[t][3], x);
+        const float n2 = __builtin_amdgcn_fmed3f(lv[t][1], lv[t][2], x);
+        const float n1 = __builtin_amdgcn_fmed3f(lv[t][0], lv[t][1], x);
+        lv[t][0] = __builtin_amdgcn_fmed3f(lv[t][0], x, fbig);
+        lv[t][1] = n1;
+        lv[t][2] = n2;
+        lv[t][3] = n3;
+        lv[t][4] = n4;
+    };
+
+    // Software pipeline inside the wave, per segment: while block i's MFMAs fill one accumulator set, the VALU
+    // inserts block i-1's values out of the other set (with its bias terms, held in 16 registers) and settles
+    // the ids of block i-2's insertions during the first k-step.  Nothing but the LDS reads of the next bias
+    // terms and the workgroup barrier is left outside the MFMA stream; the hot loop has no data-dependent
+    // control flow.  The pipeline drains at the end of a segment (3 times per sweep); the DMA stream does not.
+    float bias[16];
+    f32x16 accA[NT], accB[NT];
+    uint32_t g = 0;  // global block number: LDS buffer parity and DMA source
+
+    auto block_iter = [&](uint32_t settle_id, f32x16 (&cur)[NT], const f32x16 (&prev)[NT]) {
+        // block g has landed (every wave waits for its own pieces, then the barrier), and every wave is done
+        // reading the other buffer, which the next DMA overwrites
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        dma_block(g + 1, (g + 1) & 1);  // one past the end on the last block: the record array is padded
+        const uint8_t *buf = smem + (g & 1) * F16H_BLOCK_BYTES;
+        ++g;
+        const half8 *fr = reinterpret_cast<const half8 *>(buf) + lane;
+        half8 ahn = fr[0];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const half8 ah = ahn;
+            if (s < 15) ahn = fr[(s + 1) * 64];
+            __builtin_amdgcn_sched_barrier(0);  // the reads stay up here, one step ahead of their MFMAs
+            if (s == 0) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], z, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], cur[t], 0, 0, 0);
+            }
+            if (s == 0) settle(settle_id);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) insert(t, prev[t][s], bias[s], s);
+            if (s == 0) {
+#pragma unroll
+                for (int gi = 0; gi < NT; ++gi) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 28, 0);  // VALU (settle + insertion)
+                }
+            } else {
+#pragma unroll
+                for (int gi = 0; gi < NT; ++gi) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // VALU (insertion)
+                }
+            }
+        }
+        // D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h'; its bias terms
+        // (the buffer is recycled after the next barrier)
+        const float4 *cn = reinterpret_cast<const float4 *>(buf + 16 * 1024) + h;
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {
+            const float4 c4 = cn[2 * m4];
+            bias[4 * m4 + 0] = c4.x;
+            bias[4 * m4 + 1] = c4.y;
+            bias[4 * m4 + 2] = c4.z;
+            bias[4 * m4 + 3] = c4.w;
+        }
+    };
+    // drain: the last block's values (in `last`, bias terms loaded), ids, then the segment's lists go out
+    auto finish = [&](int seg, uint32_t nb, const f32x16 (&last)[NT]) {
+        settle(nb - 2);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) insert(t, last[t][s], bias[s], s);
+        settle(nb - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint64_t qi = q0 + 32 * t + j;
+            if (qi < N) {
+                                uint32_t ix[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t r = (__float_as_uint(lv[t][c]) >> 1) & 15u;
+                    ix[c] = (lb[t][c] == CX_SENT || big[t]) ? 0xFFFFFFFFu
+                                                             : lb[t][c] * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
+                }
+                cand_store(cand_v, cand_i, cand_u, seg, h, qi, N, lv[t][0], lv[t][1], lv[t][2], lv[t][3], ix[0], ix[1], ix[2], ix[3], big[t] ? 3.0e38f : lv[t][4]);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int seg = 0; seg < NSEG; ++seg) {
+        const uint32_t nb = seg == 0 ? nblk_ref : seg == 1 ? nblk_pos : nblk_neg;
+        if (nb == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint64_t qi = q0 + 32 * t + j;
+                if (qi < N) {
+                                        cand_store_empty(cand_v, cand_i, cand_u, seg, h, qi, N);
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) lv[t][c] = vempty;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) lb[t][c] = CX_SENT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[t][r] = -3.35e38f;  // "block -1": below the empty slots, never accepted
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bias[r] = 0.0f;
+        uint32_t i = 0;
+#pragma unroll 1
+        for (; i + 1 < nb; i += 2) {
+            block_iter(i - 2, accA, accB);
+            block_iter(i - 1, accB, accA);
+        }
+        if (i < nb) {
+            block_iter(i - 2, accA, accB);
+            finish(seg, nb, accA);
+        } else {
+            finish(seg, nb, accB);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch before the LDS is released
+}
+
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu) {
     const size_t lds = 2 * F16_BLOCK_BYTES;
@@ -625,6 +933,17 @@ int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d
         PHK_CX_LAUNCH(2, 8);
     }
 #undef PHK_CX_LAUNCH
+    return PHK_OK;
+}
+
+int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
+                             uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu) {
+    const size_t lds = 2 * F16H_BLOCK_BYTES;
+    const uint4 *af = (const uint4 *)m->d_Af16h + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16H_BLOCK_BYTES / 16);
+    const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * 8 * 2);
+    PHK_LAUNCH(ctx, "phk_knn_f16h_kernel",
+               (phk_knn_f16h_kernel<2, 8><<<dim3(gblocks), dim3(64 * 8), lds, ctx->stream>>>(
+                   d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu)));
     return PHK_OK;
 }
 
@@ -927,6 +1246,7 @@ int phk_score_f16_init_device(phk_ctx *ctx) {
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16h_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F16H_BLOCK_BYTES));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     return PHK_OK;

@@ -40,6 +40,7 @@
 #include "score_lists.h"
 
 #define NG 33          // 32 k-groups + the norm group
+#define PHK_HI_REFINE 6 // candidates per query whose low product the high-parts-only decision stage evaluates
 #define FB_CHUNKS 16   // column chunks per queued query in the exact brute-force fallback
 #define FB_LDS_MAX (160u * 1024u - 1024u)   // its dynamic LDS: one chunk of distances + the query, float64
 
@@ -147,7 +148,7 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
         hipMemcpy(m->d_mu32, mu32.data(), D * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(m->d_mu64, mu.data(), D * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         return PHK_ERR_HIP;
-    PHK_TRY(phk_model_build_f16(m, pos, neg, cpos, cneg, mu.data()));
+    PHK_TRY(phk_model_build_f16(m, pos, neg, cpos, cneg, mu.data(), colnorm.data()));
     m->max_colnorm = max_norm;
     m->mu_norm = std::sqrt(mu2);
     m->fast = true;
@@ -159,6 +160,10 @@ void phk_model_free_fast(phk_model *m) {
     if (m->d_colnorm) (void)hipFree(m->d_colnorm);
     if (m->d_Af16) (void)hipFree(m->d_Af16);
     m->d_Af16 = nullptr;
+    if (m->d_Af16h) (void)hipFree(m->d_Af16h);
+    if (m->d_lo16) (void)hipFree(m->d_lo16);
+    m->d_Af16h = nullptr;
+    m->d_lo16 = nullptr;
     if (m->d_cn16) (void)hipFree(m->d_cn16);
     if (m->d_beta16) (void)hipFree(m->d_beta16);
     m->d_cn16 = nullptr;
@@ -332,6 +337,7 @@ struct RerankParams {
     // candidate lists sit at the dense positions 0 .. min(*map_count, N) of a second list set of capacity N
     const uint32_t *map = nullptr;
     const uint32_t *map_count = nullptr;
+    uint32_t *counters = nullptr;           // the batch's counter words (see phk_score_fast)
     uint32_t *stat_total = nullptr;         // [0] += fallback queue length, [1] += orderings decided by exact distances
     const uint32_t *exact_extra = nullptr;  // exact-distance decisions of an earlier pass of the same batch
 };
@@ -1067,6 +1073,302 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
 }
 
 // ------------------------------------------------------------------------------------
+// 2d. decision stage of the high-parts-only proposal (phk_knn_f16h_kernel; D = 256, uint32 counts).
+//     The lists hold HIGH-PART values  w^h_j  whose distance from the count-exact value  w_j  is the low product
+//         w_j - w^h_j = sum_i (c_i - T mu_i) lo_ji,      |.| <= T S |q'| lam_j,   lam_j = |lo_j| / S   (Cauchy-Schwarz).
+//     With  e_h = |q'| lam*(R0) + e22  (lam* = the largest lam_j among the columns within reach R0, HiParams.lam_tab;
+//     e22 = the count-exact error model, which also covers this pass's fewer MFMA roundings):
+//       window   every column whose true value can be among the `need` best has  w^h >= h_need - 2 e_h,  h_need = the
+//                need-th best high-part value.  Columns in the window must all be list members: the best value either
+//                half-list dropped has to be below the window, else the query takes the second chance.
+//       refine   the window's members (3 to 8 columns, typically 3 or 4) get the low product in float64, 16 lanes per
+//                query, from the row-major low parts (512 B per column, L2 resident); they then carry count-exact
+//                values and the count-exact margin test decides their order exactly as phk_decide_kernel does.
+//       centroid segments (need = 1): the leader is certified by its high-part margin (h_1 - h_2 > 2 e_h; both are list
+//                members: each half-list keeps its 4 best) and its exact float64 distance is computed as before; a
+//                leader that is not certified sends the query to the second chance.
+//     Phases as in phk_decide_kernel: A one lane per query (lists, window), B 16 lanes per query (row norms, low
+//     products, exact centroid distances), C one lane per query (margin tests, vote, metric).
+// ------------------------------------------------------------------------------------
+struct HiParams {
+    const _Float16 *lo16;     // [columns][256] low parts, row-major
+    double lam_tab[65];
+    double lam_r0, lam_inv_step;
+};
+
+__device__ __forceinline__ double phk_lam_of(const HiParams &hp, double R) {
+    int i = (int)ceil((R - hp.lam_r0) * hp.lam_inv_step);
+    i = i < 0 ? 0 : (i > 64 ? 64 : i);
+    return hp.lam_tab[i];
+}
+
+__global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__restrict__ counts, RerankParams p, HiParams hp) {
+    __shared__ uint32_t s_c0[8][64];        // train-segment candidates by descending high-part value
+    __shared__ uint32_t s_ix[2][64];        // centroid-segment leaders
+    __shared__ double s_corr[PHK_HI_REFINE][64];
+    __shared__ double s_T[64], s_nq2[64], s_nqp2[64], s_dp2[64], s_dn2[64];
+    const int tid = threadIdx.x, t = tid & 15;
+    const uint64_t qb = (uint64_t)blockIdx.x * 64;
+    const bool want_knn = (p.method & PHK_METHOD_KNN) != 0, want_cen = (p.method & PHK_METHOD_KMEANS) != 0;
+    auto rowptr = [&](int pass) {
+        const int ql = pass * 4 + (tid >> 4);
+        const uint64_t q = qb + ql < p.N ? qb + ql : p.N - 1;
+        return reinterpret_cast<const uint4 *>(counts + q * FAST_D + 16 * t);
+    };
+    uint4 pre[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pre[0][i] = rowptr(0)[i];
+        pre[1][i] = rowptr(1)[i];
+    }
+
+    // ---- phase A: one lane per query ----
+    const uint64_t qa = qb + tid;
+    const bool in_a = qa < p.N;
+    const uint64_t qc = in_a ? qa : p.N - 1;
+    // train segment: the 8 candidates sorted by high-part value (descending; empty / padding slots last)
+    float v8[8];
+    uint32_t i8[8];
+    float U0 = 0.f;
+    bool ok0 = true;          // the need-th list position holds a real column
+    if (want_knn) {
+        U0 = fmaxf(p.cand_u[candu_at(0, 0, qc, p.N)], p.cand_u[candu_at(0, 1, qc, p.N)]);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint32_t ix = p.cand_i[cand_at(0, c >> 2, c & 3, qc, p.N)];
+            const float w = p.cand_v[cand_at(0, c >> 2, c & 3, qc, p.N)];
+            v8[c] = ix >= (uint32_t)p.M ? -3.0e38f : w;
+            i8[c] = ix;
+        }
+#pragma unroll
+        for (int a = 1; a < 8; ++a)          // insertion sort network, fully unrolled (descending)
+#pragma unroll
+            for (int b = a; b > 0; --b) {
+                const bool sw = v8[b] > v8[b - 1];
+                const float tv = v8[b]; const uint32_t ti = i8[b];
+                v8[b] = sw ? v8[b - 1] : v8[b]; i8[b] = sw ? i8[b - 1] : i8[b];
+                v8[b - 1] = sw ? tv : v8[b - 1]; i8[b - 1] = sw ? ti : i8[b - 1];
+            }
+    }
+    // centroid segments: leader and runner-up by high-part value
+    float ch1[2] = {0.f, 0.f}, ch2[2] = {0.f, 0.f};
+    uint32_t cl[2] = {0u, 0u};
+    bool cfill[2] = {true, true};
+    if (want_cen) {
+#pragma unroll
+        for (int sg = 1; sg <= 2; ++sg) {
+            const uint32_t ncols = sg == 1 ? (uint32_t)p.n_cpos : (uint32_t)p.n_cneg;
+            float b1 = -3.0e38f, b2 = -3.0e38f;
+            uint32_t bi = 0xFFFFFFFFu;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t ix = p.cand_i[cand_at(sg, c >> 2, c & 3, qc, p.N)];
+                const float w = ix >= ncols ? -3.0e38f : p.cand_v[cand_at(sg, c >> 2, c & 3, qc, p.N)];
+                const bool up = w > b1;
+                b2 = up ? b1 : fmaxf(b2, w);
+                bi = up ? ix : bi;
+                b1 = up ? w : b1;
+            }
+            ch1[sg - 1] = b1; ch2[sg - 1] = b2; cl[sg - 1] = bi;
+            cfill[sg - 1] = bi < ncols;
+        }
+    }
+    s_ix[0][tid] = cl[0] < (uint32_t)p.n_cpos ? cl[0] : 0u;
+    s_ix[1][tid] = cl[1] < (uint32_t)p.n_cneg ? cl[1] : 0u;
+    // speculative gathers, consumed in phase C
+    double cn0[3];
+    uint32_t labbits = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t c = (want_knn && i8[r] < (uint32_t)p.M) ? i8[r] : 0u;
+        if (r < 3) cn0[r] = p.colnorm[c];
+        labbits |= (uint32_t)(p.labels[c] ? 1u : 0u) << r;
+        s_c0[r][tid] = c;
+    }
+    const double cnp = p.colnorm[p.M + s_ix[0][tid]], cnn = p.colnorm[p.M + p.n_cpos + s_ix[1][tid]];
+    if (want_knn) ok0 = i8[p.kn - 1] < (uint32_t)p.M;
+    __syncthreads();
+
+    // ---- phase B: 16 lanes per query, 4 queries per pass ----
+    {
+        double mu[16];
+        const double2 *mp = reinterpret_cast<const double2 *>(p.mu64 + 16 * t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double2 m2 = mp[i];
+            mu[2 * i] = m2.x;
+            mu[2 * i + 1] = m2.y;
+        }
+#pragma unroll 2
+        for (int pass = 0; pass < 16; ++pass) {
+            const int ql = pass * 4 + (tid >> 4);
+            double qd[16];
+            uint4 cur[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cur[i] = pre[pass & 1][i];
+            if (pass + 2 < 16) {
+                const uint4 *nrow = rowptr(pass + 2);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pre[pass & 1][i] = nrow[i];
+            }
+            uint32_t sum = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 c = cur[i];
+                sum += c.x + c.y + c.z + c.w;
+                qd[4 * i + 0] = (double)c.x;
+                qd[4 * i + 1] = (double)c.y;
+                qd[4 * i + 2] = (double)c.z;
+                qd[4 * i + 3] = (double)c.w;
+            }
+            sum += __shfl_xor(sum, 8);
+            sum += __shfl_xor(sum, 4);
+            sum += __shfl_xor(sum, 2);
+            sum += __shfl_xor(sum, 1);
+            const bool bad = sum == 0;
+            const double Tq = (double)sum, invT2 = 1.0 / (Tq * Tq);
+            double dp2 = 0.0, dn2 = 0.0;
+            if (want_cen) {
+                dp2 = exact_d2_g16(qd, Tq, invT2, p.C64 + (uint64_t)s_ix[0][ql] * FAST_D, t);
+                dn2 = exact_d2_g16(qd, Tq, invT2, p.C64 + (p.n_cpos + (uint64_t)s_ix[1][ql]) * FAST_D, t);
+            }
+            double aq = 0.0, ap = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {   // qd becomes c - T mu (the centred counts) in place
+                aq = fma(qd[i], qd[i], aq);
+                qd[i] = fma(-Tq, mu[i], qd[i]);
+                ap = fma(qd[i], qd[i], ap);
+            }
+            const double nq2 = group16_sum(aq) * invT2, nqp2 = group16_sum(ap) * invT2;
+            // low products of the train segment's first PHK_HI_REFINE candidates (descending high-part value), fetched
+            // unconditionally: their addresses depend on the lists only, so the loads are in flight while the row is still
+            // being reduced (a window-sized fetch, tried, made them wait for the row and cost 60 % more time); phase C,
+            // which knows the window, only uses the members
+            if (want_knn) {
+                uint4 l0[PHK_HI_REFINE], l1[PHK_HI_REFINE];
+#pragma unroll
+                for (int r = 0; r < PHK_HI_REFINE; ++r) {
+                    const uint4 *lp = reinterpret_cast<const uint4 *>(hp.lo16 + (uint64_t)s_c0[r][ql] * FAST_D + 16 * t);
+                    l0[r] = lp[0];
+                    l1[r] = lp[1];
+                }
+#pragma unroll
+                for (int r = 0; r < PHK_HI_REFINE; ++r) {
+                    const _Float16 *lh0 = reinterpret_cast<const _Float16 *>(&l0[r]), *lh1 = reinterpret_cast<const _Float16 *>(&l1[r]);
+                    double acc = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        acc = fma(qd[i], (double)lh0[i], acc);
+                        acc = fma(qd[8 + i], (double)lh1[i], acc);
+                    }
+                    acc = group16_sum(acc);
+                    if (t == 0) s_corr[r][ql] = acc;
+                }
+            }
+            if (t == 0) {
+                s_T[ql] = bad ? 0.0 : Tq;   // 0 marks a NaN row
+                s_nq2[ql] = nq2;
+                s_nqp2[ql] = nqp2;
+                s_dp2[ql] = dp2;
+                s_dn2[ql] = dn2;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: one lane per query ----
+    if (!in_a) return;
+    const double Tq = s_T[tid];
+    if (Tq == 0.0) {  // zero-count contig: the reference's normalised row is NaN
+        p.scores[p.q_base + qa] = __builtin_nan("");
+        if (p.status) atomicAdd(p.status, 1u);
+        return;
+    }
+    const double nq2 = s_nq2[tid], nqp2 = s_nqp2[tid];
+    const double vs = p.vscale / Tq;
+    ErrBound eb;
+    eb.A = sqrt(nq2) + p.mu_norm;
+    eb.P = sqrt(nqp2);
+    eb.Q = sqrt(nq2);
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ;
+    const double nqp = eb.P;
+    auto e_hi = [&](double R) { return nqp * phk_lam_of(hp, R) + eb(R); };
+    bool cert = true;
+    double knn = 0.0, cen = 0.0;
+    if (want_knn) {
+        const int need = p.kn;
+        cert = ok0;
+        if (cert) {
+            // reach of the need nearest columns from the need-th high-part value; error bounds at that reach when the
+            // leaders lie within it
+            const double eg = e_hi(p.rmax);
+            const double d2up = fmax(nqp2 - 2.0 * ((double)v8[need - 1] * vs - eg), 0.0);
+            const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
+            bool near = true;
+            for (int r = 0; r < need; ++r) near = near && cn0[r] <= R0;
+            const double eh = near ? e_hi(R0) : eg, e22 = near ? eb(R0) : eb(p.rmax);
+            // window members: list positions 0 .. nw-1 (sorted by high-part value)
+            const double thr = (double)v8[need - 1] * vs - 2.0 * eh;
+            int nw = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) nw += ((double)v8[r] * vs >= thr && i8[r] < (uint32_t)p.M) ? 1 : 0;
+            // every column of the window has to be a list member with a refined value
+            cert = nw <= PHK_HI_REFINE && (double)U0 * vs < thr;
+            if (!cert) atomicAdd(p.counters + (nw > PHK_HI_REFINE ? 8 : 9), 1u);   // diagnostics: window too wide / reaches past the lists
+            if (cert) {
+                // refined values of the window's members, descending
+                double rv[PHK_HI_REFINE];
+                uint32_t rl[PHK_HI_REFINE];
+#pragma unroll
+                for (int r = 0; r < PHK_HI_REFINE; ++r) {
+                    const bool in = r < nw;
+                    rv[r] = in ? ((double)v8[r] + s_corr[r][tid]) * vs : -1.0e300;
+                    rl[r] = (labbits >> r) & 1u;
+                }
+#pragma unroll
+                for (int a = 1; a < PHK_HI_REFINE; ++a)
+#pragma unroll
+                    for (int b = a; b > 0; --b) {
+                        const bool sw = rv[b] > rv[b - 1];
+                        const double tv = rv[b]; const uint32_t tl = rl[b];
+                        rv[b] = sw ? rv[b - 1] : rv[b]; rl[b] = sw ? rl[b - 1] : rl[b];
+                        rv[b - 1] = sw ? tv : rv[b - 1]; rl[b - 1] = sw ? tl : rl[b - 1];
+                    }
+                // the need-th and (need+1)-th refined values decide (a window of exactly `need` members is decided)
+                const double hi_v = need == 1 ? rv[0] : need == 2 ? rv[1] : rv[2];
+                const double lo_v = need == 1 ? rv[1] : need == 2 ? rv[2] : rv[3];
+                cert = nw == need || hi_v - lo_v > 2.0 * e22;
+                if (!cert) atomicAdd(p.counters + 10, 1u);   // diagnostics: refined values too close
+                int votes = 0;
+                for (int r = 0; r < need; ++r) votes += (int)rl[r];
+                knn = (2 * votes > need) ? 1.0 : -1.0;
+            }
+        }
+    }
+    if (want_cen && cert) {
+        const double eg = e_hi(p.rmax);
+        auto leader_ok = [&](int k2, double cnorm) {
+            if (!cfill[k2]) return false;
+            const double d2up = fmax(nqp2 - 2.0 * ((double)ch1[k2] * vs - eg), 0.0);
+            const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
+            const double eh = cnorm <= R0 ? e_hi(R0) : eg;
+            return ((double)ch1[k2] - (double)ch2[k2]) * vs > 2.0 * eh;
+        };
+        cert = leader_ok(0, cnp) && leader_ok(1, cnn);
+        if (!cert) atomicAdd(p.counters + 11, 1u);   // diagnostics: centroid leader not certified
+        const double ep = sqrt(s_dp2[tid]), en = sqrt(s_dn2[tid]);
+        cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
+    }
+    if (cert) {
+        p.scores[p.q_base + qa] = knn + cen;  // scripts/phamer.py:313
+    } else {
+        // not decided here: phk_rerank16_kernel (MODE 1) takes the query's lists as they are -- high-part values under the
+        // high-part error model -- and decides by exact float64 candidate distances where that suffices
+        p.slow_list[atomicAdd(p.fb_count + 2, 1u)] = (uint32_t)qa;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // 3. exact brute force for queued queries.  Work item = (queued query, column chunk): a block
 //    computes the direct-difference float64 distances of its chunk (one thread per column), then
 //    reduces them to a partial record (3 nearest train columns of the chunk + nearest positive /
@@ -1177,6 +1479,9 @@ __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p)
     if (blockIdx.x == 0 && threadIdx.x == 0 && p.stat_total) {   // statistics: this batch's counters into the call's totals
         p.stat_total[0] += p.fb_count[0];
         p.stat_total[1] += p.fb_count[1] + (p.exact_extra ? *p.exact_extra : 0u);
+        if (p.map_count) p.stat_total[2] += *p.map_count;   // queries that took the second chance
+        if (p.counters)                                      // why the high-parts-only decision stage passed them on
+            for (int i = 0; i < 4; ++i) p.stat_total[3 + i] += p.counters[8 + i];
     }
     const FbRecord *rec = static_cast<const FbRecord *>(p.fb_rec);
     for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < count;
@@ -1275,6 +1580,9 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // split-query MFMA kernel (any magnitude: the counts are normalised, centred and split on the fly) addressed through
     // the first pass's queue, with their own list set; only what that pass cannot certify either is brute-forced.
     const bool second = use_cx && D == FAST_D;
+    // first pass at k = 4: the high-parts-only kernel (1 MFMA per k-step) + its decision stage; proposal=cx2 keeps the
+    // count-exact kernel with both parts (2 MFMAs per k-step) and the margin-test decision kernels
+    const bool hi_only = second && m->d_Af16h && !(prop[0] == 'c' && prop[1] == 'x' && prop[2] == '2');
     const uint64_t cap2 = second ? (nb_max / 8 > 4096 ? nb_max / 8 : (nb_max < 4096 ? nb_max : 4096)) : 0;
     const uint64_t per_list = nb_max * NSEG * 2, per_list2 = cap2 * NSEG * 2;
     const uint64_t list_bytes = sizeof(float4) + sizeof(uint4) + sizeof(float);
@@ -1285,15 +1593,18 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     float *cv2 = (float *)((char *)cv + per_list * list_bytes);
     uint32_t *ci2 = (uint32_t *)((char *)cv2 + per_list2 * sizeof(float4));
     float *cu2 = (float *)((char *)ci2 + per_list2 * sizeof(uint4));
-    PHK_TRY(phk_ws(ctx, WS_DIST, (3 * nb_max + 16) * sizeof(uint32_t), &fb));
+    PHK_TRY(phk_ws(ctx, WS_DIST, (3 * nb_max + 32) * sizeof(uint32_t), &fb));
     PHK_TRY(phk_ws(ctx, WS_QF32, nb_max * FB_CHUNKS * sizeof(FbRecord), &rec));
-    // counter words: [0] first-pass queue length, [1] exact-distance decisions, [2] decide kernel's hand-over count,
-    // [3] brute-force queue length after the second chance, [4] its exact-distance decisions, [8], [9] totals of the call
-    uint32_t *fbc = (uint32_t *)fb, *fb_list = fbc + 16, *slow_list = fb_list + nb_max, *fb2_list = slow_list + nb_max;
+    // counter words, per batch: [0] first-pass queue length, [1] exact-distance decisions, [2] decide kernel's hand-over
+    // count, [3] brute-force queue length after the second chance, [4] its exact-distance decisions, [8..11] why the
+    // high-parts-only decision stage passed a query on (window wider than the refined set, window reaching past the
+    // lists, refined values too close, centroid leader not certified); [16 ..] totals of the call: brute-forced queries,
+    // exact-distance decisions, second-chance queries, the four reasons
+    uint32_t *fbc = (uint32_t *)fb, *fb_list = fbc + 32, *slow_list = fb_list + nb_max, *fb2_list = slow_list + nb_max;
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
     const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + D) * sizeof(double);
     PHK_REQUIRE(fb_lds <= FB_LDS_MAX, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);  // phk_model_build_fast keeps such models off this path
-    PHK_HIP(hipMemsetAsync(fbc, 0, 64, ctx->stream));   // words 8, 9: statistics totals of this call
+    PHK_HIP(hipMemsetAsync(fbc, 0, 128, ctx->stream));   // incl. the totals of this call
     for (uint64_t s = 0; s < N; s += BATCH) {
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
         const void *src = d_counts ? (const void *)(d_counts + s * D) : (const void *)(d_Q + s * D);
@@ -1302,14 +1613,15 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         const uint32_t nref = (method & PHK_METHOD_KNN) ? m->n_rblk_ref : 0;
         const uint32_t npos = (method & PHK_METHOD_KMEANS) ? m->n_rblk_pos : 0;
         const uint32_t nneg = (method & PHK_METHOD_KMEANS) ? m->n_rblk_neg : 0;
-        PHK_HIP(hipMemsetAsync(fbc, 0, 32, ctx->stream));
+        PHK_HIP(hipMemsetAsync(fbc, 0, 64, ctx->stream));
         RerankParams p;
         p.N = nb; p.M = m->M; p.n_cpos = m->n_cpos; p.n_cneg = m->n_cneg; p.D = D;
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
         p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.colnorm = m->d_colnorm; p.labels = m->d_labels;
         p.cand_v = (const float *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
         p.scores = d_scores; p.status = d_status; p.fb_count = fbc; p.fb_list = fb_list; p.slow_list = slow_list; p.q_base = s;
-        p.stat_total = fbc + 8;
+        p.stat_total = fbc + 16;
+        p.counters = fbc;
         p.eb_cQ = 0.0; p.per_row_scale = 0;
         auto split_f16_bound = [&](RerankParams &r) {
             // 3D/16 MFMA instructions, each charged 2u (|acc_in| + sum |products|) <= 2u (P + dq) R -- the
@@ -1337,6 +1649,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         if (D != FAST_D) {
             PHK_TRY(phk_launch_proposal_f16_general(ctx, m, src, d_counts != nullptr, use_cx, rsum, nb, nref, npos, nneg,
                                                     (float *)cv, ci, cu));
+        } else if (hi_only) {
+            PHK_TRY(phk_launch_proposal_f16h(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu));
         } else if (use_cx) {
             PHK_TRY(phk_launch_proposal_f16c(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu));
         } else if (use_f16) {
@@ -1356,8 +1670,28 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             }
         }
         const unsigned rblocks = (unsigned)phk_div_up(nb, 4);
-        if (d_counts) PHK_TRY(launch_rerank<0>(ctx, rblocks, src, p));
-        else PHK_TRY(launch_rerank<1>(ctx, rblocks, src, p));
+        if (hi_only) {
+            HiParams hp;
+            hp.lo16 = m->d_lo16;
+            for (int i = 0; i <= 64; ++i) hp.lam_tab[i] = m->lam_tab[i];
+            hp.lam_r0 = m->lam_r0;
+            hp.lam_inv_step = 1.0 / m->lam_step;
+            PHK_LAUNCH(ctx, "phk_decide_h_kernel",
+                       phk_decide_h_kernel<<<dim3((unsigned)phk_div_up(nb, 64)), dim3(64), 0, ctx->stream>>>((const uint32_t *)src, p, hp));
+            // what it passes on is decided from the same lists by exact candidate distances where possible.  For that
+            // kernel the lists' error model is the count-exact one plus the missing low product, |q'| |lo_j| / S with
+            // |lo_j| <= 2^-11 (1 + 2^-11) S |r'_j| + sqrt(D) 2^-25 (half an ulp of the high part per element; the
+            // second term covers fp16 subnormals): 2^-11 / u = 8192 more on cP, the absolute term doubled
+            RerankParams ph = p;
+            ph.eb_cP += 8192.0 * (1.0 + 1.0 / 2048.0) + 1.0;
+            ph.eb_abs *= 2.0;
+            PHK_LAUNCH(ctx, "phk_rerank16_kernel",
+                       (phk_rerank16_kernel<0, 1><<<dim3((unsigned)phk_div_up(nb, 16)), dim3(256), 0, ctx->stream>>>(src, ph)));
+        } else if (d_counts) {
+            PHK_TRY(launch_rerank<0>(ctx, rblocks, src, p));
+        } else {
+            PHK_TRY(launch_rerank<1>(ctx, rblocks, src, p));
+        }
         RerankParams pf = p;   // what the brute force works from
         if (second) {
             const uint64_t cap = nb < cap2 ? nb : cap2;

@@ -17,6 +17,13 @@ struct phk_model {
     void *d_Af16 = nullptr;       // split-f16 fragment-ordered block records (score_f16.hip)
     float *d_cn16 = nullptr;      // split-f16 norm terms per column slot (general-D kernel)
     float *d_beta16 = nullptr;    // count-exact bias terms S (mu.r~' + |r~'|^2/2) per column slot (general-D kernel)
+    // high-parts-only proposal (k = 4, phk_knn_f16h_kernel): 17-piece block records (16 hi fragments + the bias terms
+    // S mu.hi + S |r~'|^2/2 per unit of row sum), the low parts row-major for the decision stage's refinement, and
+    // lam_tab[i] = max |lo_j| / S over the columns with |r'_j| <= lam_r0 + i * lam_step (error of a high-parts-only value)
+    void *d_Af16h = nullptr;
+    _Float16 *d_lo16 = nullptr;   // [M + n_cpos + n_cneg][D]
+    double lam_tab[65] = {0};
+    double lam_r0 = 0.0, lam_step = 0.0;
     float *d_mu32 = nullptr;      // centring vector, fp32
     double *d_mu64 = nullptr;     // centring vector, fp64
     uint32_t n_rblk_ref = 0, n_rblk_pos = 0, n_rblk_neg = 0;  // 32-column blocks per segment
@@ -38,12 +45,14 @@ void phk_model_free_fast(phk_model *m);
 static inline bool phk_model_has_fast(const phk_model *m) { return m->fast; }
 // split-f16 proposal (score_f16.hip)
 int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, const double *cpos,
-                        const double *cneg, const double *mu);
+                        const double *cneg, const double *mu, const double *colnorm);
 int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                             const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
                             float *cv, uint32_t *ci, float *cu, const uint32_t *qmap = nullptr,
                             const uint32_t *qcount = nullptr);
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
+                             uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu);
+int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu);
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, bool count_exact,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,

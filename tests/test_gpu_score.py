@@ -164,11 +164,11 @@ def test_fast_and_exact_gpu_paths_agree_on_a_larger_batch(monkeypatch):
     d_nwin = device.DeviceArray(ctx, n, np.uint32)
     device.count(ctx, d_packed, None, T, d_off, n, 4, d_counts, d_nwin)
     out = {}
-    # proposal kernel: count-exact f16 MFMA (default, "cx"), split-query f16 MFMA and fp32 MFMA;
-    # "exact" = float64 brute force path
-    for path in ("cx", "f16", "f32", "exact"):
+    # proposal kernel: high-parts-only f16 MFMA (default, "hi"), count-exact f16 MFMA with both parts ("cx2"), split-query
+    # f16 MFMA and fp32 MFMA; "exact" = float64 brute force path
+    for path in ("hi", "cx2", "f16", "f32", "exact"):
         ctx.set_option("force_exact", "1" if path == "exact" else "0")
-        ctx.set_option("proposal", path if path != "exact" else "")
+        ctx.set_option("proposal", {"hi": "", "exact": ""}.get(path, path))
         for method in ("knn", "kmeans", "combo"):
             d_scores = device.DeviceArray(ctx, n, np.float64)
             d_status = device.DeviceArray(ctx, 1, np.uint32)
@@ -178,7 +178,7 @@ def test_fast_and_exact_gpu_paths_agree_on_a_larger_batch(monkeypatch):
         if path != "exact":
             n_fallback, n_exact = ctx.score_stats()
             assert n_fallback < n // 100, (path, n_fallback)     # the proposal must certify nearly everything
-    for path in ("cx", "f16", "f32"):
+    for path in ("hi", "cx2", "f16", "f32"):
         assert np.array_equal(out[(path, "knn")], out[("exact", "knn")]), path
         assert set(np.unique(out[(path, "knn")])) <= {-1.0, 1.0}
         assert helpers.rel_err(out[(path, "kmeans")], out[("exact", "kmeans")]) < 1e-9, path
@@ -371,7 +371,8 @@ def test_count_exact_kernel_shapes_and_large_counts(monkeypatch, cfg):
             assert d_status.to_host()[0] == 0
             n_fallback, _ = ctx.score_stats()
             # rows with counts above 2048 take the second chance (split-query MFMA pass), not the brute-force queue
-            assert n_fallback <= 2, (n, method, n_fallback, len(big))
+            # (or, for fewer than 24 queued rows, straight the brute force: PHK_SECOND_MIN)
+            assert n_fallback < 24 and (n < 500 or n_fallback <= 2), (n, method, n_fallback, len(big))
             assert helpers.rel_err(got, want) < RTOL, (cfg, n, method)
     model.close()
 
@@ -457,7 +458,9 @@ def test_scoring_in_several_batches_matches_one_batch_and_exact_path():
         ctx.set_option("score_batch", "0")
         ctx.set_option("force_exact", "0")
     assert np.array_equal(out["one"], out["four"])
-    assert stats["one"] == stats["four"] and stats["one"][1] > 0   # totals over the four batches
+    # totals over the four batches (the tail routes depend on the batch split: a handful of queued rows per batch goes
+    # straight to the brute force, so the totals are compared loosely)
+    assert stats["four"][1] > 0 and abs(stats["four"][1] - stats["one"][1]) <= 64
     assert np.array_equal(np.sign(out["one"]), np.sign(out["exact"]))
     assert helpers.rel_err(out["one"], out["exact"]) < 1e-9
     model.close()
