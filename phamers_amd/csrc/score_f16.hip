@@ -160,22 +160,26 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
         if (hipMemcpy(m->d_Af16h, rech.data(), rech.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
         if (hipMalloc((void **)&m->d_lo16, lo_rows.size() * sizeof(_Float16)) != hipSuccess) return PHK_ERR_NOMEM;
         if (hipMemcpy(m->d_lo16, lo_rows.data(), lo_rows.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
-        // lam_tab: the largest |lo_j| / S among the columns within a radius, on a 64-step grid of radii
-        double rmin = 1e300, rmax = 0.0;
-        for (uint64_t c = 0; c < ncols; ++c) {
-            rmin = colnorm[c] < rmin ? colnorm[c] : rmin;
-            rmax = colnorm[c] > rmax ? colnorm[c] : rmax;
+        // lam_tab: per segment, the largest |lo_j| / S among its columns within a radius, on a 64-step grid of radii
+        const uint64_t seg0[4] = {0, m->M, m->M + m->n_cpos, ncols};
+        for (int sg = 0; sg < 3; ++sg) {
+            double rmin = 1e300, rmax = 0.0;
+            for (uint64_t c = seg0[sg]; c < seg0[sg + 1]; ++c) {
+                rmin = colnorm[c] < rmin ? colnorm[c] : rmin;
+                rmax = colnorm[c] > rmax ? colnorm[c] : rmax;
+            }
+            if (seg0[sg] == seg0[sg + 1]) rmin = rmax = 0.0;
+            m->lam_r0[sg] = rmin;
+            m->lam_step[sg] = rmax > rmin ? (rmax - rmin) / 64.0 : 1.0;
+            for (int i = 0; i <= 64; ++i) m->lam_tab[sg][i] = 0.0;
+            for (uint64_t c = seg0[sg]; c < seg0[sg + 1]; ++c) {
+                int i = (int)std::ceil((colnorm[c] - rmin) / m->lam_step[sg] - 1e-12);
+                i = i < 0 ? 0 : (i > 64 ? 64 : i);
+                if (lonorm[c] > m->lam_tab[sg][i]) m->lam_tab[sg][i] = lonorm[c];
+            }
+            for (int i = 1; i <= 64; ++i)
+                if (m->lam_tab[sg][i - 1] > m->lam_tab[sg][i]) m->lam_tab[sg][i] = m->lam_tab[sg][i - 1];
         }
-        m->lam_r0 = rmin;
-        m->lam_step = rmax > rmin ? (rmax - rmin) / 64.0 : 1.0;
-        for (int i = 0; i <= 64; ++i) m->lam_tab[i] = 0.0;
-        for (uint64_t c = 0; c < ncols; ++c) {
-            int i = (int)std::ceil((colnorm[c] - rmin) / m->lam_step - 1e-12);
-            i = i < 0 ? 0 : (i > 64 ? 64 : i);
-            if (lonorm[c] > m->lam_tab[i]) m->lam_tab[i] = lonorm[c];
-        }
-        for (int i = 1; i <= 64; ++i)
-            if (m->lam_tab[i - 1] > m->lam_tab[i]) m->lam_tab[i] = m->lam_tab[i - 1];
     }
     return PHK_OK;
 }

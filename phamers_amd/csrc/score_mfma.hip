@@ -338,6 +338,9 @@ struct RerankParams {
     const uint32_t *map = nullptr;
     const uint32_t *map_count = nullptr;
     uint32_t *counters = nullptr;           // the batch's counter words (see phk_score_fast)
+    int slow_back = 0;                      // phk_rerank16_kernel MODE 1: 0 = slow_list[0 ..) counted by fb_count[2],
+                                            // 1 = the list that grows down from slow_list[slow_cap - 1], counted by counters[12]
+    uint64_t slow_cap = 0;
     uint32_t *stat_total = nullptr;         // [0] += fallback queue length, [1] += orderings decided by exact distances
     const uint32_t *exact_extra = nullptr;  // exact-distance decisions of an earlier pass of the same batch
 };
@@ -719,11 +722,17 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     uint64_t qraw = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
     bool inrange;
     uint64_t q, ql;   // the query's row in src / scores; the position of its candidate lists
+    uint32_t todo = 3u;
     if (MODE == 1) {
-        const uint64_t cnt = p.fb_count[2];
+        const uint64_t cnt = p.slow_back ? p.counters[12] : p.fb_count[2];
         if ((qraw & ~3ull) >= cnt) return;
         inrange = qraw < cnt;
-        q = ql = p.slow_list[inrange ? qraw : cnt - 1];
+        // entry = query | todo << 30: which parts are still open (bit 0 the k-NN vote, bit 1 the centroid metric; 0 = both).
+        // A part the sender has decided already sits in scores[q] and is only added to.
+        const uint64_t pos = inrange ? qraw : cnt - 1;
+        const uint32_t entry = p.slow_list[p.slow_back ? p.slow_cap - 1 - pos : pos];
+        q = ql = entry & 0x3FFFFFFFu;
+        todo = entry >> 30 ? entry >> 30 : 3u;
     } else if (MODE == 2) {
         const uint64_t cnt_all = *p.map_count;
         // a handful of rows is cheaper to brute-force than to sweep (one workgroup's sweep is ~0.2 ms of latency):
@@ -819,30 +828,35 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     double knn = 0.0, cen = 0.0;
     uint32_t idx[3];
     double d2 = 0.0;
-    if (p.method & PHK_METHOD_KNN) {
-        ok = resolve_segment_g16(p, q, 0, (uint32_t)p.M, p.kn, qd, Tq, invT2, nqp2, eb, vs, p.R64, p.colnorm, false, live, lane, lv[0], lix[0],
-                                 lu[0], idx, d2);
+    const bool do_knn = (p.method & PHK_METHOD_KNN) && (todo & 1u), do_cen = (p.method & PHK_METHOD_KMEANS) && (todo & 2u);
+    // wave-uniform skips: a segment nobody in the wave needs is not touched
+    if (__any(do_knn)) {
+        const bool okk = resolve_segment_g16(p, q, 0, (uint32_t)p.M, p.kn, qd, Tq, invT2, nqp2, eb, vs, p.R64, p.colnorm, false,
+                                             live && do_knn, lane, lv[0], lix[0], lu[0], idx, d2);
         int votes = 0;
         for (int r = 0; r < p.kn; ++r) votes += (idx[r] < p.M && p.labels[idx[r]]) ? 1 : 0;
-        knn = (2 * votes > p.kn) ? 1.0 : -1.0;
+        knn = do_knn ? ((2 * votes > p.kn) ? 1.0 : -1.0) : 0.0;
+        ok = okk || !do_knn;
     }
-    if (p.method & PHK_METHOD_KMEANS) {
+    if (__any(do_cen)) {
         double dp2 = 0.0, dn2 = 0.0;
         const bool ok1 = resolve_segment_g16(p, q, 1, (uint32_t)p.n_cpos, 1, qd, Tq, invT2, nqp2, eb, vs, p.C64, p.colnorm + p.M, true,
-                                             live && ok, lane, lv[1], lix[1], lu[1], idx, dp2);
+                                             live && ok && do_cen, lane, lv[1], lix[1], lu[1], idx, dp2);
         const bool ok2 = resolve_segment_g16(p, q, 2, (uint32_t)p.n_cneg, 1, qd, Tq, invT2, nqp2, eb, vs, p.C64 + p.n_cpos * FAST_D,
-                                             p.colnorm + p.M + p.n_cpos, true, live && ok && ok1, lane, lv[2], lix[2], lu[2],
-                                             idx, dn2);
-        ok = ok && ok1 && ok2;
+                                             p.colnorm + p.M + p.n_cpos, true, live && ok && ok1 && do_cen, lane, lv[2], lix[2],
+                                             lu[2], idx, dn2);
+        ok = ok && ((ok1 && ok2) || !do_cen);
         const double ep = sqrt(dp2), en = sqrt(dn2);
-        cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
+        cen = do_cen ? tanh((en - ep) / (ep + en)) : 0.0;  // scripts/phamer.py:206-209
     }
+    // parts the sender had decided already are in scores[q]
+    const double prev = (MODE == 1 && todo != 3u && inrange && !nan_row) ? p.scores[p.q_base + q] : 0.0;
     if (t == 0 && inrange) {
         if (nan_row) {  // zero-count contig: the reference's normalised row is NaN
             p.scores[p.q_base + q] = __builtin_nan("");
             if (p.status) atomicAdd(p.status, 1u);
         } else if (ok) {
-            p.scores[p.q_base + q] = knn + cen;  // scripts/phamer.py:313
+            p.scores[p.q_base + q] = prev + knn + cen;  // scripts/phamer.py:313
         } else {
             const uint32_t slot = atomicAdd(p.fb_count, 1u);
             p.fb_list[slot] = (uint32_t)q;
@@ -1092,14 +1106,14 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
 // ------------------------------------------------------------------------------------
 struct HiParams {
     const _Float16 *lo16;     // [columns][256] low parts, row-major
-    double lam_tab[65];
-    double lam_r0, lam_inv_step;
+    double lam_tab[3][65];    // per segment
+    double lam_r0[3], lam_inv_step[3];
 };
 
-__device__ __forceinline__ double phk_lam_of(const HiParams &hp, double R) {
-    int i = (int)ceil((R - hp.lam_r0) * hp.lam_inv_step);
+__device__ __forceinline__ double phk_lam_of(const HiParams &hp, int sg, double R) {
+    int i = (int)ceil((R - hp.lam_r0[sg]) * hp.lam_inv_step[sg]);
     i = i < 0 ? 0 : (i > 64 ? 64 : i);
-    return hp.lam_tab[i];
+    return hp.lam_tab[sg][i];
 }
 
 __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__restrict__ counts, RerankParams p, HiParams hp) {
@@ -1292,8 +1306,9 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
     eb.Q = sqrt(nq2);
     eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ;
     const double nqp = eb.P;
-    auto e_hi = [&](double R) { return nqp * phk_lam_of(hp, R) + eb(R); };
-    bool cert = true;
+    auto e_hi = [&](int sg, double R) { return nqp * phk_lam_of(hp, sg, R) + eb(R); };
+    bool cert = true;      // the k-NN part
+    bool cert_c = true;    // the centroid part
     double knn = 0.0, cen = 0.0;
     if (want_knn) {
         const int need = p.kn;
@@ -1301,12 +1316,12 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
         if (cert) {
             // reach of the need nearest columns from the need-th high-part value; error bounds at that reach when the
             // leaders lie within it
-            const double eg = e_hi(p.rmax);
+            const double eg = e_hi(0, p.rmax);
             const double d2up = fmax(nqp2 - 2.0 * ((double)v8[need - 1] * vs - eg), 0.0);
             const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
             bool near = true;
             for (int r = 0; r < need; ++r) near = near && cn0[r] <= R0;
-            const double eh = near ? e_hi(R0) : eg, e22 = near ? eb(R0) : eb(p.rmax);
+            const double eh = near ? e_hi(0, R0) : eg, e22 = near ? eb(R0) : eb(p.rmax);
             // window members: list positions 0 .. nw-1 (sorted by high-part value)
             const double thr = (double)v8[need - 1] * vs - 2.0 * eh;
             int nw = 0;
@@ -1345,26 +1360,32 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
             }
         }
     }
-    if (want_cen && cert) {
-        const double eg = e_hi(p.rmax);
+    if (want_cen) {
         auto leader_ok = [&](int k2, double cnorm) {
             if (!cfill[k2]) return false;
+            const double eg = e_hi(1 + k2, p.rmax);
             const double d2up = fmax(nqp2 - 2.0 * ((double)ch1[k2] * vs - eg), 0.0);
             const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
-            const double eh = cnorm <= R0 ? e_hi(R0) : eg;
+            const double eh = cnorm <= R0 ? e_hi(1 + k2, R0) : eg;
             return ((double)ch1[k2] - (double)ch2[k2]) * vs > 2.0 * eh;
         };
-        cert = leader_ok(0, cnp) && leader_ok(1, cnn);
-        if (!cert) atomicAdd(p.counters + 11, 1u);   // diagnostics: centroid leader not certified
+        cert_c = leader_ok(0, cnp) && leader_ok(1, cnn);
+        if (!cert_c) atomicAdd(p.counters + 11, 1u);   // diagnostics: centroid leader not certified
         const double ep = sqrt(s_dp2[tid]), en = sqrt(s_dn2[tid]);
         cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
     }
-    if (cert) {
+    if (cert && cert_c) {
         p.scores[p.q_base + qa] = knn + cen;  // scripts/phamer.py:313
     } else {
-        // not decided here: phk_rerank16_kernel (MODE 1) takes the query's lists as they are -- high-part values under the
-        // high-part error model -- and decides by exact float64 candidate distances where that suffices
-        p.slow_list[atomicAdd(p.fb_count + 2, 1u)] = (uint32_t)qa;
+        // the open part(s) go to phk_rerank16_kernel (MODE 1), which takes the query's lists as they are -- high-part
+        // values under the high-part error model -- and decides by exact float64 candidate distances where that
+        // suffices; the decided part waits in scores[q]  (entry = query | open parts << 30)
+        p.scores[p.q_base + qa] = (cert ? knn : 0.0) + (cert_c ? cen : 0.0);
+        const uint32_t open_parts = ((want_knn && !cert) ? 1u : 0u) | ((want_cen && !cert_c) ? 2u : 0u);
+        // two lists in one array, so that a wave of the next kernel works on one kind of segment: queries with the k-NN
+        // part open from the front, those with only the centroid part open from the back
+        if (open_parts == 2u) p.slow_list[p.slow_cap - 1 - atomicAdd(p.counters + 12, 1u)] = (uint32_t)qa | (open_parts << 30);
+        else p.slow_list[atomicAdd(p.fb_count + 2, 1u)] = (uint32_t)qa | (open_parts << 30);
     }
 }
 
@@ -1622,6 +1643,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.scores = d_scores; p.status = d_status; p.fb_count = fbc; p.fb_list = fb_list; p.slow_list = slow_list; p.q_base = s;
         p.stat_total = fbc + 16;
         p.counters = fbc;
+        p.slow_cap = nb_max;
         p.eb_cQ = 0.0; p.per_row_scale = 0;
         auto split_f16_bound = [&](RerankParams &r) {
             // 3D/16 MFMA instructions, each charged 2u (|acc_in| + sum |products|) <= 2u (P + dq) R -- the
@@ -1673,9 +1695,11 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         if (hi_only) {
             HiParams hp;
             hp.lo16 = m->d_lo16;
-            for (int i = 0; i <= 64; ++i) hp.lam_tab[i] = m->lam_tab[i];
-            hp.lam_r0 = m->lam_r0;
-            hp.lam_inv_step = 1.0 / m->lam_step;
+            for (int sg = 0; sg < 3; ++sg) {
+                for (int i = 0; i <= 64; ++i) hp.lam_tab[sg][i] = m->lam_tab[sg][i];
+                hp.lam_r0[sg] = m->lam_r0[sg];
+                hp.lam_inv_step[sg] = 1.0 / m->lam_step[sg];
+            }
             PHK_LAUNCH(ctx, "phk_decide_h_kernel",
                        phk_decide_h_kernel<<<dim3((unsigned)phk_div_up(nb, 64)), dim3(64), 0, ctx->stream>>>((const uint32_t *)src, p, hp));
             // what it passes on is decided from the same lists by exact candidate distances where possible.  For that
@@ -1685,6 +1709,9 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             RerankParams ph = p;
             ph.eb_cP += 8192.0 * (1.0 + 1.0 / 2048.0) + 1.0;
             ph.eb_abs *= 2.0;
+            PHK_LAUNCH(ctx, "phk_rerank16_kernel",
+                       (phk_rerank16_kernel<0, 1><<<dim3((unsigned)phk_div_up(nb, 16)), dim3(256), 0, ctx->stream>>>(src, ph)));
+            ph.slow_back = 1;
             PHK_LAUNCH(ctx, "phk_rerank16_kernel",
                        (phk_rerank16_kernel<0, 1><<<dim3((unsigned)phk_div_up(nb, 16)), dim3(256), 0, ctx->stream>>>(src, ph)));
         } else if (d_counts) {

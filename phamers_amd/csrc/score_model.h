@@ -19,11 +19,11 @@ struct phk_model {
     float *d_beta16 = nullptr;    // count-exact bias terms S (mu.r~' + |r~'|^2/2) per column slot (general-D kernel)
     // high-parts-only proposal (k = 4, phk_knn_f16h_kernel): 17-piece block records (16 hi fragments + the bias terms
     // S mu.hi + S |r~'|^2/2 per unit of row sum), the low parts row-major for the decision stage's refinement, and
-    // lam_tab[i] = max |lo_j| / S over the columns with |r'_j| <= lam_r0 + i * lam_step (error of a high-parts-only value)
+    // lam_tab[s][i] = max |lo_j| / S over segment s's columns with |r'_j| <= lam_r0[s] + i * lam_step[s] (error of a high-parts-only value)
     void *d_Af16h = nullptr;
     _Float16 *d_lo16 = nullptr;   // [M + n_cpos + n_cneg][D]
-    double lam_tab[65] = {0};
-    double lam_r0 = 0.0, lam_step = 0.0;
+    double lam_tab[3][65] = {{0}};     // per segment (train rows, positive centroids, negative centroids)
+    double lam_r0[3] = {0, 0, 0}, lam_step[3] = {1, 1, 1};
     float *d_mu32 = nullptr;      // centring vector, fp32
     double *d_mu64 = nullptr;     // centring vector, fp64
     uint32_t n_rblk_ref = 0, n_rblk_pos = 0, n_rblk_neg = 0;  // 32-column blocks per segment
