@@ -195,6 +195,16 @@ int phk_model_create(phk_ctx *ctx, const double *pos, uint64_t n_pos, const doub
                      uint64_t n_neg, const double *cpos, uint64_t n_cpos, const double *cneg,
                      uint64_t n_cneg, uint64_t D, int kn, phk_model **out);
 int phk_model_destroy(phk_ctx *ctx, phk_model *model);
+/* Cross-validation service (cross_validator.cross_validate, scripts/cross_validate.py:57-101: N folds whose train
+ * sets share (N-1)/N of the rows): ONE model holds every reference row; a fold is a column mask over its train rows
+ * (mask[n_pos + n_neg] host bytes in vstack(pos, neg) order, non-zero = held out, excluded from the k-NN search;
+ * NULL lifts the mask) plus that fold's centroids (same counts as at creation).  Scores then equal those of a model
+ * built from the unmasked rows alone: the search is translation invariant, so keeping the full matrix's centring
+ * vector changes nothing but the error bounds, which are evaluated for it.  Not followed by the fp32 MFMA proposal
+ * (proposal=f32), which refuses such a model. */
+int phk_model_set_centroids(phk_ctx *ctx, phk_model *model, const double *cpos, uint64_t n_cpos, const double *cneg,
+                            uint64_t n_cneg);
+int phk_model_set_column_mask(phk_ctx *ctx, phk_model *model, const uint8_t *mask);
 
 /* Deterministic device k-means (opt-in alternative to the scikit-learn fit of scripts/learning.py:131-146,
  * whose centroids depend on the scikit-learn version): k-means++ seeding driven by splitmix64(seed + j),

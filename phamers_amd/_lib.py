@@ -65,6 +65,8 @@ SIGNATURES = {
     "phk_model_create": (c_int, [c_void_p, c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_u64,
                                  c_void_p, c_u64, c_u64, c_int, P(c_void_p)]),
     "phk_model_destroy": (c_int, [c_void_p, c_void_p]),
+    "phk_model_set_centroids": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_void_p, c_u64]),
+    "phk_model_set_column_mask": (c_int, [c_void_p, c_void_p, c_void_p]),
     "phk_score": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_void_p]),
     "phk_pack_ascii_dev": (c_int, [c_void_p, c_void_p, c_u64, c_char_p, c_void_p, c_void_p, c_void_p]),
     "phk_count_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_void_p, c_u64, c_int,
@@ -253,6 +255,19 @@ class Model(object):
             self.close()
         except Exception:
             pass
+
+    def set_centroids(self, positive_centroids, negative_centroids):
+        """Replace the centroid segments (same counts as at creation): a cross-validation fold's k-means result."""
+        cp = np.ascontiguousarray(positive_centroids, dtype=np.float64)
+        cn = np.ascontiguousarray(negative_centroids, dtype=np.float64)
+        if np.isnan(cp).any() or np.isnan(cn).any():
+            raise ValueError("Input contains NaN.")
+        check(self.ctx.lib.phk_model_set_centroids(self.ctx.handle, self.handle, ptr(cp), cp.shape[0], ptr(cn), cn.shape[0]))
+
+    def set_column_mask(self, mask):
+        """Exclude train rows from the k-NN search (``mask``: bool over vstack(positive, negative); None lifts it)."""
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        check(self.ctx.lib.phk_model_set_column_mask(self.ctx.handle, self.handle, ptr(m)))
 
     def score(self, Q, method="combo"):
         Q = np.ascontiguousarray(Q, dtype=np.float64)

@@ -79,6 +79,13 @@ __global__ __launch_bounds__(256) void phk_dist2_f64_kernel(const double *__rest
 // k-NN vote: one wavefront per query over its distance row.  Neighbours are taken in
 // (distance, index) lexicographic order, i.e. ties go to the lower train index.
 // ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void phk_mask_dist_kernel(double *__restrict__ dist, uint64_t nq, uint64_t M,
+                                                            const uint8_t *__restrict__ mask) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq * M) return;
+    if (mask[i % M] && dist[i] == dist[i]) dist[i] = __builtin_inf();   // (a NaN query row stays NaN)
+}
+
 __global__ __launch_bounds__(256) void phk_knn_vote_kernel(const double *__restrict__ dist, uint64_t nq,
                                                            uint64_t M, uint64_t ld,
                                                            const uint8_t *__restrict__ labels, int kn,
@@ -236,6 +243,11 @@ int phk_score_exact_batch(phk_ctx *ctx, const phk_model *m, const double *d_Q, u
         PHK_LAUNCH(ctx, "phk_dist2_f64_kernel",
                    phk_dist2_f64_kernel<<<grid, dim3(256), 0, ctx->stream>>>(d_Q, nq, m->d_R64, m->M, D,
                                                                             (double *)dist, m->M));
+        if (m->has_mask) {   // cross-validation fold: excluded train rows are infinitely far
+            PHK_LAUNCH(ctx, "phk_mask_dist_kernel",
+                       phk_mask_dist_kernel<<<dim3((unsigned)phk_div_up(nq * m->M, 256)), dim3(256), 0, ctx->stream>>>(
+                           (double *)dist, nq, m->M, m->d_col_mask));
+        }
         PHK_LAUNCH(ctx, "phk_knn_vote_kernel",
                    phk_knn_vote_kernel<<<dim3((unsigned)phk_div_up(nq, 4)), dim3(256), 0, ctx->stream>>>(
                        (const double *)dist, nq, m->M, m->M, m->d_labels, m->kn, d_knn, d_status));

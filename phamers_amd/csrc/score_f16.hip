@@ -148,6 +148,17 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
     if (hipMemcpy(m->d_cn16, cn_all.data(), cn_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     if (hipMalloc(&m->d_beta16, beta_all.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMemcpy(m->d_beta16, beta_all.data(), beta_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    {   // the train segment's column terms as built (restored when a column mask is lifted)
+        const uint64_t ns = (uint64_t)m->n_rblk_ref * 32;
+        std::vector<float> orig(3 * ns, 0.0f);
+        for (uint64_t i = 0; i < ns; ++i) {
+            orig[i] = cn_all[i];
+            orig[ns + i] = beta_all[i];
+            orig[2 * ns + i] = hi_only ? betah_all[i] : 0.0f;
+        }
+        if (hipMalloc((void **)&m->d_term_orig, orig.size() * sizeof(float) + 16) != hipSuccess) return PHK_ERR_NOMEM;
+        if (hipMemcpy(m->d_term_orig, orig.data(), orig.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    }
     if (hi_only) {
         // 17-piece records: the 16 hi fragments of the full record + one piece of bias terms
         std::vector<uint8_t> rech((nblk + 1) * F16H_BLOCK_BYTES, 0);
@@ -181,6 +192,96 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
                 if (m->lam_tab[sg][i - 1] > m->lam_tab[sg][i]) m->lam_tab[sg][i] = m->lam_tab[sg][i - 1];
         }
     }
+    return PHK_OK;
+}
+
+// Replace the centroid segments of a built model (same counts): block records, column terms, low parts, error tables.
+// colnorm_c: |r'| of the new centroids (positive then negative), computed by the caller as at build time.
+int phk_model_update_centroids_f16(phk_model *m, const double *cpos, const double *cneg, const double *colnorm_c) {
+    const uint64_t D = m->D;
+    const uint64_t nbc = (uint64_t)m->n_rblk_pos + m->n_rblk_neg, ncc = m->n_cpos + m->n_cneg;
+    const uint64_t rec_bytes = (D / 256 * 32 + 1) * 1024;
+    const bool hi_only = D == FAST_D && m->d_Af16h;
+    std::vector<uint8_t> rec(nbc * rec_bytes, 0);
+    std::vector<float> cn_all(nbc * 32, PAD_V), beta_all(nbc * 32, -PAD_V), betah_all(nbc * 32, -PAD_V);
+    std::vector<_Float16> lo_rows;
+    std::vector<double> lonorm;
+    HiOnlyOut ho;
+    if (hi_only) {
+        lo_rows.assign(ncc * D, (_Float16)0.0f);
+        lonorm.assign(ncc, 0.0);
+        ho.betah_all = &betah_all;
+        ho.lo_rows = &lo_rows;
+        ho.lonorm = &lonorm;
+    }
+    ho.col0 = 0;
+    pack_segment_f16(cpos, m->n_cpos, D, m->h_mu.data(), rec, rec_bytes, 0, cn_all, beta_all, ho);
+    ho.col0 = m->n_cpos;
+    pack_segment_f16(cneg, m->n_cneg, D, m->h_mu.data(), rec, rec_bytes, m->n_rblk_pos, cn_all, beta_all, ho);
+    const uint64_t b0 = m->n_rblk_ref;
+    if (hipMemcpy((uint8_t *)m->d_Af16 + b0 * rec_bytes, rec.data(), rec.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_cn16 + b0 * 32, cn_all.data(), cn_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->d_beta16 + b0 * 32, beta_all.data(), beta_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return PHK_ERR_HIP;
+    if (hi_only) {
+        std::vector<uint8_t> rech(nbc * F16H_BLOCK_BYTES, 0);
+        for (uint64_t b = 0; b < nbc; ++b) {
+            for (int st = 0; st < 16; ++st)
+                memcpy(rech.data() + b * F16H_BLOCK_BYTES + st * 1024, rec.data() + b * rec_bytes + (2 * st) * 1024, 1024);
+            memcpy(rech.data() + b * F16H_BLOCK_BYTES + 16 * 1024, betah_all.data() + b * 32, 32 * sizeof(float));
+        }
+        if (hipMemcpy((uint8_t *)m->d_Af16h + b0 * F16H_BLOCK_BYTES, rech.data(), rech.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(m->d_lo16 + m->M * D, lo_rows.data(), lo_rows.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess)
+            return PHK_ERR_HIP;
+        const uint64_t seg0[3] = {0, m->n_cpos, ncc};
+        for (int sg = 1; sg <= 2; ++sg) {
+            double rmin = 1e300, rmax = 0.0;
+            for (uint64_t c = seg0[sg - 1]; c < seg0[sg]; ++c) {
+                rmin = colnorm_c[c] < rmin ? colnorm_c[c] : rmin;
+                rmax = colnorm_c[c] > rmax ? colnorm_c[c] : rmax;
+            }
+            m->lam_r0[sg] = rmin;
+            m->lam_step[sg] = rmax > rmin ? (rmax - rmin) / 64.0 : 1.0;
+            for (int i = 0; i <= 64; ++i) m->lam_tab[sg][i] = 0.0;
+            for (uint64_t c = seg0[sg - 1]; c < seg0[sg]; ++c) {
+                int i = (int)std::ceil((colnorm_c[c] - rmin) / m->lam_step[sg] - 1e-12);
+                i = i < 0 ? 0 : (i > 64 ? 64 : i);
+                if (lonorm[c] > m->lam_tab[sg][i]) m->lam_tab[sg][i] = lonorm[c];
+            }
+            for (int i = 1; i <= 64; ++i)
+                if (m->lam_tab[sg][i - 1] > m->lam_tab[sg][i]) m->lam_tab[sg][i] = m->lam_tab[sg][i - 1];
+        }
+    }
+    return PHK_OK;
+}
+
+// column mask -> the train segment's column terms: a masked column carries the terms of a padding column (its value
+// can never enter a list), an unmasked one the terms it was built with
+__global__ __launch_bounds__(256) void phk_mask_terms_kernel(const uint8_t *__restrict__ mask, uint64_t M, uint64_t nslots,
+                                                             const float *__restrict__ orig, uint8_t *__restrict__ rec,
+                                                             uint64_t rec_bytes, uint64_t term_off, uint8_t *__restrict__ rech,
+                                                             float *__restrict__ cn16, float *__restrict__ beta16) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nslots) return;
+    const bool masked = s < M && mask && mask[s];
+    const uint64_t b = s / 32, i = s % 32;
+    const float cn = masked ? PAD_V : orig[s], be = masked ? -PAD_V : orig[nslots + s], bh = masked ? -PAD_V : orig[2 * nslots + s];
+    float *t = reinterpret_cast<float *>(rec + b * rec_bytes + term_off);
+    t[i] = cn;
+    t[32 + i] = be;
+    cn16[s] = cn;
+    beta16[s] = be;
+    if (rech) reinterpret_cast<float *>(rech + b * F16H_BLOCK_BYTES + 16 * 1024)[i] = bh;
+}
+
+int phk_model_apply_mask_f16(phk_ctx *ctx, phk_model *m) {
+    const uint64_t ns = (uint64_t)m->n_rblk_ref * 32;
+    if (ns == 0) return PHK_OK;
+    const uint64_t rec_bytes = (m->D / 256 * 32 + 1) * 1024;
+    PHK_LAUNCH(ctx, "phk_mask_terms_kernel",
+               phk_mask_terms_kernel<<<dim3((unsigned)phk_div_up(ns, 256)), dim3(256), 0, ctx->stream>>>(
+                   m->has_mask ? m->d_col_mask : nullptr, m->M, ns, m->d_term_orig, (uint8_t *)m->d_Af16, rec_bytes,
+                   (m->D / 256) * 32 * 1024, (uint8_t *)m->d_Af16h, m->d_cn16, m->d_beta16));
     return PHK_OK;
 }
 

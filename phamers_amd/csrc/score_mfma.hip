@@ -149,6 +149,10 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
         hipMemcpy(m->d_mu64, mu.data(), D * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         return PHK_ERR_HIP;
     PHK_TRY(phk_model_build_f16(m, pos, neg, cpos, cneg, mu.data(), colnorm.data()));
+    m->h_mu = mu;
+    m->max_colnorm_train = 0.0;
+    for (uint64_t c = 0; c < m->M; ++c)
+        if (colnorm[c] > m->max_colnorm_train) m->max_colnorm_train = colnorm[c];
     m->max_colnorm = max_norm;
     m->mu_norm = std::sqrt(mu2);
     m->fast = true;
@@ -160,6 +164,10 @@ void phk_model_free_fast(phk_model *m) {
     if (m->d_colnorm) (void)hipFree(m->d_colnorm);
     if (m->d_Af16) (void)hipFree(m->d_Af16);
     m->d_Af16 = nullptr;
+    if (m->d_term_orig) (void)hipFree(m->d_term_orig);
+    if (m->d_col_mask) (void)hipFree(m->d_col_mask);
+    m->d_term_orig = nullptr;
+    m->d_col_mask = nullptr;
     if (m->d_Af16h) (void)hipFree(m->d_Af16h);
     if (m->d_lo16) (void)hipFree(m->d_lo16);
     m->d_Af16h = nullptr;
@@ -333,6 +341,7 @@ struct RerankParams {
     uint32_t *fb_list;      // fallback queue (query indices)
     uint32_t *slow_list;    // queries the one-lane-per-query decision kernel could not certify (fb_count[2] of them)
     uint64_t q_base;        // index of this batch's first query within the caller's arrays
+    const uint8_t *col_mask = nullptr;   // train columns excluded from the search (cross-validation folds), or null
     // "second chance" pass (phk_rerank16_kernel MODE 2): the queries are rows map[0 .. *map_count) of the batch, their
     // candidate lists sit at the dense positions 0 .. min(*map_count, N) of a second list set of capacity N
     const uint32_t *map = nullptr;
@@ -1451,7 +1460,7 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
             acc += __shfl_xor(acc, 4);
             acc += __shfl_xor(acc, 2);
             acc += __shfl_xor(acc, 1);
-            if (t16 == 0 && c < c1) fb_dist[c - c0] = acc;
+            if (t16 == 0 && c < c1) fb_dist[c - c0] = (p.col_mask && c < p.M && p.col_mask[c]) ? INFINITY : acc;
         }
         __syncthreads();
         if (wave == 0) {
@@ -1593,6 +1602,11 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // proposal pass: split-f16 MFMA by default; proposal=f32 selects the fp32-input MFMA kernel (k = 4 only)
     const char *prop = ctx->knobs.proposal;
     const bool use_f16 = D != FAST_D || !(prop[0] == 'f' && prop[1] == '3');
+    if (!use_f16 && m->bf_stale) {
+        phk_set_error("phk_score: the fp32 MFMA proposal (proposal=f32) does not follow phk_model_set_centroids / "
+                      "phk_model_set_column_mask; use the default proposal");
+        return PHK_ERR_UNSUPPORTED;
+    }
     // counts at k = 4: the count-exact kernel (2 MFMAs per k-step); proposal=f16 keeps the split-query one
     const bool use_cx = use_f16 && d_counts && !(prop[0] == 'f' && prop[1] == '1');
     // Second chance (k = 4, count-exact first pass): what the first pass cannot decide -- rows holding a count above
@@ -1643,6 +1657,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.scores = d_scores; p.status = d_status; p.fb_count = fbc; p.fb_list = fb_list; p.slow_list = slow_list; p.q_base = s;
         p.stat_total = fbc + 16;
         p.counters = fbc;
+        p.col_mask = m->has_mask ? m->d_col_mask : nullptr;
         p.slow_cap = nb_max;
         p.eb_cQ = 0.0; p.per_row_scale = 0;
         auto split_f16_bound = [&](RerankParams &r) {
@@ -1753,5 +1768,59 @@ int phk_score_mfma_init_device(phk_ctx *ctx) {
     (void)ctx;
     PHK_HIP(hipFuncSetAttribute((const void *)phk_fallback_partial_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_MAX));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_fallback_partial_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS_MAX));
+    return PHK_OK;
+}
+
+// ---- cross-validation service: one resident model, a fold = a column mask + that fold's centroids ----
+extern "C" int phk_model_set_centroids(phk_ctx *ctx, phk_model *m, const double *cpos, uint64_t n_cpos, const double *cneg,
+                                       uint64_t n_cneg) {
+    PHK_ENTER(ctx, "phk_model_set_centroids");
+    PHK_REQUIRE(m && cpos && cneg, "phk_model_set_centroids: NULL");
+    PHK_REQUIRE(n_cpos == m->n_cpos && n_cneg == m->n_cneg && n_cpos > 0,
+                "phk_model_set_centroids: the model was created with %llu + %llu centroids (got %llu + %llu)",
+                (unsigned long long)m->n_cpos, (unsigned long long)m->n_cneg, (unsigned long long)n_cpos, (unsigned long long)n_cneg);
+    const uint64_t D = m->D;
+    PHK_HIP(hipStreamSynchronize(ctx->stream));   // kernels still reading the old centroids
+    PHK_HIP(hipMemcpy(m->d_C64, cpos, n_cpos * D * sizeof(double), hipMemcpyHostToDevice));
+    PHK_HIP(hipMemcpy(m->d_C64 + n_cpos * D, cneg, n_cneg * D * sizeof(double), hipMemcpyHostToDevice));
+    if (!m->fast) return PHK_OK;
+    std::vector<double> cnorm(n_cpos + n_cneg);
+    double mx = m->max_colnorm_train;
+    for (uint64_t r = 0; r < n_cpos + n_cneg; ++r) {
+        const double *row = r < n_cpos ? cpos + r * D : cneg + (r - n_cpos) * D;
+        double s2 = 0.0;
+        for (uint64_t d = 0; d < D; ++d) {
+            const double v = (double)(float)(row[d] - m->h_mu[d]);
+            s2 += v * v;
+        }
+        cnorm[r] = std::sqrt(s2);
+        PHK_REQUIRE(cnorm[r] == cnorm[r] && !std::isinf(cnorm[r]), "phk_model_set_centroids: centroid %llu is not finite", (unsigned long long)r);
+        mx = cnorm[r] > mx ? cnorm[r] : mx;
+    }
+    PHK_HIP(hipMemcpy(m->d_colnorm + m->M, cnorm.data(), cnorm.size() * sizeof(double), hipMemcpyHostToDevice));
+    m->max_colnorm = mx;
+    m->bf_stale = true;
+    return phk_model_update_centroids_f16(m, cpos, cneg, cnorm.data());
+}
+
+extern "C" int phk_model_set_column_mask(phk_ctx *ctx, phk_model *m, const uint8_t *mask) {
+    PHK_ENTER(ctx, "phk_model_set_column_mask");
+    PHK_REQUIRE(m, "phk_model_set_column_mask: NULL model");
+    if (!mask && !m->has_mask) return PHK_OK;
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    if (mask) {
+        uint64_t kept = 0;
+        for (uint64_t c = 0; c < m->M; ++c) kept += mask[c] ? 0 : 1;
+        PHK_REQUIRE(kept >= (uint64_t)m->kn, "phk_model_set_column_mask: %llu unmasked train rows, k_neighbors = %d",
+                    (unsigned long long)kept, m->kn);
+        if (!m->d_col_mask) PHK_HIP(hipMalloc((void **)&m->d_col_mask, m->M + 16));
+        PHK_HIP(hipMemcpy(m->d_col_mask, mask, m->M, hipMemcpyHostToDevice));
+    }
+    m->has_mask = mask != nullptr;
+    if (m->fast) {
+        m->bf_stale = true;
+        PHK_TRY(phk_model_apply_mask_f16(ctx, m));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+    }
     return PHK_OK;
 }

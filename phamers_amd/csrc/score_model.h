@@ -26,6 +26,15 @@ struct phk_model {
     double lam_r0[3] = {0, 0, 0}, lam_step[3] = {1, 1, 1};
     float *d_mu32 = nullptr;      // centring vector, fp32
     double *d_mu64 = nullptr;     // centring vector, fp64
+    // cross-validation service (phk_model_set_centroids / phk_model_set_column_mask): the train segment's column terms as
+    // built (a masked column's terms are overwritten with the padding values and restored from here), the mask itself
+    // for the float64 kernels, the host copy of the centring vector and the train segment's largest column norm
+    float *d_term_orig = nullptr;     // [3][n_rblk_ref * 32]: norm terms, bias terms, high-part bias terms
+    uint8_t *d_col_mask = nullptr;    // [M], 1 = excluded; null until a mask is set
+    bool has_mask = false;
+    bool bf_stale = false;            // the fp32 MFMA operand no longer matches (centroids replaced / mask set)
+    std::vector<double> h_mu;
+    double max_colnorm_train = 0.0;
     uint32_t n_rblk_ref = 0, n_rblk_pos = 0, n_rblk_neg = 0;  // 32-column blocks per segment
     double max_colnorm = 0.0;     // max ||r'|| over real columns (error bound)
     double mu_norm = 0.0;         // ||mu||
@@ -46,6 +55,8 @@ static inline bool phk_model_has_fast(const phk_model *m) { return m->fast; }
 // split-f16 proposal (score_f16.hip)
 int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, const double *cpos,
                         const double *cneg, const double *mu, const double *colnorm);
+int phk_model_update_centroids_f16(phk_model *m, const double *cpos, const double *cneg, const double *colnorm_c);
+int phk_model_apply_mask_f16(phk_ctx *ctx, phk_model *m);
 int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                             const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
                             float *cv, uint32_t *ci, float *cu, const uint32_t *qmap = nullptr,

@@ -547,3 +547,89 @@ def test_device_resident_batch_facade():
     # the string-list convenience of the facade runs on the same path
     got = phamer.score_contigs(seqs, pos, neg, 4, "knn")
     assert np.array_equal(got, g["knn_full"])
+
+
+@pytest.mark.gpu
+def test_cross_validation_matches_the_reference_fixture_with_one_model_upload():
+    """tests/golden/cross_validation.npz: the reference's own cross_validator.cross_validate (scripts/cross_validate.py:
+    57-101, scoring function phamer.score_points) on the real matrix, equalised, 20 folds 'combo' and 7 folds 'knn',
+    NumPy generator seeded right before the call.  The batched service replays the same fold assignment, uploads the
+    model ONCE (a fold = column mask + that fold's centroids) and reproduces the fold scores."""
+    from phamers_amd import cross_validate
+    z = helpers.load_npz("cross_validation.npz")
+    pos, neg = _ref_matrices()
+    for tag, method in (("n7_knn", "knn"), ("n20_combo", "combo")):
+        seed, N, n_pos, n_neg = (int(x) for x in z["meta_" + tag])
+        v = cross_validate.cross_validator()
+        v.positive_data, v.negative_data = pos.copy(), neg.copy()
+        v.positive_ids, v.negative_ids = np.arange(len(pos)), np.arange(len(neg))
+        v.equalize_reference, v.N, v.method, v.seed = True, N, method, seed
+        ps, ns = v.cross_validate()
+        assert v.model_uploads == 1
+        assert ps.shape == (n_pos,) and ns.shape == (n_neg,)
+        assert np.array_equal(v.positive_assignment, z["pos_asmt_" + tag])
+        assert np.array_equal(v.negative_assignment, z["neg_asmt_" + tag])
+        want_p, want_n = z["pos_scores_" + tag], z["neg_scores_" + tag]
+        if method == "knn":
+            assert np.array_equal(ps, want_p) and np.array_equal(ns, want_n)
+        else:
+            # the k-NN part of every score is exact; the centroid part follows this box's scikit-learn fit (same
+            # version as the fixture's: equal to rounding; another build: compared through the sign and a loose bound)
+            assert np.array_equal(np.sign(ps), np.sign(want_p)) and np.array_equal(np.sign(ns), np.sign(want_n))
+            err = max(helpers.rel_err(ps, want_p), helpers.rel_err(ns, want_n))
+            import sklearn
+            if sklearn.__version__ == helpers.load_json("MANIFEST.json")["scikit-learn"]:
+                assert err < 1e-6, err
+            else:
+                assert err < 0.5, err
+
+
+@pytest.mark.gpu
+def test_column_mask_and_centroid_update_equal_a_fresh_model():
+    """phk_model_set_column_mask / phk_model_set_centroids: a masked, re-centred model scores like a model built from the
+    unmasked rows alone -- float64-row queries, count queries (high-parts-only + second chance + brute force), the
+    float64 path -- and lifting the mask restores the original scores."""
+    from oracle import oracle
+    from phamers_amd import _lib, device
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    pos, neg = pos[:900], neg[:1000]
+    rng = np.random.default_rng(8)
+    mp, mn = rng.random(len(pos)) < 0.3, rng.random(len(neg)) < 0.2
+    cp1, cn1 = g["cpos_full"], g["cneg_full"]
+    cp2 = np.stack([pos[~mp][i::86].mean(axis=0) for i in range(86)])
+    cn2 = np.stack([neg[~mn][i::86].mean(axis=0) for i in range(86)])
+    ctx = _lib.get_context()
+    full = _lib.Model(ctx, pos, neg, cp1, cn1, 3)
+    fresh = _lib.Model(ctx, pos[~mp], neg[~mn], cp2, cn2, 3)
+    q = np.vstack((g["q"], pos[mp][:50], neg[mn][:50]))        # held-out rows are the interesting queries
+    counts = np.vstack((g["q_counts"], rng.multinomial(4000, pos[3], 40), rng.multinomial(900000, neg[5], 3))).astype(np.uint32)
+    d_counts = device.DeviceArray.from_host(ctx, counts)
+    d_scores = device.DeviceArray(ctx, len(counts), np.float64)
+    d_status = device.DeviceArray(ctx, 1, np.uint32)
+
+    def count_scores(model, method):
+        device.score_counts(ctx, model, d_counts, len(counts), method, d_scores, d_status)
+        return d_scores.to_host()
+
+    before = {m: full.score(q, m) for m in ("knn", "kmeans", "combo")}
+    full.set_column_mask(np.concatenate((mp, mn)))
+    full.set_centroids(cp2, cn2)
+    for method in ("knn", "kmeans", "combo"):
+        assert helpers.rel_err(full.score(q, method), fresh.score(q, method)) < 1e-12, method
+        assert helpers.rel_err(count_scores(full, method), count_scores(fresh, method)) < 1e-12, method
+    want = oracle.knn_score_points(q, pos[~mp], neg[~mn], 3) + oracle.centroid_score_points_fast(q, cp2, cn2)
+    assert helpers.rel_err(full.score(q, "combo"), want) < RTOL
+    ctx.set_option("force_exact", "1")
+    assert helpers.rel_err(full.score(q, "combo"), want) < RTOL
+    ctx.set_option("force_exact", "0")
+    ctx.set_option("proposal", "f32")
+    with pytest.raises(_lib.PhkError):
+        full.score(q, "knn")
+    ctx.set_option("proposal", "")
+    full.set_column_mask(None)
+    full.set_centroids(cp1, cn1)
+    for method in ("knn", "kmeans", "combo"):
+        assert np.array_equal(full.score(q, method), before[method]), method
+    full.close()
+    fresh.close()

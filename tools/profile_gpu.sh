@@ -3,7 +3,7 @@
 # separate PMC passes for HBM traffic (FETCH_SIZE / WRITE_SIZE never share a pass; no other trace
 # domains).  Results land under gpurun_out/prof_<tag>/; summaries are copied into profiles/ afterwards.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 N=${2:-1000000}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -18,7 +18,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIV
 done
 python3 - <<'PY'
 import csv,glob,collections,os,json
-root=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/prof_'+os.environ.get('PROF_TAG','r01')
+root=os.environ.get('GRAFT_REPO_ROOT','.')+'/gpurun_out/prof_'+os.environ.get('PROF_TAG','r02')
 res={}
 for d in sorted(glob.glob(root+'/pmc_*')):
     if not os.path.isdir(d): continue
