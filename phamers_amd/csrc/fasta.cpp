@@ -15,12 +15,14 @@
 //     count as non-symbols later).
 #include <fcntl.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <stdlib.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -29,8 +31,20 @@
 
 static inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
 
+// byte buffer without value-initialisation (std::vector<char>::resize would zero-fill gigabytes)
+struct RawBytes {
+    std::unique_ptr<char[]> p;
+    size_t n = 0;
+    void resize(size_t m) {
+        p.reset(new char[m]);
+        n = m;
+    }
+    char *data() { return p.get(); }
+    const char *data() const { return p.get(); }
+};
+
 struct phk_fasta {
-    std::vector<char> bases;          // all sequences, concatenated
+    RawBytes bases;                   // all sequences, concatenated
     std::vector<uint64_t> offsets;    // n + 1
     std::vector<char> titles;         // all titles, concatenated (no terminators)
     std::vector<uint64_t> title_off;  // n + 1
@@ -158,6 +172,43 @@ extern "C" int phk_parse_id(const char *header, uint64_t header_len, char *id_ou
     return PHK_OK;
 }
 
+// The file's bytes: a read-only mapping for a plain file (no copy, no zero-fill of a multi-GB buffer; the worker threads
+// fault the pages in while they scan), an inflated buffer for a .gz file.
+struct FileBytes {
+    const char *data = nullptr;
+    size_t size = 0;
+    void *map = nullptr;
+    size_t map_len = 0;
+    std::vector<char> owned;
+    ~FileBytes() {
+        if (map) munmap(map, map_len);
+    }
+};
+
+static int map_plain_file(const char *path, FileBytes &fb) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return PHK_ERR_IO;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        close(fd);
+        return PHK_ERR_IO;
+    }
+    fb.size = (size_t)st.st_size;
+    if (fb.size == 0) {
+        close(fd);
+        fb.data = "";
+        return PHK_OK;
+    }
+    void *p = mmap(nullptr, fb.size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return PHK_ERR_IO;
+    (void)madvise(p, fb.size, MADV_SEQUENTIAL);
+    fb.map = p;
+    fb.map_len = fb.size;
+    fb.data = (const char *)p;
+    return PHK_OK;
+}
+
 static int read_whole_file(const char *path, std::vector<char> &buf) {
     const size_t plen = strlen(path);
     const bool gz = plen > 3 && strcmp(path + plen - 3, ".gz") == 0;
@@ -222,7 +273,11 @@ static void measure_record(const char *b, size_t begin, size_t end, uint64_t &n_
         eol = nl ? (size_t)(nl - b) : end;
         size_t l_end = eol;
         while (l_end > p && is_space(b[l_end - 1])) --l_end;
-        for (size_t i = p; i < l_end; ++i) n_bases += (b[i] != ' ' && b[i] != '\r');
+        if (!memchr(b + p, ' ', l_end - p) && !memchr(b + p, '\r', l_end - p)) {
+            n_bases += l_end - p;                      // the usual line: nothing to drop
+        } else {
+            for (size_t i = p; i < l_end; ++i) n_bases += (b[i] != ' ' && b[i] != '\r');
+        }
         p = eol < end ? eol + 1 : end;
     }
 }
@@ -240,35 +295,69 @@ static void write_record(const char *b, size_t begin, size_t end, char *seq_out,
         eol = nl ? (size_t)(nl - b) : end;
         size_t l_end = eol;
         while (l_end > p && is_space(b[l_end - 1])) --l_end;
-        for (size_t i = p; i < l_end; ++i)
-            if (b[i] != ' ' && b[i] != '\r') *seq_out++ = b[i];
+        if (!memchr(b + p, ' ', l_end - p) && !memchr(b + p, '\r', l_end - p)) {
+            memcpy(seq_out, b + p, l_end - p);
+            seq_out += l_end - p;
+        } else {
+            for (size_t i = p; i < l_end; ++i)
+                if (b[i] != ' ' && b[i] != '\r') *seq_out++ = b[i];
+        }
         p = eol < end ? eol + 1 : end;
     }
 }
 
 extern "C" int phk_fasta_read(const char *path, int threads, phk_fasta **out) {
     PHK_REQUIRE(path && out, "phk_fasta_read: NULL argument");
-    std::vector<char> buf;
-    const int rc = read_whole_file(path, buf);
-    if (rc != PHK_OK) {
-        phk_set_error("phk_fasta_read: cannot read %s", path);
-        return rc;
+    FileBytes fb;
+    {
+        const size_t plen = strlen(path);
+        int rc;
+        if (plen > 3 && strcmp(path + plen - 3, ".gz") == 0) {
+            rc = read_whole_file(path, fb.owned);
+            fb.data = fb.owned.data();
+            fb.size = fb.owned.size();
+        } else {
+            rc = map_plain_file(path, fb);
+        }
+        if (rc != PHK_OK) {
+            phk_set_error("phk_fasta_read: cannot read %s", path);
+            return rc;
+        }
     }
-    const char *b = buf.data();
-    const size_t n = buf.size();
-    // record starts: '>' at the beginning of a line
+    const char *b = fb.data;
+    const size_t n = fb.size;
+    if (threads < 1) threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    // record starts: '>' at the beginning of a line -- the file is cut into one slice per thread, each thread lists the
+    // starts inside its slice (a slice begins at the first line start at or after its cut)
     std::vector<size_t> starts;
-    for (size_t p = 0; p < n;) {
-        if (b[p] == '>') starts.push_back(p);
-        const char *nl = (const char *)memchr(b + p, '\n', n - p);
-        if (!nl) break;
-        p = (size_t)(nl - b) + 1;
+    {
+        const int nt = (int)std::min<size_t>((size_t)threads, std::max<size_t>(n >> 20, 1));
+        std::vector<std::vector<size_t>> part((size_t)nt);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nt; ++t)
+            pool.emplace_back([&, t]() {
+                size_t lo = n * (size_t)t / (size_t)nt, hi = n * (size_t)(t + 1) / (size_t)nt;
+                if (t > 0) {   // first line start at or after lo
+                    const char *nl = (const char *)memchr(b + lo - 1, '\n', n - (lo - 1));
+                    lo = nl ? (size_t)(nl - b) + 1 : n;
+                }
+                for (size_t p = lo; p < hi;) {
+                    if (b[p] == '>') part[t].push_back(p);
+                    const char *nl = (const char *)memchr(b + p, '\n', n - p);
+                    if (!nl) break;
+                    p = (size_t)(nl - b) + 1;
+                }
+            });
+        for (auto &th : pool) th.join();
+        size_t total = 0;
+        for (auto &v : part) total += v.size();
+        starts.reserve(total);
+        for (auto &v : part) starts.insert(starts.end(), v.begin(), v.end());
     }
     const size_t nrec = starts.size();
     phk_fasta *f = new phk_fasta();
     f->offsets.assign(nrec + 1, 0);
     f->title_off.assign(nrec + 1, 0);
-    if (threads < 1) threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
     threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(nrec, 1));
     auto span = [&](size_t r) { return RecSpan{starts[r], r + 1 < nrec ? starts[r + 1] : n}; };
     auto run = [&](int pass) {
@@ -296,6 +385,7 @@ extern "C" int phk_fasta_read(const char *path, int threads, phk_fasta **out) {
         f->title_off[r + 1] += f->title_off[r];
     }
     f->bases.resize(f->offsets[nrec] + 64);  // slack: the device packer reads whole 16-byte groups
+    memset(f->bases.data() + f->offsets[nrec], 0, 64);
     f->titles.resize(f->title_off[nrec] + 1);
     run(1);
     // ids: the PhaMers id of every record.id (first white-space delimited word of the title), in parallel
