@@ -374,7 +374,7 @@ def main():
             ach = work * steps / (ms / 1e3)
             kernels[name].update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
     dom = max((kname for kname in kernels if kname in alg), key=lambda kname: kernels[kname]["ms_per_step"])
-    per_contig, tsrc = latest_traffic(dom) if args.config == 1 else (None, None)
+    per_contig, tsrc = latest_traffic(dom) if (args.config == 1 and not ragged and L == 5000) else (None, None)
     roofline = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
                 "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
                 "traffic": per_contig * n if per_contig else None}
