@@ -117,7 +117,8 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
     const uint64_t nblk = (uint64_t)m->n_rblk_ref + m->n_rblk_pos + m->n_rblk_neg;
     const uint64_t rec_bytes = (D / 256 * 32 + 1) * 1024;
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
-    const bool hi_only = D == FAST_D;   // the high-parts-only proposal exists for k = 4
+    const bool hi_only = true;          // high-parts-only first pass: bias terms, row-major low parts, error tables
+    const bool hi_records = D == FAST_D;   // ... and, for the k = 4 kernel, its own 17-piece block records
     std::vector<uint8_t> rec((nblk + 1) * rec_bytes, 0);  // + one block: the DMA prefetch runs one past the end
     std::vector<float> cn_all((nblk + 1) * 32, PAD_V), beta_all((nblk + 1) * 32, -PAD_V), betah_all;
     std::vector<_Float16> lo_rows;
@@ -160,6 +161,10 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
         if (hipMemcpy(m->d_term_orig, orig.data(), orig.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     }
     if (hi_only) {
+        if (hipMalloc((void **)&m->d_betah16, betah_all.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
+        if (hipMemcpy(m->d_betah16, betah_all.data(), betah_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    }
+    if (hi_only && hi_records) {
         // 17-piece records: the 16 hi fragments of the full record + one piece of bias terms
         std::vector<uint8_t> rech((nblk + 1) * F16H_BLOCK_BYTES, 0);
         for (uint64_t b = 0; b < nblk; ++b) {
@@ -169,6 +174,8 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
         }
         if (hipMalloc(&m->d_Af16h, rech.size()) != hipSuccess) return PHK_ERR_NOMEM;
         if (hipMemcpy(m->d_Af16h, rech.data(), rech.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    }
+    if (hi_only) {
         if (hipMalloc((void **)&m->d_lo16, lo_rows.size() * sizeof(_Float16)) != hipSuccess) return PHK_ERR_NOMEM;
         if (hipMemcpy(m->d_lo16, lo_rows.data(), lo_rows.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
         // lam_tab: per segment, the largest |lo_j| / S among its columns within a radius, on a 64-step grid of radii
@@ -201,7 +208,7 @@ int phk_model_update_centroids_f16(phk_model *m, const double *cpos, const doubl
     const uint64_t D = m->D;
     const uint64_t nbc = (uint64_t)m->n_rblk_pos + m->n_rblk_neg, ncc = m->n_cpos + m->n_cneg;
     const uint64_t rec_bytes = (D / 256 * 32 + 1) * 1024;
-    const bool hi_only = D == FAST_D && m->d_Af16h;
+    const bool hi_only = m->d_lo16 != nullptr;
     std::vector<uint8_t> rec(nbc * rec_bytes, 0);
     std::vector<float> cn_all(nbc * 32, PAD_V), beta_all(nbc * 32, -PAD_V), betah_all(nbc * 32, -PAD_V);
     std::vector<_Float16> lo_rows;
@@ -224,13 +231,17 @@ int phk_model_update_centroids_f16(phk_model *m, const double *cpos, const doubl
         hipMemcpy(m->d_beta16 + b0 * 32, beta_all.data(), beta_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return PHK_ERR_HIP;
     if (hi_only) {
-        std::vector<uint8_t> rech(nbc * F16H_BLOCK_BYTES, 0);
-        for (uint64_t b = 0; b < nbc; ++b) {
-            for (int st = 0; st < 16; ++st)
-                memcpy(rech.data() + b * F16H_BLOCK_BYTES + st * 1024, rec.data() + b * rec_bytes + (2 * st) * 1024, 1024);
-            memcpy(rech.data() + b * F16H_BLOCK_BYTES + 16 * 1024, betah_all.data() + b * 32, 32 * sizeof(float));
+        if (m->d_Af16h) {
+            std::vector<uint8_t> rech(nbc * F16H_BLOCK_BYTES, 0);
+            for (uint64_t b = 0; b < nbc; ++b) {
+                for (int st = 0; st < 16; ++st)
+                    memcpy(rech.data() + b * F16H_BLOCK_BYTES + st * 1024, rec.data() + b * rec_bytes + (2 * st) * 1024, 1024);
+                memcpy(rech.data() + b * F16H_BLOCK_BYTES + 16 * 1024, betah_all.data() + b * 32, 32 * sizeof(float));
+            }
+            if (hipMemcpy((uint8_t *)m->d_Af16h + b0 * F16H_BLOCK_BYTES, rech.data(), rech.size(), hipMemcpyHostToDevice) != hipSuccess)
+                return PHK_ERR_HIP;
         }
-        if (hipMemcpy((uint8_t *)m->d_Af16h + b0 * F16H_BLOCK_BYTES, rech.data(), rech.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        if (hipMemcpy(m->d_betah16 + b0 * 32, betah_all.data(), betah_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(m->d_lo16 + m->M * D, lo_rows.data(), lo_rows.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess)
             return PHK_ERR_HIP;
         const uint64_t seg0[3] = {0, m->n_cpos, ncc};
@@ -260,7 +271,8 @@ int phk_model_update_centroids_f16(phk_model *m, const double *cpos, const doubl
 __global__ __launch_bounds__(256) void phk_mask_terms_kernel(const uint8_t *__restrict__ mask, uint64_t M, uint64_t nslots,
                                                              const float *__restrict__ orig, uint8_t *__restrict__ rec,
                                                              uint64_t rec_bytes, uint64_t term_off, uint8_t *__restrict__ rech,
-                                                             float *__restrict__ cn16, float *__restrict__ beta16) {
+                                                             float *__restrict__ cn16, float *__restrict__ beta16,
+                                                             float *__restrict__ betah16) {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nslots) return;
     const bool masked = s < M && mask && mask[s];
@@ -271,6 +283,7 @@ __global__ __launch_bounds__(256) void phk_mask_terms_kernel(const uint8_t *__re
     t[32 + i] = be;
     cn16[s] = cn;
     beta16[s] = be;
+    if (betah16) betah16[s] = bh;
     if (rech) reinterpret_cast<float *>(rech + b * F16H_BLOCK_BYTES + 16 * 1024)[i] = bh;
 }
 
@@ -281,7 +294,7 @@ int phk_model_apply_mask_f16(phk_ctx *ctx, phk_model *m) {
     PHK_LAUNCH(ctx, "phk_mask_terms_kernel",
                phk_mask_terms_kernel<<<dim3((unsigned)phk_div_up(ns, 256)), dim3(256), 0, ctx->stream>>>(
                    m->has_mask ? m->d_col_mask : nullptr, m->M, ns, m->d_term_orig, (uint8_t *)m->d_Af16, rec_bytes,
-                   (m->D / 256) * 32 * 1024, (uint8_t *)m->d_Af16h, m->d_cn16, m->d_beta16));
+                   (m->D / 256) * 32 * 1024, (uint8_t *)m->d_Af16h, m->d_cn16, m->d_beta16, m->d_betah16));
     return PHK_OK;
 }
 
@@ -1141,7 +1154,10 @@ __global__ __launch_bounds__(256) void phk_split_queries_kernel(const void *__re
 // beta_all), rows flagged in `big` get empty lists (-> exact brute-force queue)
 // GEN_CT = column blocks per tile (accumulators per wave): a query chunk fetched from memory serves GEN_CT x 16 k-steps;
 // the count-exact flavour has no lo query fragments and spends the registers on 8 accumulators instead of 4
-template <bool CX, int GEN_CT>
+// HI (with CX): high parts of the columns only -- ONE MFMA per k-step, only the 16 hi pieces of a (block, chunk) item are
+// streamed, the bias is the high-part one (beta_all = betah); the decision stage (phk_rerank_h_kernel) adds the low
+// product to the window's members
+template <bool CX, int GEN_CT, bool HI = false>
 __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4 *__restrict__ Bq, uint64_t N,
                                                                      uint32_t nchunk,
                                                                      const uint4 *__restrict__ Af,
@@ -1180,8 +1196,8 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
         if (blk >= total) blk = total - 1;  // partial last tile: harmless re-read, result discarded
         const uint4 *g = Af + (uint64_t)(blk0 + blk) * rec_u4 + (uint64_t)c * 32 * 64 + lane;
         const uint32_t l = lds_base + (uint32_t)buf * 32768u;
-        for (int p = wave; p < 32; p += 4) {
-            const uint4 *gp = g + p * 64;
+        for (int p = wave; p < (HI ? 16 : 32); p += 4) {   // HI: source pieces 0, 2, 4, .. (hi) land as pieces 0, 1, 2, ..
+            const uint4 *gp = g + (HI ? 2 * p : p) * 64;
             const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
         }
@@ -1239,11 +1255,16 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
                 const half8 *fr = reinterpret_cast<const half8 *>(smem + (it & 1) * 32768u) + lane;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
-                    const half8 ah = fr[(2 * s) * 64];
-                    const half8 al = fr[(2 * s + 1) * 64];
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc[cb], 0, 0, 0);
-                    if (!CX) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc[cb], 0, 0, 0);
-                    acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc[cb], 0, 0, 0);
+                    if (HI) {
+                        const half8 ah = fr[s * 64];
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc[cb], 0, 0, 0);
+                    } else {
+                        const half8 ah = fr[(2 * s) * 64];
+                        const half8 al = fr[(2 * s + 1) * 64];
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc[cb], 0, 0, 0);
+                        if (!CX) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc[cb], 0, 0, 0);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc[cb], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1295,7 +1316,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
 // proposal pass for D = 256 * nchunk > 256: row sums (if needed) -> split queries -> sweep
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, bool count_exact,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                                    float *cv, uint32_t *ci, float *cu) {
+                                    float *cv, uint32_t *ci, float *cu, bool hi_only) {
     const uint64_t D = m->D, nchunk = D / 256;
     const uint64_t nqb = phk_div_up(nb, 32);
     void *bq, *rs = nullptr;
@@ -1328,7 +1349,12 @@ int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void
     }
     const uint64_t rec_u4 = (nchunk * 32 + 1) * 64;
     const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
-    if (d_big) {
+    if (d_big && hi_only) {
+        PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
+                   (phk_knn_f16_general_kernel<true, 8, true><<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
+                       (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_betah16, d_rowsum,
+                       d_big, blk0, nref, npos, nneg, cv, ci, cu)));
+    } else if (d_big) {
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
                    phk_knn_f16_general_kernel<true, 8><<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, d_rowsum,
@@ -1354,5 +1380,6 @@ int phk_score_f16_init_device(phk_ctx *ctx) {
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16h_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F16H_BLOCK_BYTES));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     return PHK_OK;
 }

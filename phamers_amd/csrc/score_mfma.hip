@@ -168,6 +168,8 @@ void phk_model_free_fast(phk_model *m) {
     if (m->d_col_mask) (void)hipFree(m->d_col_mask);
     m->d_term_orig = nullptr;
     m->d_col_mask = nullptr;
+    if (m->d_betah16) (void)hipFree(m->d_betah16);
+    m->d_betah16 = nullptr;
     if (m->d_Af16h) (void)hipFree(m->d_Af16h);
     if (m->d_lo16) (void)hipFree(m->d_lo16);
     m->d_Af16h = nullptr;
@@ -493,8 +495,13 @@ template <int SRC, int DSUB>
 __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict__ src, RerankParams p) {
     constexpr int D = 256 * DSUB;
     const int lane = threadIdx.x & 63;
-    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (q >= p.N) return;
+    uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (p.slow_back == 2) {   // listed: only the queries phk_rerank_h_kernel passed on (slow_list, fb_count[2] of them)
+        if (q >= p.fb_count[2]) return;
+        q = p.slow_list[q] & 0x3FFFFFFFu;
+    } else if (q >= p.N) {
+        return;
+    }
     // exact float64 query elements of this lane (kmer.normalize_counts arithmetic): dims 256*sub + 4*lane .. +3
     double qd[4 * DSUB];
     double vs = p.vscale;
@@ -1399,6 +1406,184 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
 }
 
 // ------------------------------------------------------------------------------------
+// 2e. the same decision for general D (k = 5, 6; phk_knn_f16_general_kernel with HI): one wave per query, as
+//     phk_rerank_kernel.  Window, low products (float64, 4 DSUB dimensions per lane, 2 D bytes of lo16 per member),
+//     count-exact margin test among the refined members; centroid leaders certified by their high-part margin and
+//     given their exact distance.  A query it cannot decide goes to phk_rerank_kernel (listed), which works from the
+//     same lists under the high-part error model with exact candidate distances.
+// ------------------------------------------------------------------------------------
+template <int DSUB>
+__global__ __launch_bounds__(256) void phk_rerank_h_kernel(const uint32_t *__restrict__ counts, RerankParams p, HiParams hp) {
+    constexpr int D = 256 * DSUB;
+    const int lane = threadIdx.x & 63;
+    const uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (q >= p.N) return;
+    const uint32_t *row = counts + q * D;
+    uint4 c[DSUB];
+    uint32_t s = 0;
+#pragma unroll
+    for (int sub = 0; sub < DSUB; ++sub) {
+        c[sub] = reinterpret_cast<const uint4 *>(row + 256 * sub)[lane];
+        s += c[sub].x + c[sub].y + c[sub].z + c[sub].w;
+    }
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+    if (s == 0) {  // zero-count contig: the reference's normalised row is NaN
+        if (lane == 0) {
+            p.scores[p.q_base + q] = __builtin_nan("");
+            if (p.status) atomicAdd(p.status, 1u);
+        }
+        return;
+    }
+    const double Tq = (double)s;
+    double qd[4 * DSUB];   // normalised row (exact distances), then reused
+    double aq = 0.0, ap = 0.0;
+#pragma unroll
+    for (int sub = 0; sub < DSUB; ++sub) {
+        qd[4 * sub + 0] = (double)c[sub].x / Tq;
+        qd[4 * sub + 1] = (double)c[sub].y / Tq;
+        qd[4 * sub + 2] = (double)c[sub].z / Tq;
+        qd[4 * sub + 3] = (double)c[sub].w / Tq;
+        const double2 m0 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane];
+        const double2 m1 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane + 1];
+        const double c0 = qd[4 * sub + 0] - m0.x, c1 = qd[4 * sub + 1] - m0.y, c2 = qd[4 * sub + 2] - m1.x, c3 = qd[4 * sub + 3] - m1.y;
+        aq = fma(qd[4 * sub + 0], qd[4 * sub + 0], fma(qd[4 * sub + 1], qd[4 * sub + 1],
+                 fma(qd[4 * sub + 2], qd[4 * sub + 2], fma(qd[4 * sub + 3], qd[4 * sub + 3], aq))));
+        ap = fma(c0, c0, fma(c1, c1, fma(c2, c2, fma(c3, c3, ap))));
+    }
+    const double nq2 = wave_sum(aq), nqp2 = wave_sum(ap);
+    const double vs = p.vscale / Tq;
+    ErrBound eb;
+    eb.A = sqrt(nq2) + p.mu_norm;
+    eb.P = sqrt(nqp2);
+    eb.Q = sqrt(nq2);
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ;
+    const double nqp = eb.P;
+    auto e_hi = [&](int sg, double R) { return nqp * phk_lam_of(hp, sg, R) + eb(R); };
+    // low product of column `col` (global column index): sum_i (c_i - T mu_i) lo_i, the whole wave
+    auto low_product = [&](uint64_t col) {
+        const _Float16 *lr = hp.lo16 + col * D;
+        double acc = 0.0;
+#pragma unroll
+        for (int sub = 0; sub < DSUB; ++sub) {
+            const uint2 l = reinterpret_cast<const uint2 *>(lr + 256 * sub)[lane];
+            const _Float16 *lh = reinterpret_cast<const _Float16 *>(&l);
+            const double2 m0 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane];
+            const double2 m1 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane + 1];
+            acc = fma(fma(-Tq, m0.x, (double)c[sub].x), (double)lh[0], acc);
+            acc = fma(fma(-Tq, m0.y, (double)c[sub].y), (double)lh[1], acc);
+            acc = fma(fma(-Tq, m1.x, (double)c[sub].z), (double)lh[2], acc);
+            acc = fma(fma(-Tq, m1.y, (double)c[sub].w), (double)lh[3], acc);
+        }
+        return wave_sum(acc);
+    };
+    // the 8 candidates of a segment sorted by high-part value (descending), on every lane
+    auto sorted8 = [&](int seg, uint32_t ncols, float (&rv)[8], uint32_t (&ri)[8], double &U) {
+        float v = -3.0e38f;
+        uint32_t ix = 0xFFFFFFFFu;
+        if (lane < 8) {
+            const uint64_t o = cand_at(seg, lane >> 2, lane & 3, q, p.N);
+            v = p.cand_v[o];
+            ix = p.cand_i[o];
+            if (ix >= ncols) v = -3.0e38f;
+        }
+        U = fmax((double)p.cand_u[candu_at(seg, 0, q, p.N)], (double)p.cand_u[candu_at(seg, 1, q, p.N)]) * vs;
+        int rank = 0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const float ov = __shfl(v, m);
+            rank += (lane < 8 && (ov > v || (ov == v && m < lane))) ? 1 : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const unsigned long long bal = __ballot(lane < 8 && rank == r);
+            const int srcl = __ffsll((long long)bal) - 1;
+            rv[r] = __shfl(v, srcl);
+            ri[r] = __shfl(ix, srcl);
+        }
+    };
+    bool ok = true;
+    double knn = 0.0, cen = 0.0;
+    if (p.method & PHK_METHOD_KNN) {
+        const int need = p.kn;
+        float rv[8];
+        uint32_t ri[8];
+        double U;
+        sorted8(0, (uint32_t)p.M, rv, ri, U);
+        ok = ri[need - 1] < (uint32_t)p.M;
+        if (ok) {
+            const double eg = e_hi(0, p.rmax);
+            const double d2up = fmax(nqp2 - 2.0 * ((double)rv[need - 1] * vs - eg), 0.0);
+            const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
+            bool near = true;
+            for (int r = 0; r < need; ++r) near = near && p.colnorm[ri[r]] <= R0;
+            const double eh = near ? e_hi(0, R0) : eg, e22 = near ? eb(R0) : eb(p.rmax);
+            const double thr = (double)rv[need - 1] * vs - 2.0 * eh;
+            int nw = 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) nw += ((double)rv[r] * vs >= thr && ri[r] < (uint32_t)p.M) ? 1 : 0;
+            ok = nw <= PHK_HI_REFINE && U < thr;
+            if (ok) {
+                double fv[PHK_HI_REFINE];
+                uint32_t fl[PHK_HI_REFINE];
+#pragma unroll
+                for (int r = 0; r < PHK_HI_REFINE; ++r) {
+                    fv[r] = -1.0e300;
+                    fl[r] = 0;
+                    if (r < nw) {   // wave-uniform
+                        fv[r] = ((double)rv[r] + (nw > need ? low_product(ri[r]) : 0.0)) * vs;
+                        fl[r] = p.labels[ri[r]] ? 1u : 0u;
+                    }
+                }
+#pragma unroll
+                for (int a = 1; a < PHK_HI_REFINE; ++a)
+#pragma unroll
+                    for (int b = a; b > 0; --b) {
+                        const bool sw = fv[b] > fv[b - 1];
+                        const double tv = fv[b]; const uint32_t tl = fl[b];
+                        fv[b] = sw ? fv[b - 1] : fv[b]; fl[b] = sw ? fl[b - 1] : fl[b];
+                        fv[b - 1] = sw ? tv : fv[b - 1]; fl[b - 1] = sw ? tl : fl[b - 1];
+                    }
+                const double hi_v = need == 1 ? fv[0] : need == 2 ? fv[1] : fv[2];
+                const double lo_v = need == 1 ? fv[1] : need == 2 ? fv[2] : fv[3];
+                ok = nw == need || hi_v - lo_v > 2.0 * e22;
+                int votes = 0;
+                for (int r = 0; r < need; ++r) votes += (int)fl[r];
+                knn = (2 * votes > need) ? 1.0 : -1.0;
+            }
+        }
+    }
+    if (ok && (p.method & PHK_METHOD_KMEANS)) {
+        double d2[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const uint32_t ncols = k2 == 0 ? (uint32_t)p.n_cpos : (uint32_t)p.n_cneg;
+            float rv[8];
+            uint32_t ri[8];
+            double U;
+            sorted8(1 + k2, ncols, rv, ri, U);
+            bool good = ok && ri[0] < ncols;
+            if (good) {
+                const double eg = e_hi(1 + k2, p.rmax);
+                const double d2up = fmax(nqp2 - 2.0 * ((double)rv[0] * vs - eg), 0.0);
+                const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
+                const double cn = p.colnorm[p.M + (k2 ? p.n_cpos : 0) + ri[0]];
+                const double eh = cn <= R0 ? e_hi(1 + k2, R0) : eg;
+                good = ((double)rv[0] - (double)rv[1]) * vs > 2.0 * eh;
+                if (good) d2[k2] = exact_d2<DSUB>(qd, p.C64 + ((k2 ? p.n_cpos : 0) + (uint64_t)ri[0]) * D, lane);
+            }
+            ok = good;
+        }
+        const double ep = sqrt(d2[0]), en = sqrt(d2[1]);
+        cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
+    }
+    if (lane == 0) {
+        if (ok) p.scores[p.q_base + q] = knn + cen;  // scripts/phamer.py:313
+        else p.slow_list[atomicAdd(p.fb_count + 2, 1u)] = (uint32_t)q;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // 3. exact brute force for queued queries.  Work item = (queued query, column chunk): a block
 //    computes the direct-difference float64 distances of its chunk (one thread per column), then
 //    reduces them to a partial record (3 nearest train columns of the chunk + nearest positive /
@@ -1618,6 +1803,11 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // first pass at k = 4: the high-parts-only kernel (1 MFMA per k-step) + its decision stage; proposal=cx2 keeps the
     // count-exact kernel with both parts (2 MFMAs per k-step) and the margin-test decision kernels
     const bool hi_only = second && m->d_Af16h && !(prop[0] == 'c' && prop[1] == 'x' && prop[2] == '2');
+    // general D (k = 5, 6): the same idea exists (HI flavour of the general kernel + phk_rerank_h_kernel) but is opt-in
+    // (proposal=hi): on the BASELINE configurations' synthetic reference genomes, which are nearly equidistant from every
+    // query, the high-part windows are wide -- 20 % of config 4's queries fell through to the brute force -- and the
+    // kernel time saved (111 -> 72 ms) is lost in the tail (profiles/r02/README.md)
+    const bool hi_gen = use_cx && D != FAST_D && m->d_lo16 && m->d_betah16 && prop[0] == 'h' && prop[1] == 'i';
     const uint64_t cap2 = second ? (nb_max / 8 > 4096 ? nb_max / 8 : (nb_max < 4096 ? nb_max : 4096)) : 0;
     const uint64_t per_list = nb_max * NSEG * 2, per_list2 = cap2 * NSEG * 2;
     const uint64_t list_bytes = sizeof(float4) + sizeof(uint4) + sizeof(float);
@@ -1685,7 +1875,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         }
         if (D != FAST_D) {
             PHK_TRY(phk_launch_proposal_f16_general(ctx, m, src, d_counts != nullptr, use_cx, rsum, nb, nref, npos, nneg,
-                                                    (float *)cv, ci, cu));
+                                                    (float *)cv, ci, cu, hi_gen));
         } else if (hi_only) {
             PHK_TRY(phk_launch_proposal_f16h(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu));
         } else if (use_cx) {
@@ -1729,6 +1919,24 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             ph.slow_back = 1;
             PHK_LAUNCH(ctx, "phk_rerank16_kernel",
                        (phk_rerank16_kernel<0, 1><<<dim3((unsigned)phk_div_up(nb, 16)), dim3(256), 0, ctx->stream>>>(src, ph)));
+        } else if (hi_gen) {
+            HiParams hp;
+            hp.lo16 = m->d_lo16;
+            for (int sg = 0; sg < 3; ++sg) {
+                for (int i = 0; i <= 64; ++i) hp.lam_tab[sg][i] = m->lam_tab[sg][i];
+                hp.lam_r0[sg] = m->lam_r0[sg];
+                hp.lam_inv_step[sg] = 1.0 / m->lam_step[sg];
+            }
+#define PHK_RH(DS) PHK_LAUNCH(ctx, "phk_rerank_h_kernel", (phk_rerank_h_kernel<DS><<<dim3(rblocks), dim3(256), 0, ctx->stream>>>((const uint32_t *)src, p, hp)))
+            if (D == 512) { PHK_RH(2); } else if (D == 1024) { PHK_RH(4); } else if (D == 2048) { PHK_RH(8); } else { PHK_RH(16); }
+#undef PHK_RH
+            // what it passes on: the one-wave-per-query kernel on the listed queries, the lists under the high-part error
+            // model (see the k = 4 path above)
+            RerankParams ph = p;
+            ph.eb_cP += 8192.0 * (1.0 + 1.0 / 2048.0) + 1.0;
+            ph.eb_abs *= 2.0;
+            ph.slow_back = 2;
+            PHK_TRY(launch_rerank<0>(ctx, rblocks, src, ph));
         } else if (d_counts) {
             PHK_TRY(launch_rerank<0>(ctx, rblocks, src, p));
         } else {

@@ -20,6 +20,7 @@ struct phk_model {
     // high-parts-only proposal (k = 4, phk_knn_f16h_kernel): 17-piece block records (16 hi fragments + the bias terms
     // S mu.hi + S |r~'|^2/2 per unit of row sum), the low parts row-major for the decision stage's refinement, and
     // lam_tab[s][i] = max |lo_j| / S over segment s's columns with |r'_j| <= lam_r0[s] + i * lam_step[s] (error of a high-parts-only value)
+    float *d_betah16 = nullptr;   // high-part bias terms per column slot (general-D kernel; mask restore target)
     void *d_Af16h = nullptr;
     _Float16 *d_lo16 = nullptr;   // [M + n_cpos + n_cneg][D]
     double lam_tab[3][65] = {{0}};     // per segment (train rows, positive centroids, negative centroids)
@@ -67,6 +68,6 @@ int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu);
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, bool count_exact,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                                    float *cv, uint32_t *ci, float *cu);
+                                    float *cv, uint32_t *ci, float *cu, bool hi_only = false);
 int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
                    const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status);

@@ -248,8 +248,9 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
     model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
     d_q = device_counts(90 + k, n_q, 10000)
     out = {}
-    for path in ("f16", "exact"):
+    for path in ("f16", "hi", "exact"):   # count-exact general-D kernel (default), its high-parts-only flavour (opt-in), float64
         ctx.set_option("force_exact", "1" if path == "exact" else "0")
+        ctx.set_option("proposal", "hi" if path == "hi" else "")
         for method in ("knn", "kmeans", "combo"):
             d_scores = device.DeviceArray(ctx, n_q, np.float64)
             d_status = device.DeviceArray(ctx, 1, np.uint32)
@@ -259,6 +260,10 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
         if path == "f16":
             n_fallback, _ = ctx.score_stats()
             assert n_fallback < max(n_q // 20, 8)
+    ctx.set_option("proposal", "")
+    for method in ("knn", "kmeans", "combo"):
+        assert np.array_equal(np.sign(out[("hi", method)]), np.sign(out[("exact", method)])), method
+        assert helpers.rel_err(out[("hi", method)], out[("exact", method)]) < 1e-9, method
     assert np.array_equal(out[("f16", "knn")], out[("exact", "knn")])
     assert helpers.rel_err(out[("f16", "kmeans")], out[("exact", "kmeans")]) < 1e-9
     assert helpers.rel_err(out[("f16", "combo")], out[("exact", "combo")]) < 1e-9
