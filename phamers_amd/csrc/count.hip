@@ -500,7 +500,9 @@ __global__ __launch_bounds__(256) void phk_sort_scatter_kernel(const uint64_t *_
 // A workgroup runs as many stages as its longest contig needs, so contigs much longer than the batch
 // mean are not counted here: they are appended to `long_list` for the wave-per-contig kernel, which follows.
 // ------------------------------------------------------------------------------------
+#ifndef SLOT_LINES
 #define SLOT_LINES 2                       // 128-byte lines per contig and stage
+#endif
 #define SLOT_ROW (32 * SLOT_LINES + 4)     // staging row stride in words (data + 1 look-ahead + pad: conflict-free b128 reads)
 // LDS-only workgroup barrier: waits for this wave's LDS operations, NOT for its global loads (a
 // __syncthreads() would also drain the prefetch of the next stage, issued just before)

@@ -462,7 +462,8 @@ def test_scoring_in_several_batches_matches_one_batch_and_exact_path():
         assert np.array_equal(d_scores.to_host(), out[name]), name
         ctx.set_option("score_batch", "0")
         ctx.set_option("force_exact", "0")
-    assert np.array_equal(out["one"], out["four"])
+    # (equal up to the arithmetic form of the few queries whose tail route depends on the batch split)
+    assert np.array_equal(np.sign(out["one"]), np.sign(out["four"])) and helpers.rel_err(out["one"], out["four"]) < 1e-12
     # totals over the four batches (the tail routes depend on the batch split: a handful of queued rows per batch goes
     # straight to the brute force, so the totals are compared loosely)
     assert stats["four"][1] > 0 and abs(stats["four"][1] - stats["one"][1]) <= 64
