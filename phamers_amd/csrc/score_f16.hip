@@ -1157,8 +1157,11 @@ __global__ __launch_bounds__(256) void phk_split_queries_kernel(const void *__re
 // HI (with CX): high parts of the columns only -- ONE MFMA per k-step, only the 16 hi pieces of a (block, chunk) item are
 // streamed, the bias is the high-part one (beta_all = betah); the decision stage (phk_rerank_h_kernel) adds the low
 // product to the window's members
-template <bool CX, int GEN_CT, bool HI = false>
-__global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4 *__restrict__ Bq, uint64_t N,
+// GEN_NW = waves per workgroup: the (block, chunk) items streamed into LDS are shared by all of them, so 8 waves (one
+// workgroup per CU) halve the L2 -> LDS traffic per MFMA of two 4-wave workgroups that each stream their own copy --
+// and that stream is what bounds the kernel (32 KiB per 32 MFMAs per wave: ~64 GB/s per CU at 4 waves)
+template <bool CX, int GEN_CT, bool HI = false, int GEN_NW = 8>
+__global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_general_kernel(const uint4 *__restrict__ Bq, uint64_t N,
                                                                      uint32_t nchunk,
                                                                      const uint4 *__restrict__ Af,
                                                                      uint64_t rec_u4,  // uint4 per block record
@@ -1173,10 +1176,12 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
                                                                      uint32_t *__restrict__ cand_i,
                                                                      float *__restrict__ cand_u) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x 32 KiB
+    // (a third buffer with the DMA running two items ahead and counted vmcnt waits was measured: 106 instead of 96 ms at
+    // config 4 -- the deeper queue does not pay)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const uint64_t qb = (uint64_t)blockIdx.x * 4 + wave;
+    const uint64_t qb = (uint64_t)blockIdx.x * GEN_NW + wave;
     const uint64_t q0 = qb * 32;
     const uint64_t nqb = (N + 31) / 32;
     const uint64_t qbc = qb < nqb ? qb : nqb - 1;  // padding waves re-read the last block; nothing is written
@@ -1196,7 +1201,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_general_kernel(const uint4
         if (blk >= total) blk = total - 1;  // partial last tile: harmless re-read, result discarded
         const uint4 *g = Af + (uint64_t)(blk0 + blk) * rec_u4 + (uint64_t)c * 32 * 64 + lane;
         const uint32_t l = lds_base + (uint32_t)buf * 32768u;
-        for (int p = wave; p < (HI ? 16 : 32); p += 4) {   // HI: source pieces 0, 2, 4, .. (hi) land as pieces 0, 1, 2, ..
+        for (int p = wave; p < (HI ? 16 : 32); p += GEN_NW) {   // HI: source pieces 0, 2, 4, .. (hi) land as pieces 0, 1, 2, ..
             const uint4 *gp = g + (HI ? 2 * p : p) * 64;
             const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
@@ -1351,19 +1356,19 @@ int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void
     const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
     if (d_big && hi_only) {
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
-                   (phk_knn_f16_general_kernel<true, 8, true><<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
+                   (phk_knn_f16_general_kernel<true, 8, true><<<dim3((unsigned)phk_div_up(nqb, 8)), dim3(512), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_betah16, d_rowsum,
                        d_big, blk0, nref, npos, nneg, cv, ci, cu)));
     } else if (d_big) {
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
-                   phk_knn_f16_general_kernel<true, 8><<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
+                   (phk_knn_f16_general_kernel<true, 8><<<dim3((unsigned)phk_div_up(nqb, 8)), dim3(512), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, d_rowsum,
-                       d_big, blk0, nref, npos, nneg, cv, ci, cu));
+                       d_big, blk0, nref, npos, nneg, cv, ci, cu)));
     } else {
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
-                   phk_knn_f16_general_kernel<false, 4><<<dim3((unsigned)phk_div_up(nqb, 4)), dim3(256), 65536, ctx->stream>>>(
+                   (phk_knn_f16_general_kernel<false, 4><<<dim3((unsigned)phk_div_up(nqb, 8)), dim3(512), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, nullptr,
-                       nullptr, blk0, nref, npos, nneg, cv, ci, cu));
+                       nullptr, blk0, nref, npos, nneg, cv, ci, cu)));
     }
     return PHK_OK;
 }
