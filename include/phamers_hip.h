@@ -82,7 +82,8 @@ int phk_sync(phk_ctx *ctx);
  * kernel whatever the batch looks like), "count_cfg" ("<copies>,<pack16>"), "slot_threads" ("256"),
  * "count_sort" ("0" = no length-bucketed order for ragged batches), "force_exact" ("1" = float64 scoring
  * path for every model), "proposal" ("f32" | "f16" | "" default), "cx_cfg" ("14" | "24" | "28"), "rerank"
- * ("w" | "g"), "score_batch" (queries per scoring batch).  Unknown key -> PHK_ERR_ARG.  The results of every
+ * ("w" | "g"), "score_batch" (queries per scoring batch), "pipeline" (chunks of phk_count_score_dev's count / score
+ * pipeline at k = 4; "1" = off).  Unknown key -> PHK_ERR_ARG.  The results of every
  * entry point are the same under every setting; the parity tests use the knobs to cross-check the paths. */
 int phk_set_option(phk_ctx *ctx, const char *key, const char *value);
 

@@ -838,9 +838,11 @@ int phk_count_init_device(phk_ctx *ctx) {
     return PHK_OK;
 }
 
+// mean_bases: the batch's mean contig length when `d_offsets` addresses a sub-range of the stream (T then only bounds
+// the loads); 0 = T / n
 int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t T,
                      const uint64_t *d_offsets, uint64_t n, int k, uint32_t *d_counts,
-                     uint32_t *d_nwin) {
+                     uint32_t *d_nwin, uint64_t mean_bases) {
     PHK_REQUIRE(k >= 1, "phk_count: k must be >= 1 (got %d)", k);
     if (k > PHK_MAX_K) {
         phk_set_error("phk_count: k=%d is above PHK_MAX_K=%d (4^k bins no longer fit LDS)", k, PHK_MAX_K);
@@ -866,7 +868,7 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         // contig): with count_sort they go to the wave-per-contig kernel as PIECES of 32768 windows, each its own work
         // item adding onto the zeroed row, so that one 500 kb contig is shared by 15 waves instead of pinning one
         const uint32_t piece_w = sorted ? 32768u : 0u;
-        const uint64_t mean_len = T / n + 1;
+        const uint64_t mean_len = (mean_bases ? mean_bases : T / n) + 1;
         uint64_t thr64 = 4 * mean_len + 1024;
         if (sorted && thr64 < 2ull * piece_w) thr64 = 2ull * piece_w;
         const uint32_t long_thr = thr64 < 0xFFFFFFFFull ? (uint32_t)thr64 : 0xFFFFFFFFu;

@@ -36,6 +36,7 @@ static int set_knob(PhkKnobs &k, const char *key, const char *value) {
     else if (!strcmp(key, "rerank")) k.rerank = v[0];
     else if (!strcmp(key, "count_sort")) k.count_sort = v[0] != '0';
     else if (!strcmp(key, "score_batch")) k.score_batch = strtoull(v, nullptr, 10);
+    else if (!strcmp(key, "pipeline")) k.pipeline = v[0] ? atoi(v) : 1;
     else return PHK_ERR_ARG;
     return PHK_OK;
 }
@@ -45,7 +46,7 @@ static void knobs_from_env(PhkKnobs &k) {
                                            {"slot_threads", "PHK_SLOT_THREADS"}, {"force_exact", "PHK_FORCE_EXACT"},
                                            {"proposal", "PHK_PROPOSAL"}, {"cx_cfg", "PHK_CX_CFG"},
                                            {"rerank", "PHK_RERANK"}, {"count_sort", "PHK_COUNT_SORT"},
-                                           {"score_batch", "PHK_SCORE_BATCH"}};
+                                           {"score_batch", "PHK_SCORE_BATCH"}, {"pipeline", "PHK_PIPELINE"}};
     for (auto &n : names) {
         const char *e = getenv(n[1]);
         if (e) (void)set_knob(k, n[0], e);
@@ -114,6 +115,13 @@ extern "C" int phk_destroy(phk_ctx *ctx) {
     for (auto &t : ctx->timed)
         for (auto e : t.ev) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->aux) {
+        (void)hipStreamSynchronize(ctx->aux);
+        (void)hipStreamDestroy(ctx->aux);
+    }
+    for (auto e : ctx->ev_chunk)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PHK_OK;
@@ -434,8 +442,54 @@ extern "C" int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const u
                 (unsigned long long)model->D);
     void *d_nwin;  // row sums straight from the count kernel (saves the scorer a pass over the counts)
     PHK_TRY(phk_ws(ctx, WS_NWIN, n * sizeof(uint32_t), &d_nwin));
-    PHK_TRY(phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets, n, k, d_counts, (uint32_t *)d_nwin));
-    return phk_score_rows(ctx, model, nullptr, d_counts, (const uint32_t *)d_nwin, n, method, d_scores, d_status);
+    uint32_t *nwin = (uint32_t *)d_nwin;
+    // Chunk pipeline (k = 4, large batches; opt-in, option "pipeline"): the batch is cut into chunks; chunk i+1 is counted
+    // on this stream while chunk i is scored on a second stream, forked and joined with events inside the call (the caller
+    // sees one stream-ordered operation).  Measured on the BASELINE batch it LOSES: 5.32 ms unchunked, 5.71 / 6.39 / 7.94
+    // with 2 / 4 / 8 chunks -- every chunk pays the latency-bound tail of the scoring chain (second-chance sweep, exact-
+    // distance kernels) again, and the overlapped kernels slow each other.  Kept for batches that arrive in pieces.
+    int chunks = ctx->knobs.pipeline;
+    chunks = chunks < 1 ? 1 : (chunks > 8 ? 8 : chunks);
+    if (k != 4 || !phk_model_has_fast(model) || ctx->knobs.force_exact || n < 65536ull * (uint64_t)chunks) chunks = 1;
+    if (chunks == 1) {
+        PHK_TRY(phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets, n, k, d_counts, nwin));
+        return phk_score_rows(ctx, model, nullptr, d_counts, nwin, n, method, d_scores, d_status);
+    }
+    if (!ctx->aux) {
+        PHK_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+        for (auto &e : ctx->ev_chunk) PHK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        PHK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    }
+    const uint64_t D = model->D;
+    const uint64_t per = ((n / (uint64_t)chunks + 4095) / 4096) * 4096;   // whole proposal workgroups and slot groups
+    const uint64_t mean = total_bases / n;
+    hipStream_t main_stream = ctx->stream;
+    int rc = PHK_OK;
+    ctx->keep_score_state = false;
+    for (int c = 0; c < chunks && rc == PHK_OK; ++c) {
+        const uint64_t c0 = per * (uint64_t)c;
+        if (c0 >= n) break;
+        const uint64_t m = n - c0 < per ? n - c0 : per;
+        rc = phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets + c0, m, k, d_counts + c0 * D, nwin + c0, mean);
+        if (rc != PHK_OK) break;
+        if (hipEventRecord(ctx->ev_chunk[c], main_stream) != hipSuccess ||
+            hipStreamWaitEvent(ctx->aux, ctx->ev_chunk[c], 0) != hipSuccess) {
+            phk_set_error("phk_count_score_dev: event hand-over failed");
+            rc = PHK_ERR_HIP;
+            break;
+        }
+        ctx->stream = ctx->aux;   // the scoring chain (launch helpers, workspaces, kernel timers) follows ctx->stream
+        rc = phk_score_rows(ctx, model, nullptr, d_counts + c0 * D, nwin + c0, m, method, d_scores + c0, d_status);
+        ctx->stream = main_stream;
+        ctx->keep_score_state = true;
+    }
+    ctx->keep_score_state = false;
+    // join: everything enqueued on the second stream is done before anything the caller enqueues next
+    if (hipEventRecord(ctx->ev_join, ctx->aux) != hipSuccess || hipStreamWaitEvent(main_stream, ctx->ev_join, 0) != hipSuccess) {
+        phk_set_error("phk_count_score_dev: join failed");
+        return PHK_ERR_HIP;
+    }
+    return rc;
 }
 
 extern "C" int phk_check_counts_dev(phk_ctx *ctx, const uint32_t *d_counts, const uint32_t *d_other, uint64_t n, uint64_t D,

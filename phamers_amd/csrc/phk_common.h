@@ -90,6 +90,8 @@ struct PhkKnobs {
     char rerank = 0;           // 'w' wave per query, 'g' 16 lanes per query for all
     bool count_sort = true;    // length-bucketed contig order for the slot count kernel on ragged batches
     uint64_t score_batch = 0;  // queries per scoring batch of the MFMA path (0 = default 2^20; tests shrink it)
+    int pipeline = 1;          // chunks of phk_count_score_dev's count / score pipeline at k = 4 (1 = off, the default:
+                               // measured 5.32 / 5.71 / 6.39 / 7.94 ms per 1M contigs with 1 / 2 / 4 / 8 chunks)
 };
 
 struct phk_ctx {
@@ -98,6 +100,12 @@ struct phk_ctx {
     bool slots_lds0 = true;        // the slot count kernel's dynamic LDS starts at address 0 (checked at creation)
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // second stream of phk_count_score_dev's chunk pipeline (count of chunk i+1 beside the scoring of chunk i): forked
+    // from / joined to `stream` with events inside the call, so the caller still sees one stream-ordered operation
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_join = nullptr;
+    bool keep_score_state = false;   // a later chunk of one logical call: NaN counter and statistics totals carry on
     int num_cus = 256;
     PhkBuf ws[WS_SLOTS];
     bool profile = false;
@@ -153,7 +161,7 @@ int phk_launch_pack(phk_ctx *ctx, const char *d_bases, uint64_t T, const char *s
                     uint32_t *d_packed, uint32_t *d_mask, uint32_t *d_any_invalid);
 int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t T,
                      const uint64_t *d_offsets, uint64_t n, int k, uint32_t *d_counts,
-                     uint32_t *d_nwin);
+                     uint32_t *d_nwin, uint64_t mean_bases = 0);
 int phk_launch_widen(phk_ctx *ctx, const uint32_t *d_in, uint64_t count, int64_t *d_out);
 int phk_launch_normalize_u32(phk_ctx *ctx, const uint32_t *d_counts, uint64_t n, uint64_t D,
                              double *d_out);

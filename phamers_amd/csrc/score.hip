@@ -281,7 +281,7 @@ int phk_score_rows(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
                    const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status) {
     PHK_REQUIRE(m && d_scores && (d_Q || d_counts), "phk_score: NULL pointer");
     PHK_TRY(check_method(m, method));
-    if (d_status) PHK_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), ctx->stream));
+    if (d_status && !ctx->keep_score_state) PHK_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), ctx->stream));
     if (N == 0) return PHK_OK;
     const uint64_t D = m->D;
 

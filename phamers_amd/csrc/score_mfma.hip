@@ -1829,7 +1829,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
     const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + D) * sizeof(double);
     PHK_REQUIRE(fb_lds <= FB_LDS_MAX, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);  // phk_model_build_fast keeps such models off this path
-    PHK_HIP(hipMemsetAsync(fbc, 0, 128, ctx->stream));   // incl. the totals of this call
+    if (!ctx->keep_score_state) PHK_HIP(hipMemsetAsync(fbc, 0, 128, ctx->stream));   // incl. the totals of this call
     for (uint64_t s = 0; s < N; s += BATCH) {
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
         const void *src = d_counts ? (const void *)(d_counts + s * D) : (const void *)(d_Q + s * D);

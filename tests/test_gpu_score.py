@@ -442,7 +442,7 @@ def test_scoring_in_several_batches_matches_one_batch_and_exact_path():
     pos, neg = _ref_matrices()
     ctx = _lib.get_context()
     model = _lib.Model(ctx, pos, neg, g["cpos_full"], g["cneg_full"], 3)
-    n, L = 3 * 4096 + 100, 3000
+    n, L = 3 * 65536 + 100, 3000
     T = n * L
     d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
     d_off = device.DeviceArray(ctx, n + 1, np.uint64)
@@ -451,7 +451,7 @@ def test_scoring_in_several_batches_matches_one_batch_and_exact_path():
     d_scores = device.DeviceArray(ctx, n, np.float64)
     d_status = device.DeviceArray(ctx, 1, np.uint32)
     out, stats = {}, {}
-    for name, opts in (("one", {}), ("four", {"score_batch": "4096"}), ("exact", {"force_exact": "1"})):
+    for name, opts in (("one", {}), ("four", {"score_batch": "4096"}), ("piped", {"pipeline": "3"}), ("exact", {"force_exact": "1"})):
         for k_, v_ in opts.items():
             ctx.set_option(k_, v_)
         # the fused entry point (row sums come from the count kernel) and the counts-only one
@@ -462,6 +462,9 @@ def test_scoring_in_several_batches_matches_one_batch_and_exact_path():
         assert np.array_equal(d_scores.to_host(), out[name]), name
         ctx.set_option("score_batch", "0")
         ctx.set_option("force_exact", "0")
+        ctx.set_option("pipeline", "1")
+    # the chunk pipeline of phk_count_score_dev (count of chunk i+1 beside the scoring of chunk i on a second stream)
+    assert np.array_equal(np.sign(out["one"]), np.sign(out["piped"])) and helpers.rel_err(out["one"], out["piped"]) < 1e-12
     # (equal up to the arithmetic form of the few queries whose tail route depends on the batch split)
     assert np.array_equal(np.sign(out["one"]), np.sign(out["four"])) and helpers.rel_err(out["one"], out["four"]) < 1e-12
     # totals over the four batches (the tail routes depend on the batch split: a handful of queued rows per batch goes
