@@ -669,6 +669,7 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
     }
     const double nqp = sqrt(nqp2);
     const double eps_g = eb(p.rmax);
+    double eps_w = eps_g;   // the bound the window of the exact route uses (the margin test's)
     bool certified = false;
     if (ri[need - 1] < ncols) {
         const double d2up = fmax(nqp2 - 2.0 * ((double)rv[need - 1] * vs - eps_g), 0.0);
@@ -681,6 +682,7 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
 #pragma unroll
         for (int r = 0; r < 3; ++r) near = near && (r >= need || cnr[r] <= R0);
         const double eps_m = near ? eb(R0) : eps_g;
+        eps_w = eps_m;
         certified = ((double)rv[need - 1] - (double)rv[need]) * vs > 2.0 * eps_m;
     }
     bool ok = certified;
@@ -689,10 +691,15 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
     const bool need_exact = live && !certified;
     if (__any(need_exact)) {  // wave-uniform: some group must decide by exact float64 distances
         if (need_exact && t == 0) atomicAdd(p.fb_count + 1, 1u);
+        // only candidates inside the window can be among the `need` nearest: one whose computed value lies more than
+        // 2 eps below the need-th best has a true value below the true need-th best (same argument as the margin test).
+        // The lists are sorted within each half, so the late slots are skipped by whole waves most of the time.
+        const double wthr = (double)rv[need - 1] * vs - 2.0 * eps_w;
 #pragma unroll 1
         for (int m = 0; m < 8; ++m) {
             const uint32_t c = cix[m];
-            const bool valid = need_exact && c < ncols;
+            const bool valid = need_exact && c < ncols && (double)cvv[m] * vs >= wthr;
+            if (!__any(valid)) continue;
             const double d2 = exact_d2_g16(qd, Tq, invT2, rows + (uint64_t)(valid ? c : 0u) * FAST_D, t);
             if (valid && (d2 < best[2] || (d2 == best[2] && c < bidx[2]))) {
                 best[2] = d2; bidx[2] = c;
