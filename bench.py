@@ -393,7 +393,7 @@ def main():
         "value": world * T * steps / elapsed / 1e9,
         "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
-        "vs_baseline": None, "dtype": "u32 counts + f16 MFMA proposal (exact integer counts x split-f16 reference, f32 accumulate) + f64 decision",
+        "vs_baseline": None, "dtype": "u32 counts + f16 MFMA proposal (exact integer counts x fp16 reference parts, f32 accumulate; k=4: high parts in the sweep, low parts added in f64 to the window's candidates) + f64 decision",
         "data": ("synthetic (seeded, device-generated: heavy-tailed lengths 5-500 kb in arbitrary order, per-contig GC "
                  "0.3-0.7, 0.1 % invalid bases); reference matrix: " if ragged else
                  "synthetic (seeded uniform ATGC contigs, device-generated); reference matrix: ") + ref_name,
