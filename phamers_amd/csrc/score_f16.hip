@@ -50,8 +50,17 @@ static void split_f16(double x, _Float16 &hi, _Float16 &lo) {
 // chunk: dims 256c + 128*(lane>>5) + 8s .. +7), then one piece with the 32 norm terms.  For D = 256
 // this is the 33-piece record of the k = 4 kernel.  cn_all (one float per column slot, padding
 // included) duplicates the norm terms for the general-D kernel, which reads them from global memory.
-// hi-only extras (D = 256 models): betah_all = S mu.hi + S |r~'|^2 / 2 per column slot, lo_rows = the low parts row-major
+// hi-only extras (D = 256 models): betah_all = S mu.hi + S |r~'|^2 / 2 per column slot, lo_rows = the low parts, one row
 // per REAL column (col0 + r), lonorm = |lo| / S per real column
+// Position of dimension d inside a low-part row.  D = 256 rows are stored in the order phk_decide_h_kernel's 16-lane
+// groups read them (score_mfma.hip, "G16 ownership": lane t holds dimensions 32 i + 2 t + j): lane t's 16 halves sit in two
+// 16-byte pieces, [i >> 2][t][(i & 3) * 2 + j], so the group's two loads per row are contiguous 256 B each.  Other D:
+// row-major (phk_rerank_h_kernel).
+static inline uint64_t lo_pos(uint64_t D, uint64_t d) {
+    if (D != FAST_D) return d;
+    const uint64_t i = d >> 5, t = (d >> 1) & 15, j = d & 1;
+    return ((i >> 2) * 16 + t) * 8 + (i & 3) * 2 + j;
+}
 struct HiOnlyOut {
     std::vector<float> *betah_all = nullptr;
     std::vector<_Float16> *lo_rows = nullptr;
@@ -95,7 +104,7 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
                             mudot += mu[d] * xt;
                             mulo += mu[d] * (double)lo;
                             lo2 += (double)lo * (double)lo;
-                            if (ho.lo_rows) (*ho.lo_rows)[(ho.col0 + r) * D + d] = lo;
+                            if (ho.lo_rows) (*ho.lo_rows)[(ho.col0 + r) * D + lo_pos(D, d)] = lo;
                         }
             if (ho.betah_all) (*ho.betah_all)[(cb0 + b) * 32 + i] = (float)(mudot - mulo + 0.5 * nrm2 / (double)F16_SCALE);
             if (ho.lonorm) (*ho.lonorm)[ho.col0 + r] = std::sqrt(lo2) / (double)F16_SCALE;

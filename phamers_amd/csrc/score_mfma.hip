@@ -356,9 +356,53 @@ struct RerankParams {
     const uint32_t *exact_extra = nullptr;  // exact-distance decisions of an earlier pass of the same batch
 };
 
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s);
+// Sums inside each group of 16 lanes = one DPP row: rotations by 8, 4, 2, 1 (row_ror) leave the total on every lane, in
+// the VALU (a __shfl_xor butterfly is 4 dependent ds_bpermute round trips per sum -- with eleven sums per pass that chain
+// was most of phk_decide_h_kernel's time).  Same operand pairs as the xor butterfly, so the same bits.
+template <int ROR>
+__device__ __forceinline__ int row_ror_i32(int v) {
+    return __builtin_amdgcn_mov_dpp(v, 0x120 + ROR, 0xF, 0xF, true);
+}
+template <int ROR>
+__device__ __forceinline__ double row_ror_f64(double x) {
+    return __hiloint2double(row_ror_i32<ROR>(__double2hiint(x)), row_ror_i32<ROR>(__double2loint(x)));
+}
+__device__ __forceinline__ double group16_sum(double x) {
+    x += row_ror_f64<8>(x);
+    x += row_ror_f64<4>(x);
+    x += row_ror_f64<2>(x);
+    x += row_ror_f64<1>(x);
+    return x;
+}
+__device__ __forceinline__ float group16_sum(float x) {
+    x += __int_as_float(row_ror_i32<8>(__float_as_int(x)));
+    x += __int_as_float(row_ror_i32<4>(__float_as_int(x)));
+    x += __int_as_float(row_ror_i32<2>(__float_as_int(x)));
+    x += __int_as_float(row_ror_i32<1>(__float_as_int(x)));
+    return x;
+}
+__device__ __forceinline__ uint32_t group16_sum(uint32_t x) {
+    x += (uint32_t)row_ror_i32<8>((int)x);
+    x += (uint32_t)row_ror_i32<4>((int)x);
+    x += (uint32_t)row_ror_i32<2>((int)x);
+    x += (uint32_t)row_ror_i32<1>((int)x);
+    return x;
+}
+
+// Exact squared distance of the group's query to `row`.  The query is held UNNORMALISED: qd = the integer
+// counts (or the float64 row with Tq = 1), Tq = their sum, and
+//     |q - r|^2 = sum_i (c_i - Tq r_i)^2 / Tq^2        (one rounding per difference, inside the fma)
+// which needs no per-element division and is at least as accurate as forming q = c / Tq first.
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
+    x = group16_sum(x);
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+__device__ __forceinline__ double wave_sum(double x) {   // rows in the VALU, the four row totals through two bpermute steps
+    x = group16_sum(x);
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
     return x;
 }
 
@@ -515,8 +559,7 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
             c[sub] = reinterpret_cast<const uint4 *>(row + 256 * sub)[lane];
             s += c[sub].x + c[sub].y + c[sub].z + c[sub].w;
         }
-#pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+        s = wave_sum(s);
         nan_row = s == 0;
         const double ds = (double)s;
         if (p.per_row_scale) vs = p.vscale / ds;
@@ -605,28 +648,48 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
 //     such chains per SIMD.  Control flow is uniform per wave: a group that does not need a step
 //     runs it predicated on safe addresses.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ double group16_sum(double x) {
-    x += __shfl_xor(x, 8);
-    x += __shfl_xor(x, 4);
-    x += __shfl_xor(x, 2);
-    x += __shfl_xor(x, 1);
-    return x;
-}
-
-// Exact squared distance of the group's query to `row`.  The query is held UNNORMALISED: qd = the integer
-// counts (or the float64 row with Tq = 1), Tq = their sum, and
-//     |q - r|^2 = sum_i (c_i - Tq r_i)^2 / Tq^2        (one rounding per difference, inside the fma)
-// which needs no per-element division and is at least as accurate as forming q = c / Tq first.
+// G16 ownership: the 16 lanes of a group share a 256-element row; lane t holds elements 32 i + 2 t + j (i < 8, j < 2) as
+// qd[2 i + j], so that every load instruction of the group covers ONE contiguous piece (256 B of a float64 row, 128 B of a
+// uint32 row).  With 16 consecutive elements per lane -- the first layout -- each instruction touched 16 lines per query
+// (64 per wave) for 16 B each, and the L1's line rate, not latency or HBM, set these kernels' time (clock64 phase timers:
+// 16 k cycles per pass with every operand cache-resident; profiles/r02/README.md).
 __device__ __forceinline__ double exact_d2_g16(const double (&qd)[16], double Tq, double invT2, const double *row, int t) {
-    const double2 *r = reinterpret_cast<const double2 *>(row + 16 * t);
+    const double2 *r = reinterpret_cast<const double2 *>(row) + t;   // G16 ownership: one contiguous 256 B per load
+    double2 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = r[16 * i];
+    // all eight loads in flight before the first use: left alone, the scheduler trades them for registers and emits
+    // load, wait, 4 FMAs, load, wait, ... -- eight exposed round trips per row
+    __builtin_amdgcn_sched_barrier(0);
     double acc = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const double2 v = r[i];
-        const double d0 = fma(-Tq, v.x, qd[2 * i]), d1 = fma(-Tq, v.y, qd[2 * i + 1]);
+        const double d0 = fma(-Tq, v[i].x, qd[2 * i]), d1 = fma(-Tq, v[i].y, qd[2 * i + 1]);
         acc = fma(d0, d0, fma(d1, d1, acc));
     }
     return group16_sum(acc) * invT2;
+}
+// two rows at once (the nearest centroid of either class): sixteen loads in flight, one round trip
+__device__ __forceinline__ void exact_d2_pair_g16(const double (&qd)[16], double Tq, double invT2, const double *rowa,
+                                                  const double *rowb, int t, double &da, double &db) {
+    const double2 *ra = reinterpret_cast<const double2 *>(rowa) + t, *rb = reinterpret_cast<const double2 *>(rowb) + t;
+    double2 va[8], vb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        va[i] = ra[16 * i];
+        vb[i] = rb[16 * i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double acca = 0.0, accb = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double a0 = fma(-Tq, va[i].x, qd[2 * i]), a1 = fma(-Tq, va[i].y, qd[2 * i + 1]);
+        const double b0 = fma(-Tq, vb[i].x, qd[2 * i]), b1 = fma(-Tq, vb[i].y, qd[2 * i + 1]);
+        acca = fma(a0, a0, fma(a1, a1, acca));
+        accb = fma(b0, b0, fma(b1, b1, accb));
+    }
+    da = group16_sum(acca) * invT2;
+    db = group16_sum(accb) * invT2;
 }
 
 // per-group version of resolve_segment; `live` = this group still needs an answer.  Returns ok.
@@ -789,36 +852,31 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
         lu[sg] = p.cand_u[candu_at(sg, t & 1, ql, p.N)];
     }
     if (SRC == 0) {
-        const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
-        uint4 c[4];
+        const uint2 *row = reinterpret_cast<const uint2 *>(static_cast<const uint32_t *>(src) + q * FAST_D) + t;
+        uint2 c[8];
         uint32_t sum = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            c[i] = row[i];
-            sum += c[i].x + c[i].y + c[i].z + c[i].w;
+        for (int i = 0; i < 8; ++i) {
+            c[i] = row[16 * i];
+            sum += c[i].x + c[i].y;
         }
-        sum += __shfl_xor(sum, 8);
-        sum += __shfl_xor(sum, 4);
-        sum += __shfl_xor(sum, 2);
-        sum += __shfl_xor(sum, 1);
+        sum = group16_sum(sum);
         nan_row = sum == 0;
         const double ds = (double)sum;
         if (p.per_row_scale) vs = p.vscale / ds;
         Tq = ds;
         invT2 = 1.0 / (ds * ds);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {   // the counts themselves: see exact_d2_g16
-            qd[4 * i + 0] = (double)c[i].x;
-            qd[4 * i + 1] = (double)c[i].y;
-            qd[4 * i + 2] = (double)c[i].z;
-            qd[4 * i + 3] = (double)c[i].w;
+        for (int i = 0; i < 8; ++i) {   // the counts themselves: see exact_d2_g16
+            qd[2 * i + 0] = (double)c[i].x;
+            qd[2 * i + 1] = (double)c[i].y;
         }
     } else {
-        const double2 *row = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D + 16 * t);
+        const double2 *row = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D) + t;
         bool bad = false;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const double2 v = row[i];
+            const double2 v = row[16 * i];
             qd[2 * i] = v.x;
             qd[2 * i + 1] = v.y;
             bad |= v.x != v.x || v.y != v.y;
@@ -830,10 +888,10 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
     }
     double aq = 0.0, ap = 0.0;
     {
-        const double2 *mp = reinterpret_cast<const double2 *>(p.mu64 + 16 * t);
+        const double2 *mp = reinterpret_cast<const double2 *>(p.mu64) + t;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const double2 m = mp[i];
+            const double2 m = mp[16 * i];
             const double c0 = fma(-Tq, m.x, qd[2 * i]), c1 = fma(-Tq, m.y, qd[2 * i + 1]);
             aq = fma(qd[2 * i], qd[2 * i], fma(qd[2 * i + 1], qd[2 * i + 1], aq));
             ap = fma(c0, c0, fma(c1, c1, ap));
@@ -915,14 +973,14 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
     auto rowptr = [&](int pass) {
         const int ql = pass * (QB / 16) + (tid >> 4);
         const uint64_t q = qb + ql < p.N ? qb + ql : p.N - 1;
-        return reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + q * FAST_D + 16 * t);
+        return reinterpret_cast<const uint2 *>(static_cast<const uint32_t *>(src) + q * FAST_D) + t;
     };
-    uint4 pre[2][4];
+    uint2 pre[2][8];
     if (SRC == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            pre[0][i] = rowptr(0)[i];
-            pre[1][i] = rowptr(1)[i];
+        for (int i = 0; i < 8; ++i) {
+            pre[0][i] = rowptr(0)[16 * i];
+            pre[1][i] = rowptr(1)[16 * i];
         }
     }
 
@@ -987,10 +1045,10 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
     // ---- phase B: 16 lanes per query, 16 queries per pass ----
     {
         double mu[16];
-        const double2 *mp = reinterpret_cast<const double2 *>(p.mu64 + 16 * t);
+        const double2 *mp = reinterpret_cast<const double2 *>(p.mu64) + t;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const double2 m2 = mp[i];
+            const double2 m2 = mp[16 * i];
             mu[2 * i] = m2.x;
             mu[2 * i + 1] = m2.y;
         }
@@ -1001,36 +1059,31 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
             double qd[16], Tq = 1.0, invT2 = 1.0;
             bool bad = false;
             if (SRC == 0) {
-                uint4 cur[4];
+                uint2 cur[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) cur[i] = pre[pass & 1][i];
+                for (int i = 0; i < 8; ++i) cur[i] = pre[pass & 1][i];
                 if (pass + 2 < 16) {
-                    const uint4 *nrow = rowptr(pass + 2);
+                    const uint2 *nrow = rowptr(pass + 2);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) pre[pass & 1][i] = nrow[i];
+                    for (int i = 0; i < 8; ++i) pre[pass & 1][i] = nrow[16 * i];
                 }
                 uint32_t sum = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint4 c = cur[i];
-                    sum += c.x + c.y + c.z + c.w;
-                    qd[4 * i + 0] = (double)c.x;
-                    qd[4 * i + 1] = (double)c.y;
-                    qd[4 * i + 2] = (double)c.z;
-                    qd[4 * i + 3] = (double)c.w;
+                for (int i = 0; i < 8; ++i) {
+                    const uint2 c = cur[i];
+                    sum += c.x + c.y;
+                    qd[2 * i + 0] = (double)c.x;
+                    qd[2 * i + 1] = (double)c.y;
                 }
-                sum += __shfl_xor(sum, 8);
-                sum += __shfl_xor(sum, 4);
-                sum += __shfl_xor(sum, 2);
-                sum += __shfl_xor(sum, 1);
+                sum = group16_sum(sum);
                 bad = sum == 0;
                 Tq = (double)sum;
                 invT2 = 1.0 / (Tq * Tq);
             } else {
-                const double2 *row = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D + 16 * t);
+                const double2 *row = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D) + t;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const double2 v2 = row[i];
+                    const double2 v2 = row[16 * i];
                     qd[2 * i] = v2.x;
                     qd[2 * i + 1] = v2.y;
                     bad |= v2.x != v2.x || v2.y != v2.y;
@@ -1049,8 +1102,8 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
             const double nq2 = group16_sum(aq) * invT2, nqp2 = group16_sum(ap) * invT2;
             double dp2 = 0.0, dn2 = 0.0;
             if (want_cen) {
-                dp2 = exact_d2_g16(qd, Tq, invT2, p.C64 + (uint64_t)s_ix[0][ql] * FAST_D, t);
-                dn2 = exact_d2_g16(qd, Tq, invT2, p.C64 + (p.n_cpos + (uint64_t)s_ix[1][ql]) * FAST_D, t);
+                exact_d2_pair_g16(qd, Tq, invT2, p.C64 + (uint64_t)s_ix[0][ql] * FAST_D,
+                                  p.C64 + (p.n_cpos + (uint64_t)s_ix[1][ql]) * FAST_D, t, dp2, dn2);
             }
             if (t == 0) {
                 s_T[ql] = bad ? 0.0 : Tq;   // 0 marks a NaN row
@@ -1128,7 +1181,7 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
 //     products, exact centroid distances), C one lane per query (margin tests, vote, metric).
 // ------------------------------------------------------------------------------------
 struct HiParams {
-    const _Float16 *lo16;     // [columns][256] low parts, row-major
+    const _Float16 *lo16;     // [columns][D] low parts (D = 256: in G16 order, see lo_pos() in score_f16.hip)
     double lam_tab[3][65];    // per segment
     double lam_r0[3], lam_inv_step[3];
 };
@@ -1139,177 +1192,237 @@ __device__ __forceinline__ double phk_lam_of(const HiParams &hp, int sg, double 
     return hp.lam_tab[sg][i];
 }
 
+template <bool KNN, bool CEN>
 __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__restrict__ counts, RerankParams p, HiParams hp) {
     __shared__ uint32_t s_c0[8][64];        // train-segment candidates by descending high-part value
     __shared__ uint32_t s_ix[2][64];        // centroid-segment leaders
-    __shared__ double s_corr[PHK_HI_REFINE][64];
+    __shared__ float s_corr[PHK_HI_REFINE][64];
+    // phase A's per-query results wait in LDS while phase B (the register-hungry part) runs
+    __shared__ float s_v8[8][64], s_u0[64], s_ch[4][64];
+    __shared__ double s_cn[5][64];
+    __shared__ uint32_t s_flags[64];
     __shared__ double s_T[64], s_nq2[64], s_nqp2[64], s_dp2[64], s_dn2[64];
+    __shared__ double s_mu[FAST_D];         // the training mean (LDS reads keep vmcnt for the row / column loads)
     const int tid = threadIdx.x, t = tid & 15;
     const uint64_t qb = (uint64_t)blockIdx.x * 64;
-    const bool want_knn = (p.method & PHK_METHOD_KNN) != 0, want_cen = (p.method & PHK_METHOD_KMEANS) != 0;
+    constexpr bool want_knn = KNN, want_cen = CEN;
+    // Every load of this kernel is issued in batches that do not depend on each other, with a scheduling barrier between
+    // a batch and its first use: left alone, the compiler trades loads in flight for registers and emits load, wait,
+    // use, load, wait, ... (24 exposed round trips in phase A and 16 per pass in phase B, by the ISA), and a load under
+    // a run-time condition makes every later wait conservative (vmcnt completes in order) -- hence the template
+    // parameters instead of `method` tests.
     auto rowptr = [&](int pass) {
         const int ql = pass * 4 + (tid >> 4);
         const uint64_t q = qb + ql < p.N ? qb + ql : p.N - 1;
-        return reinterpret_cast<const uint4 *>(counts + q * FAST_D + 16 * t);
+        return reinterpret_cast<const uint2 *>(counts + q * FAST_D) + t;
     };
-    uint4 pre[2][4];
+    uint2 cur[8];   // the count row of the pass at hand; the next one is requested a whole pass ahead
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        pre[0][i] = rowptr(0)[i];
-        pre[1][i] = rowptr(1)[i];
+    for (int i = 0; i < 8; ++i) cur[i] = rowptr(0)[16 * i];
+    {
+        const double2 m2a = reinterpret_cast<const double2 *>(p.mu64)[2 * tid], m2b = reinterpret_cast<const double2 *>(p.mu64)[2 * tid + 1];
+        reinterpret_cast<double2 *>(s_mu)[2 * tid] = m2a;
+        reinterpret_cast<double2 *>(s_mu)[2 * tid + 1] = m2b;
     }
 
     // ---- phase A: one lane per query ----
     const uint64_t qa = qb + tid;
     const bool in_a = qa < p.N;
     const uint64_t qc = in_a ? qa : p.N - 1;
-    // train segment: the 8 candidates sorted by high-part value (descending; empty / padding slots last)
     float v8[8];
     uint32_t i8[8];
     float U0 = 0.f;
     bool ok0 = true;          // the need-th list position holds a real column
-    if (want_knn) {
-        U0 = fmaxf(p.cand_u[candu_at(0, 0, qc, p.N)], p.cand_u[candu_at(0, 1, qc, p.N)]);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const uint32_t ix = p.cand_i[cand_at(0, c >> 2, c & 3, qc, p.N)];
-            const float w = p.cand_v[cand_at(0, c >> 2, c & 3, qc, p.N)];
-            v8[c] = ix >= (uint32_t)p.M ? -3.0e38f : w;
-            i8[c] = ix;
-        }
-#pragma unroll
-        for (int a = 1; a < 8; ++a)          // insertion sort network, fully unrolled (descending)
-#pragma unroll
-            for (int b = a; b > 0; --b) {
-                const bool sw = v8[b] > v8[b - 1];
-                const float tv = v8[b]; const uint32_t ti = i8[b];
-                v8[b] = sw ? v8[b - 1] : v8[b]; i8[b] = sw ? i8[b - 1] : i8[b];
-                v8[b - 1] = sw ? tv : v8[b - 1]; i8[b - 1] = sw ? ti : i8[b - 1];
-            }
-    }
-    // centroid segments: leader and runner-up by high-part value
     float ch1[2] = {0.f, 0.f}, ch2[2] = {0.f, 0.f};
     uint32_t cl[2] = {0u, 0u};
     bool cfill[2] = {true, true};
-    if (want_cen) {
+    {
+        float lv[NSEG][8], lu[2] = {0.f, 0.f};
+        uint32_t li[NSEG][8];
+        if (KNN) {
+            lu[0] = p.cand_u[candu_at(0, 0, qc, p.N)];
+            lu[1] = p.cand_u[candu_at(0, 1, qc, p.N)];
+        }
 #pragma unroll
-        for (int sg = 1; sg <= 2; ++sg) {
-            const uint32_t ncols = sg == 1 ? (uint32_t)p.n_cpos : (uint32_t)p.n_cneg;
-            float b1 = -3.0e38f, b2 = -3.0e38f;
-            uint32_t bi = 0xFFFFFFFFu;
+        for (int sg = 0; sg < NSEG; ++sg)
+            if (sg == 0 ? KNN : CEN) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    li[sg][c] = p.cand_i[cand_at(sg, c >> 2, c & 3, qc, p.N)];
+                    lv[sg][c] = p.cand_v[cand_at(sg, c >> 2, c & 3, qc, p.N)];
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        // train segment: the 8 candidates sorted by high-part value (descending; empty / padding slots last)
+        if (KNN) {
+            U0 = fmaxf(lu[0], lu[1]);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const uint32_t ix = p.cand_i[cand_at(sg, c >> 2, c & 3, qc, p.N)];
-                const float w = ix >= ncols ? -3.0e38f : p.cand_v[cand_at(sg, c >> 2, c & 3, qc, p.N)];
-                const bool up = w > b1;
-                b2 = up ? b1 : fmaxf(b2, w);
-                bi = up ? ix : bi;
-                b1 = up ? w : b1;
+                v8[c] = li[0][c] >= (uint32_t)p.M ? -3.0e38f : lv[0][c];
+                i8[c] = li[0][c];
             }
-            ch1[sg - 1] = b1; ch2[sg - 1] = b2; cl[sg - 1] = bi;
-            cfill[sg - 1] = bi < ncols;
+#pragma unroll
+            for (int a = 1; a < 8; ++a)          // insertion sort network, fully unrolled (descending)
+#pragma unroll
+                for (int b = a; b > 0; --b) {
+                    const bool sw = v8[b] > v8[b - 1];
+                    const float tv = v8[b]; const uint32_t ti = i8[b];
+                    v8[b] = sw ? v8[b - 1] : v8[b]; i8[b] = sw ? i8[b - 1] : i8[b];
+                    v8[b - 1] = sw ? tv : v8[b - 1]; i8[b - 1] = sw ? ti : i8[b - 1];
+                }
+        }
+        // centroid segments: leader and runner-up by high-part value
+        if (CEN) {
+#pragma unroll
+            for (int sg = 1; sg <= 2; ++sg) {
+                const uint32_t ncols = sg == 1 ? (uint32_t)p.n_cpos : (uint32_t)p.n_cneg;
+                float b1 = -3.0e38f, b2 = -3.0e38f;
+                uint32_t bi = 0xFFFFFFFFu;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t ix = li[sg][c];
+                    const float w = ix >= ncols ? -3.0e38f : lv[sg][c];
+                    const bool up = w > b1;
+                    b2 = up ? b1 : fmaxf(b2, w);
+                    bi = up ? ix : bi;
+                    b1 = up ? w : b1;
+                }
+                ch1[sg - 1] = b1; ch2[sg - 1] = b2; cl[sg - 1] = bi;
+                cfill[sg - 1] = bi < ncols;
+            }
         }
     }
-    s_ix[0][tid] = cl[0] < (uint32_t)p.n_cpos ? cl[0] : 0u;
-    s_ix[1][tid] = cl[1] < (uint32_t)p.n_cneg ? cl[1] : 0u;
-    // speculative gathers, consumed in phase C
-    double cn0[3];
-    uint32_t labbits = 0;
+    const uint32_t ixp = cl[0] < (uint32_t)p.n_cpos ? cl[0] : 0u, ixn = cl[1] < (uint32_t)p.n_cneg ? cl[1] : 0u;
+    s_ix[0][tid] = ixp;
+    s_ix[1][tid] = ixn;
+    {
+        // gathers consumed in phase C: one batch
+        double cn0[3];
+        uint8_t lab[8];
+        uint32_t c8[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const uint32_t c = (want_knn && i8[r] < (uint32_t)p.M) ? i8[r] : 0u;
-        if (r < 3) cn0[r] = p.colnorm[c];
-        labbits |= (uint32_t)(p.labels[c] ? 1u : 0u) << r;
-        s_c0[r][tid] = c;
+        for (int r = 0; r < 8; ++r) c8[r] = (KNN && i8[r] < (uint32_t)p.M) ? i8[r] : 0u;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r < 3) cn0[r] = p.colnorm[c8[r]];
+            lab[r] = p.labels[c8[r]];
+        }
+        const double cnp = p.colnorm[p.M + ixp], cnn = p.colnorm[p.M + p.n_cpos + ixn];
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t labbits = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            labbits |= (uint32_t)(lab[r] ? 1u : 0u) << r;
+            s_c0[r][tid] = c8[r];
+            s_v8[r][tid] = (KNN && i8[r] < (uint32_t)p.M) ? v8[r] : -3.0e38f;
+        }
+        if (KNN) ok0 = i8[p.kn - 1] < (uint32_t)p.M;
+        s_u0[tid] = U0;
+        s_ch[0][tid] = ch1[0]; s_ch[1][tid] = ch2[0]; s_ch[2][tid] = ch1[1]; s_ch[3][tid] = ch2[1];
+        s_cn[0][tid] = cn0[0]; s_cn[1][tid] = cn0[1]; s_cn[2][tid] = cn0[2]; s_cn[3][tid] = cnp; s_cn[4][tid] = cnn;
+        s_flags[tid] = labbits | (ok0 ? 0x100u : 0u) | (cfill[0] ? 0x200u : 0u) | (cfill[1] ? 0x400u : 0u);
     }
-    const double cnp = p.colnorm[p.M + s_ix[0][tid]], cnn = p.colnorm[p.M + p.n_cpos + s_ix[1][tid]];
-    if (want_knn) ok0 = i8[p.kn - 1] < (uint32_t)p.M;
     __syncthreads();
 
     // ---- phase B: 16 lanes per query, 4 queries per pass ----
-    {
-        double mu[16];
-        const double2 *mp = reinterpret_cast<const double2 *>(p.mu64 + 16 * t);
+    // A pass issues all its column loads -- the two centroid rows (float64) and the low parts of the first
+    // PHK_HI_REFINE train candidates, whose addresses depend on the lists only -- and, youngest, the count row of the
+    // NEXT pass; then it reduces its own row (in registers since the pass before).  One exposed L2 round trip per pass,
+    // and no wait ever covers the count row's HBM miss.  The low products are fetched for all PHK_HI_REFINE candidates
+    // (a window-sized fetch, tried, has to wait for the row first and cost 60 % more time); phase C, which knows the
+    // window, only uses the members.
+#pragma unroll 2
+    for (int pass = 0; pass < 16; ++pass) {
+        const int ql = pass * 4 + (tid >> 4);
+        double2 ca[8], cb[8];
+        uint4 l0[PHK_HI_REFINE], l1[PHK_HI_REFINE];
+        uint2 nxt[8];
+        if (CEN) {
+            const double2 *ra = reinterpret_cast<const double2 *>(p.C64 + (uint64_t)s_ix[0][ql] * FAST_D) + t;
+            const double2 *rb = reinterpret_cast<const double2 *>(p.C64 + (p.n_cpos + (uint64_t)s_ix[1][ql]) * FAST_D) + t;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                ca[i] = ra[16 * i];
+                cb[i] = rb[16 * i];
+            }
+        }
+        if (KNN) {
+#pragma unroll
+            for (int r = 0; r < PHK_HI_REFINE; ++r) {
+                const uint4 *lp = reinterpret_cast<const uint4 *>(hp.lo16 + (uint64_t)s_c0[r][ql] * FAST_D) + t;   // G16-ordered rows
+                l0[r] = lp[0];
+                l1[r] = lp[16];
+            }
+        }
+        {
+            const uint2 *nrow = rowptr((pass + 1) & 15);   // (the last pass re-reads row 0: a load under a condition would
+#pragma unroll                                             //  make the waits below conservative)
+            for (int i = 0; i < 8; ++i) nxt[i] = nrow[16 * i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double qd[16];
+        uint32_t sum = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const double2 m2 = mp[i];
-            mu[2 * i] = m2.x;
-            mu[2 * i + 1] = m2.y;
+            const uint2 c = cur[i];
+            sum += c.x + c.y;
+            qd[2 * i + 0] = (double)c.x;
+            qd[2 * i + 1] = (double)c.y;
         }
-#pragma unroll 2
-        for (int pass = 0; pass < 16; ++pass) {
-            const int ql = pass * 4 + (tid >> 4);
-            double qd[16];
-            uint4 cur[4];
+        sum = group16_sum(sum);
+        const bool bad = sum == 0;
+        const double Tq = (double)sum, invT2 = 1.0 / (Tq * Tq);
+        double dp2 = 0.0, dn2 = 0.0;
+        if (CEN) {   // exact float64 distances to the two leading centroids (as exact_d2_g16)
+            double acca = 0.0, accb = 0.0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cur[i] = pre[pass & 1][i];
-            if (pass + 2 < 16) {
-                const uint4 *nrow = rowptr(pass + 2);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) pre[pass & 1][i] = nrow[i];
+            for (int i = 0; i < 8; ++i) {
+                const double a0 = fma(-Tq, ca[i].x, qd[2 * i]), a1 = fma(-Tq, ca[i].y, qd[2 * i + 1]);
+                const double b0 = fma(-Tq, cb[i].x, qd[2 * i]), b1 = fma(-Tq, cb[i].y, qd[2 * i + 1]);
+                acca = fma(a0, a0, fma(a1, a1, acca));
+                accb = fma(b0, b0, fma(b1, b1, accb));
             }
-            uint32_t sum = 0;
+            dp2 = group16_sum(acca) * invT2;
+            dn2 = group16_sum(accb) * invT2;
+        }
+        double aq = 0.0, ap = 0.0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const uint4 c = cur[i];
-                sum += c.x + c.y + c.z + c.w;
-                qd[4 * i + 0] = (double)c.x;
-                qd[4 * i + 1] = (double)c.y;
-                qd[4 * i + 2] = (double)c.z;
-                qd[4 * i + 3] = (double)c.w;
-            }
-            sum += __shfl_xor(sum, 8);
-            sum += __shfl_xor(sum, 4);
-            sum += __shfl_xor(sum, 2);
-            sum += __shfl_xor(sum, 1);
-            const bool bad = sum == 0;
-            const double Tq = (double)sum, invT2 = 1.0 / (Tq * Tq);
-            double dp2 = 0.0, dn2 = 0.0;
-            if (want_cen) {
-                dp2 = exact_d2_g16(qd, Tq, invT2, p.C64 + (uint64_t)s_ix[0][ql] * FAST_D, t);
-                dn2 = exact_d2_g16(qd, Tq, invT2, p.C64 + (p.n_cpos + (uint64_t)s_ix[1][ql]) * FAST_D, t);
-            }
-            double aq = 0.0, ap = 0.0;
+        for (int i = 0; i < 8; ++i) {   // qd becomes c - T mu (the centred counts) in place
+            const double2 m2 = reinterpret_cast<const double2 *>(s_mu)[16 * i + t];
+            aq = fma(qd[2 * i], qd[2 * i], fma(qd[2 * i + 1], qd[2 * i + 1], aq));
+            qd[2 * i] = fma(-Tq, m2.x, qd[2 * i]);
+            qd[2 * i + 1] = fma(-Tq, m2.y, qd[2 * i + 1]);
+            ap = fma(qd[2 * i], qd[2 * i], fma(qd[2 * i + 1], qd[2 * i + 1], ap));
+        }
+        const double nq2 = group16_sum(aq) * invT2, nqp2 = group16_sum(ap) * invT2;
+        if (KNN) {
+            // float32 products (v_fma_mix takes the half operand as it is): 16 + 4 roundings per sum, bounded in
+            // phase C by 2^-19 |q'| lam* -- 1e-6 of the low product's own bound
+            float qf[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {   // qd becomes c - T mu (the centred counts) in place
-                aq = fma(qd[i], qd[i], aq);
-                qd[i] = fma(-Tq, mu[i], qd[i]);
-                ap = fma(qd[i], qd[i], ap);
-            }
-            const double nq2 = group16_sum(aq) * invT2, nqp2 = group16_sum(ap) * invT2;
-            // low products of the train segment's first PHK_HI_REFINE candidates (descending high-part value), fetched
-            // unconditionally: their addresses depend on the lists only, so the loads are in flight while the row is still
-            // being reduced (a window-sized fetch, tried, made them wait for the row and cost 60 % more time); phase C,
-            // which knows the window, only uses the members
-            if (want_knn) {
-                uint4 l0[PHK_HI_REFINE], l1[PHK_HI_REFINE];
+            for (int i = 0; i < 16; ++i) qf[i] = (float)qd[i];
 #pragma unroll
-                for (int r = 0; r < PHK_HI_REFINE; ++r) {
-                    const uint4 *lp = reinterpret_cast<const uint4 *>(hp.lo16 + (uint64_t)s_c0[r][ql] * FAST_D + 16 * t);
-                    l0[r] = lp[0];
-                    l1[r] = lp[1];
+            for (int r = 0; r < PHK_HI_REFINE; ++r) {
+                const _Float16 *lh0 = reinterpret_cast<const _Float16 *>(&l0[r]), *lh1 = reinterpret_cast<const _Float16 *>(&l1[r]);
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc = fmaf(qf[i], (float)lh0[i], acc);
+                    acc = fmaf(qf[8 + i], (float)lh1[i], acc);
                 }
-#pragma unroll
-                for (int r = 0; r < PHK_HI_REFINE; ++r) {
-                    const _Float16 *lh0 = reinterpret_cast<const _Float16 *>(&l0[r]), *lh1 = reinterpret_cast<const _Float16 *>(&l1[r]);
-                    double acc = 0.0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        acc = fma(qd[i], (double)lh0[i], acc);
-                        acc = fma(qd[8 + i], (double)lh1[i], acc);
-                    }
-                    acc = group16_sum(acc);
-                    if (t == 0) s_corr[r][ql] = acc;
-                }
-            }
-            if (t == 0) {
-                s_T[ql] = bad ? 0.0 : Tq;   // 0 marks a NaN row
-                s_nq2[ql] = nq2;
-                s_nqp2[ql] = nqp2;
-                s_dp2[ql] = dp2;
-                s_dn2[ql] = dn2;
+                acc = group16_sum(acc);
+                if (t == 0) s_corr[r][ql] = acc;
             }
         }
+        if (t == 0) {
+            s_T[ql] = bad ? 0.0 : Tq;   // 0 marks a NaN row
+            s_nq2[ql] = nq2;
+            s_nqp2[ql] = nqp2;
+            s_dp2[ql] = dp2;
+            s_dn2[ql] = dn2;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
     }
     __syncthreads();
 
@@ -1323,6 +1436,21 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
     }
     const double nq2 = s_nq2[tid], nqp2 = s_nqp2[tid];
     const double vs = p.vscale / Tq;
+    double cn0[3];
+    uint32_t labbits;
+    {   // phase A's results back from LDS
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v8[r] = s_v8[r][tid];
+        U0 = s_u0[tid];
+        ch1[0] = s_ch[0][tid]; ch2[0] = s_ch[1][tid]; ch1[1] = s_ch[2][tid]; ch2[1] = s_ch[3][tid];
+        cn0[0] = s_cn[0][tid]; cn0[1] = s_cn[1][tid]; cn0[2] = s_cn[2][tid];
+        const uint32_t fl = s_flags[tid];
+        labbits = fl & 0xFFu;
+        ok0 = (fl & 0x100u) != 0;
+        cfill[0] = (fl & 0x200u) != 0;
+        cfill[1] = (fl & 0x400u) != 0;
+    }
+    const double cnp2 = s_cn[3][tid], cnn2 = s_cn[4][tid];
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
@@ -1344,12 +1472,14 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
             const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
             bool near = true;
             for (int r = 0; r < need; ++r) near = near && cn0[r] <= R0;
-            const double eh = near ? e_hi(0, R0) : eg, e22 = near ? eb(R0) : eb(p.rmax);
+            const double Rw = near ? R0 : p.rmax;
+            // count-exact error model + the float32 rounding of the low products (22 roundings x 2^-24 < 2^-19)
+            const double eh = near ? e_hi(0, R0) : eg, e22 = eb(Rw) + 0x1p-19 * nqp * phk_lam_of(hp, 0, Rw);
             // window members: list positions 0 .. nw-1 (sorted by high-part value)
             const double thr = (double)v8[need - 1] * vs - 2.0 * eh;
             int nw = 0;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) nw += ((double)v8[r] * vs >= thr && i8[r] < (uint32_t)p.M) ? 1 : 0;
+            for (int r = 0; r < 8; ++r) nw += ((double)v8[r] * vs >= thr && v8[r] > -1.0e38f) ? 1 : 0;
             // every column of the window has to be a list member with a refined value
             cert = nw <= PHK_HI_REFINE && (double)U0 * vs < thr;
             if (!cert) atomicAdd(p.counters + (nw > PHK_HI_REFINE ? 8 : 9), 1u);   // diagnostics: window too wide / reaches past the lists
@@ -1360,7 +1490,7 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
 #pragma unroll
                 for (int r = 0; r < PHK_HI_REFINE; ++r) {
                     const bool in = r < nw;
-                    rv[r] = in ? ((double)v8[r] + s_corr[r][tid]) * vs : -1.0e300;
+                    rv[r] = in ? ((double)v8[r] + (double)s_corr[r][tid]) * vs : -1.0e300;
                     rl[r] = (labbits >> r) & 1u;
                 }
 #pragma unroll
@@ -1392,7 +1522,7 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
             const double eh = cnorm <= R0 ? e_hi(1 + k2, R0) : eg;
             return ((double)ch1[k2] - (double)ch2[k2]) * vs > 2.0 * eh;
         };
-        cert_c = leader_ok(0, cnp) && leader_ok(1, cnn);
+        cert_c = leader_ok(0, cnp2) && leader_ok(1, cnn2);
         if (!cert_c) atomicAdd(p.counters + 11, 1u);   // diagnostics: centroid leader not certified
         const double ep = sqrt(s_dp2[tid]), en = sqrt(s_dn2[tid]);
         cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
@@ -1433,8 +1563,7 @@ __global__ __launch_bounds__(256) void phk_rerank_h_kernel(const uint32_t *__res
         c[sub] = reinterpret_cast<const uint4 *>(row + 256 * sub)[lane];
         s += c[sub].x + c[sub].y + c[sub].z + c[sub].w;
     }
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+    s = wave_sum(s);
     if (s == 0) {  // zero-count contig: the reference's normalised row is NaN
         if (lane == 0) {
             p.scores[p.q_base + q] = __builtin_nan("");
@@ -1627,8 +1756,7 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
             const uint32_t *row = static_cast<const uint32_t *>(src) + q * D;
             uint32_t s = 0;
             for (uint64_t d = lane; d < D; d += 64) s += row[d];  // every wave sums the whole row
-#pragma unroll
-            for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+            s = wave_sum(s);
             for (uint64_t d = threadIdx.x; d < D; d += 256) fb_q[d] = (double)row[d] / (double)s;
         } else {
             for (uint64_t d = threadIdx.x; d < D; d += 256) fb_q[d] = static_cast<const double *>(src)[q * D + d];
@@ -1648,10 +1776,7 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
                 acc = fma(d0, d0, acc);
                 acc = fma(d1, d1, acc);
             }
-            acc += __shfl_xor(acc, 8);
-            acc += __shfl_xor(acc, 4);
-            acc += __shfl_xor(acc, 2);
-            acc += __shfl_xor(acc, 1);
+            acc = group16_sum(acc);
             if (t16 == 0 && c < c1) fb_dist[c - c0] = (p.col_mask && c < p.M && p.col_mask[c]) ? INFINITY : acc;
         }
         __syncthreads();
@@ -1912,8 +2037,15 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
                 hp.lam_r0[sg] = m->lam_r0[sg];
                 hp.lam_inv_step[sg] = 1.0 / m->lam_step[sg];
             }
-            PHK_LAUNCH(ctx, "phk_decide_h_kernel",
-                       phk_decide_h_kernel<<<dim3((unsigned)phk_div_up(nb, 64)), dim3(64), 0, ctx->stream>>>((const uint32_t *)src, p, hp));
+            const dim3 dg((unsigned)phk_div_up(nb, 64)), db(64);
+            const bool d_knn = (p.method & PHK_METHOD_KNN) != 0, d_cen = (p.method & PHK_METHOD_KMEANS) != 0;
+            if (d_knn && d_cen) {
+                PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<true, true><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, p, hp)));
+            } else if (d_knn) {
+                PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<true, false><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, p, hp)));
+            } else {
+                PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<false, true><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, p, hp)));
+            }
             // what it passes on is decided from the same lists by exact candidate distances where possible.  For that
             // kernel the lists' error model is the count-exact one plus the missing low product, |q'| |lo_j| / S with
             // |lo_j| <= 2^-11 (1 + 2^-11) S |r'_j| + sqrt(D) 2^-25 (half an ulp of the high part per element; the
