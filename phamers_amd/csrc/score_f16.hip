@@ -811,7 +811,7 @@ __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn
 // count-exact kernel; with one MFMA per value the loop is bound by the VALU issue of the insertions (~7 per value).
 // ====================================================================================
 template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn_f16h_kernel(
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rowsum, uint64_t N, const uint4 *__restrict__ Af,
     uint32_t nblk_ref, uint32_t nblk_pos, uint32_t nblk_neg, float *__restrict__ cand_v, uint32_t *__restrict__ cand_i,
     float *__restrict__ cand_u) {
@@ -1067,10 +1067,20 @@ int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu) {
     const size_t lds = 2 * F16H_BLOCK_BYTES;
     const uint4 *af = (const uint4 *)m->d_Af16h + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16H_BLOCK_BYTES / 16);
-    const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * 8 * 2);
-    PHK_LAUNCH(ctx, "phk_knn_f16h_kernel",
-               (phk_knn_f16h_kernel<2, 8><<<dim3(gblocks), dim3(64 * 8), lds, ctx->stream>>>(
-                   d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu)));
+    // Two 4-wave workgroups per CU (default, "24") or one 8-wave workgroup ("28"): with two workgroups the two waves of a
+    // SIMD share no barrier, and the one that lost the issue arbitration does not hold the other up at every block
+    // (2.44 vs 2.62 ms on configs[1]; one wave per SIMD with 3 or 4 tiles, tried through AGPRs, ran 2.9 / 3.3 ms, and
+    // 2-wave workgroups quadruple the L2 -> LDS record traffic: 13.6 ms).
+    const char *e = ctx->knobs.cx_cfg;
+    if (e[0] == '2' && e[1] == '8') {
+        PHK_LAUNCH(ctx, "phk_knn_f16h_kernel",
+                   (phk_knn_f16h_kernel<2, 8><<<dim3((unsigned)phk_div_up(nb, 32 * 8 * 2)), dim3(64 * 8), lds, ctx->stream>>>(
+                       d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu)));
+    } else {
+        PHK_LAUNCH(ctx, "phk_knn_f16h_kernel",
+                   (phk_knn_f16h_kernel<2, 4><<<dim3((unsigned)phk_div_up(nb, 32 * 4 * 2)), dim3(64 * 4), lds, ctx->stream>>>(
+                       d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu)));
+    }
     return PHK_OK;
 }
 
@@ -1392,6 +1402,7 @@ int phk_score_f16_init_device(phk_ctx *ctx) {
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16h_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F16H_BLOCK_BYTES));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16h_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F16H_BLOCK_BYTES));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));

@@ -40,7 +40,9 @@
 #include "score_lists.h"
 
 #define NG 33          // 32 k-groups + the norm group
-#define PHK_HI_REFINE 6 // candidates per query whose low product the high-parts-only decision stage evaluates
+#ifndef PHK_HI_REFINE
+#define PHK_HI_REFINE 6  // candidates per query whose low product the high-parts-only decision stage evaluates
+#endif
 #define FB_CHUNKS 16   // column chunks per queued query in the exact brute-force fallback
 #define FB_LDS_MAX (160u * 1024u - 1024u)   // its dynamic LDS: one chunk of distances + the query, float64
 
@@ -693,6 +695,11 @@ __device__ __forceinline__ void exact_d2_pair_g16(const double (&qd)[16], double
 }
 
 // per-group version of resolve_segment; `live` = this group still needs an answer.  Returns ok.
+// element i of a small register array, by selects: a run-time index into a local array sends it to scratch memory
+template <typename T>
+__device__ __forceinline__ T pick4(const T (&a)[4], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : i == 2 ? a[2] : a[3]; }
+template <typename T>
+__device__ __forceinline__ T pick3(const T (&a)[3], int i) { return i == 0 ? a[0] : i == 1 ? a[1] : a[2]; }
 __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
                                     const double (&qd)[16], double Tq, double invT2, double nqp2, const ErrBound &eb,
                                     const double vs, const double *rows, const double *colnorm, bool want_d2, bool live,
@@ -734,8 +741,8 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
     const double eps_g = eb(p.rmax);
     double eps_w = eps_g;   // the bound the window of the exact route uses (the margin test's)
     bool certified = false;
-    if (ri[need - 1] < ncols) {
-        const double d2up = fmax(nqp2 - 2.0 * ((double)rv[need - 1] * vs - eps_g), 0.0);
+    if (pick4(ri, need - 1) < ncols) {
+        const double d2up = fmax(nqp2 - 2.0 * ((double)pick4(rv, need - 1) * vs - eps_g), 0.0);
         const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
         double cnr[3] = {0.0, 0.0, 0.0};  // independent loads (no short-circuit chain of round trips)
 #pragma unroll
@@ -746,7 +753,7 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
         for (int r = 0; r < 3; ++r) near = near && (r >= need || cnr[r] <= R0);
         const double eps_m = near ? eb(R0) : eps_g;
         eps_w = eps_m;
-        certified = ((double)rv[need - 1] - (double)rv[need]) * vs > 2.0 * eps_m;
+        certified = ((double)pick4(rv, need - 1) - (double)pick4(rv, need)) * vs > 2.0 * eps_m;
     }
     bool ok = certified;
     double best[3] = {INFINITY, INFINITY, INFINITY};
@@ -757,8 +764,8 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
         // only candidates inside the window can be among the `need` nearest: one whose computed value lies more than
         // 2 eps below the need-th best has a true value below the true need-th best (same argument as the margin test).
         // The lists are sorted within each half, so the late slots are skipped by whole waves most of the time.
-        const double wthr = (double)rv[need - 1] * vs - 2.0 * eps_w;
-#pragma unroll 1
+        const double wthr = (double)pick4(rv, need - 1) * vs - 2.0 * eps_w;
+#pragma unroll   // (fully: cix[m] / cvv[m] under a run-time m would live in scratch memory)
         for (int m = 0; m < 8; ++m) {
             const uint32_t c = cix[m];
             const bool valid = need_exact && c < ncols && (double)cvv[m] * vs >= wthr;
@@ -778,9 +785,10 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
         }
         if (need_exact) {
             ok = false;
-            if (bidx[need - 1] != 0xFFFFFFFFu) {
-                const double R0x = fmin(p.rmax, (nqp + sqrt(best[need - 1])) * (1.0 + 1e-6));
-                const double tv = 0.5 * (nqp2 - best[need - 1]);
+            if (pick3(bidx, need - 1) != 0xFFFFFFFFu) {
+                const double bneed = pick3(best, need - 1);
+                const double R0x = fmin(p.rmax, (nqp + sqrt(bneed)) * (1.0 + 1e-6));
+                const double tv = 0.5 * (nqp2 - bneed);
                 ok = tv > U + eb(R0x);
             }
         }
@@ -803,7 +811,7 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
 // MODE 0: every query of the batch; 1: the queries phk_decide_kernel handed over (slow_list); 2: second chance -- rows
 // map[0 .. *map_count) with their lists at dense positions (see RerankParams)
 template <int SRC, int MODE>
-__global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restrict__ src, RerankParams p) {
+__global__ __launch_bounds__(256, 4) void phk_rerank16_kernel(const void *__restrict__ src, RerankParams p) {
     const int lane = threadIdx.x & 63, t = lane & 15;
     uint64_t qraw = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
     bool inrange;
@@ -915,7 +923,8 @@ __global__ __launch_bounds__(256) void phk_rerank16_kernel(const void *__restric
         const bool okk = resolve_segment_g16(p, q, 0, (uint32_t)p.M, p.kn, qd, Tq, invT2, nqp2, eb, vs, p.R64, p.colnorm, false,
                                              live && do_knn, lane, lv[0], lix[0], lu[0], idx, d2);
         int votes = 0;
-        for (int r = 0; r < p.kn; ++r) votes += (idx[r] < p.M && p.labels[idx[r]]) ? 1 : 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) votes += (r < p.kn && idx[r] < p.M && p.labels[idx[r] < p.M ? idx[r] : 0u]) ? 1 : 0;
         knn = do_knn ? ((2 * votes > p.kn) ? 1.0 : -1.0) : 0.0;
         ok = okk || !do_knn;
     }
@@ -1482,7 +1491,10 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
             for (int r = 0; r < 8; ++r) nw += ((double)v8[r] * vs >= thr && v8[r] > -1.0e38f) ? 1 : 0;
             // every column of the window has to be a list member with a refined value
             cert = nw <= PHK_HI_REFINE && (double)U0 * vs < thr;
-            if (!cert) atomicAdd(p.counters + (nw > PHK_HI_REFINE ? 8 : 9), 1u);   // diagnostics: window too wide / reaches past the lists
+            // diagnostics: window too wide / reaches past the lists (one uniform address per statement, so that the
+            // compiler folds a wave's increments into one atomic; a per-lane address costs ~10 ns per lane)
+            if (!cert && nw > PHK_HI_REFINE) atomicAdd(p.counters + 8, 1u);
+            if (!cert && nw <= PHK_HI_REFINE) atomicAdd(p.counters + 9, 1u);
             if (cert) {
                 // refined values of the window's members, descending
                 double rv[PHK_HI_REFINE];

@@ -25,5 +25,5 @@ lib.phk_dbg_read(buf)
 step(); torch.cuda.synchronize()
 lib.phk_dbg_read(buf)
 w = buf[6]
-names = ["phaseA", "phaseB", "B.row_wait+sum", "B.centroid", "B.lo", "phaseC", "waves", "B.centre"]
+names = ["phaseA", "phaseB", "B.row_wait+sum", "B.centroid", "B.lo", "phaseC", "waves", "B.centre", "B.issue"]
 for i, nm in enumerate(names): print(f"{nm:18s} {buf[i]/w:10.0f} cycles/wave")
