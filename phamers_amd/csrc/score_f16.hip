@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     // sized for N, so workgroups wholly past the device-side count leave at once (before any DMA / barrier)
     const uint64_t Nlist = N;
     if (qmap) {
-        const uint64_t cnt = *qcount;
+        const uint64_t cnt = phk_uniform_load(qcount);
         N = cnt < PHK_SECOND_MIN ? 0 : (cnt < N ? cnt : N);   // a handful of rows: left to the brute force
         if ((uint64_t)blockIdx.x * F16_WAVES * 32 >= N) return;
     }

@@ -10,6 +10,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define NSEG 3         // train rows, positive centroids, negative centroids
 #define PAD_V (-1.0e30f)
 
+// A word every wave of a (large) grid reads -- a device-side list length written by the kernel before -- through the
+// scalar cache.  As a vector load it is one and the same L2 line requested by every wave of the grid: with 250 k waves
+// that line's channel became a queue every other load of the kernel stood in (40 k cycles for the first two loads of
+// phk_rerank16_kernel, by its phase timers; profiles/r02/README.md).  The pointer must be wave-uniform.
+__device__ __forceinline__ uint32_t phk_uniform_load(const uint32_t *p) {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
+
 // Candidate lists of a batch of N queries, structure of arrays (a wave of the proposal kernels writes, and
 // a lane-per-query reader reads, consecutive queries at consecutive addresses):
 //   value / column index of slot c of half-list h of segment seg of query q : [((seg*2 + h)*CAND + c) * N + q]

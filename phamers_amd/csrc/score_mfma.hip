@@ -351,7 +351,7 @@ struct RerankParams {
     const uint32_t *map = nullptr;
     const uint32_t *map_count = nullptr;
     uint32_t *counters = nullptr;           // the batch's counter words (see phk_score_fast)
-    int slow_back = 0;                      // phk_rerank16_kernel MODE 1: 0 = slow_list[0 ..) counted by fb_count[2],
+    int slow_back = 0;                      // phk_rerank16_kernel MODE 1: 3 = both of the following in one launch; 0 = slow_list[0 ..) counted by fb_count[2],
                                             // 1 = the list that grows down from slow_list[slow_cap - 1], counted by counters[12]
     uint64_t slow_cap = 0;
     uint32_t *stat_total = nullptr;         // [0] += fallback queue length, [1] += orderings decided by exact distances
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
     const int lane = threadIdx.x & 63;
     uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (p.slow_back == 2) {   // listed: only the queries phk_rerank_h_kernel passed on (slow_list, fb_count[2] of them)
-        if (q >= p.fb_count[2]) return;
+        if (q >= phk_uniform_load(p.fb_count + 2)) return;
         q = p.slow_list[q] & 0x3FFFFFFFu;
     } else if (q >= p.N) {
         return;
@@ -818,17 +818,28 @@ __global__ __launch_bounds__(256, 4) void phk_rerank16_kernel(const void *__rest
     uint64_t q, ql;   // the query's row in src / scores; the position of its candidate lists
     uint32_t todo = 3u;
     if (MODE == 1) {
-        const uint64_t cnt = p.slow_back ? p.counters[12] : p.fb_count[2];
+        // slow_back == 3: both lists in one launch -- waves from the front of the grid take the front list (counted by
+        // fb_count[2]), waves from its end the back list (counters[12]); front + back <= N, so the two never meet, and a
+        // wave serves one kind of list.  (Two launches, each over the whole grid, spent 0.09 ms apiece on waves that
+        // read a count and left.)
+        uint64_t cnt = phk_uniform_load(p.slow_back == 1 ? p.counters + 12 : p.fb_count + 2);
+        bool back = p.slow_back == 1;
+        if (p.slow_back == 3 && (qraw & ~3ull) >= cnt) {
+            const uint64_t nwave4 = (((uint64_t)gridDim.x * blockDim.x) >> 6) * 4;
+            qraw = nwave4 - 4 - (qraw & ~3ull) + (qraw & 3ull);   // wave k from the end, same lane group
+            cnt = phk_uniform_load(p.counters + 12);
+            back = true;
+        }
         if ((qraw & ~3ull) >= cnt) return;
         inrange = qraw < cnt;
         // entry = query | todo << 30: which parts are still open (bit 0 the k-NN vote, bit 1 the centroid metric; 0 = both).
         // A part the sender has decided already sits in scores[q] and is only added to.
         const uint64_t pos = inrange ? qraw : cnt - 1;
-        const uint32_t entry = p.slow_list[p.slow_back ? p.slow_cap - 1 - pos : pos];
+        const uint32_t entry = p.slow_list[back ? p.slow_cap - 1 - pos : pos];
         q = ql = entry & 0x3FFFFFFFu;
         todo = entry >> 30 ? entry >> 30 : 3u;
     } else if (MODE == 2) {
-        const uint64_t cnt_all = *p.map_count;
+        const uint64_t cnt_all = phk_uniform_load(p.map_count);
         // a handful of rows is cheaper to brute-force than to sweep (one workgroup's sweep is ~0.2 ms of latency):
         // the second proposal pass stands down below PHK_SECOND_MIN rows (score_model.h) and so does this kernel
         const uint64_t cnt = cnt_all < PHK_SECOND_MIN ? 0 : (cnt_all < p.N ? cnt_all : p.N);
@@ -1754,7 +1765,7 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
     const uint64_t D = p.D;
     double *fb_q = fb_lds, *fb_dist = fb_lds + D;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t count = *p.fb_count;
+    const uint32_t count = phk_uniform_load(p.fb_count);
     const uint64_t ncols = p.M + p.n_cpos + p.n_cneg;
     const uint64_t cw = (ncols + FB_CHUNKS - 1) / FB_CHUNKS;
     FbRecord *rec = static_cast<FbRecord *>(p.fb_rec);
@@ -2065,11 +2076,9 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             RerankParams ph = p;
             ph.eb_cP += 8192.0 * (1.0 + 1.0 / 2048.0) + 1.0;
             ph.eb_abs *= 2.0;
+            ph.slow_back = 3;   // front and back list in one launch
             PHK_LAUNCH(ctx, "phk_rerank16_kernel",
-                       (phk_rerank16_kernel<0, 1><<<dim3((unsigned)phk_div_up(nb, 16)), dim3(256), 0, ctx->stream>>>(src, ph)));
-            ph.slow_back = 1;
-            PHK_LAUNCH(ctx, "phk_rerank16_kernel",
-                       (phk_rerank16_kernel<0, 1><<<dim3((unsigned)phk_div_up(nb, 16)), dim3(256), 0, ctx->stream>>>(src, ph)));
+                       (phk_rerank16_kernel<0, 1><<<dim3((unsigned)phk_div_up(nb, 16) + 1), dim3(256), 0, ctx->stream>>>(src, ph)));
         } else if (hi_gen) {
             HiParams hp;
             hp.lo16 = m->d_lo16;
