@@ -333,7 +333,8 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
                                                              uint32_t *__restrict__ cand_i,
                                                              float *__restrict__ cand_u,
                                                              const uint32_t *__restrict__ qmap,
-                                                             const uint32_t *__restrict__ qcount) {
+                                                             const uint32_t *__restrict__ qcount,
+                                                             uint64_t set_bytes) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x F16_BLOCK_BYTES
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -351,6 +352,22 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     // NB: every wave of the workgroup takes part in the DMA + barriers even if its queries are padding
     const uint64_t qpos = (q0 + j < N) ? q0 + j : N - 1;
     const uint64_t qrow = qmap ? (uint64_t)qmap[qpos] : qpos;
+    // Column split (gridDim.y > 1; the second-chance launches, whose few thousand queries fill a fraction of the chip):
+    // workgroup row y sweeps the y-th part of the train blocks -- the last one the centroid blocks as well, which follow
+    // the train blocks in the record array -- and writes list set y (set_bytes apart); phk_merge_list_sets_kernel folds
+    // the sets into set 0.
+    uint32_t col0 = 0;
+    if (gridDim.y > 1) {
+        const uint32_t S = gridDim.y, y = blockIdx.y;
+        const uint32_t b0 = (uint32_t)((uint64_t)nblk_ref * y / S), b1 = (uint32_t)((uint64_t)nblk_ref * (y + 1) / S);
+        Af += (uint64_t)b0 * (F16_BLOCK_BYTES / 16);
+        col0 = 32u * b0;
+        nblk_ref = b1 - b0;
+        if (y != S - 1) nblk_pos = nblk_neg = 0;
+        cand_v = reinterpret_cast<float *>(reinterpret_cast<char *>(cand_v) + y * set_bytes);
+        cand_i = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cand_i) + y * set_bytes);
+        cand_u = reinterpret_cast<float *>(reinterpret_cast<char *>(cand_u) + y * set_bytes);
+    }
     const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
     const uint32_t seg_end0 = nblk_ref, seg_end1 = nblk_ref + nblk_pos;
 
@@ -437,7 +454,10 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     auto flush_if_segment_end = [&](uint32_t b) {
         while (seg < NSEG && b + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
             if (q0 + j < N) {
-                cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, Nlist, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2], li[3], ldrop);
+                const uint32_t o = seg == 0 ? col0 : 0u;   // (a column split: indices relative to the whole train segment)
+                cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, Nlist, lv[0], lv[1], lv[2], lv[3],
+                           li[0] == 0xFFFFFFFFu ? li[0] : li[0] + o, li[1] == 0xFFFFFFFFu ? li[1] : li[1] + o,
+                           li[2] == 0xFFFFFFFFu ? li[2] : li[2] + o, li[3] == 0xFFFFFFFFu ? li[3] : li[3] + o, ldrop);
             }
 #pragma unroll
             for (int c = 0; c < CAND; ++c) {
@@ -526,20 +546,65 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     }
 }
 
+// Folds the list sets 1 .. S-1 of a column-split launch into set 0: per (query, half-list) the 4 S train candidates
+// are re-inserted into one list (the best value dropped = the largest any part dropped or the merge drops); the centroid
+// segments, swept by the last part alone, are copied.
+__global__ __launch_bounds__(256) void phk_merge_list_sets_kernel(float *__restrict__ cv, uint32_t *__restrict__ ci,
+                                                                  float *__restrict__ cu, uint64_t Nlist, uint64_t set_bytes,
+                                                                  int S, const uint32_t *__restrict__ qcount) {
+    const uint64_t cnt_all = phk_uniform_load(qcount);
+    const uint64_t cnt = cnt_all < PHK_SECOND_MIN ? 0 : (cnt_all < Nlist ? cnt_all : Nlist);
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t q = id >> 1;
+    const int h = (int)(id & 1);
+    if (q >= cnt) return;
+    auto set_v = [&](int y) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(cv) + (uint64_t)y * set_bytes); };
+    auto set_i = [&](int y) { return reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ci) + (uint64_t)y * set_bytes); };
+    auto set_u = [&](int y) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(cu) + (uint64_t)y * set_bytes); };
+    float lv[CAND] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    uint32_t li[CAND] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    float drop = -3.0e38f;
+    for (int y = 0; y < S; ++y) {
+        drop = fmaxf(drop, set_u(y)[candu_at(0, h, q, Nlist)]);
+#pragma unroll
+        for (int c = 0; c < CAND; ++c) {
+            const uint32_t ix = set_i(y)[cand_at(0, h, c, q, Nlist)];
+            if (ix != 0xFFFFFFFFu) list_insert(lv, li, drop, set_v(y)[cand_at(0, h, c, q, Nlist)], ix);
+        }
+    }
+    cand_store(cv, ci, cu, 0, h, q, Nlist, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2], li[3], drop);
+    for (int seg = 1; seg < NSEG; ++seg) {
+#pragma unroll
+        for (int c = 0; c < CAND; ++c) {
+            cv[cand_at(seg, h, c, q, Nlist)] = set_v(S - 1)[cand_at(seg, h, c, q, Nlist)];
+            ci[cand_at(seg, h, c, q, Nlist)] = set_i(S - 1)[cand_at(seg, h, c, q, Nlist)];
+        }
+        cu[candu_at(seg, h, q, Nlist)] = set_u(S - 1)[candu_at(seg, h, q, Nlist)];
+    }
+}
+
+// splits > 1 (second-chance launches only): `splits` list sets, set_bytes apart, merged into the first
 int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                             const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                            float *cv, uint32_t *ci, float *cu, const uint32_t *qmap, const uint32_t *qcount) {
+                            float *cv, uint32_t *ci, float *cu, const uint32_t *qmap, const uint32_t *qcount, int splits,
+                            uint64_t set_bytes) {
     const size_t lds = 2 * F16_BLOCK_BYTES;
+    if (splits < 1 || !qmap || (uint32_t)splits > nref) splits = 1;
     const uint4 *af = (const uint4 *)m->d_Af16 + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16_BLOCK_BYTES / 16);
     const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * F16_WAVES);
     if (src_counts) {
         PHK_LAUNCH(ctx, "phk_knn_f16_kernel",
-                   phk_knn_f16_kernel<0><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
-                       src, d_rowsum, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu, qmap, qcount));
+                   phk_knn_f16_kernel<0><<<dim3(gblocks, (unsigned)splits), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
+                       src, d_rowsum, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu, qmap, qcount, set_bytes));
     } else {
         PHK_LAUNCH(ctx, "phk_knn_f16_kernel",
-                   phk_knn_f16_kernel<1><<<dim3(gblocks), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
-                       src, nullptr, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu, qmap, qcount));
+                   phk_knn_f16_kernel<1><<<dim3(gblocks, (unsigned)splits), dim3(64 * F16_WAVES), lds, ctx->stream>>>(
+                       src, nullptr, nb, af, m->d_mu32, m->d_mu64, nref, npos, nneg, cv, ci, cu, qmap, qcount, set_bytes));
+    }
+    if (splits > 1) {
+        PHK_LAUNCH(ctx, "phk_merge_list_sets_kernel",
+                   phk_merge_list_sets_kernel<<<dim3((unsigned)phk_div_up(2 * nb, 256)), dim3(256), 0, ctx->stream>>>(
+                       cv, ci, cu, nb, set_bytes, splits, qcount));
     }
     return PHK_OK;
 }

@@ -1967,7 +1967,9 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     const uint64_t per_list = nb_max * NSEG * 2, per_list2 = cap2 * NSEG * 2;
     const uint64_t list_bytes = sizeof(float4) + sizeof(uint4) + sizeof(float);
     void *cv, *fb, *rec;
-    PHK_TRY(phk_ws(ctx, WS_CAND, (per_list + per_list2) * list_bytes, &cv));
+    // the second chance sweeps the reference in PHK_SECOND_SPLITS column parts, each with a list set of its own
+    const uint64_t set2_bytes = per_list2 * list_bytes;
+    PHK_TRY(phk_ws(ctx, WS_CAND, per_list * list_bytes + PHK_SECOND_SPLITS * set2_bytes, &cv));
     uint32_t *ci = (uint32_t *)((char *)cv + per_list * sizeof(float4));
     float *cu = (float *)((char *)ci + per_list * sizeof(uint4));
     float *cv2 = (float *)((char *)cv + per_list * list_bytes);
@@ -2105,7 +2107,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         RerankParams pf = p;   // what the brute force works from
         if (second) {
             const uint64_t cap = nb < cap2 ? nb : cap2;
-            PHK_TRY(phk_launch_proposal_f16(ctx, m, src, true, rsum, cap, nref, npos, nneg, cv2, ci2, cu2, fb_list, fbc));
+            PHK_TRY(phk_launch_proposal_f16(ctx, m, src, true, rsum, cap, nref, npos, nneg, cv2, ci2, cu2, fb_list, fbc,
+                                            PHK_SECOND_SPLITS, set2_bytes));
             RerankParams p2 = p;
             split_f16_bound(p2);
             p2.N = cap;

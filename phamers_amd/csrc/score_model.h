@@ -43,6 +43,7 @@ struct phk_model {
 
 // second-chance pass of phk_score_fast: below this many queued rows the float64 brute force is the cheaper last resort
 #define PHK_SECOND_MIN 24
+#define PHK_SECOND_SPLITS 8   // column parts of a second-chance sweep (its few thousand queries alone fill ~1/6 of the CUs)
 
 // exact float64 batch scorer (score.hip)
 int phk_score_exact_batch(phk_ctx *ctx, const phk_model *m, const double *d_Q, uint64_t nq, int method,
@@ -61,7 +62,7 @@ int phk_model_apply_mask_f16(phk_ctx *ctx, phk_model *m);
 int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts,
                             const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
                             float *cv, uint32_t *ci, float *cu, const uint32_t *qmap = nullptr,
-                            const uint32_t *qcount = nullptr);
+                            const uint32_t *qcount = nullptr, int splits = 1, uint64_t set_bytes = 0);
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu);
 int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
