@@ -873,7 +873,10 @@ __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn
 //     w_j   = w^h_j + sum_i (c_i - T mu_i) lo_ji                     (= the count-exact kernel's value, refined later).
 // |w_j - w^h_j| <= T S |q'| |lo_j| / S by Cauchy-Schwarz: that is the window the decision stage refines inside.
 // List maintenance, index bits in the value, the two-tile ping-pong and the segment pipeline are those of the
-// count-exact kernel; with one MFMA per value the loop is bound by the VALU issue of the insertions (~7 per value).
+// count-exact kernel; with one MFMA per value the loop would be bound by the VALU issue of the insertions (7 operations
+// per value), so an insertion no lane of the wave needs is skipped (see insert()).  In-kernel cycle stamps per block
+// iteration of a wave (32 MFMAs): 3005 cycles in the k-step loop, 293 issuing its 5 DMA pieces, 130 at the barrier,
+// 160 between iterations -- 57 % of the SIMD's matrix-pipe time at the 1.84 GHz the chip sustains under this load.
 // ====================================================================================
 template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
@@ -967,6 +970,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     auto insert = [&](int t, float a, float bias, int r) {
         const float w = fmaf(negT[t], bias, a);
         const float x = __uint_as_float((__float_as_uint(w) & ~31u) | (uint32_t)(2 * r + 1));
+        // A value no lane of the wave can place (x <= the best value its list has dropped, in every lane) changes nothing:
+        // wave-uniform skip of the five v_med3.  A lane's list holds the 5 best of the n values it has seen, so a value
+        // enters with probability 5 / n and some lane of the wave takes one with 1 - (1 - 5/n)^64: 63 % of the insertions
+        // of a 4000-column sweep are skipped (2.39 -> 2.23 ms on configs[1]).  The branch is uniform; the MFMAs stay one
+        // per basic block.
+        if (__builtin_amdgcn_ballot_w64(x > lv[t][4]) == 0) return;
         const float n4 = __builtin_amdgcn_fmed3f(lv[t][3], lv[t][4], x);
         const float n3 = __builtin_amdgcn_fmed3f(lv[t][2], lv[t][3], x);
         const float n2 = __builtin_amdgcn_fmed3f(lv[t][1], lv[t][2], x);
@@ -981,8 +990,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     // Software pipeline inside the wave, per segment: while block i's MFMAs fill one accumulator set, the VALU
     // inserts block i-1's values out of the other set (with its bias terms, held in 16 registers) and settles
     // the ids of block i-2's insertions during the first k-step.  Nothing but the LDS reads of the next bias
-    // terms and the workgroup barrier is left outside the MFMA stream; the hot loop has no data-dependent
-    // control flow.  The pipeline drains at the end of a segment (3 times per sweep); the DMA stream does not.
+    // terms and the workgroup barrier is left outside the MFMA stream; the only data-dependent control
+    // flow of the hot loop is the wave-uniform skip inside insert().  The pipeline drains at the end of a segment (3 times per sweep); the DMA stream does not.
     float bias[16];
     f32x16 accA[NT], accB[NT];
     uint32_t g = 0;  // global block number: LDS buffer parity and DMA source
@@ -1015,19 +1024,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
             if (s == 0) settle(settle_id);
 #pragma unroll
             for (int t = 0; t < NT; ++t) insert(t, prev[t][s], bias[s], s);
-            if (s == 0) {
-#pragma unroll
-                for (int gi = 0; gi < NT; ++gi) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 28, 0);  // VALU (settle + insertion)
-                }
-            } else {
-#pragma unroll
-                for (int gi = 0; gi < NT; ++gi) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // VALU (insertion)
-                }
-            }
+
         }
         // D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h'; its bias terms
         // (the buffer is recycled after the next barrier)
@@ -1357,7 +1354,8 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
                 }
             }
         }
-        // epilogue of the tile: norm terms from global memory, branch-free insertion, segment flushes
+        // epilogue of the tile: norm terms from global memory, insertion (skipped by the whole wave when no lane can place
+        // the value), segment flushes
 #pragma unroll
         for (int cb = 0; cb < GEN_CT; ++cb) {
             const uint32_t blk = t * GEN_CT + cb;
@@ -1368,10 +1366,10 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
 #pragma unroll
                 for (int m4 = 0; m4 < 4; ++m4) {
                     const float4 c4 = cn[2 * m4];
-                    list_insert(lv, li, ldrop, fmaf(mul, c4.x, acc[cb][4 * m4 + 0]), cbase + 8u * m4 + 0u);
-                    list_insert(lv, li, ldrop, fmaf(mul, c4.y, acc[cb][4 * m4 + 1]), cbase + 8u * m4 + 1u);
-                    list_insert(lv, li, ldrop, fmaf(mul, c4.z, acc[cb][4 * m4 + 2]), cbase + 8u * m4 + 2u);
-                    list_insert(lv, li, ldrop, fmaf(mul, c4.w, acc[cb][4 * m4 + 3]), cbase + 8u * m4 + 3u);
+                    list_insert_needed(lv, li, ldrop, fmaf(mul, c4.x, acc[cb][4 * m4 + 0]), cbase + 8u * m4 + 0u);
+                    list_insert_needed(lv, li, ldrop, fmaf(mul, c4.y, acc[cb][4 * m4 + 1]), cbase + 8u * m4 + 1u);
+                    list_insert_needed(lv, li, ldrop, fmaf(mul, c4.z, acc[cb][4 * m4 + 2]), cbase + 8u * m4 + 2u);
+                    list_insert_needed(lv, li, ldrop, fmaf(mul, c4.w, acc[cb][4 * m4 + 3]), cbase + 8u * m4 + 3u);
                 }
                 while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
                     if (qb < nqb && q0 + j < N) {

@@ -92,3 +92,9 @@ __device__ __forceinline__ void list_insert(float (&v)[CAND], uint32_t (&ix)[CAN
     v[2] = n2;
     v[3] = n3;
 }
+// The same, skipped by the whole wave when no lane can place the value: x <= drop (<= v[3]) leaves list and drop as they
+// are.  A list keeps the 4 best (+ the best dropped) of the n values it has seen, so late in a sweep almost every value
+// is skipped; the branch is wave-uniform.
+__device__ __forceinline__ void list_insert_needed(float (&v)[CAND], uint32_t (&ix)[CAND], float &drop, float x, uint32_t c) {
+    if (__builtin_amdgcn_ballot_w64(x > drop) != 0) list_insert(v, ix, drop, x, c);
+}
