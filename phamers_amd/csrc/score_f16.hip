@@ -1273,22 +1273,26 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
 
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
     // item it = ((tile * nchunk) + chunk) * CT + cb  ->  32 pieces of (block, chunk)
-    auto dma_item = [&](uint64_t it, int buf) {
-        if (it >= nitem) it = nitem - 1;
-        const uint32_t cb = (uint32_t)(it % GEN_CT);
-        const uint64_t tc = it / GEN_CT;
-        const uint32_t c = (uint32_t)(tc % nchunk);
-        uint32_t blk = (uint32_t)(tc / nchunk) * GEN_CT + cb;
+    // Source of the pieces of item (tile, chunk, cb); this wave's are p = wave, wave + GEN_NW, ..  (Coordinates, not the
+    // item number: the 64-bit divisions that recover them from it cost ~400 cycles per item.)
+    constexpr int NPIECE = (HI ? 16 : 32) / GEN_NW;   // pieces per wave and item
+    auto item_src = [&](uint32_t tile, uint32_t c, uint32_t cb) {
+        if (tile >= ntile) { tile = ntile - 1; c = nchunk - 1; cb = GEN_CT - 1; }   // one past the end: harmless re-read
+        uint32_t blk = tile * GEN_CT + cb;
         if (blk >= total) blk = total - 1;  // partial last tile: harmless re-read, result discarded
-        const uint4 *g = Af + (uint64_t)(blk0 + blk) * rec_u4 + (uint64_t)c * 32 * 64 + lane;
-        const uint32_t l = lds_base + (uint32_t)buf * 32768u;
-        for (int p = wave; p < (HI ? 16 : 32); p += GEN_NW) {   // HI: source pieces 0, 2, 4, .. (hi) land as pieces 0, 1, 2, ..
-            const uint4 *gp = g + (HI ? 2 * p : p) * 64;
-            const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
-        }
+        return Af + (uint64_t)(blk0 + blk) * rec_u4 + (uint64_t)c * 32 * 64 + lane;
     };
-    if (nitem) dma_item(0, 0);
+    auto dma_piece = [&](const uint4 *g, int buf, int i) {   // i-th piece of this wave
+        const int p = wave + GEN_NW * i;   // HI: source pieces 0, 2, 4, .. (hi) land as pieces 0, 1, 2, ..
+        const uint4 *gp = g + (HI ? 2 * p : p) * 64;
+        const uint32_t lp = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)buf * 32768u + (uint32_t)p * 1024u);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
+    };
+    if (nitem) {
+        const uint4 *g0 = item_src(0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) dma_piece(g0, 0, i);
+    }
 
     float lv[CAND];
     uint32_t li[CAND];
@@ -1337,10 +1341,15 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
             for (int cb = 0; cb < GEN_CT; ++cb, ++it) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                dma_item(it + 1, (int)((it + 1) & 1));
+                // The next item's pieces are issued BETWEEN this item's first k-steps, not in a burst after the barrier:
+                // there the 32 pieces of the 8 waves queued at the CU's DMA path and every wave spent ~950 cycles per
+                // item (of 4200, by in-kernel stamps) doing nothing else.
+                const uint4 *gnext = cb + 1 < GEN_CT ? item_src(t, c, cb + 1) : (c + 1 < nchunk ? item_src(t, c + 1, 0) : item_src(t + 1, 0, 0));
+                const int nbuf = (int)((it + 1) & 1);
                 const half8 *fr = reinterpret_cast<const half8 *>(smem + (it & 1) * 32768u) + lane;
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
+                    if (s < NPIECE) dma_piece(gnext, nbuf, s);
                     if (HI) {
                         const half8 ah = fr[s * 64];
                         acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc[cb], 0, 0, 0);
