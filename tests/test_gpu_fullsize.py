@@ -1,7 +1,7 @@
 """BASELINE configs[1] at full size (k = 4, 1M x 5 kb contigs on one GPU) through size-independent
 properties: the two count kernels agree bit for bit, every row sums to L - k + 1, scores do not depend on
-where in a batch (which tile, which workgroup, which launch) a contig sits, combo = knn + kmeans, and a
-random sample of rows matches the oracle."""
+where in a batch (which tile, which workgroup, which launch) a contig sits, combo = knn + kmeans, a
+random sample of rows matches the oracle, and ALL 10^6 scores equal those of the float64 brute-force path."""
 import os
 
 import numpy as np
@@ -70,6 +70,17 @@ def test_full_size_batch_properties(monkeypatch):
     q = oracle.normalize_counts(want_counts)
     want = oracle.knn_score_points(q, pos, neg, 3) + oracle.centroid_score_points_fast(q, g["cpos_eq"], g["cneg_eq"])
     assert helpers.rel_err(out["combo"][sample], want) < 1e-6
+
+    # the whole batch through the float64 brute-force path (no MFMA proposal, no certification logic): every vote
+    # identical, every metric equal to rounding -- 10^6 queries, not a sample
+    ctx.set_option("force_exact", "1")
+    exact = {}
+    for method in ("knn", "kmeans"):
+        device.score_counts(ctx, model, d_counts, N, method, d_scores, d_status)
+        exact[method] = d_scores.to_host()
+    ctx.set_option("force_exact", "0")
+    assert np.array_equal(out["knn"], exact["knn"])
+    assert helpers.rel_err(out["kmeans"], exact["kmeans"]) < 1e-9
 
     # position independence: a permuted sub-batch (different tiles, workgroups and launch size) scores identically
     perm = rng.permutation(N)[:300001]
