@@ -875,8 +875,8 @@ __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn
 // List maintenance, index bits in the value, the two-tile ping-pong and the segment pipeline are those of the
 // count-exact kernel; with one MFMA per value the loop would be bound by the VALU issue of the insertions (7 operations
 // per value), so an insertion no lane of the wave needs is skipped (see insert()).  In-kernel cycle stamps per block
-// iteration of a wave (32 MFMAs): 3005 cycles in the k-step loop, 293 issuing its 5 DMA pieces, 130 at the barrier,
-// 160 between iterations -- 57 % of the SIMD's matrix-pipe time at the 1.84 GHz the chip sustains under this load.
+// iteration of a wave (32 MFMAs): 83 % of the time in the k-step loop, 8 % issuing its 5 DMA pieces, 4 % at the barrier,
+// 4 % between iterations; by the counters the matrix pipe is 48 % busy at the 2.15 GHz the chip holds under this kernel.
 // ====================================================================================
 template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
