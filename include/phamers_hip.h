@@ -157,6 +157,16 @@ int phk_write_scores_csv(const char *path, const char *prefix, const char *ids, 
                          const double *scores, uint64_t n);
 /* one float64 in that notation (NUL-terminated) */
 int phk_format_float(double v, char *out, int cap);
+/* fileIO.read_feature_file (scripts/fileIO.py:134-166) for files of the shape save_counts writes: '#' comment lines
+ * and blank lines skipped, every other line "id,int,int,...".  phk_features_open maps the file and indexes its rows
+ * (n rows, D count columns, the longest id in bytes); phk_features_read parses them on all cores into counts[n][D]
+ * int64 and ids[n][id_width] (zero padded: a NumPy 'S<id_width>' array).  Anything np.loadtxt would treat differently
+ * -- a '#' inside a line, a row with another number of fields, a field that is not a plain decimal integer, a
+ * non-ASCII id -- gives PHK_ERR_UNSUPPORTED, and the caller reads the file the reference's way (np.loadtxt). */
+typedef struct phk_features phk_features;
+int phk_features_open(const char *path, phk_features **out, uint64_t *n, uint64_t *D, uint64_t *id_width);
+int phk_features_read(const phk_features *f, int64_t *counts, char *ids, uint64_t id_width);
+int phk_features_close(phk_features *f);
 
 /* ---- device-resident contig batches (the facade's data path) ------------------------- */
 /* What a PhaMers user calls on a FASTA input -- phamer_scorer.load_data + score_points (scripts/phamer.py:131, 139,

@@ -57,6 +57,9 @@ SIGNATURES = {
     "phk_write_counts_csv": (c_int, [c_char_p, c_char_p, c_void_p, c_void_p, c_void_p, c_int, c_u64, c_u64]),
     "phk_write_scores_csv": (c_int, [c_char_p, c_char_p, c_void_p, c_void_p, c_void_p, c_u64]),
     "phk_format_float": (c_int, [c_double, c_char_p, c_int]),
+    "phk_features_open": (c_int, [c_char_p, P(c_void_p), P(c_u64), P(c_u64), P(c_u64)]),
+    "phk_features_read": (c_int, [c_void_p, c_void_p, c_void_p, c_u64]),
+    "phk_features_close": (c_int, [c_void_p]),
     "phk_batch_normalized": (c_int, [c_void_p, c_void_p, c_void_p]),
     "phk_batch_select": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, P(c_void_p)]),
     "phk_batch_score": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

@@ -43,12 +43,47 @@ def _id_table(ids):
     return np.frombuffer(b''.join(raw) or b'\0', dtype=np.uint8), offsets
 
 
+def _read_feature_file_native(feature_file):
+    """(ids, int64 features) of a file of the shape save_counts writes, parsed on all cores by the native reader
+    (np.loadtxt needs minutes for the features cache of 10^6 contigs); None for any other shape of file, which
+    np.loadtxt then reads as the reference does."""
+    import ctypes
+    lib = _lib.load()
+    handle = ctypes.c_void_p()
+    n, D, w = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    rc = lib.phk_features_open(str(feature_file).encode(), ctypes.byref(handle), ctypes.byref(n), ctypes.byref(D),
+                               ctypes.byref(w))
+    if rc == _lib.PHK_ERR_UNSUPPORTED:
+        return None
+    if rc == _lib.PHK_ERR_IO:
+        np.loadtxt(feature_file, delimiter=',', dtype=str)   # raises what the reference raises for this path
+        return None
+    _lib.check(rc)
+    try:
+        if n.value == 0:
+            return None          # np.loadtxt's empty-file behaviour (a warning and an empty array) stays np.loadtxt's
+        features = np.empty((n.value, D.value), dtype=np.int64)
+        idb = np.zeros((n.value, w.value), dtype=np.uint8)
+        rc = lib.phk_features_read(handle, _lib.ptr(features), _lib.ptr(idb), w.value)
+        if rc == _lib.PHK_ERR_UNSUPPORTED:
+            return None
+        _lib.check(rc)
+    finally:
+        lib.phk_features_close(handle)
+    ids = idb.view("S%d" % w.value)[:, 0].astype("U%d" % w.value)
+    return ids, features
+
+
 def read_feature_file(feature_file, normalize=False, id=None):
     """'id,c0,c1,...' rows ('#' comment lines skipped) -> (ids, int features), optionally row
     normalised on the GPU (kmer.normalize_counts); ``id`` selects one row's features."""
-    data = np.atleast_2d(np.loadtxt(feature_file, delimiter=',', dtype=str))
-    ids = np.array(list(data[:, 0]))
-    features = data[:, 1:].astype(int)
+    native = _read_feature_file_native(feature_file)
+    if native is not None:
+        ids, features = native
+    else:   # any other shape of file: the reference's own parse
+        data = np.atleast_2d(np.loadtxt(feature_file, delimiter=',', dtype=str))
+        ids = np.array(list(data[:, 0]))
+        features = data[:, 1:].astype(int)
     if normalize:
         from . import kmer
         features = kmer.normalize_counts(features)

@@ -78,6 +78,11 @@ class phamer_scorer(object):
         # query side: device-resident batch and / or host rows
         self._batch = None
         self._rows = None
+        # host work that runs beside the path (main() only; the methods below are synchronous for API callers):
+        # the features-cache write and the per-run k-means fit of the reference matrices
+        self._defer_io = False
+        self._pending_io = []
+        self._centroid_future = None
 
     # ---- data_points: the reference's attribute, lazily backed by the device batch --------------------
     @property
@@ -114,8 +119,14 @@ class phamer_scorer(object):
         written through to ``<fasta>_features.csv`` and stay on the device for scoring.  A truthy
         ``length_requirement`` applies the length screen -- always with self.length_requirement (5000), as in the
         reference, whose CLI value is never forwarded."""
+        self._load_reference()
+        self._load_queries(length_requirement)
+
+    def _load_reference(self):
         self.positive_ids, self.positive_data = fileIO.read_feature_file(self.positive_features_file, normalize=True)
         self.negative_ids, self.negative_data = fileIO.read_feature_file(self.negative_features_file, normalize=True)
+
+    def _load_queries(self, length_requirement=True):
         self.find_input_files()
         lengths = None
         if self.features_file and os.path.exists(self.features_file):
@@ -143,8 +154,28 @@ class phamer_scorer(object):
         finally:
             fasta.close()
         self.features_file = "{base}_features.csv".format(base=os.path.splitext(self.fasta_file)[0])
-        fileIO.save_counts(self._batch.counts_u32(), self.data_ids, self.features_file)
+        counts, ids, path = self._batch.counts_u32(), self.data_ids, self.features_file
+        if self._defer_io:
+            # main(): the 0.6 s (1M contigs) of formatting and writing the cache run beside the k-means fit and the
+            # scoring; the file appears under its name only when complete
+            import threading
+
+            def write():
+                tmp = path + ".part"
+                fileIO.save_counts(counts, ids, tmp)
+                os.replace(tmp, path)
+            th = threading.Thread(target=write, name="phamers-features-cache")
+            th.start()
+            self._pending_io.append(th)
+        else:
+            fileIO.save_counts(counts, ids, path)
         return lengths
+
+    def finish_io(self):
+        """Waits for file writes main() left running beside the scoring."""
+        pending, self._pending_io = self._pending_io, []
+        for th in pending:
+            th.join()
 
     def screen_by_length(self, length_requirement=None, _lengths=None):
         """Keep contigs of at least ``length_requirement`` bases (scripts/phamer.py:144-157): ids filtered on the host,
@@ -200,10 +231,29 @@ class phamer_scorer(object):
         raise NotImplementedError("scoring method %r is outside the accelerated path; knn / kmeans / combo are "
                                   "available" % (self.scoring_method,))
 
+    def _centroids_of(self, pos, neg, k_clusters):
+        return tuple(learning.get_centroids(d, learning.kmeans(d, k_clusters)) for d in (pos, neg))
+
+    def prefetch_centroids(self):
+        """Starts the k-means fit of the reference matrices as they are NOW on a host thread (scikit-learn releases the
+        GIL), so that it runs beside the FASTA ingest and the counting; _fit_centroids takes the result if the matrices
+        have not been replaced since, and fits afresh otherwise.  Host (scikit-learn) k-means only."""
+        if os.environ.get("PHAMERS_KMEANS", "sklearn") != "sklearn":
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        pos, neg, k = self.positive_data, self.negative_data, self.k_clusters
+        ex = ThreadPoolExecutor(max_workers=1, thread_name_prefix="phamers-kmeans")
+        self._centroid_future = (pos, neg, k, ex.submit(self._centroids_of, pos, neg, k))
+        ex.shutdown(wait=False)
+
     def _fit_centroids(self):
         """k-means with k_clusters on each class, then the cluster means (scripts/phamer.py:245-248)."""
-        self.positive_centroids, self.negative_centroids = (
-            learning.get_centroids(d, learning.kmeans(d, self.k_clusters)) for d in (self.positive_data, self.negative_data))
+        fut, self._centroid_future = self._centroid_future, None
+        if fut is not None and fut[0] is self.positive_data and fut[1] is self.negative_data and fut[2] == self.k_clusters:
+            self.positive_centroids, self.negative_centroids = fut[3].result()
+            return
+        self.positive_centroids, self.negative_centroids = self._centroids_of(self.positive_data, self.negative_data,
+                                                                              self.k_clusters)
 
     def _gpu_score(self, method):
         with_centroids = method != 'knn'
@@ -295,12 +345,31 @@ def main(argv=None):
         ap.error("give -data <dir with reference_features/> or -pf and -nf")
     scorer.output_directory = args.output_directory or os.path.join(
         args.input_directory or os.path.dirname(args.fasta_file or args.features_file or '.'), "phamer_output")
-    scorer.load_data(length_requirement=args.length_requirement)
-    if args.equalize_reference:
-        scorer.equalize_reference_data()
-    os.makedirs(scorer.output_directory, exist_ok=True)
-    scorer.score_points()
-    scorer.make_summary_file(args=args)
+    # load_data(), with the host work that does not depend on the contigs started early: the reference matrices are
+    # read (and equalised) first, their k-means fit runs beside the FASTA ingest and the counting, and the features
+    # cache is written beside the scoring.  Same files, same numbers as the sequential order of the reference.
+    import time
+    t0 = time.perf_counter()
+
+    def lap(what):
+        logger.debug("%-28s %.3f s" % (what, time.perf_counter() - t0))
+    scorer._defer_io = True
+    try:
+        scorer._load_reference()
+        if args.equalize_reference:
+            scorer.equalize_reference_data()
+        lap("reference matrices")
+        scorer.prefetch_centroids()
+        scorer._load_queries(args.length_requirement)
+        lap("contigs counted")
+        os.makedirs(scorer.output_directory, exist_ok=True)
+        scorer.score_points()
+        lap("scored")
+        scorer.make_summary_file(args=args)
+        lap("scores written")
+    finally:
+        scorer.finish_io()
+        lap("features cache complete")
     return scorer
 
 

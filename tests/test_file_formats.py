@@ -31,6 +31,25 @@ def test_writers_are_byte_compatible(tmp_path):
     assert got == doc["scores_read_back"]
 
 
+def test_native_writers_keep_row_order_across_chunks_and_threads(tmp_path):
+    """More rows than one formatting chunk (4096) per worker thread: the chunks are formatted and written by different
+    threads at offsets handed from chunk to chunk; the file must be the rows in order, byte for byte."""
+    from phamers_amd import fileIO
+    n = 5 * 4096 + 17
+    rng = np.random.default_rng(3)
+    counts = rng.integers(0, 10 ** rng.integers(1, 9, size=(n, 1)), size=(n, 6)).astype(np.uint32)
+    ids = np.array(["contig_%d" % (i * 7919 % 100003) for i in range(n)])
+    path = str(tmp_path / "features.csv")
+    fileIO.save_counts(counts, ids, path, header="K-mer count file")
+    body = [ln for ln in open(path).read().split("\n") if ln and not ln.startswith("#")]
+    assert body == [",".join([ids[i]] + [str(int(v)) for v in counts[i]]) for i in range(n)]
+    scores = rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, size=n)
+    spath = str(tmp_path / "scores.csv")
+    fileIO.save_phamer_scores(ids, scores, spath)
+    body = [ln for ln in open(spath).read().split("\n") if ln and not ln.startswith("#")]
+    assert body == ["%s, %s" % (ids[i], str(np.float64(scores[i]))) for i in range(n)]
+
+
 def test_native_float_notation_is_numpys():
     """phk_write_scores_csv writes a score as str(numpy.float64) does (what the reference's astype(str) yields)."""
     import ctypes
@@ -191,3 +210,39 @@ def test_config0_cli_end_to_end(tmp_path):
     again = fileIO.read_phamer_output(str(out))
     assert helpers.rel_err(np.array([again[str(c)] for c in range(100)]), scores) < 1e-12
     assert first.count("\n") == out.read_text().count("\n") - 1    # the 12-base contig is scored without the screen
+
+
+def test_native_feature_file_reader_equals_loadtxt_and_steps_aside(tmp_path, monkeypatch):
+    """read_feature_file through the native reader == np.loadtxt's result on files save_counts writes (several formatting
+    chunks, header block, CRLF, no trailing newline); files of any other shape are left to np.loadtxt."""
+    from phamers_amd import fileIO
+    rng = np.random.default_rng(5)
+    n = 3 * 4096 + 5
+    counts = rng.integers(0, 5000, size=(n, 16))
+    ids = np.array(["NODE_%d_length_%d" % (i, 5000 + i % 977) for i in range(n)])
+    path = str(tmp_path / "features.csv")
+    fileIO.save_counts(counts, ids, path, header="K-mer count file\nsecond header line")
+    got_ids, got = fileIO.read_feature_file(path)
+    want = np.atleast_2d(np.loadtxt(path, delimiter=",", dtype=str))
+    assert got.dtype == np.int64 and np.array_equal(got, want[:, 1:].astype(int)) and np.array_equal(got, counts)
+    assert got_ids.dtype.kind == "U" and list(got_ids) == list(want[:, 0]) == list(ids)
+    assert fileIO._read_feature_file_native(path) is not None
+    # one row, CRLF line ends, no newline at the end
+    one = str(tmp_path / "one.csv")
+    open(one, "wb").write(b"# h\r\nabc,1,2,3")
+    i1, f1 = fileIO.read_feature_file(one)
+    assert list(i1) == ["abc"] and f1.tolist() == [[1, 2, 3]]
+    # shapes the native reader refuses: inline comment, blanks, a float field, ragged rows -> np.loadtxt decides
+    for text in ("a,1,2 # note\nb,3,4\n", "a, 1, 2\nb, 3, 4\n", "a,1.0,2\nb,3,4\n"):
+        other = str(tmp_path / "other.csv")
+        open(other, "w").write(text)
+        assert fileIO._read_feature_file_native(other) is None
+    open(other, "w").write("a,1,2 # note\nb,3,4\n")
+    i2, f2 = fileIO.read_feature_file(other)
+    assert f2.tolist() == [[1, 2], [3, 4]]
+    open(other, "w").write("a,1,2\nb,3\n")
+    assert fileIO._read_feature_file_native(other) is None
+    with pytest.raises(ValueError):
+        fileIO.read_feature_file(other)
+    with pytest.raises((IOError, OSError)):
+        fileIO.read_feature_file(str(tmp_path / "missing.csv"))
