@@ -31,16 +31,41 @@
 
 static inline bool is_space(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
 
-// byte buffer without value-initialisation (std::vector<char>::resize would zero-fill gigabytes)
+// Byte buffer without value-initialisation (std::vector<char>::resize would zero-fill gigabytes).  Large buffers are
+// anonymous mappings with transparent huge pages asked for: the sequence buffer of a 5 GB FASTA is first touched by the
+// parser's threads, and 4 KB pages mean 1.2 M page faults in the phase that writes it.
 struct RawBytes {
-    std::unique_ptr<char[]> p;
-    size_t n = 0;
+    char *p = nullptr;
+    size_t n = 0, mapped = 0;
+    RawBytes() = default;
+    RawBytes(const RawBytes &) = delete;
+    RawBytes &operator=(const RawBytes &) = delete;
+    ~RawBytes() { release(); }
+    void release() {
+        if (!p) return;
+        if (mapped) munmap(p, mapped);
+        else delete[] p;
+        p = nullptr;
+        n = mapped = 0;
+    }
     void resize(size_t m) {
-        p.reset(new char[m]);
+        release();
+        if (m >= (size_t)(4u << 20)) {
+            const size_t len = (m + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+            void *q = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q != MAP_FAILED) {
+                (void)madvise(q, len, MADV_HUGEPAGE);
+                p = (char *)q;
+                mapped = len;
+                n = m;
+                return;
+            }
+        }
+        p = new char[m];
         n = m;
     }
-    char *data() { return p.get(); }
-    const char *data() const { return p.get(); }
+    char *data() { return p; }
+    const char *data() const { return p; }
 };
 
 struct phk_fasta {
@@ -255,32 +280,8 @@ static int read_whole_file(const char *path, std::vector<char> &buf) {
     return PHK_OK;
 }
 
-// One record = [begin, end) of the file buffer, begin pointing at its '>'.  Pass 0 measures, pass 1
-// writes at the given cursors.
+// One record = [begin, end) of the file buffer, begin pointing at its '>'; written at the cursors the scan pass fixed.
 struct RecSpan { size_t begin, end; };
-
-static void measure_record(const char *b, size_t begin, size_t end, uint64_t &n_bases, uint64_t &n_title) {
-    size_t p = begin + 1;
-    const char *nl = (const char *)memchr(b + p, '\n', end - p);
-    size_t eol = nl ? (size_t)(nl - b) : end;
-    size_t t_end = eol;
-    while (t_end > p && is_space(b[t_end - 1])) --t_end;
-    n_title = t_end - p;
-    n_bases = 0;
-    p = eol < end ? eol + 1 : end;
-    while (p < end) {
-        nl = (const char *)memchr(b + p, '\n', end - p);
-        eol = nl ? (size_t)(nl - b) : end;
-        size_t l_end = eol;
-        while (l_end > p && is_space(b[l_end - 1])) --l_end;
-        if (!memchr(b + p, ' ', l_end - p) && !memchr(b + p, '\r', l_end - p)) {
-            n_bases += l_end - p;                      // the usual line: nothing to drop
-        } else {
-            for (size_t i = p; i < l_end; ++i) n_bases += (b[i] != ' ' && b[i] != '\r');
-        }
-        p = eol < end ? eol + 1 : end;
-    }
-}
 
 static void write_record(const char *b, size_t begin, size_t end, char *seq_out, char *title_out) {
     size_t p = begin + 1;
@@ -327,12 +328,15 @@ extern "C" int phk_fasta_read(const char *path, int threads, phk_fasta **out) {
     const char *b = fb.data;
     const size_t n = fb.size;
     if (threads < 1) threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-    // record starts: '>' at the beginning of a line -- the file is cut into one slice per thread, each thread lists the
-    // starts inside its slice (a slice begins at the first line start at or after its cut)
-    std::vector<size_t> starts;
+    // One pass finds the records and measures them: the file is cut into one slice per thread (a slice begins at the
+    // first line start at or after its cut); each thread lists the '>' line starts inside its slice with the title length
+    // and the number of bases of the record's lines INSIDE the slice, plus the bases of the lines before its first '>'
+    // (they belong to the last record of an earlier slice).
+    struct RecInfo { size_t start; uint64_t n_title, n_bases; };
+    const int nt = (int)std::min<size_t>((size_t)threads, std::max<size_t>(n >> 20, 1));
+    std::vector<std::vector<RecInfo>> part((size_t)nt);
+    std::vector<uint64_t> lead((size_t)nt, 0);
     {
-        const int nt = (int)std::min<size_t>((size_t)threads, std::max<size_t>(n >> 20, 1));
-        std::vector<std::vector<size_t>> part((size_t)nt);
         std::vector<std::thread> pool;
         for (int t = 0; t < nt; ++t)
             pool.emplace_back([&, t]() {
@@ -341,45 +345,61 @@ extern "C" int phk_fasta_read(const char *path, int threads, phk_fasta **out) {
                     const char *nl = (const char *)memchr(b + lo - 1, '\n', n - (lo - 1));
                     lo = nl ? (size_t)(nl - b) + 1 : n;
                 }
+                if (t + 1 < nt) {   // the slice ends where the next one begins
+                    const char *nl = hi ? (const char *)memchr(b + hi - 1, '\n', n - (hi - 1)) : nullptr;
+                    hi = hi ? (nl ? (size_t)(nl - b) + 1 : n) : 0;
+                }
+                uint64_t *acc = &lead[t];
                 for (size_t p = lo; p < hi;) {
-                    if (b[p] == '>') part[t].push_back(p);
                     const char *nl = (const char *)memchr(b + p, '\n', n - p);
-                    if (!nl) break;
-                    p = (size_t)(nl - b) + 1;
+                    const size_t eol = nl ? (size_t)(nl - b) : n;
+                    size_t l_end = eol;
+                    while (l_end > p && is_space(b[l_end - 1])) --l_end;
+                    if (b[p] == '>') {
+                        part[t].push_back(RecInfo{p, (uint64_t)(l_end > p + 1 ? l_end - (p + 1) : 0), 0});
+                        acc = &part[t].back().n_bases;
+                    } else if (!memchr(b + p, ' ', l_end - p) && !memchr(b + p, '\r', l_end - p)) {
+                        *acc += l_end - p;                      // the usual line: nothing to drop
+                    } else {
+                        for (size_t i = p; i < l_end; ++i) *acc += (b[i] != ' ' && b[i] != '\r');
+                    }
+                    p = eol < n ? eol + 1 : n;
                 }
             });
         for (auto &th : pool) th.join();
+    }
+    std::vector<size_t> starts;
+    {
         size_t total = 0;
         for (auto &v : part) total += v.size();
         starts.reserve(total);
-        for (auto &v : part) starts.insert(starts.end(), v.begin(), v.end());
+    }
+    phk_fasta *f = new phk_fasta();
+    f->offsets.push_back(0);
+    f->title_off.push_back(0);
+    for (int t = 0; t < nt; ++t) {
+        if (lead[t] && !starts.empty()) f->offsets.back() += lead[t];   // (text before the first record of the file is dropped)
+        for (const RecInfo &ri : part[t]) {
+            starts.push_back(ri.start);
+            f->offsets.push_back(ri.n_bases);
+            f->title_off.push_back(ri.n_title);
+        }
     }
     const size_t nrec = starts.size();
-    phk_fasta *f = new phk_fasta();
-    f->offsets.assign(nrec + 1, 0);
-    f->title_off.assign(nrec + 1, 0);
     threads = (int)std::min<size_t>((size_t)threads, std::max<size_t>(nrec, 1));
     auto span = [&](size_t r) { return RecSpan{starts[r], r + 1 < nrec ? starts[r + 1] : n}; };
-    auto run = [&](int pass) {
+    auto write_all_records = [&]() {
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; ++t)
             pool.emplace_back([&, t]() {
                 const size_t lo = nrec * (size_t)t / (size_t)threads, hi = nrec * (size_t)(t + 1) / (size_t)threads;
                 for (size_t r = lo; r < hi; ++r) {
                     const RecSpan s = span(r);
-                    if (pass == 0) {
-                        uint64_t nb, nt;
-                        measure_record(b, s.begin, s.end, nb, nt);
-                        f->offsets[r + 1] = nb;
-                        f->title_off[r + 1] = nt;
-                    } else {
-                        write_record(b, s.begin, s.end, f->bases.data() + f->offsets[r], f->titles.data() + f->title_off[r]);
-                    }
+                    write_record(b, s.begin, s.end, f->bases.data() + f->offsets[r], f->titles.data() + f->title_off[r]);
                 }
             });
         for (auto &th : pool) th.join();
     };
-    run(0);
     for (size_t r = 0; r < nrec; ++r) {
         f->offsets[r + 1] += f->offsets[r];
         f->title_off[r + 1] += f->title_off[r];
@@ -387,7 +407,7 @@ extern "C" int phk_fasta_read(const char *path, int threads, phk_fasta **out) {
     f->bases.resize(f->offsets[nrec] + 64);  // slack: the device packer reads whole 16-byte groups
     memset(f->bases.data() + f->offsets[nrec], 0, 64);
     f->titles.resize(f->title_off[nrec] + 1);
-    run(1);
+    write_all_records();
     // ids: the PhaMers id of every record.id (first white-space delimited word of the title), in parallel
     {
         std::vector<std::string> chunk((size_t)threads);

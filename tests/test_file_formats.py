@@ -132,6 +132,39 @@ def test_native_fasta_reader_matches_seqio_rules(tmp_path, threads):
     assert f.n_records == 0 and f.sequences() == []
 
 
+def test_native_fasta_reader_slices_of_a_large_file(tmp_path):
+    """A file big enough to be cut into one slice per thread (>= 1 MB each): records that straddle the cuts, long
+    records spanning whole slices, CR / blanks inside lines, text before the first record -- every thread count gives
+    the single-thread result, which equals the Bio.SeqIO restatement."""
+    from phamers_amd import _lib
+    rng = np.random.default_rng(11)
+    parts = ["junk before the first record\n"]
+    alphabet = np.frombuffer(b"ATGCN", dtype=np.uint8)
+    for c in range(260):
+        n = 2500000 if c == 77 else int(rng.choice([40, 3000, 70000, 9000]))
+        seq = alphabet[rng.integers(0, 5, size=n)].tobytes().decode()
+        w = int(rng.integers(20, 200))
+        lines = [seq[i:i + w] for i in range(0, n, w)]
+        if c % 7 == 0:
+            lines = [ln[:5] + " " + ln[5:] + "\r" for ln in lines]       # blanks and CR inside / at the end of lines
+        parts.append(">contig_%d_length_%d some description \n" % (c, n) + "\n".join(lines) + ("\n\n" if c % 5 == 0 else "\n"))
+    text = "".join(parts)
+    assert len(text) > 6 * (1 << 20)   # at least 6 slices of 1 MB
+    path = tmp_path / "big.fasta"
+    path.write_text(text)
+    want_titles, want_seqs = _seqio_like(text)
+    ref = None
+    for threads in (1, 2, 5, 0):
+        f = _lib.Fasta(str(path), threads=threads)
+        got = (f.titles(), f.sequences(), f.lengths().tolist(), f.ids())
+        f.close()
+        if ref is None:
+            ref = got
+            assert got[0] == want_titles and got[1] == want_seqs
+        else:
+            assert got == ref, threads
+
+
 @pytest.mark.gpu
 def test_count_file_and_feature_file_round_trip(tmp_path):
     """kmer.count_file on plain and gzip FASTA (ids by the reference's header rules), the soft IOError
