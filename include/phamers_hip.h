@@ -155,6 +155,12 @@ int phk_write_counts_csv(const char *path, const char *prefix, const char *ids, 
  * str(numpy.float64) writes it (shortest round-trip digits, Python's positional / scientific rule). */
 int phk_write_scores_csv(const char *path, const char *prefix, const char *ids, const uint64_t *id_offsets,
                          const double *scores, uint64_t n);
+/* the same two writers with the ids given as a NumPy 'U<id_width>' array as it lies in memory ([n][id_width] UCS-4 code
+ * points, NUL padded; written as str(id).encode('latin-1', 'replace')): no per-id Python work for 10^6 rows */
+int phk_write_counts_csv_ucs4(const char *path, const char *prefix, const uint32_t *ids, uint64_t id_width,
+                              const void *counts, int elem_bytes, uint64_t n, uint64_t D);
+int phk_write_scores_csv_ucs4(const char *path, const char *prefix, const uint32_t *ids, uint64_t id_width,
+                              const double *scores, uint64_t n);
 /* one float64 in that notation (NUL-terminated) */
 int phk_format_float(double v, char *out, int cap);
 /* fileIO.read_feature_file (scripts/fileIO.py:134-166) for files of the shape save_counts writes: '#' comment lines

@@ -56,6 +56,8 @@ SIGNATURES = {
     "phk_batch_counts_u32": (c_int, [c_void_p, c_void_p, c_void_p]),
     "phk_write_counts_csv": (c_int, [c_char_p, c_char_p, c_void_p, c_void_p, c_void_p, c_int, c_u64, c_u64]),
     "phk_write_scores_csv": (c_int, [c_char_p, c_char_p, c_void_p, c_void_p, c_void_p, c_u64]),
+    "phk_write_counts_csv_ucs4": (c_int, [c_char_p, c_char_p, c_void_p, c_u64, c_void_p, c_int, c_u64, c_u64]),
+    "phk_write_scores_csv_ucs4": (c_int, [c_char_p, c_char_p, c_void_p, c_u64, c_void_p, c_u64]),
     "phk_format_float": (c_int, [c_double, c_char_p, c_int]),
     "phk_features_open": (c_int, [c_char_p, P(c_void_p), P(c_u64), P(c_u64), P(c_u64)]),
     "phk_features_read": (c_int, [c_void_p, c_void_p, c_void_p, c_u64]),
@@ -404,7 +406,8 @@ class Fasta(object):
         width = max(int(np.diff(offs.astype(np.int64)).max()), 1)
         fixed = np.zeros(n, dtype="S%d" % width)
         check(self.lib.phk_fasta_ids_fixed(self.handle, width, ptr(fixed)))
-        out = np.char.decode(fixed, "latin-1")
+        # latin-1 decode = code point identity: bytes -> uint32 -> 'U' view, without a Python loop over the ids
+        out = np.ascontiguousarray(fixed.view(np.uint8).reshape(n, width).astype(np.uint32)).view("U%d" % width)[:, 0]
         if (status == 2).any():
             out = out.astype(object)
             out[status == 2] = None

@@ -83,12 +83,29 @@ static int write_rows(const char *path, const char *prefix, uint64_t n, F fmt_ro
     return rc;
 }
 
-extern "C" int phk_write_counts_csv(const char *path, const char *prefix, const char *ids, const uint64_t *id_offsets,
-                                    const void *counts, int elem_bytes, uint64_t n, uint64_t D) {
-    PHK_REQUIRE(path && (n == 0 || (ids && id_offsets && counts)), "phk_write_counts_csv: NULL argument");
-    PHK_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "phk_write_counts_csv: counts must be uint32 or int64");
+// ids of the rows: concatenated bytes + offsets, or a NumPy 'U<width>' array as it lies in memory (UCS-4 code points,
+// NUL padded) -- written as str(id).encode('latin-1', 'replace') would write them, without a Python loop over 10^6 ids
+struct IdSource {
+    const char *blob;
+    const uint64_t *off;
+    const uint32_t *ucs4;
+    uint64_t width;
+    void append(uint64_t r, std::string &out) const {
+        if (ucs4) {
+            const uint32_t *p = ucs4 + r * width;
+            uint64_t l = width;
+            while (l && p[l - 1] == 0) --l;
+            for (uint64_t i = 0; i < l; ++i) out.push_back(p[i] < 256 ? (char)p[i] : '?');
+        } else {
+            out.append(blob + off[r], off[r + 1] - off[r]);
+        }
+    }
+};
+
+static int write_counts(const char *path, const char *prefix, IdSource ids, const void *counts, int elem_bytes, uint64_t n,
+                        uint64_t D) {
     return write_rows(path, prefix, n, [=](uint64_t r, std::string &out) {
-        out.append(ids + id_offsets[r], id_offsets[r + 1] - id_offsets[r]);
+        ids.append(r, out);
         char buf[24];
         for (uint64_t j = 0; j < D; ++j) {
             out.push_back(',');
@@ -101,6 +118,20 @@ extern "C" int phk_write_counts_csv(const char *path, const char *prefix, const 
         }
         out.push_back('\n');
     });
+}
+
+extern "C" int phk_write_counts_csv(const char *path, const char *prefix, const char *ids, const uint64_t *id_offsets,
+                                    const void *counts, int elem_bytes, uint64_t n, uint64_t D) {
+    PHK_REQUIRE(path && (n == 0 || (ids && id_offsets && counts)), "phk_write_counts_csv: NULL argument");
+    PHK_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "phk_write_counts_csv: counts must be uint32 or int64");
+    return write_counts(path, prefix, IdSource{ids, id_offsets, nullptr, 0}, counts, elem_bytes, n, D);
+}
+
+extern "C" int phk_write_counts_csv_ucs4(const char *path, const char *prefix, const uint32_t *ids, uint64_t id_width,
+                                         const void *counts, int elem_bytes, uint64_t n, uint64_t D) {
+    PHK_REQUIRE(path && (n == 0 || (ids && id_width && counts)), "phk_write_counts_csv_ucs4: NULL argument");
+    PHK_REQUIRE(elem_bytes == 4 || elem_bytes == 8, "phk_write_counts_csv_ucs4: counts must be uint32 or int64");
+    return write_counts(path, prefix, IdSource{nullptr, nullptr, ids, id_width}, counts, elem_bytes, n, D);
 }
 
 // str(numpy.float64) / Python repr: the shortest digit string that round-trips, laid out as Python does --
@@ -146,15 +177,25 @@ static void append_py_float(std::string &out, double v) {
     }
 }
 
-extern "C" int phk_write_scores_csv(const char *path, const char *prefix, const char *ids, const uint64_t *id_offsets,
-                                    const double *scores, uint64_t n) {
-    PHK_REQUIRE(path && (n == 0 || (ids && id_offsets && scores)), "phk_write_scores_csv: NULL argument");
+static int write_scores(const char *path, const char *prefix, IdSource ids, const double *scores, uint64_t n) {
     return write_rows(path, prefix, n, [=](uint64_t r, std::string &out) {
-        out.append(ids + id_offsets[r], id_offsets[r + 1] - id_offsets[r]);
+        ids.append(r, out);
         out += ", ";
         append_py_float(out, scores[r]);
         out.push_back('\n');
     });
+}
+
+extern "C" int phk_write_scores_csv(const char *path, const char *prefix, const char *ids, const uint64_t *id_offsets,
+                                    const double *scores, uint64_t n) {
+    PHK_REQUIRE(path && (n == 0 || (ids && id_offsets && scores)), "phk_write_scores_csv: NULL argument");
+    return write_scores(path, prefix, IdSource{ids, id_offsets, nullptr, 0}, scores, n);
+}
+
+extern "C" int phk_write_scores_csv_ucs4(const char *path, const char *prefix, const uint32_t *ids, uint64_t id_width,
+                                         const double *scores, uint64_t n) {
+    PHK_REQUIRE(path && (n == 0 || (ids && id_width && scores)), "phk_write_scores_csv_ucs4: NULL argument");
+    return write_scores(path, prefix, IdSource{nullptr, nullptr, ids, id_width}, scores, n);
 }
 
 extern "C" int phk_format_float(double v, char *out, int cap) {

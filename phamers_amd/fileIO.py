@@ -43,6 +43,20 @@ def _id_table(ids):
     return np.frombuffer(b''.join(raw) or b'\0', dtype=np.uint8), offsets
 
 
+def _ucs4_ids(ids, n_rows):
+    """A NumPy 'U' id array (what count_file / read_feature_file / the FASTA reader return) as the native writers take
+    it -- (code point matrix, width in characters) -- or None for any other kind of id sequence."""
+    a = ids if isinstance(ids, np.ndarray) else None
+    if a is None or a.dtype.kind != 'U' or a.ndim != 1 or a.dtype.itemsize == 0:
+        return None
+    if a.shape[0] != n_rows:
+        raise ValueError("%d ids for %d rows" % (a.shape[0], n_rows))
+    a = np.ascontiguousarray(a)
+    if not a.dtype.isnative:
+        a = a.astype(a.dtype.newbyteorder('='))
+    return a.view(np.uint32), a.dtype.itemsize // 4
+
+
 def _read_feature_file_native(feature_file):
     """(ids, int64 features) of a file of the shape save_counts writes, parsed on all cores by the native reader
     (np.loadtxt needs minutes for the features cache of 10^6 contigs); None for any other shape of file, which
@@ -70,7 +84,8 @@ def _read_feature_file_native(feature_file):
         _lib.check(rc)
     finally:
         lib.phk_features_close(handle)
-    ids = idb.view("S%d" % w.value)[:, 0].astype("U%d" % w.value)
+    # (ASCII bytes -> code points -> a 'U' view: no per-id Python work)
+    ids = np.ascontiguousarray(idb.astype(np.uint32)).view("U%d" % w.value)[:, 0]
     return ids, features
 
 
@@ -101,10 +116,15 @@ def save_counts(counts, ids, file_name, args=None, header='K-mer count file'):
     if counts.dtype not in (np.dtype(np.uint32), np.dtype(np.int64)):
         counts = counts.astype(np.int64)
     counts = np.ascontiguousarray(counts)
+    lib = _lib.load()
+    u = _ucs4_ids(ids, counts.shape[0])
+    if u is not None:
+        _lib.check(lib.phk_write_counts_csv_ucs4(str(file_name).encode(), _comment_block(header), _lib.ptr(u[0]), u[1],
+                                                 _lib.ptr(counts), counts.dtype.itemsize, counts.shape[0], counts.shape[1]))
+        return
     idb, ido = _id_table(ids)
     if len(ido) - 1 != counts.shape[0]:
         raise ValueError("%d ids for %d rows" % (len(ido) - 1, counts.shape[0]))
-    lib = _lib.load()
     _lib.check(lib.phk_write_counts_csv(str(file_name).encode(), _comment_block(header), _lib.ptr(idb), _lib.ptr(ido),
                                         _lib.ptr(counts), counts.dtype.itemsize, counts.shape[0], counts.shape[1]))
 
@@ -115,10 +135,15 @@ def save_phamer_scores(ids, scores, file_name, args=None):
     if args is not None:
         header = generate_summary(args, header=header)
     scores = np.ascontiguousarray(scores, dtype=np.float64)
+    lib = _lib.load()
+    u = _ucs4_ids(ids, scores.shape[0])
+    if u is not None:
+        _lib.check(lib.phk_write_scores_csv_ucs4(str(file_name).encode(), _comment_block(header), _lib.ptr(u[0]), u[1],
+                                                 _lib.ptr(scores), scores.shape[0]))
+        return
     idb, ido = _id_table(ids)
     if len(ido) - 1 != scores.shape[0]:
         raise ValueError("%d ids for %d scores" % (len(ido) - 1, scores.shape[0]))
-    lib = _lib.load()
     _lib.check(lib.phk_write_scores_csv(str(file_name).encode(), _comment_block(header), _lib.ptr(idb), _lib.ptr(ido),
                                         _lib.ptr(scores), scores.shape[0]))
 
