@@ -418,34 +418,53 @@ __global__ __launch_bounds__(256) void phk_count_stats_kernel(const uint64_t *__
 // 1024-window stages (descending: the longest groups start first, the short tail fills the machine at the end) makes
 // every group homogeneous.  Three small kernels, all gated ON THE DEVICE by the batch statistics: for a batch that is
 // not ragged they return at once (no host round trip decides this).
-//   key(c) = min(ceil(W_c / 1024), SORT_KEYS - 1), 0 for contigs handed over (they do no work in the slot kernel)
+// What is sorted are work ITEMS (contig, piece): a contig of more than long_thr windows is cut into pieces of piece_w
+// windows, each an item of its own with its own histogram column in the slot kernel, added onto the contig's (zeroed) row
+// with atomics at the flush -- one 500 kb contig is shared by 15 columns instead of setting the length of its group.
+//   key(item) = min(ceil(W_item / 1024), SORT_KEYS - 1)
 // ------------------------------------------------------------------------------------
 #define SORT_KEYS 2048
-__device__ __forceinline__ uint32_t phk_sort_key(const uint64_t *offsets, uint64_t c, int k, uint32_t long_thr) {
-    const uint64_t len = offsets[c + 1] - offsets[c];
-    const uint64_t w = len >= (uint64_t)k ? len - k + 1 : 0;
-    if (w > long_thr) return 0;
+__device__ __forceinline__ uint32_t phk_windows_key(uint64_t w) {
     const uint64_t key = (w + 1023) >> 10;
     return (uint32_t)(key < SORT_KEYS - 1 ? key : SORT_KEYS - 1);
 }
+// windows of contig c and the number of items it is cut into (1: counted whole)
+__device__ __forceinline__ uint64_t phk_contig_windows(const uint64_t *offsets, uint64_t c, int k, uint32_t long_thr,
+                                                       uint32_t piece_w, uint32_t &pieces) {
+    const uint64_t len = offsets[c + 1] - offsets[c];
+    const uint64_t w = len >= (uint64_t)k ? len - k + 1 : 0;
+    pieces = (w > long_thr && piece_w) ? (uint32_t)((w + piece_w - 1) / piece_w) : 1u;
+    return w;
+}
+// windows of piece pc of a contig of w windows cut into `pieces`
+__device__ __forceinline__ uint64_t phk_piece_windows(uint64_t w, uint32_t pieces, uint32_t pc, uint32_t piece_w) {
+    if (pieces == 1) return w;
+    return pc + 1 < pieces ? (uint64_t)piece_w : w - (uint64_t)(pieces - 1) * piece_w;
+}
 
 __global__ __launch_bounds__(256) void phk_sort_hist_kernel(const uint64_t *__restrict__ offsets, uint64_t n, int k,
-                                                            uint32_t long_thr, const unsigned long long *__restrict__ stats,
+                                                            uint32_t long_thr, uint32_t piece_w,
+                                                            const unsigned long long *__restrict__ stats,
                                                             uint32_t *__restrict__ hist) {
     if (phk_slots_apply(stats)) return;
     __shared__ uint32_t h[SORT_KEYS];
     for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x) h[i] = 0;
     __syncthreads();
-    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (uint64_t)gridDim.x * blockDim.x)
-        atomicAdd(&h[phk_sort_key(offsets, c, k, long_thr)], 1u);
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t np;
+        const uint64_t w = phk_contig_windows(offsets, c, k, long_thr, piece_w, np);
+        if (np > 1) atomicAdd(&h[phk_windows_key(piece_w)], np - 1);
+        atomicAdd(&h[phk_windows_key(phk_piece_windows(w, np, np - 1, piece_w))], 1u);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x)
         if (h[i]) atomicAdd(hist + i, h[i]);
 }
 
-// cursor[key] = number of contigs with a LARGER key (descending order); one block
+// cursor[key] = number of items with a LARGER key (descending order); *n_items = their total; one block
 __global__ __launch_bounds__(1024) void phk_sort_scan_kernel(const unsigned long long *__restrict__ stats,
-                                                             uint32_t *__restrict__ hist /* in: counts, out: cursors */) {
+                                                             uint32_t *__restrict__ hist /* in: counts, out: cursors */,
+                                                             uint32_t *__restrict__ n_items) {
     if (phk_slots_apply(stats)) return;
     __shared__ uint32_t v[SORT_KEYS];
     for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x) v[i] = hist[SORT_KEYS - 1 - i];   // descending keys
@@ -457,28 +476,47 @@ __global__ __launch_bounds__(1024) void phk_sort_scan_kernel(const unsigned long
             v[i] = run;
             run += cnt;
         }
+        *n_items = run;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x) hist[SORT_KEYS - 1 - i] = v[i];
 }
 
-// every block reserves, per key, a range for its contigs with one global atomic, then places them
+// every block reserves, per key, a range for its items with one global atomic, then places them; the row (and window
+// count) of a contig that is cut into pieces is zeroed here, ahead of the pieces' atomic adds
 __global__ __launch_bounds__(256) void phk_sort_scatter_kernel(const uint64_t *__restrict__ offsets, uint64_t n, int k,
-                                                               uint32_t long_thr, const unsigned long long *__restrict__ stats,
-                                                               uint32_t *__restrict__ cursor, uint32_t *__restrict__ order) {
+                                                               uint32_t long_thr, uint32_t piece_w,
+                                                               const unsigned long long *__restrict__ stats,
+                                                               uint32_t *__restrict__ cursor, uint2 *__restrict__ items,
+                                                               uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin) {
     if (phk_slots_apply(stats)) return;
     __shared__ uint32_t h[SORT_KEYS];   // per-block count, then the block's base position, per key
     const uint64_t per_block = (n + gridDim.x - 1) / gridDim.x;
     const uint64_t lo = per_block * blockIdx.x, hi = lo + per_block < n ? lo + per_block : n;
+    const uint64_t D = 1ull << (2 * k);
     for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x) h[i] = 0;
     __syncthreads();
-    for (uint64_t c = lo + threadIdx.x; c < hi; c += blockDim.x) atomicAdd(&h[phk_sort_key(offsets, c, k, long_thr)], 1u);
+    for (uint64_t c = lo + threadIdx.x; c < hi; c += blockDim.x) {
+        uint32_t np;
+        const uint64_t w = phk_contig_windows(offsets, c, k, long_thr, piece_w, np);
+        if (np > 1) atomicAdd(&h[phk_windows_key(piece_w)], np - 1);
+        atomicAdd(&h[phk_windows_key(phk_piece_windows(w, np, np - 1, piece_w))], 1u);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x)
         if (h[i]) h[i] = atomicAdd(cursor + i, h[i]);
     __syncthreads();
-    for (uint64_t c = lo + threadIdx.x; c < hi; c += blockDim.x)
-        order[atomicAdd(&h[phk_sort_key(offsets, c, k, long_thr)], 1u)] = (uint32_t)c;
+    for (uint64_t c = lo + threadIdx.x; c < hi; c += blockDim.x) {
+        uint32_t np;
+        const uint64_t w = phk_contig_windows(offsets, c, k, long_thr, piece_w, np);
+        for (uint32_t pc = 0; pc < np; ++pc)
+            items[atomicAdd(&h[phk_windows_key(phk_piece_windows(w, np, pc, piece_w))], 1u)] = make_uint2((uint32_t)c, pc);
+        if (np > 1) {
+            uint4 *row = reinterpret_cast<uint4 *>(counts + c * D);
+            for (uint64_t i = 0; i < D / 4; ++i) row[i] = make_uint4(0, 0, 0, 0);
+            if (nwin) nwin[c] = 0;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -527,8 +565,8 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                                                              uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin,
                                                              uint2 *__restrict__ long_list,
                                                              uint32_t *__restrict__ long_count,
-                                                             const uint32_t *__restrict__ order,   // length-bucketed contig order (ragged batches), or NULL
-                                                             uint32_t piece_w) {                    // windows per hand-over piece (0: whole contigs)
+                                                             const uint2 *__restrict__ order,      // length-bucketed (contig, piece) items (ragged batches), or NULL
+                                                             uint32_t piece_w) {                    // windows per piece (0: whole contigs)
     constexpr uint32_t D = 1u << (2 * K);
     constexpr int CH = 8 * SLOT_LINES;      // 4-word chunks per contig and stage
     constexpr int PARTS = NTH / SLOTS;      // lanes per contig
@@ -540,10 +578,12 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
     uint32_t *stage = lds + D * SLOTS;
     uint32_t *smax_p = stage + 2 * SLOTS * SLOT_ROW;
     uint32_t *nwin_s = smax_p + 4;   // [SLOTS] counted windows per contig (MASK)
+    uint32_t *split_s = nwin_s + SLOTS;   // [SLOTS] contig id + 1 of a slot that holds a PIECE (its column is added atomically), else 0
     // a batch in arbitrary order whose groups of SLOTS contigs are ragged is walked in the length-bucketed order the
     // sort kernels prepared; without one (count_sort off) the kernel stands down and the wave-per-contig kernel counts
     if (phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) order = nullptr;
     else if (!order) return;
+    if (order) n = long_count[1];   // the work list of a ragged batch: items, counted by the sort kernels
     const int t = threadIdx.x, lane = t & 63;
     const int slot = t & (SLOTS - 1), part = t / SLOTS;          // counting role: contig slot, chunk (mod PARTS) within the stage
     for (uint32_t b = t * 4; b < D * SLOTS; b += 4 * NTH) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
@@ -574,11 +614,22 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
         // ---- counting role: this lane's contig ----
         const uint64_t ci = batch * SLOTS + slot;
         const bool have = ci < n;
-        const uint64_t c = have ? (order ? (uint64_t)order[ci] : ci) : 0;
-        const uint64_t st = have ? offsets[c] : 0, en = have ? offsets[c + 1] : 0;
+        const uint2 item = (have && order) ? order[ci] : make_uint2(0, 0);
+        const uint64_t c = have ? (order ? (uint64_t)item.x : ci) : 0;
+        uint64_t st = have ? offsets[c] : 0;
+        const uint64_t en = have ? offsets[c + 1] : 0;
         const uint64_t len = en - st;
         uint32_t W = len >= (uint64_t)K ? (uint32_t)((len - K + 1) < 0xFFFFFFFFull ? (len - K + 1) : 0xFFFFFFFFull) : 0;
-        const bool handed_over = W > long_thr;
+        // an item of the sorted work list is a whole contig or one piece of a long one: the piece's windows start at
+        // st + piece * piece_w, and its histogram is added onto the contig's row (zeroed by the sort) at the flush
+        const bool split = order && piece_w && W > long_thr;
+        if (split) {
+            const uint64_t first = (uint64_t)item.y * piece_w;
+            st += first;
+            W = (uint32_t)((uint64_t)W - first < piece_w ? (uint64_t)W - first : piece_w);
+        }
+        const bool handed_over = !order && W > long_thr;
+        if (order && part == 0) split_s[slot] = split ? (uint32_t)c + 1u : 0u;
         if (handed_over) {
             if (part == 0) {   // as pieces of piece_w windows (each its own work item of the wave-per-contig kernel) or whole
                 const uint32_t np = piece_w ? (W + piece_w - 1) / piece_w : 1u;
@@ -607,7 +658,18 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const uint64_t cl = batch * SLOTS + (uint32_t)(t + NTH * i) / CH;
-            lw0[i] = cl < n ? (offsets[order ? (uint64_t)order[cl] : cl] >> 6) * 4 : 0;   // first word of its first chunk
+            uint64_t first = 0;   // first base of the item whose lines this thread stages
+            if (cl < n) {
+                if (order) {
+                    const uint2 it = order[cl];
+                    const uint64_t s0 = offsets[it.x], ln = offsets[it.x + 1] - s0;
+                    const bool cut = piece_w && ln >= (uint64_t)K && ln - K + 1 > long_thr;
+                    first = s0 + (cut ? (uint64_t)it.y * piece_w : 0);
+                } else {
+                    first = offsets[cl];
+                }
+            }
+            lw0[i] = (first >> 6) * 4;   // first word of its first chunk
         }
         auto gload = [&](uint32_t s, uint4 (&v)[LPT], uint32_t (&la)[LPT]) {   // 16 bytes each (+ a look-ahead word)
 #pragma unroll
@@ -730,6 +792,22 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
         }
         if (MASK && cnt_ok) atomicAdd(nwin_s + slot, cnt_ok);
         phk_lds_barrier();  // every wave's adds have landed
+        // ---- pieces first: wave w adds the columns of slots w, w + NTH/64, .. onto their contigs' rows, 64 consecutive
+        // codes per instruction (the reads of a column are a 64-way bank conflict -- 4 KB per column, a few thousand LDS
+        // cycles per batch -- but the global atomics are coalesced: from the per-(slot, group) threads below they went
+        // out as 8192 scattered single-dword atomics per batch, which tripled the time of a batch of pieces)
+        if (order) {
+            for (int sl = t >> 6; sl < SLOTS; sl += NTH / 64) {
+                const uint32_t cs = split_s[sl];
+                if (!cs) continue;
+                uint32_t *rowp = counts + (uint64_t)(cs - 1u) * D;
+                for (uint32_t code = lane; code < D; code += 64) {
+                    const uint32_t v = lds[code * SLOTS + sl];
+                    if (v) atomicAdd(rowp + code, v);
+                }
+            }
+            phk_lds_barrier();
+        }
         // ---- flush: thread (slot, group g) writes codes [g D/PARTS, (g+1) D/PARTS) of contig `slot` and clears them ----
         {
             const int g = part;
@@ -741,9 +819,12 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                 const uint4 o = make_uint4(cell[0], cell[SLOTS], cell[2 * SLOTS], cell[3 * SLOTS]);
                 cell[0] = 0; cell[SLOTS] = 0; cell[2 * SLOTS] = 0; cell[3 * SLOTS] = 0;
                 // (a contig handed over in pieces gets its zero row here: the pieces are added onto it atomically)
-                if (have && (!handed_over || piece_w)) *reinterpret_cast<uint4 *>(rowo + 4 * i) = o;
+                if (!split && have && (!handed_over || piece_w)) *reinterpret_cast<uint4 *>(rowo + 4 * i) = o;
             }
-            if (nwin && have && (!handed_over || piece_w) && g == 0) nwin[c] = MASK ? nwin_s[slot] : W;
+            if (nwin && have && g == 0) {
+                if (split) atomicAdd(nwin + c, MASK ? nwin_s[slot] : W);
+                else if (!handed_over || piece_w) nwin[c] = MASK ? nwin_s[slot] : W;
+            }
         }
         phk_lds_barrier();
         if (MASK && t < SLOTS) nwin_s[t] = 0;
@@ -876,10 +957,12 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         // piece), then the sort's key cursors and the contig order
         const uint64_t max_items = n + (piece_w ? T / piece_w : 0) + 16;
         void *ws;
-        PHK_TRY(phk_ws(ctx, WS_LONG, (16 + 2 * max_items + SORT_KEYS + n + 16) * sizeof(uint32_t), &ws));
+        // ([1] = number of (contig, piece) items of a sorted batch)
+        PHK_TRY(phk_ws(ctx, WS_LONG, (16 + 2 * max_items + SORT_KEYS + 2 * max_items + 16) * sizeof(uint32_t), &ws));
         uint32_t *d_long_count = (uint32_t *)ws;
         uint2 *d_long_list = (uint2 *)((uint32_t *)ws + 16);
-        uint32_t *d_cursor = (uint32_t *)ws + 16 + 2 * max_items, *d_order = d_cursor + SORT_KEYS;
+        uint32_t *d_cursor = (uint32_t *)ws + 16 + 2 * max_items;
+        uint2 *d_order = (uint2 *)(d_cursor + SORT_KEYS);
         PHK_HIP(hipMemsetAsync(d_long_count, 0, 64, ctx->stream));
         if (lanes_knob != '2')  // count_lanes=2: slot kernel whatever the batch looks like (tests)
         PHK_LAUNCH(ctx, "phk_count_stats_kernel",
@@ -891,17 +974,19 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
             uint64_t sb = phk_div_up(n, 2048);
             sb = sb > 1024 ? 1024 : (sb < 1 ? 1 : sb);
             PHK_LAUNCH(ctx, "phk_sort_hist_kernel",
-                       phk_sort_hist_kernel<<<dim3((unsigned)sb), dim3(256), 0, ctx->stream>>>(d_offsets, n, k, long_thr, st, d_cursor));
-            PHK_LAUNCH(ctx, "phk_sort_scan_kernel", phk_sort_scan_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(st, d_cursor));
+                       phk_sort_hist_kernel<<<dim3((unsigned)sb), dim3(256), 0, ctx->stream>>>(d_offsets, n, k, long_thr, piece_w, st, d_cursor));
+            PHK_LAUNCH(ctx, "phk_sort_scan_kernel",
+                       phk_sort_scan_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(st, d_cursor, d_long_count + 1));
             PHK_LAUNCH(ctx, "phk_sort_scatter_kernel",
-                       phk_sort_scatter_kernel<<<dim3((unsigned)sb), dim3(256), 0, ctx->stream>>>(d_offsets, n, k, long_thr, st, d_cursor, d_order));
+                       phk_sort_scatter_kernel<<<dim3((unsigned)sb), dim3(256), 0, ctx->stream>>>(d_offsets, n, k, long_thr, piece_w, st,
+                                                                                                  d_cursor, d_order, d_counts, d_nwin));
         }
-        const uint32_t *d_ord = sorted ? d_order : nullptr;
-        const size_t lds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * SLOT_ROW * 4 + 16 + slots * 4;
+        const uint2 *d_ord = sorted ? d_order : nullptr;
+        const size_t lds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * SLOT_ROW * 4 + 16 + 2 * slots * 4;
         // resident blocks per CU: the LDS allocation granule keeps a block that would exactly fill the 160 KiB out
         const unsigned fit = (unsigned)((160u * 1024u - 1024u) / lds);
         const unsigned per_cu = fit > 8 ? 8 : fit;
-        uint64_t blocks = phk_div_up(n, slots);
+        uint64_t blocks = phk_div_up(sorted ? max_items : n, slots);   // (a sorted batch works on items; surplus workgroups leave)
         const uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
         if (blocks > cap) blocks = cap;
 #define PHK_SLOTS(K_, S_, T_)                                                                                               \
