@@ -535,8 +535,9 @@ __global__ __launch_bounds__(256) void phk_sort_scatter_kernel(const uint64_t *_
 // line -- and each of the 8 lanes that serve a contig then counts the 64 windows starting in one 4-word
 // chunk of it.  Chunks are word aligned, so no funnel shift is needed; windows outside [start, last
 // window] only occur in a contig's first and last chunk, which take a predicated copy of the loop.
-// A workgroup runs as many stages as its longest contig needs, so contigs much longer than the batch
-// mean are not counted here: they are appended to `long_list` for the wave-per-contig kernel, which follows.
+// A workgroup runs as many stages as its longest contig needs.  In a batch of similar lengths the few contigs much
+// longer than the mean are appended to `long_list` for the wave-per-contig kernel, which follows; a ragged batch is
+// walked as a sorted list of (contig, piece) items, a long contig being cut into pieces that are columns like any other.
 // ------------------------------------------------------------------------------------
 #ifndef SLOT_LINES
 #define SLOT_LINES 2                       // 128-byte lines per contig and stage
