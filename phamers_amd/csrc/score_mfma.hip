@@ -2064,18 +2064,22 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             }
             const dim3 dg((unsigned)phk_div_up(nb, 64)), db(64);
             const bool d_knn = (p.method & PHK_METHOD_KNN) != 0, d_cen = (p.method & PHK_METHOD_KMEANS) != 0;
+            // the high-parts-only kernel issues D/16 MFMAs per value, not the count-exact kernel's 2D/16: cQ = 2 (D/16 + 1) + 1
+            // (the low product the decision stage adds has its own term, see phk_decide_h_kernel)
+            RerankParams pd = p;
+            pd.eb_cQ = 2.0 * ((double)D / 16.0 + 1.0) + 1.0;
             if (d_knn && d_cen) {
-                PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<true, true><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, p, hp)));
+                PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<true, true><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, pd, hp)));
             } else if (d_knn) {
-                PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<true, false><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, p, hp)));
+                PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<true, false><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, pd, hp)));
             } else {
-                PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<false, true><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, p, hp)));
+                PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<false, true><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, pd, hp)));
             }
             // what it passes on is decided from the same lists by exact candidate distances where possible.  For that
             // kernel the lists' error model is the count-exact one plus the missing low product, |q'| |lo_j| / S with
             // |lo_j| <= 2^-11 (1 + 2^-11) S |r'_j| + sqrt(D) 2^-25 (half an ulp of the high part per element; the
             // second term covers fp16 subnormals): 2^-11 / u = 8192 more on cP, the absolute term doubled
-            RerankParams ph = p;
+            RerankParams ph = pd;
             ph.eb_cP += 8192.0 * (1.0 + 1.0 / 2048.0) + 1.0;
             ph.eb_abs *= 2.0;
             ph.slow_back = 3;   // front and back list in one launch
