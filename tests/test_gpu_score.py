@@ -642,3 +642,43 @@ def test_column_mask_and_centroid_update_equal_a_fresh_model():
         assert np.array_equal(full.score(q, method), before[method]), method
     full.close()
     fresh.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_train", [40, 300, 1111])
+def test_second_chance_column_parts_for_small_and_uneven_references(n_train):
+    """Several hundred rows with counts above 2048 (long contigs) against references of 2 / 10 / 35 column blocks per
+    class half: the second-chance sweep runs whole (fewer blocks than parts), in parts of one or two blocks, and in uneven
+    parts; every score equals the float64 brute-force path's."""
+    from phamers_amd import _lib, device
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    pos, neg = pos[:n_train], neg[:n_train // 2 + 7]
+    ctx = _lib.get_context()
+    model = _lib.Model(ctx, pos, neg, g["cpos_eq"], g["cneg_eq"], 3)
+    rng = np.random.default_rng(23)
+    base = np.vstack([pos, neg])
+    n = 700
+    rows = base[rng.integers(0, len(base), n)]
+    T = rng.integers(3000, 9000, n)
+    T[::2] = rng.integers(600000, 2000000, (n + 1) // 2)      # every other row: a contig of megabases
+    counts = np.stack([rng.multinomial(t, r) for t, r in zip(T, rows)]).astype(np.uint32)
+    d_counts = device.DeviceArray.from_host(ctx, counts)
+    out = {}
+    for path in ("fast", "exact"):
+        ctx.set_option("force_exact", "1" if path == "exact" else "0")
+        for method in ("knn", "kmeans", "combo"):
+            d_scores = device.DeviceArray(ctx, n, np.float64)
+            d_status = device.DeviceArray.from_host(ctx, np.zeros(1, np.uint32))
+            device.score_counts(ctx, model, d_counts, n, method, d_scores, d_status)
+            out[(path, method)] = d_scores.to_host()
+            assert d_status.to_host()[0] == 0
+            if path == "fast":
+                stats = ctx.score_stats_ex()
+                assert stats["second_chance"] >= n // 2, stats            # the big rows took the second chance ...
+                assert stats["brute_forced"] < 24, stats                  # ... and next to nothing was brute-forced
+    ctx.set_option("force_exact", "0")
+    assert np.array_equal(out[("fast", "knn")], out[("exact", "knn")])
+    assert helpers.rel_err(out[("fast", "kmeans")], out[("exact", "kmeans")]) < 1e-9
+    assert helpers.rel_err(out[("fast", "combo")], out[("exact", "combo")]) < 1e-9
+    model.close()
