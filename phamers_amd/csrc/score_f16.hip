@@ -897,6 +897,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
         // insertions away from the MFMAs they are meant to hide behind); the bias piece is fetched by every wave
 #pragma unroll
         for (int k = 0; k < 16 / NW + 1; ++k) {
+            if (k == 16 / NW && wave != (int)(blk % NW)) break;   // the bias piece: one wave's job, taken in turn
             const int p = k < 16 / NW ? wave + NW * k : 16;
             const uint4 *gp = g + p * 64;
             const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
