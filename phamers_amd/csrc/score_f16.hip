@@ -977,15 +977,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
         // of a 4000-column sweep are skipped (2.39 -> 2.23 ms on configs[1]).  The branch is uniform; the MFMAs stay one
         // per basic block.
         if (__builtin_amdgcn_ballot_w64(x > lv[t][4]) == 0) return;
-        const float n4 = __builtin_amdgcn_fmed3f(lv[t][3], lv[t][4], x);
-        const float n3 = __builtin_amdgcn_fmed3f(lv[t][2], lv[t][3], x);
-        const float n2 = __builtin_amdgcn_fmed3f(lv[t][1], lv[t][2], x);
-        const float n1 = __builtin_amdgcn_fmed3f(lv[t][0], lv[t][1], x);
-        lv[t][0] = __builtin_amdgcn_fmed3f(lv[t][0], x, fbig);
-        lv[t][1] = n1;
-        lv[t][2] = n2;
-        lv[t][3] = n3;
-        lv[t][4] = n4;
+        // in place, last slot first (slot c takes med3(slot c-1, slot c, x), both still the old values): as builtins the
+        // five results are temporaries that the join after the skip has to move into the list's registers -- 129 v_mov
+        // per block iteration, a quarter of its vector instructions
+        asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(lv[t][4]) : "v"(lv[t][3]), "v"(x));
+        asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(lv[t][3]) : "v"(lv[t][2]), "v"(x));
+        asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(lv[t][2]) : "v"(lv[t][1]), "v"(x));
+        asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(lv[t][1]) : "v"(lv[t][0]), "v"(x));
+        asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(lv[t][0]) : "v"(x), "v"(fbig));
     };
 
     // Software pipeline inside the wave, per segment: while block i's MFMAs fill one accumulator set, the VALU
