@@ -7,7 +7,9 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int LDSR, int INS, int NW>
+// HI = 1: the high-parts-only kernel's loop -- one MFMA per value (2 per k-step), one fragment read per step;
+// INS = 2: insertions under the wave-uniform skip
+template <int LDSR, int INS, int NW, int HI = 0>
 __global__ __launch_bounds__(64 * NW, 1) void k(const float *in, float *out, int iters) {
     __shared__ __attribute__((aligned(16))) uint8_t smem[33 * 1024];
     const int lane = threadIdx.x & 63;
@@ -30,6 +32,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k(const float *in, float *out, int
     auto insert = [&](int t, float a, float b, int r) {
         const float w = fmaf(negT[t], b, a);
         const float x = __uint_as_float((__float_as_uint(w) & ~31u) | (uint32_t)(2 * r + 1));
+        if (INS == 2 && __builtin_amdgcn_ballot_w64(x > lv[t][4]) == 0) return;
         const float n4 = __builtin_amdgcn_fmed3f(lv[t][3], lv[t][4], x);
         const float n3 = __builtin_amdgcn_fmed3f(lv[t][2], lv[t][3], x);
         const float n2 = __builtin_amdgcn_fmed3f(lv[t][1], lv[t][2], x);
@@ -55,13 +58,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k(const float *in, float *out, int
             } else {
                 for (int t = 0; t < 2; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], cur[t], 0, 0, 0);
             }
-            for (int t = 0; t < 2; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[t][s], cur[t], 0, 0, 0);
+            if (!HI)
+                for (int t = 0; t < 2; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[t][s], cur[t], 0, 0, 0);
             if (INS)
                 for (int t = 0; t < 2; ++t) insert(t, prev[t][s], bias[s], s);
-            for (int gi = 0; gi < 4; ++gi) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-            }
+            if (INS != 2)
+                for (int gi = 0; gi < (HI ? 2 : 4); ++gi) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, HI ? 8 : 4, 0);
+                }
         }
     };
 #pragma unroll 1
@@ -169,19 +174,19 @@ static void run16(const float *din, float *d, const char *name) {
            16384.0 * mf * NW * grid / (ms * 1e-3) / 1e12);
 }
 
-template <int LDSR, int INS, int NW>
+template <int LDSR, int INS, int NW, int HI = 0>
 static void run(const float *din, float *d, const char *name) {
     const int iters = 600, grid = 256;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    k<LDSR, INS, NW><<<grid, 64 * NW>>>(din, d, 20);
+    k<LDSR, INS, NW, HI><<<grid, 64 * NW>>>(din, d, 20);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<LDSR, INS, NW><<<grid, 64 * NW>>>(din, d, iters);
+    k<LDSR, INS, NW, HI><<<grid, 64 * NW>>>(din, d, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double mf = (double)iters * 64;            // MFMAs per wave
+    const double mf = (double)iters * (HI ? 32 : 64);            // MFMAs per wave
     const double wps = NW / 4.0;
     printf("%-28s waves/SIMD=%g : %7.3f ms  %6.2f ns per MFMA per SIMD  (%.0f TFLOP/s)\n", name, wps, ms,
            ms * 1e6 / (mf * wps), 32768.0 * mf * NW * grid / (ms * 1e-3) / 1e12);
@@ -201,6 +206,9 @@ int main() {
     run<1, 0, 8>(din, d, "mfma + lds reads");
     run<0, 1, 8>(din, d, "mfma + insertions");
     run<1, 1, 8>(din, d, "mfma + lds + insertions");
+    run<1, 0, 8, 1>(din, d, "HI: mfma + lds reads");
+    run<1, 1, 8, 1>(din, d, "HI: + insertions");
+    run<1, 2, 8, 1>(din, d, "HI: + insertions w/ skip");
     run16<0, 0, 4>(din, d, "mfma only");
     run16<1, 1, 4>(din, d, "mfma + lds + ins");
     run16<0, 0, 8>(din, d, "mfma only");
