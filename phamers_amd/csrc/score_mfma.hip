@@ -1191,8 +1191,9 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
 //       window   every column whose true value can be among the `need` best has  w^h >= h_need - 2 e_h,  h_need = the
 //                need-th best high-part value.  Columns in the window must all be list members: the best value either
 //                half-list dropped has to be below the window, else the query takes the second chance.
-//       refine   the window's members (3 to 8 columns, typically 3 or 4) get the low product in float64, 16 lanes per
-//                query, from the row-major low parts (512 B per column, L2 resident); they then carry count-exact
+//       refine   the window's members (3 to 8 columns, typically 3 or 4) get the low product -- float32 v_fma_mix on the
+//                float64-centred counts, 16 lanes per query, from the low parts stored in G16 order (512 B per column);
+//                its 20 roundings are bounded inside the test (2^-19 |q'| lam*).  They then carry count-exact
 //                values and the count-exact margin test decides their order exactly as phk_decide_kernel does.
 //       centroid segments (need = 1): the leader is certified by its high-part margin (h_1 - h_2 > 2 e_h; both are list
 //                members: each half-list keeps its 4 best) and its exact float64 distance is computed as before; a
