@@ -154,18 +154,22 @@ def cpu_baseline(k, L, pos, neg, cpos, cneg, budget_s=12.0, pool=None):
     return out
 
 
-def latest_traffic(kernel):
-    """HBM bytes per contig of `kernel` from the newest profiles/r*/traffic.json that has it (PMC measurement of
-    this same command, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, corrected as MI355X_MICROARCH.md
-    prescribes)."""
-    for tfile in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", "traffic.json")), reverse=True):
+def latest_traffic(kernel, config=1):
+    """HBM bytes per contig of `kernel` from the newest profiles/r*/traffic*.json of this configuration that has it
+    (PMC measurement of this same command, FETCH_SIZE / WRITE_SIZE in separate rocprofv3 passes, corrected as
+    MI355X_MICROARCH.md prescribes).  Returns (bytes per contig, source file, {kernel: bytes per contig} of that
+    file)."""
+    name = "traffic.json" if config == 1 else "traffic_config%d.json" % config
+    for tfile in sorted(glob.glob(os.path.join(REPO, "profiles", "r*", name)), reverse=True):
         try:
-            tk = json.load(open(tfile)).get("kernels", {}).get(kernel)
+            ks = json.load(open(tfile)).get("kernels", {})
         except (OSError, ValueError):
             continue
+        tk = ks.get(kernel)
         if tk:
-            return tk["hbm_bytes_per_contig"], os.path.relpath(tfile, REPO)
-    return None, None
+            per = {kn: v["hbm_bytes_per_contig"] for kn, v in ks.items() if "synth" not in kn}
+            return tk["hbm_bytes_per_contig"], os.path.relpath(tfile, REPO), per
+    return None, None, None
 
 
 def main():
@@ -185,13 +189,48 @@ def main():
                     help="uniform: the BASELINE configuration (fixed-length, uniform i.i.d. contigs; the headline). "
                          "ragged: heavy-tailed lengths 5-500 kb in arbitrary order, per-contig GC 0.3-0.7, 0.1 %% N -- "
                          "a second, separately labelled workload; --contigs defaults to 200000 there")
-    ap.add_argument("--min-seconds", type=float, default=0.0,
-                    help="keep stepping (in multiples of --steps) until the timed region is at least this long")
+    ap.add_argument("--min-seconds", type=float, default=3.0,
+                    help="time at least this long: the timed region is max(--steps, enough steps to fill it), so that a "
+                         "millisecond-scale step is measured at the sustained clock (and is visible to an outside "
+                         "GPU-activity sampler); 0 = exactly --steps")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, form the process group, all-gather the rank ids and print the line's "
+                         "n_gpus / ranks_seen; no GPU work (what the CPU test of the launcher runs, over gloo)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` started plainly (no RANK in the environment): this process becomes the launcher.  It
+    # starts the N ranks as CHILD processes before anything here touches the GPU (counting devices does not), hands
+    # through rank 0's JSON line and exits with the ranks' status.  Under torch.distributed.run RANK is set and this
+    # branch is not taken.  With fewer than N devices visible nothing is measured (exit code 2); PHK_BENCH_BACKEND=gloo
+    # lifts that check to rehearse the multi-rank code path with several ranks on one device (or, with
+    # --rendezvous-only, on none).
+    backend = os.environ.get("PHK_BENCH_BACKEND", "nccl")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        from phamers_amd import dist as pdist
+        sys.exit(pdist.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                    require_gpus=(backend == "nccl")))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world_env != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world_env))
+        sys.exit(2)
+    if args.rendezvous_only:
+        import torch.distributed as tdist
+        from phamers_amd import dist as pdist
+        rank = int(os.environ.get("RANK", "0"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        tdist.init_process_group("gloo", rank=rank, world_size=world_env)
+        seen = pdist.ranks_seen()
+        tdist.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world_env, "ranks_seen": seen, "backend": "gloo",
+                              "launched_by": os.environ.get("PHK_LAUNCHED_BY", "torch.distributed.run")}))
+        tdist.destroy_process_group()
+        return
 
     # worker processes of the all-core CPU baseline: forked now, before anything initialises the GPU in this process
     pool = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+    if world_env == 1 and args.gpus == 1 and not args.no_cpu_baseline:
         import multiprocessing as mp
         # the job's CPU share (a 1-GPU box allots 16 of the host's cores), not the host's core count
         try:
@@ -206,6 +245,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     ndev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if backend == "nccl" and ndev < local_world:
+        sys.stderr.write("bench.py: %d rank(s) on this node but %d GPU(s) visible -- not measuring\n" % (local_world, ndev))
+        sys.exit(2)
     local_dev = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -215,11 +258,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         # RCCL over xGMI in production; PHK_BENCH_BACKEND=gloo only to rehearse the multi-rank code path
         # with several ranks sharing one GPU (RCCL refuses duplicate devices)
-        backend = os.environ.get("PHK_BENCH_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    seen = 1
+    if dist:
+        from phamers_amd import dist as pdist
+        seen = pdist.ranks_seen(device=dev if backend == "nccl" else None)
+        if seen != world:
+            sys.stderr.write("bench.py: the all-gather of rank ids saw %d distinct rank(s), world size %d\n" % (seen, world))
+            sys.exit(3)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
 
@@ -366,6 +415,14 @@ def main():
     }
     if "phk_count_slots_kernel" in prof or "phk_count_pairs_kernel" in prof:
         alg.pop("phk_count_kernel", None)   # the wave-per-contig kernel then only serves the hand-over list
+    # the split-query kernel is the whole sweep only as a first pass (float64 rows / proposal=f16); as the second
+    # chance of a count-exact first pass it sees the queued rows alone: credit it with those (stats_ex[2] is the
+    # last step's queue on this rank), never with the batch
+    first_pass = [kname for kname in ("phk_knn_f16h_kernel", "phk_knn_f16c_kernel", "phk_knn_f16_general_kernel",
+                                      "phk_knn_mfma_kernel") if kname in prof]
+    if first_pass and "phk_knn_f16_kernel" in prof:
+        bound, unit, peak, _ = alg["phk_knn_f16_kernel"]
+        alg["phk_knn_f16_kernel"] = (bound, unit, peak, score_tflop * (stats_ex[2] / float(n) if n else 0.0))
     kernels = {}
     for name, (ms, launches) in prof.items():
         kernels[name] = {"ms_per_step": ms / steps, "launches_per_step": launches / steps}
@@ -374,12 +431,20 @@ def main():
             ach = work * steps / (ms / 1e3)
             kernels[name].update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
     dom = max((kname for kname in kernels if kname in alg), key=lambda kname: kernels[kname]["ms_per_step"])
-    per_contig, tsrc = latest_traffic(dom) if (args.config == 1 and not ragged and L == 5000) else (None, None)
+    as_configured = not ragged and L == cfg["length"] and k == cfg["k"] and args.refs is None
+    per_contig, tsrc, per_all = latest_traffic(dom, args.config) if as_configured else (None, None, None)
     roofline = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
                 "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
                 "traffic": per_contig * n if per_contig else None}
     if tsrc:
         roofline["traffic_source"] = tsrc
+    # the whole step against both roofs: every algorithmic flop / byte of the step over the step's wall time, and the
+    # HBM bytes all of its kernels moved (PMC, same source) beside the algorithmic bytes
+    step_s = elapsed / steps
+    roofline["whole_step"] = {
+        "mfma_frac": score_tflop / step_s / MFMA_F16_PEAK_TF, "hbm_frac": count_bytes / step_s / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_contig": count_bytes * 1e9 / n,
+        "hbm_bytes_per_contig_all_kernels": round(sum(per_all.values()), 1) if per_all else None}
     # MFMA flops ISSUED per algorithmic flop: 3 (split-query f16: hi.hi + hi.lo + lo.hi), 2 (count-exact: c.r_hi +
     # c.r_lo), 1 (count-exact, high parts only: the low parts are applied to the few candidates by the decision stage)
     issue = {"phk_knn_f16_kernel": 3.0, "phk_knn_f16c_kernel": 2.0, "phk_knn_f16h_kernel": 1.0,
@@ -391,7 +456,7 @@ def main():
         "metric": ("Gbases/s k-mer-count+score, k=%d, ragged 5-500 kb contigs" % k) if ragged else
                   "Gbases/s k-mer-count+score, k=%d, %d kb contigs" % (k, L // 1000),
         "value": world * T * steps / elapsed / 1e9,
-        "unit": "Gbases/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "unit": "Gbases/s", "n_gpus": world, "ranks_seen": seen, "steps": steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "u32 counts + f16 MFMA proposal (exact integer counts x fp16 reference parts, f32 accumulate; k=4: high parts in the sweep, low parts added in f64 to the window's candidates) + f64 decision",
         "data": ("synthetic (seeded, device-generated: heavy-tailed lengths 5-500 kb in arbitrary order, per-contig GC "

@@ -122,6 +122,14 @@ int phk_permute_columns_i64(phk_ctx *ctx, const int64_t *rows, uint64_t n, uint6
  * Returns PHK_ERR_IO when the file cannot be read (count_file then returns (None, None),
  * scripts/kmer.py:126-128). */
 int phk_fasta_read(const char *path, int threads, phk_fasta **out);
+/* The same pass over ONE rank's share of the file (the multi-GPU form of kmer.count_file's loop, scripts/kmer.py:
+ * 124-140 with fileIO.get_fasta_ids scripts/fileIO.py:62-77: records are independent, so the file is cut by bytes):
+ * the records whose '>' line begins in bytes [byte_lo, byte_hi) of the file (of the decompressed stream for ".gz").
+ * Ranges that tile [0, size) give every record to exactly one range wherever the cuts fall (inside a sequence line, a
+ * title, at a '>' that does not begin a line); byte_hi past the end = to the end.  Only the range's own bytes are
+ * read from a plain file.  phk_fasta_read_part: range `part` of `n_parts` equal byte ranges. */
+int phk_fasta_read_range(const char *path, uint64_t byte_lo, uint64_t byte_hi, int threads, phk_fasta **out);
+int phk_fasta_read_part(const char *path, uint32_t part, uint32_t n_parts, int threads, phk_fasta **out);
 int phk_fasta_shape(const phk_fasta *f, uint64_t *n_records, uint64_t *total_bases, uint64_t *title_bytes);
 /* borrowed pointers, valid until phk_fasta_free: concatenated sequence bytes + offsets[n+1] (exactly the
  * arguments of phk_count_ascii), concatenated titles + title_offsets[n+1] */
@@ -243,6 +251,11 @@ int phk_kmeans(phk_ctx *ctx, const double *X, uint64_t n, uint64_t D, uint32_t k
  * scikit-learn call raises on such input. */
 int phk_score(phk_ctx *ctx, const phk_model *model, const double *Q, uint64_t N, int method,
               double *scores);
+
+/* learning.distances (scripts/learning.py:47-56; with np.argmin on its result: learning.closest_to :59-66): the
+ * Euclidean distances of every row of Q[N][D] to every row of X[M][D], out[N][M], float64, in the reference's
+ * direct-difference form sqrt(sum_d (q_d - x_d)^2).  Host pointers. */
+int phk_distances(phk_ctx *ctx, const double *Q, uint64_t N, const double *X, uint64_t M, uint64_t D, double *out);
 
 /* ---- device API -------------------------------------------------------------------- */
 /* ASCII -> packed stream (+ mask).  d_any_invalid (one uint32, device) is set non-zero when

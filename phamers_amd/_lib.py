@@ -41,6 +41,8 @@ SIGNATURES = {
     "phk_normalize_f64": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p]),
     "phk_permute_columns_i64": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p, c_void_p]),
     "phk_fasta_read": (c_int, [c_char_p, c_int, P(c_void_p)]),
+    "phk_fasta_read_range": (c_int, [c_char_p, c_u64, c_u64, c_int, P(c_void_p)]),
+    "phk_fasta_read_part": (c_int, [c_char_p, c_u32, c_u32, c_int, P(c_void_p)]),
     "phk_fasta_shape": (c_int, [c_void_p, P(c_u64), P(c_u64), P(c_u64)]),
     "phk_fasta_data": (c_int, [c_void_p, P(c_void_p), P(c_void_p), P(c_void_p), P(c_void_p)]),
     "phk_fasta_free": (c_int, [c_void_p]),
@@ -73,6 +75,7 @@ SIGNATURES = {
     "phk_model_set_centroids": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_void_p, c_u64]),
     "phk_model_set_column_mask": (c_int, [c_void_p, c_void_p, c_void_p]),
     "phk_score": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_void_p]),
+    "phk_distances": (c_int, [c_void_p, c_void_p, c_u64, c_void_p, c_u64, c_u64, c_void_p]),
     "phk_pack_ascii_dev": (c_int, [c_void_p, c_void_p, c_u64, c_char_p, c_void_p, c_void_p, c_void_p]),
     "phk_count_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_void_p, c_u64, c_int,
                               c_void_p, c_void_p]),
@@ -357,10 +360,18 @@ class Batch(object):
 class Fasta(object):
     """A FASTA file parsed by the native multi-threaded reader (phk_fasta_read)."""
 
-    def __init__(self, path, threads=0):
+    def __init__(self, path, threads=0, part=None, byte_range=None):
+        """``part`` = (i, n): only the records that begin in the i-th of n equal byte ranges of the file (one rank's
+        share, phk_fasta_read_part); ``byte_range`` = (lo, hi): those that begin in [lo, hi) (phk_fasta_read_range)."""
         self.lib = load()
         h = ctypes.c_void_p()
-        rc = self.lib.phk_fasta_read(os.fsencode(path), int(threads), ctypes.byref(h))
+        if part is not None:
+            rc = self.lib.phk_fasta_read_part(os.fsencode(path), int(part[0]), int(part[1]), int(threads), ctypes.byref(h))
+        elif byte_range is not None:
+            hi = 0xFFFFFFFFFFFFFFFF if byte_range[1] is None else int(byte_range[1])
+            rc = self.lib.phk_fasta_read_range(os.fsencode(path), int(byte_range[0]), hi, int(threads), ctypes.byref(h))
+        else:
+            rc = self.lib.phk_fasta_read(os.fsencode(path), int(threads), ctypes.byref(h))
         if rc == PHK_ERR_IO:
             raise IOError(self.lib.phk_last_error().decode("utf-8", "replace"))
         check(rc)

@@ -18,7 +18,9 @@ struct phk_batch {
     int k = 0;
     uint32_t *d_counts = nullptr;   // [n][D]
     uint32_t *d_nwin = nullptr;     // [n] row sums (= counted windows)
-    bool any_invalid = false;
+    bool any_invalid = false;       // some base of the source batch was not one of the symbols (inherited by a selection:
+                                    // "may hold invalid bases", not re-derived per row)
+    std::vector<uint64_t> len;      // [n] bases per contig (host): what a selection's total_bases is summed from
 };
 
 #define BATCH_CHUNK (256ull << 20)   // bases per upload chunk (a multiple of 32: chunks pack independently)
@@ -54,6 +56,8 @@ extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint6
     b->k = k;
     b->D = phk_pow4(k);
     b->T = T;
+    b->len.resize(n);
+    for (uint64_t c = 0; c < n; ++c) b->len[c] = offsets[c + 1] - offsets[c];
     if (n == 0) {
         *out = b;
         return PHK_OK;
@@ -215,6 +219,11 @@ extern "C" int phk_batch_select(phk_ctx *ctx, const phk_batch *b, const uint64_t
     s->k = b->k;
     s->D = b->D;
     s->any_invalid = b->any_invalid;
+    s->len.resize(m);
+    for (uint64_t i = 0; i < m; ++i) {
+        s->len[i] = b->len[rows[i]];
+        s->T += s->len[i];
+    }
     if (m == 0) {
         *out = s;
         return PHK_OK;

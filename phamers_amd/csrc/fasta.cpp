@@ -307,26 +307,76 @@ static void write_record(const char *b, size_t begin, size_t end, char *seq_out,
     }
 }
 
+static int open_fasta_bytes(const char *path, FileBytes &fb) {
+    const size_t plen = strlen(path);
+    int rc;
+    if (plen > 3 && strcmp(path + plen - 3, ".gz") == 0) {
+        rc = read_whole_file(path, fb.owned);
+        fb.data = fb.owned.data();
+        fb.size = fb.owned.size();
+    } else {
+        rc = map_plain_file(path, fb);
+    }
+    if (rc != PHK_OK) phk_set_error("phk_fasta_read: cannot read %s", path);
+    return rc;
+}
+
+// first '>' that begins a line at or after `from` (the file's size when there is none)
+static size_t next_record_start(const char *b, size_t n, size_t from) {
+    size_t p = from;
+    if (p >= n) return n;
+    if (p > 0 && b[p - 1] != '\n') {   // inside a line: move to the next line start
+        const char *nl = (const char *)memchr(b + p, '\n', n - p);
+        if (!nl) return n;
+        p = (size_t)(nl - b) + 1;
+    }
+    while (p < n) {
+        if (b[p] == '>') return p;
+        const char *nl = (const char *)memchr(b + p, '\n', n - p);
+        if (!nl) return n;
+        p = (size_t)(nl - b) + 1;
+    }
+    return n;
+}
+
+static int parse_fasta_bytes(const char *b, size_t n, int threads, phk_fasta **out);
+
 extern "C" int phk_fasta_read(const char *path, int threads, phk_fasta **out) {
     PHK_REQUIRE(path && out, "phk_fasta_read: NULL argument");
     FileBytes fb;
-    {
-        const size_t plen = strlen(path);
-        int rc;
-        if (plen > 3 && strcmp(path + plen - 3, ".gz") == 0) {
-            rc = read_whole_file(path, fb.owned);
-            fb.data = fb.owned.data();
-            fb.size = fb.owned.size();
-        } else {
-            rc = map_plain_file(path, fb);
-        }
-        if (rc != PHK_OK) {
-            phk_set_error("phk_fasta_read: cannot read %s", path);
-            return rc;
-        }
-    }
-    const char *b = fb.data;
+    PHK_TRY(open_fasta_bytes(path, fb));
+    return parse_fasta_bytes(fb.data, fb.size, threads, out);
+}
+
+// The records whose '>' line begins in bytes [byte_lo, byte_hi) of the file (of the decompressed stream for ".gz"):
+// consecutive ranges that tile [0, size) give every record to exactly one range, whatever the cuts hit -- the middle of
+// a sequence line, of a title, a '>' inside a title.  Nothing outside [first such '>', next range's first '>') is
+// touched, so a rank that reads its range of a plain file never pages in another rank's shard.
+extern "C" int phk_fasta_read_range(const char *path, uint64_t byte_lo, uint64_t byte_hi, int threads, phk_fasta **out) {
+    PHK_REQUIRE(path && out, "phk_fasta_read_range: NULL argument");
+    PHK_REQUIRE(byte_lo <= byte_hi, "phk_fasta_read_range: byte_lo > byte_hi");
+    FileBytes fb;
+    PHK_TRY(open_fasta_bytes(path, fb));
     const size_t n = fb.size;
+    const size_t lo = next_record_start(fb.data, n, byte_lo < n ? (size_t)byte_lo : n);
+    const size_t hi = byte_hi >= n ? n : next_record_start(fb.data, n, (size_t)byte_hi);
+    return parse_fasta_bytes(fb.data + lo, hi > lo ? hi - lo : 0, threads, out);
+}
+
+// part `part` of `n_parts` equal byte ranges of the file (what rank `part` of `n_parts` reads)
+extern "C" int phk_fasta_read_part(const char *path, uint32_t part, uint32_t n_parts, int threads, phk_fasta **out) {
+    PHK_REQUIRE(path && out, "phk_fasta_read_part: NULL argument");
+    PHK_REQUIRE(n_parts >= 1 && part < n_parts, "phk_fasta_read_part: part %u of %u", part, n_parts);
+    FileBytes fb;
+    PHK_TRY(open_fasta_bytes(path, fb));
+    const size_t n = fb.size;
+    const size_t cut_lo = (size_t)((unsigned __int128)n * part / n_parts), cut_hi = (size_t)((unsigned __int128)n * (part + 1) / n_parts);
+    const size_t lo = next_record_start(fb.data, n, cut_lo);
+    const size_t hi = part + 1 == n_parts ? n : next_record_start(fb.data, n, cut_hi);
+    return parse_fasta_bytes(fb.data + lo, hi > lo ? hi - lo : 0, threads, out);
+}
+
+static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fasta **out) {
     if (threads < 1) threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
     // One pass finds the records and measures them: the file is cut into one slice per thread (a slice begins at the
     // first line start at or after its cut); each thread lists the '>' line starts inside its slice with the title length

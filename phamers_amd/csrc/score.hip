@@ -267,6 +267,38 @@ int phk_score_exact_batch(phk_ctx *ctx, const phk_model *m, const double *d_Q, u
     return PHK_OK;
 }
 
+__global__ __launch_bounds__(256) void phk_sqrt_kernel(double *__restrict__ x, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = sqrt(x[i]);
+}
+
+// learning.distances (scripts/learning.py:47-56): out[q][x] = || Q[q] - X[x] ||_2 in the reference's direct-difference
+// form, float64.  Host pointers; row blocks of Q so that the distance tile stays within a fixed workspace.
+extern "C" int phk_distances(phk_ctx *ctx, const double *Q, uint64_t N, const double *X, uint64_t M, uint64_t D, double *out) {
+    PHK_ENTER(ctx, "phk_distances");
+    if (N == 0 || M == 0) return PHK_OK;
+    PHK_REQUIRE(Q && X && out && D > 0, "phk_distances: NULL pointer / zero dimension");
+    void *d_x, *d_q, *d_o;
+    uint64_t rows = (256ull << 20) / (M * sizeof(double));   // <= 256 MiB of distances per block of queries
+    rows = rows < 1 ? 1 : (rows > N ? N : rows);
+    while (rows > 1 && rows * D * sizeof(double) > (1ull << 30)) rows >>= 1;
+    PHK_TRY(phk_ws(ctx, WS_WIDE, M * D * sizeof(double), &d_x));
+    PHK_TRY(phk_ws(ctx, WS_Q64, rows * D * sizeof(double), &d_q));
+    PHK_TRY(phk_ws(ctx, WS_DIST, rows * M * sizeof(double), &d_o));
+    PHK_HIP(hipMemcpyAsync(d_x, X, M * D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    for (uint64_t s = 0; s < N; s += rows) {
+        const uint64_t nb = N - s < rows ? N - s : rows;
+        PHK_HIP(hipMemcpyAsync(d_q, Q + s * D, nb * D * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        dim3 grid((unsigned)phk_div_up(M, DT), (unsigned)phk_div_up(nb, DT));
+        PHK_LAUNCH(ctx, "phk_dist2_f64_kernel",
+                   phk_dist2_f64_kernel<<<grid, dim3(256), 0, ctx->stream>>>((const double *)d_q, nb, (const double *)d_x, M, D, (double *)d_o, M));
+        PHK_LAUNCH(ctx, "phk_sqrt_kernel", phk_sqrt_kernel<<<dim3((unsigned)phk_div_up(nb * M, 256)), dim3(256), 0, ctx->stream>>>((double *)d_o, nb * M));
+        PHK_HIP(hipMemcpyAsync(out + s * M, d_o, nb * M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PHK_OK;
+}
+
 static int check_method(const phk_model *m, int method) {
     PHK_REQUIRE(method == PHK_METHOD_KNN || method == PHK_METHOD_KMEANS || method == PHK_METHOD_COMBO,
                 "phk_score: unknown method %d", method);

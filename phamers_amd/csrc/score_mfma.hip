@@ -1775,33 +1775,63 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
         const uint64_t qi = it / FB_CHUNKS, ch = it % FB_CHUNKS;
         const uint64_t q = p.fb_list[qi];
         const uint64_t c0 = ch * cw, c1 = (c0 + cw < ncols) ? c0 + cw : ncols;
-        // the query row in float64 (kmer.normalize_counts arithmetic)
+        // The distances are evaluated in the SAME float64 form, element ownership and summation order as every other
+        // exact evaluation of this model shape, so that a query's score does not depend on the route that decided it
+        // (which depends on how many rows its batch queued): D = 256 -- exact_d2_g16 (raw counts c and the row sum T,
+        // sum (c_i - T r_i)^2 / T^2, 16 lanes per column in G16 ownership); other D -- exact_d2<DSUB> (the normalised
+        // row c / T of kmer.normalize_counts, one wave per column, lane l on dimensions 256 sub + 4 l .. + 3).
+        const bool g16 = D == FAST_D;
+        double Tq = 1.0, invT2 = 1.0;
         if (SRC == 0) {
             const uint32_t *row = static_cast<const uint32_t *>(src) + q * D;
             uint32_t s = 0;
             for (uint64_t d = lane; d < D; d += 64) s += row[d];  // every wave sums the whole row
             s = wave_sum(s);
-            for (uint64_t d = threadIdx.x; d < D; d += 256) fb_q[d] = (double)row[d] / (double)s;
+            if (g16) {
+                Tq = (double)s;
+                invT2 = 1.0 / (Tq * Tq);
+                for (uint64_t d = threadIdx.x; d < D; d += 256) fb_q[d] = (double)row[d];
+            } else {
+                for (uint64_t d = threadIdx.x; d < D; d += 256) fb_q[d] = (double)row[d] / (double)s;
+            }
         } else {
             for (uint64_t d = threadIdx.x; d < D; d += 256) fb_q[d] = static_cast<const double *>(src)[q * D + d];
         }
         __syncthreads();
-        // 16 lanes per column (contiguous 256-byte pieces of its row per load), 16 columns per pass
-        for (uint64_t cb = c0; cb < c1; cb += 16) {
-            const uint64_t c = cb + (threadIdx.x >> 4);
-            const int t16 = threadIdx.x & 15;
-            const uint64_t cc = c < c1 ? c : c1 - 1;
-            const double2 *row = reinterpret_cast<const double2 *>(cc < p.M ? p.R64 + cc * D : p.C64 + (cc - p.M) * D);
-            double acc = 0.0;
-#pragma unroll 4
-            for (uint64_t d = t16; d < D / 2; d += 16) {
-                const double2 r = row[d];
-                const double d0 = fb_q[2 * d] - r.x, d1 = fb_q[2 * d + 1] - r.y;
-                acc = fma(d0, d0, acc);
-                acc = fma(d1, d1, acc);
+        if (g16) {
+            // 16 lanes per column (contiguous 256-byte pieces of its row per load), 16 columns per pass
+            for (uint64_t cb = c0; cb < c1; cb += 16) {
+                const uint64_t c = cb + (threadIdx.x >> 4);
+                const int t16 = threadIdx.x & 15;
+                const uint64_t cc = c < c1 ? c : c1 - 1;
+                const double2 *row = reinterpret_cast<const double2 *>(cc < p.M ? p.R64 + cc * D : p.C64 + (cc - p.M) * D) + t16;
+                double acc = 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const double2 r = row[16 * i];
+                    const double d0 = fma(-Tq, r.x, fb_q[32 * i + 2 * t16]), d1 = fma(-Tq, r.y, fb_q[32 * i + 2 * t16 + 1]);
+                    acc = fma(d0, d0, fma(d1, d1, acc));
+                }
+                acc = group16_sum(acc) * invT2;
+                if (t16 == 0 && c < c1) fb_dist[c - c0] = (p.col_mask && c < p.M && p.col_mask[c]) ? INFINITY : acc;
             }
-            acc = group16_sum(acc);
-            if (t16 == 0 && c < c1) fb_dist[c - c0] = (p.col_mask && c < p.M && p.col_mask[c]) ? INFINITY : acc;
+        } else {
+            // one wave per column, 4 columns per pass
+            for (uint64_t cb = c0; cb < c1; cb += 4) {
+                const uint64_t c = cb + wave;
+                const uint64_t cc = c < c1 ? c : c1 - 1;
+                const double *row = cc < p.M ? p.R64 + cc * D : p.C64 + (cc - p.M) * D;
+                double acc = 0.0;
+                for (uint64_t sub = 0; sub < D / 256; ++sub) {
+                    const double2 a = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane];
+                    const double2 b = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane + 1];
+                    const double *qv = fb_q + 256 * sub + 4 * lane;
+                    const double d0 = qv[0] - a.x, d1 = qv[1] - a.y, d2 = qv[2] - b.x, d3 = qv[3] - b.y;
+                    acc = fma(d0, d0, fma(d1, d1, fma(d2, d2, fma(d3, d3, acc))));
+                }
+                acc = wave_sum(acc);
+                if (lane == 0 && c < c1) fb_dist[c - c0] = (p.col_mask && c < p.M && p.col_mask[c]) ? INFINITY : acc;
+            }
         }
         __syncthreads();
         if (wave == 0) {

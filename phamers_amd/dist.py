@@ -5,9 +5,95 @@ the final gather of the per-rank score vectors (RCCL all-gather over xGMI; gloo 
 Contigs are independent (scripts/kmer.py:102-105, scripts/phamer.py:251-255), so the batch is cut
 into contiguous contig ranges balanced in bases, every rank counts + scores its own range against
 a replicated reference matrix, and nothing is exchanged until the scores are gathered.  One
-process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE).
+process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE) or by
+launch_ranks() below, which starts the rank processes itself.
 """
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
+
+
+def visible_gpus():
+    """Number of GPUs this process may use.  Counting devices does not initialise the GPU (so a launcher may call
+    this and still start its ranks as children)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n_ranks, argv, require_gpus=True, timeout=None, extra_env=None):
+    """Start ``n_ranks`` copies of the command ``argv`` as CHILD processes, one per GPU, with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (the variables torch.distributed.run would set), forward rank 0's
+    standard output and wait for all of them.  The caller must not have initialised the GPU: the ranks are children
+    of a process that holds no device state, and nothing is exec'ed over a process that does.  Returns the first
+    non-zero exit code of a rank, or 0; when a rank fails the others are terminated.  ``require_gpus``: refuse
+    (exit code 2, nothing started) when fewer than ``n_ranks`` devices are visible, instead of putting several ranks
+    on one device."""
+    n_ranks = int(n_ranks)
+    if n_ranks < 1:
+        raise ValueError("n_ranks must be >= 1")
+    if require_gpus:
+        have = visible_gpus()
+        if have < n_ranks:
+            sys.stderr.write("launch_ranks: %d rank(s) asked for, %d GPU(s) visible -- not started\n" % (n_ranks, have))
+            return 2
+    port = free_port()
+    procs = []
+    for rank in range(n_ranks):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n_ranks),
+                   LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   PHK_LAUNCHED_BY="launch_ranks")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if rank == 0 else subprocess.DEVNULL))
+    import time
+    t0 = time.monotonic()
+    rc = 0
+    live = set(range(n_ranks))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write("launch_ranks: rank %d exited with code %d; stopping the others\n" % (r, code))
+                for o in live:
+                    procs[o].terminate()
+        if live:
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                sys.stderr.write("launch_ranks: timeout after %.0f s; stopping %d rank(s)\n" % (timeout, len(live)))
+                for o in live:
+                    procs[o].kill()
+                rc = rc or 124
+                timeout = None
+            time.sleep(0.05)
+    return rc
+
+
+def ranks_seen(group=None, device=None):
+    """How many distinct ranks answer an all-gather of the rank ids (the launcher's self-check: equals the world
+    size when every rank is its own process in one group)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    mine = torch.tensor([dist.get_rank(group)], dtype=torch.int64, device=device or "cpu")
+    out = torch.empty(world, dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return int(torch.unique(out.cpu()).numel())
 
 
 def shard_bounds(lengths, world_size):
@@ -104,3 +190,52 @@ def score_contigs_distributed(sequences, positive, negative, positive_centroids=
     dev = torch.device("cuda", gpu) if use_cuda else torch.device("cpu")
     full = gather_variable(torch.from_numpy(local).to(dev), group=group)
     return full.cpu().numpy()
+
+
+def score_fasta_distributed(path, positive, negative, positive_centroids=None, negative_centroids=None,
+                            kmer_length=4, method="combo", k_neighbors=3, group=None, length_requirement=None,
+                            threads=0):
+    """The sharded form of phamer_scorer.load_data + score_points on a FASTA file (scripts/kmer.py:124-140,
+    scripts/phamer.py:131-142, 177-195): every rank parses ONLY the records that begin in its byte range of the file
+    (phk_fasta_read_part: no rank ever holds another rank's shard), counts and scores them device resident, and the
+    ranks exchange nothing but their ids and score vectors at the end.  ``length_requirement``: keep contigs of at least
+    that many bases (screen_by_length, scripts/phamer.py:144-157; the reference's fixed 5000 when the screen is on).
+    Returns (ids, scores) in file order on every rank."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    if not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised (launch with torch.distributed.run or launch_ranks)")
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    use_cuda = dist.get_backend(group) == "nccl"
+    gpu = rank_device()
+    ctx = _lib.get_context(gpu)
+    fasta = _lib.Fasta(path, threads=threads, part=(rank, world))
+    try:
+        ids = fasta.phamers_ids()
+        lengths = fasta.lengths()
+        batch = _lib.Batch.from_fasta(ctx, fasta, kmer_length) if fasta.n_records else None
+    finally:
+        fasta.close()
+    local = np.zeros(0)
+    if batch is not None:
+        model = _lib.Model(ctx, positive, negative, positive_centroids if method != "knn" else None,
+                           negative_centroids if method != "knn" else None, k_neighbors)
+        try:
+            if length_requirement:
+                keep = np.flatnonzero(lengths >= int(length_requirement))
+                ids = ids[keep]
+                sub = batch.select(keep) if len(keep) else None
+                batch.close()
+                batch = sub
+            if batch is not None:
+                local = batch.score(model, method)
+        finally:
+            model.close()
+            if batch is not None:
+                batch.close()
+    dev = torch.device("cuda", gpu) if use_cuda else torch.device("cpu")
+    scores = gather_variable(torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64)).to(dev), group=group)
+    all_ids = [None] * world
+    dist.all_gather_object(all_ids, [str(x) for x in ids], group=group)
+    return np.array([x for part in all_ids for x in part]), scores.cpu().numpy()

@@ -2,6 +2,8 @@
 learning.py -- drop-in for the hot-path helpers of PhaMers' scripts/learning.py.
 
     knn(queries, ref_data, ref_labels, k=3)       scripts/learning.py:118-128   -> GPU
+    distances(vector, data)                       scripts/learning.py:47-56     -> GPU (float64, direct differences)
+    closest_to(point, picks)                      scripts/learning.py:59-66     -> GPU distances + first-index argmin
     kmeans(data, k, ...)                          scripts/learning.py:131-146   -> scikit-learn (default) / GPU
     get_centroids(data, assignment)               scripts/learning.py:69-81     -> NumPy (86 means)
 
@@ -39,6 +41,34 @@ def knn(queries, ref_data, ref_labels, k=3):
         return model.score(queries, "knn")
     finally:
         model.close()
+
+
+def distances(vector, data):
+    """Distances from one point to many (scripts/learning.py:47-56): ``vector`` (D,) or (1, D), ``data`` (M, D) ->
+    (M,) float64, sqrt of the direct-difference sums, computed on the device (phk_distances).  Any other ``vector``
+    shape fails to broadcast in the reference's ``np.repeat(vector, M, axis=0) - data`` and raises here as well."""
+    vector = np.asarray(vector, dtype=np.float64)
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    if vector.ndim == 1:
+        vector = vector[None, :]
+    if vector.shape[0] != 1:
+        # np.repeat(vector, M, axis=0) - data only broadcasts for one row; anything else raises in the reference too
+        raise ValueError("operands could not be broadcast together with shapes %s %s"
+                         % ((vector.shape[0] * data.shape[0], vector.shape[1]), data.shape))
+    if vector.shape[1] != data.shape[1]:
+        raise ValueError("operands could not be broadcast together with shapes %s %s"
+                         % ((data.shape[0], vector.shape[1]), data.shape))
+    out = np.empty((1, data.shape[0]), dtype=np.float64)
+    ctx = _lib.get_context()
+    _lib.check(ctx.lib.phk_distances(ctx.handle, _lib.ptr(np.ascontiguousarray(vector)), 1, _lib.ptr(data),
+                                     data.shape[0], data.shape[1], _lib.ptr(out)))
+    return out[0]
+
+
+def closest_to(point, picks):
+    """The row of ``picks`` closest to ``point`` (scripts/learning.py:59-66): first index wins ties, as np.argmin."""
+    picks = np.asarray(picks)
+    return picks[np.argmin(distances(point, picks))]
 
 
 def kmeans_gpu(data, k, seed=kmeans_seed, max_iter=300):

@@ -156,26 +156,41 @@ class phamer_scorer(object):
         self.features_file = "{base}_features.csv".format(base=os.path.splitext(self.fasta_file)[0])
         counts, ids, path = self._batch.counts_u32(), self.data_ids, self.features_file
         if self._defer_io:
-            # main(): the 0.6 s (1M contigs) of formatting and writing the cache run beside the k-means fit and the
-            # scoring; the file appears under its name only when complete
-            import threading
-
-            def write():
-                tmp = path + ".part"
-                fileIO.save_counts(counts, ids, tmp)
-                os.replace(tmp, path)
-            th = threading.Thread(target=write, name="phamers-features-cache")
-            th.start()
-            self._pending_io.append(th)
+            self._write_cache_async(counts, ids, path)
         else:
             fileIO.save_counts(counts, ids, path)
         return lengths
 
+    def _write_cache_async(self, counts, ids, path):
+        """main(): the 0.6 s (1M contigs) of formatting and writing the features cache run beside the k-means fit and
+        the scoring; the file appears under its name only when complete, and a failed write is raised by finish_io()."""
+        import threading
+
+        def write():
+            tmp = path + ".part"
+            try:
+                fileIO.save_counts(counts, ids, tmp)
+                os.replace(tmp, path)
+            except BaseException as e:   # noqa: BLE001 -- handed to finish_io(), which raises it where the
+                th.error = e             # reference's sequential save_counts would have
+                try:
+                    os.unlink(tmp)
+                except OSError:
+                    pass
+        th = threading.Thread(target=write, name="phamers-features-cache")
+        th.error = None
+        th.start()
+        self._pending_io.append(th)
+
     def finish_io(self):
         """Waits for file writes main() left running beside the scoring."""
         pending, self._pending_io = self._pending_io, []
+        first = None
         for th in pending:
             th.join()
+            first = first or getattr(th, "error", None)
+        if first is not None:   # a failed write (disk full, read-only input directory) is an error of the run
+            raise first
 
     def screen_by_length(self, length_requirement=None, _lengths=None):
         """Keep contigs of at least ``length_requirement`` bases (scripts/phamer.py:144-157): ids filtered on the host,
@@ -314,6 +329,14 @@ def main(argv=None):
         python -m phamers_amd.phamer -in <input_dir> -data <data_dir> [--equalize_reference]
     Scores go to <input_dir>/phamer_output/phamer_scores.csv (or -out).  As in the reference the method is always
     'combo' (its --method is parsed and never applied)."""
+    ap = _parser()
+    args = ap.parse_args(argv)
+    if args.do_tsne or args.plot_tsne:
+        raise NotImplementedError("t-SNE / plots (-do_tsne, -plot) are outside the accelerated path (SURVEY.md section 8)")
+    return _run(ap, args)
+
+
+def _parser():
     ap = argparse.ArgumentParser(description='This script scores contigs based on feature similarity',
                                  formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     for flags, kw in (
@@ -326,11 +349,28 @@ def main(argv=None):
             (('-out', '--output_directory'), dict(help='Output directory path')),
             (('-k', '--kmer_length'), dict(type=int, default=4, help='k-mer length')),
             (('-l', '--length_requirement'), dict(type=int, default=5000, help='Input sequence length requirement')),
-            (('-e', '--equalize_reference'), dict(action='store_true', help='Same number of reference points')),
+            (('-equal', '-e', '--equalize_reference'), dict(action='store_true', help='Same number of reference points')),
             (('-v', '--verbose'), dict(action='store_true')),
-            (('--debug',), dict(action='store_true'))):
+            (('--debug',), dict(action='store_true')),
+            # the rest of the reference's command line (scripts/phamer.py:515-553), so that its launch scripts
+            # (run.sh, submit/*.sh) parse unchanged.  The reference parses --method / --eps / --minPts and never applies
+            # them (the method is always 'combo'); t-SNE, plots and counting the reference sets from FASTA are outside
+            # the accelerated path and are refused when asked for.
+            (('-tsne', '--tsne_file'), dict(help='(outside the accelerated path)')),
+            (('-p', '--positive_fasta'), dict(help='(outside the accelerated path: give -pf)')),
+            (('-n', '--negative_fasta'), dict(help='(outside the accelerated path: give -nf)')),
+            (('-id', '--file_identifier'), dict(default='.fna', help='(used with -n only)')),
+            (('-do_tsne', '--do_tsne'), dict(action='store_true', help='(outside the accelerated path)')),
+            (('-pxty', '--perplexity'), dict(type=float, default=30, help='(t-SNE only)')),
+            (('-plot', '--plot_tsne'), dict(action='store_true', help='(outside the accelerated path)')),
+            (('-m', '--method'), dict(default='combo', help='parsed and, as in the reference, not applied')),
+            (('-eps', '--eps'), dict(type=float, default=2.1, help='parsed and, as in the reference, not applied')),
+            (('-mp', '--minPts'), dict(type=int, default=2, help='parsed and, as in the reference, not applied'))):
         ap.add_argument(*flags, **kw)
-    args = ap.parse_args(argv)
+    return ap
+
+
+def _run(ap, args):
     logger.setLevel(logging.DEBUG if args.debug else logging.INFO if args.verbose else logging.WARNING)
 
     scorer = phamer_scorer()

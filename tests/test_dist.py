@@ -142,3 +142,56 @@ def test_rank_device_follows_local_rank(monkeypatch):
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
     with pytest.raises(RuntimeError):
         pdist.rank_device()
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_starts_its_own_ranks(world):
+    """`python bench.py --gpus N` with no WORLD_SIZE / RANK in the environment (as the driver may run it) becomes the
+    launcher: N child ranks, one process group, rank 0's line says n_gpus = N and the all-gather of rank ids saw N
+    distinct ranks.  --rendezvous-only stops before any GPU work, so this runs here over gloo."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(world), "--rendezvous-only"],
+                       env=_clean_env(PHK_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # exactly one JSON line: rank 0's
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["ranks_seen"] == world and line["launched_by"] == "launch_ranks"
+
+
+def test_bench_refuses_to_measure_with_too_few_gpus():
+    """RCCL needs a device per rank: with fewer than N visible (none here) nothing is started and the exit code is
+    non-zero -- never a 1-rank measurement labelled as N."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=_clean_env(PHK_BENCH_BACKEND="nccl"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2
+    assert "not started" in r.stderr and "{" not in r.stdout
+
+
+def test_launch_ranks_env_and_failure(tmp_path):
+    """Each child gets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; a failing rank's exit code is returned and the
+    other ranks are stopped."""
+    from phamers_amd import dist as pdist
+    script = tmp_path / "child.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "assert int(os.environ['MASTER_PORT']) > 0\n"
+        "open(os.path.join(sys.argv[1], 'rank%d_of_%d' % (r, w)), 'w').close()\n"
+        "if sys.argv[2] == 'fail':\n"
+        "    if r == 1: sys.exit(7)\n"
+        "    time.sleep(60)\n")
+    assert pdist.launch_ranks(3, [sys.executable, str(script), str(tmp_path), "ok"], require_gpus=False, timeout=120) == 0
+    assert sorted(p.name for p in tmp_path.glob("rank*")) == ["rank0_of_3", "rank1_of_3", "rank2_of_3"]
+    import time
+    t0 = time.monotonic()
+    assert pdist.launch_ranks(2, [sys.executable, str(script), str(tmp_path), "fail"], require_gpus=False, timeout=120) == 7
+    assert time.monotonic() - t0 < 30        # rank 0 was terminated, not waited for

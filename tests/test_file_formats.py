@@ -165,6 +165,80 @@ def test_native_fasta_reader_slices_of_a_large_file(tmp_path):
             assert got == ref, threads
 
 
+def test_fasta_byte_ranges_give_every_record_to_exactly_one_range(tmp_path):
+    """phk_fasta_read_range / phk_fasta_read_part (one rank's share of a file): for EVERY cut position of an awkward
+    small file -- inside a sequence line, inside a title, on a '>' that does not begin a line, on blank lines, CR LF,
+    before the first record -- the two ranges [0, c) and [c, end) together hold every record once, in order; the same
+    for n equal parts, plain and gzip; a record belongs to the range its '>' line begins in."""
+    from phamers_amd import _lib
+    text = ("junk > not a record\n>a_ID_1 title with > inside\nATGC\nAT>GC\r\n\n>b_ID_2\n>c_ID_3 empty before\nGG GG\n"
+            ">gi|1|ref|NC_1.1| x\nCCCC\nTT\n\n\n>last_ID_4\nA")
+    for c in range(30):
+        text += "\n>r_ID_%d\n" % (10 + c) + "\n".join("ATGCN"[(c + j) % 5] * (1 + (c * j) % 9) for j in range(c % 6))
+    want_titles, want_seqs = _seqio_like(text)
+    path = tmp_path / "awkward.fasta"
+    path.write_bytes(text.encode("latin-1"))
+    size = len(text.encode("latin-1"))
+
+    def read(**kw):
+        f = _lib.Fasta(str(kw.pop("p", path)), threads=1, **kw)
+        out = (f.titles(), f.sequences())
+        assert f.ids() == [(t.split(None, 1) or [""])[0] for t in out[0]]
+        f.close()
+        return out
+
+    assert read() == (want_titles, want_seqs)
+    starts = [i for i in range(size) if text[i] == ">" and (i == 0 or text[i - 1] == "\n")]
+    for c in range(size + 2):
+        a, b = read(byte_range=(0, c)), read(byte_range=(c, None))
+        assert a[0] + b[0] == want_titles and a[1] + b[1] == want_seqs, c
+        assert len(a[0]) == sum(1 for st in starts if st < c), c       # ownership: where the '>' line begins
+    for lo, hi in ((7, 7), (40, 41), (size, size + 5)):
+        f = _lib.Fasta(str(path), byte_range=(lo, hi))
+        assert f.n_records == sum(1 for st in starts if lo <= st < hi)
+        f.close()
+    gz = tmp_path / "awkward.fasta.gz"
+    with gzip.open(gz, "wb") as g:
+        g.write(text.encode("latin-1"))
+    for n in (1, 2, 3, 5, 8, 64):
+        for p_ in (path, gz):
+            parts = [read(p=p_, part=(i, n)) for i in range(n)]
+            assert sum((x[0] for x in parts), []) == want_titles, (n, p_)
+            assert sum((x[1] for x in parts), []) == want_seqs, (n, p_)
+    with pytest.raises(_lib.PhkError):
+        _lib.Fasta(str(path), part=(3, 3))
+    with pytest.raises(IOError):
+        _lib.Fasta(str(tmp_path / "missing.fa"), part=(0, 2))
+
+
+def test_fasta_parts_of_a_large_file_are_balanced_and_complete(tmp_path):
+    """Eight ranks' shares of a 6 MB file read by several threads each: complete, in order, and balanced in bytes to
+    within the longest record."""
+    from phamers_amd import _lib
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b"ATGC", dtype=np.uint8)
+    recs = []
+    for c in range(1200):
+        n = int(rng.choice([500, 5000, 12000]))
+        seq = alphabet[rng.integers(0, 4, size=n)].tobytes().decode()
+        recs.append(">SuperContig_%d_length_%d_ID_%d\n" % (c, n, c) + "\n".join(seq[i:i + 70] for i in range(0, n, 70)) + "\n")
+    text = "".join(recs)
+    path = tmp_path / "many.fasta"
+    path.write_text(text)
+    whole = _lib.Fasta(str(path))
+    want_ids, want_len = list(whole.phamers_ids()), whole.lengths().tolist()
+    whole.close()
+    got_ids, got_len, share = [], [], []
+    for r in range(8):
+        f = _lib.Fasta(str(path), threads=3, part=(r, 8))
+        got_ids += list(f.phamers_ids())
+        got_len += f.lengths().tolist()
+        share.append(f.total_bases)
+        f.close()
+    assert got_ids == want_ids and got_len == want_len
+    assert max(share) - min(share) <= 2 * 12000 + 1000
+
+
 @pytest.mark.gpu
 def test_count_file_and_feature_file_round_trip(tmp_path):
     """kmer.count_file on plain and gzip FASTA (ids by the reference's header rules), the soft IOError

@@ -1,0 +1,118 @@
+"""The sharded path on the GPU: shard-count invariance of the device scorer (scores bit-identical for
+1 / 2 / 4 / 8 shards) and the product-level sharded entry points with their default (GPU) scorer under a 2-rank gloo
+group on one device (RCCL needs a device per rank; the collective itself is covered by the driver's multi-GPU run)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import helpers
+from tests.helpers import REPO
+
+pytestmark = pytest.mark.gpu
+
+
+def _contigs():
+    """A ragged, awkward batch: heavy-tailed lengths, N runs, lower case, a few long low-complexity contigs whose counts
+    exceed what the fp16 count operand carries (second chance), and near-duplicates (near-ties between neighbours)."""
+    from phamers_amd import synth
+    rng = np.random.default_rng(11)
+    lens = np.concatenate((rng.integers(300, 9000, 1500), rng.integers(20000, 90000, 40), [5000] * 500))
+    rng.shuffle(lens)
+    seqs = [synth.synth_contig(5, i, int(L), 300 if i % 7 == 0 else 0) for i, L in enumerate(lens)]
+    seqs[3] = "ATATATATAT" * 3000                     # counts far above 2048 in a few bins
+    seqs[10] = "ATGC" * 2500 + "GGGGCCCC" * 400
+    seqs[17] = seqs[16]                               # exact duplicate
+    seqs[18] = seqs[16][:-1] + ("A" if seqs[16][-1] != "A" else "T")
+    seqs[25] = seqs[24].lower()[:2000] + seqs[24][2000:]
+    return seqs
+
+
+def test_shard_count_invariance_on_the_device():
+    from oracle import oracle
+    from phamers_amd import _lib, dist as pdist
+    g = helpers.load_npz("scoring_k4.npz")
+    ref = helpers.load_npz("ref_features.npz")
+    pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))[:2255]
+    neg = oracle.normalize_counts(ref["neg_counts"].astype(np.int64))[:2255]
+    cp, cn = g["cpos_eq"], g["cneg_eq"]
+    seqs = _contigs()
+    scorer = pdist.default_scorer()
+    out = {}
+    for world in (1, 2, 4, 8):
+        parts = [scorer(seqs[lo:hi], 4, "combo", pos, neg, cp, cn, 3)
+                 for lo, hi in pdist.shard_bounds([len(s) for s in seqs], world)]
+        out[world] = np.concatenate(parts)
+        assert out[world].shape == (len(seqs),)
+    for world in (2, 4, 8):
+        assert np.array_equal(out[1], out[world]), world
+    # and against the oracle on a sample (incl. the awkward rows)
+    pick = [0, 3, 10, 16, 17, 18, 24, 25] + list(range(100, 140))
+    q = oracle.normalize_counts(oracle.count([seqs[i] for i in pick], 4))
+    want = oracle.knn_score_points(q, pos, neg, 3) + oracle.centroid_score_points_fast(q, cp, cn)
+    assert helpers.rel_err(out[1][pick], want) < 1e-6
+    # the scoring-batch split inside one shard does not matter either
+    ctx = _lib.get_context()
+    ctx.set_option("score_batch", "256")
+    again = scorer(seqs, 4, "combo", pos, neg, cp, cn, 3)
+    ctx.set_option("score_batch", "0")
+    assert np.array_equal(again, out[1])
+
+
+WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["PHK_REPO"])
+import torch.distributed as dist
+from phamers_amd import dist as pdist
+from tests import test_gpu_dist as T, helpers
+from oracle import oracle
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+g = helpers.load_npz("scoring_k4.npz")
+ref = helpers.load_npz("ref_features.npz")
+pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))[:2255]
+neg = oracle.normalize_counts(ref["neg_counts"].astype(np.int64))[:2255]
+seqs = T._contigs()
+full = pdist.score_contigs_distributed(seqs, pos, neg, g["cpos_eq"], g["cneg_eq"], 4, "combo", 3)   # default: GPU scorer
+fasta = os.environ["PHK_FASTA"]
+full_f = pdist.score_fasta_distributed(fasta, pos, neg, g["cpos_eq"], g["cneg_eq"], 4, "combo", 3)
+if dist.get_rank() == 0:
+    np.save(os.environ["PHK_OUT"], np.stack([full, full_f[1]]))
+    json.dump([str(x) for x in full_f[0][:5]], open(os.environ["PHK_OUT"] + ".ids.json", "w"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_entry_points_with_the_gpu_scorer_two_ranks(tmp_path):
+    """dist.score_contigs_distributed / score_fasta_distributed with their default scorer (device resident, this rank's
+    GPU), two ranks started by dist.launch_ranks sharing the one device over gloo: the gathered vector equals the
+    single-process device result bit for bit."""
+    from oracle import oracle
+    from phamers_amd import dist as pdist
+    seqs = _contigs()
+    fasta = tmp_path / "contigs.fasta"
+    with open(fasta, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(">SuperContig_%d_length_%d_ID_%d\n" % (i, len(s), i))
+            for j in range(0, len(s), 70):
+                f.write(s[j:j + 70] + "\n")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    outp = str(tmp_path / "out.npy")
+    rc = pdist.launch_ranks(2, [sys.executable, str(script)], require_gpus=False, timeout=900,
+                            extra_env={"PHK_REPO": REPO, "PHK_OUT": outp, "PHK_FASTA": str(fasta), "OMP_NUM_THREADS": "4"})
+    assert rc == 0
+    got = np.load(outp)
+    g = helpers.load_npz("scoring_k4.npz")
+    ref = helpers.load_npz("ref_features.npz")
+    pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))[:2255]
+    neg = oracle.normalize_counts(ref["neg_counts"].astype(np.int64))[:2255]
+    want = pdist.default_scorer()(seqs, 4, "combo", pos, neg, g["cpos_eq"], g["cneg_eq"], 3)
+    assert np.array_equal(got[0], want)
+    assert np.array_equal(got[1], want)
+    assert json.load(open(outp + ".ids.json")) == ["0", "1", "2", "3", "4"]

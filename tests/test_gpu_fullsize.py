@@ -196,3 +196,62 @@ def test_config4_k6_50k_row_reference_131072_queries():
     model.close()
     for a in (packed, offsets, counts, scores, status, sub, sub_scores):
         a.free()
+
+
+def test_config3_per_rank_share_12_5M_contigs():
+    """BASELINE configs[3] (k = 4, 100 M x 5 kb contigs over 8 GPUs) as ONE rank sees it: rank 3's share of 12.5 M
+    contigs (62.5 Gbases; 15.6 GB packed, 12.8 GB of counts) through phk_count_score_dev in one call, i.e. 12 scoring
+    batches of 2^20 queries.  Checked through size-independent properties: every row sums to L - k + 1 (on the device),
+    sampled rows equal the oracle's counts and scores, a slice equals the float64 brute-force path, and a contig's score
+    does not depend on the shard it is scored in (the same contigs as a 1 M-contig batch of their own: bit-identical,
+    which is the invariant SURVEY 8(e) asks of the sharding)."""
+    from oracle import oracle
+    from phamers_amd import _lib, device, synth, workloads
+    cfg = workloads.CONFIGS[3]
+    world, rank = 8, 3
+    n, L3, k = cfg["contigs_total"] // world, cfg["length"], cfg["k"]
+    assert n == 12500000
+    first = rank * n
+    D = 4 ** k
+    T = n * L3
+    ctx = _lib.get_context()
+    model, pos, neg, g = _model(ctx)
+    packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    offsets = device.DeviceArray(ctx, n + 1, np.uint64)
+    counts = device.DeviceArray(ctx, (n, D), np.uint32)
+    scores = device.DeviceArray(ctx, n, np.float64)
+    status = device.DeviceArray.from_host(ctx, np.zeros(1, np.uint32))
+    device.synth_packed(ctx, 0, first, n, L3, packed, offsets)
+    device.count_score(ctx, model, packed, None, T, offsets, n, k, "combo", counts, scores, status)
+    got = scores.to_host()
+    assert status.to_host()[0] == 0
+    n_fallback, n_exact = ctx.score_stats()
+    assert n_fallback < 1000 and n_exact < n // 10
+    assert device.check_counts(ctx, counts, None, n, D, L3 - k + 1) == (0, 0)
+    assert np.all(np.isfinite(got)) and np.all(np.abs(got) < 1.7616)
+    # the oracle on a sample spread over all 12 scoring batches (incl. the first and the last contig of the shard)
+    rng = np.random.default_rng(3)
+    sample = np.unique(np.concatenate(([0, n - 1], rng.choice(n, 70, replace=False))))
+    want_counts = oracle.count([synth.synth_contig(0, first + int(c), L3) for c in sample], k)
+    assert np.array_equal(device.read_rows(ctx, counts, sample, D).astype(np.int64), want_counts)
+    q = oracle.normalize_counts(want_counts)
+    want = oracle.knn_score_points(q, pos, neg, 3) + oracle.centroid_score_points_fast(q, g["cpos_eq"], g["cneg_eq"])
+    assert helpers.rel_err(got[sample], want) < 1e-6
+    # a slice that straddles a scoring-batch boundary through the float64 brute-force path
+    lo, m = 3 * (1 << 20) - 100000, 200000
+    sl_counts = counts.ptr + lo * D * 4
+    sl = device.DeviceArray(ctx, m, np.float64)
+    ctx.set_option("force_exact", "1")
+    device.score_counts(ctx, model, sl_counts, m, "knn", sl, status)
+    knn = sl.to_host()
+    device.score_counts(ctx, model, sl_counts, m, "kmeans", sl, status)
+    kme = sl.to_host()
+    ctx.set_option("force_exact", "0")
+    assert np.array_equal(np.trunc(got[lo:lo + m] + np.where(got[lo:lo + m] > 0, 0.5, -0.5)), knn)   # the vote is the integer part
+    assert helpers.rel_err(got[lo:lo + m] - knn, kme) < 1e-9
+    # shard invariance: the same contigs scored as a batch of their own (other batch split, other queues)
+    device.score_counts(ctx, model, sl_counts, m, "combo", sl, status)
+    assert np.array_equal(sl.to_host(), got[lo:lo + m])
+    model.close()
+    for a in (packed, offsets, counts, scores, status, sl):
+        a.free()

@@ -463,10 +463,11 @@ def test_scoring_in_several_batches_matches_one_batch_and_exact_path():
         ctx.set_option("score_batch", "0")
         ctx.set_option("force_exact", "0")
         ctx.set_option("pipeline", "1")
-    # the chunk pipeline of phk_count_score_dev (count of chunk i+1 beside the scoring of chunk i on a second stream)
-    assert np.array_equal(np.sign(out["one"]), np.sign(out["piped"])) and helpers.rel_err(out["one"], out["piped"]) < 1e-12
-    # (equal up to the arithmetic form of the few queries whose tail route depends on the batch split)
-    assert np.array_equal(np.sign(out["one"]), np.sign(out["four"])) and helpers.rel_err(out["one"], out["four"]) < 1e-12
+    # Scores do not depend on the batch split: every route a query can take (certified margin, exact candidate
+    # distances, second chance, brute force -- which one depends on how many rows its batch queues) ends in the same
+    # float64 evaluation (exact_d2_g16's form, element ownership and summation order) of the same operands.
+    assert np.array_equal(out["one"], out["piped"])
+    assert np.array_equal(out["one"], out["four"])
     # totals over the four batches (the tail routes depend on the batch split: a handful of queued rows per batch goes
     # straight to the brute force, so the totals are compared loosely)
     assert stats["four"][1] > 0 and abs(stats["four"][1] - stats["one"][1]) <= 64
@@ -534,6 +535,7 @@ def test_device_resident_batch_facade():
     assert np.array_equal(batch.score(model, "knn"), g["knn_full"])
     rows = np.array([99, 3, 3, 40])
     sub = batch.select(rows)
+    assert (sub.n, sub.total_bases) == (4, 20000)      # a selection knows its own bases
     assert np.array_equal(sub.counts(), g["q_counts"][rows])
     assert helpers.rel_err(sub.score(model, "kmeans"), g["kmeans_full"][rows]) < RTOL
     sub.close()
@@ -546,6 +548,7 @@ def test_device_resident_batch_facade():
     with pytest.raises(ValueError):
         b2.score(model, "combo")
     ok = b2.select([0, 2])
+    assert ok.total_bases == len(mixed[0]) + len(mixed[2])
     from oracle import oracle
     q = oracle.normalize_counts(oracle.count([mixed[0], mixed[2]], 4))
     want = oracle.score_points(q, pos, neg, "combo", 3, g["cpos_full"], g["cneg_full"])
@@ -682,3 +685,27 @@ def test_second_chance_column_parts_for_small_and_uneven_references(n_train):
     assert helpers.rel_err(out[("fast", "kmeans")], out[("exact", "kmeans")]) < 1e-9
     assert helpers.rel_err(out[("fast", "combo")], out[("exact", "combo")]) < 1e-9
     model.close()
+
+
+@pytest.mark.gpu
+def test_learning_distances_and_closest_to_match_reference():
+    """learning.distances / learning.closest_to (scripts/learning.py:47-66) on the device against the reference's own
+    outputs (tests/golden/distances.npz): distances within 1e-12 relative (float64 direct differences; the summation
+    order differs from NumPy's pairwise reduction), zero distances exactly zero, closest_to the same row -- ties to the
+    first index as np.argmin."""
+    from oracle import oracle
+    from phamers_amd import learning
+    g = helpers.load_npz("distances.npz")
+    ref = helpers.load_npz("ref_features.npz")
+    pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))[:300]
+    for i, v in enumerate(g["queries"]):
+        got = learning.distances(v, pos)
+        assert got.shape == (300,) and got.dtype == np.float64
+        assert np.allclose(got, g["dist_pos"][i], rtol=1e-12, atol=0)
+        assert np.array_equal(got == 0.0, g["dist_pos"][i] == 0.0)
+        assert np.array_equal(learning.closest_to(v, g["picks"]), g["closest_picks"][i])
+    assert np.allclose(learning.distances(g["queries"][3:4], pos), g["dist_row_2d"], rtol=1e-12, atol=0)
+    with pytest.raises(ValueError):
+        learning.distances(g["queries"][:2], pos)          # the reference's np.repeat form does not broadcast either
+    with pytest.raises(ValueError):
+        learning.distances(g["queries"][0][:100], pos)

@@ -2,6 +2,7 @@
 FASTA header -> id (tests/golden/ids.json, scripts/id_parser.py:18-100) through the native scanner and the oracle,
 and the transform_kmers index tables (tests/golden/transform.npz, scripts/transform_kmers.py:21-88).  CPU only:
 the shared library is loaded, no device is touched."""
+import os
 import random
 
 import numpy as np
@@ -78,3 +79,41 @@ def test_transform_tables_match_the_reference_fixture():
     assert len(set(z["revcomp_idx_k4"])) == 64
     with pytest.raises(IndexError):
         oracle.transform_kmers(np.zeros((1, 4 ** 5), dtype=np.int64), True, True)
+
+
+def test_command_line_accepts_the_reference_flag_set():
+    """scripts/phamer.py:515-553: every option of the reference's command line parses (so run.sh / submit/*.sh style
+    invocations do not die in argparse); -equal is the reference's short spelling of --equalize_reference; t-SNE and
+    plotting are refused explicitly, before any work."""
+    from phamers_amd import phamer
+    a = phamer._parser().parse_args(["-in", "in_dir", "-data", "data", "-equal", "-m", "knn", "-eps", "3.5", "-mp", "4",
+                                     "-pxty", "12", "-id", ".fa", "-k", "4", "-l", "5000", "-p", "p.fa", "-n", "neg_dir",
+                                     "-tsne", "t.csv", "--debug"])
+    assert a.equalize_reference and a.method == "knn" and a.eps == 3.5 and a.minPts == 4 and a.debug
+    assert a.input_directory == "in_dir" and a.data_directory == "data" and a.file_identifier == ".fa"
+    assert phamer._parser().parse_args(["-in", "x", "-e"]).equalize_reference          # the earlier spelling still works
+    assert not phamer._parser().parse_args(["-in", "x"]).equalize_reference
+    for flag in ("-do_tsne", "-plot"):
+        with pytest.raises(NotImplementedError):
+            phamer.main(["-in", "x", "-data", "y", flag])
+
+
+def test_failed_features_cache_write_is_an_error_of_the_run(tmp_path):
+    """The features cache is written on a thread beside the scoring; a write that fails (here: the directory does not
+    exist) must surface from finish_io() as it would from the reference's sequential save_counts
+    (scripts/phamer.py:132-134), and leave no partial file."""
+    from phamers_amd import phamer
+    sc = phamer.phamer_scorer()
+    counts = np.arange(12, dtype=np.uint32).reshape(3, 4)
+    ids = np.array(["a", "b", "c"])
+    bad = str(tmp_path / "no_such_dir" / "x_features.csv")
+    sc._write_cache_async(counts, ids, bad)
+    with pytest.raises(Exception) as e:
+        sc.finish_io()
+    assert not isinstance(e.value, AssertionError)
+    assert sc._pending_io == []
+    good = str(tmp_path / "x_features.csv")
+    sc._write_cache_async(counts, ids, good)
+    sc.finish_io()
+    assert os.path.exists(good) and not os.path.exists(good + ".part")
+    sc.finish_io()   # nothing pending: a no-op

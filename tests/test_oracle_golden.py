@@ -154,3 +154,17 @@ def test_reference_matrix_marginal_invariant():
     l1 = np.abs(t.sum(axis=4) - t.sum(axis=1)).sum(axis=(1, 2, 3))
     assert (l1 % 2 == 0).all() and np.median(l1) == 2
     assert ref["pos_counts"].shape == (2255, 256) and ref["neg_counts"].shape == (2418, 256)
+
+
+def test_distances_and_closest_to_golden():
+    """oracle.distances / closest_to against the reference's learning.distances / closest_to (scripts/learning.py:47-66)
+    executed on rows of the real matrix (tests/golden/distances.npz): bit for bit -- same NumPy expression."""
+    from oracle import oracle
+    g = helpers.load_npz("distances.npz")
+    ref = helpers.load_npz("ref_features.npz")
+    pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))[:300]
+    for i, v in enumerate(g["queries"]):
+        assert np.array_equal(oracle.distances(v, pos), g["dist_pos"][i])
+        assert np.array_equal(oracle.closest_to(v, g["picks"]), g["closest_picks"][i])
+    assert np.array_equal(oracle.distances(g["queries"][3:4], pos), g["dist_row_2d"])
+    assert g["dist_pos"][10, 0] == 0.0 and g["closest_idx"][14] == 43   # a reference row itself; the first of two equal picks

@@ -417,6 +417,24 @@ def gen_cross_validation(ref, phamer, pc, nc, kmer, out):
     np.savez_compressed(os.path.join(out, 'cross_validation.npz'), **arrays)
 
 
+def gen_distances(kmer, learning, pc, nc, out):
+    """learning.distances / learning.closest_to (scripts/learning.py:47-66) on rows of the real matrix: 16 query rows
+    (the scoring fixture's synthetic contigs and some reference rows themselves: zero distances, ties by duplicates)
+    against 300 positive rows and 86 strided means."""
+    with np.load(os.path.join(out, 'scoring_k4.npz')) as z:
+        q = z['q'][:10]
+    pos = kmer.normalize_counts(pc)[:300]
+    neg = kmer.normalize_counts(nc)[:200]
+    queries = np.vstack((q, pos[[0, 7, 299]], neg[[0, 5, 199]]))
+    picks = np.stack([neg[i::43].mean(axis=0) for i in range(43)] + [neg[5], neg[5]])   # a duplicate row: a tie
+    arrays = {'queries': queries, 'picks': picks,
+              'dist_pos': np.stack([learning.distances(v, pos) for v in queries]),
+              'dist_row_2d': learning.distances(queries[3:4], pos),
+              'closest_picks': np.stack([learning.closest_to(v, picks) for v in queries]),
+              'closest_idx': np.array([int(np.argmin(learning.distances(v, picks))) for v in queries])}
+    np.savez_compressed(os.path.join(out, 'distances.npz'), **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
@@ -434,6 +452,7 @@ def main():
     gen_transform(args.ref, args.out)
     gen_ids(args.ref, args.out)
     gen_cross_validation(args.ref, phamer, pc, nc, kmer, args.out)
+    gen_distances(kmer, learning, pc, nc, args.out)
     json.dump({'generator': 'tools/gen_golden.py', 'python': sys.version.split()[0],
                'numpy': np.__version__, 'scikit-learn': skl, 'count_arrays': n,
                'reference_functions': 'executed from the reference text via ast extraction; '
