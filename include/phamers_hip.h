@@ -203,6 +203,13 @@ int phk_batch_normalized(phk_ctx *ctx, const phk_batch *b, double *rows);
 /* rows[0..m) of a batch as a new batch: the row filter of phamer_scorer.screen_by_length (scripts/phamer.py:
  * 144-157) as a device gather */
 int phk_batch_select(phk_ctx *ctx, const phk_batch *b, const uint64_t *rows, uint64_t m, phk_batch **out);
+/* Column sums of a batch, sums[4^k] int64 to the host: kmer.count_directory's per-file np.sum(file_counts, axis=0)
+ * (scripts/kmer.py:170-173), which is how a reference matrix row is regenerated from a genome file. */
+int phk_batch_column_sums(phk_ctx *ctx, const phk_batch *b, int64_t *sums);
+/* transform_kmers.transform_kmers (scripts/transform_kmers.py:68-88) on resident counts: a new batch with
+ * out[r][j] = counts[r][table[j]] (table: 4^k host entries, each < 4^k; the reference's tables are not permutations, so
+ * the row sums are recomputed on the device). */
+int phk_batch_gather_columns(phk_ctx *ctx, const phk_batch *b, const uint32_t *table, phk_batch **out);
 /* phamer_scorer.score_points (scripts/phamer.py:177-195) on a batch: scores[n] float64 to the host.  PHK_ERR_NAN
  * when a row has no counted window (the reference's NaN row makes scikit-learn raise). */
 int phk_batch_score(phk_ctx *ctx, const phk_model *model, const phk_batch *b, int method, double *scores);
@@ -302,6 +309,13 @@ int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_exact_resolv
  * window wider than the refined candidates, window reaching past the lists, refined values too close, centroid
  * leader not certified */
 int phk_score_stats_ex(phk_ctx *ctx, uint64_t *out, int n_out);
+
+/* Diagnostic of the arithmetic the MFMA proposal rests on: chains of v_mfma_f32_32x32x16_f16 on caller tiles.  Per tile
+ * acc = C[32][32]; for s < steps: acc = A[s][32][16] (fp16 bits, row-major) x B[s][16][32] + acc, with D[tile][s][32][32] =
+ * acc after step s.  Host pointers.  The parity tests use it to assert the per-instruction rounding charge of the
+ * certification (2u (|acc_in| + sum |products|)) on adversarial inputs. */
+int phk_mfma_f16_probe(phk_ctx *ctx, const uint16_t *A, const uint16_t *B, const float *C, uint64_t n_tiles, uint32_t steps,
+                       float *D);
 
 /* seeded synthetic batch generated on the device (phamers_amd/synth.py defines the hash):
  * n contigs of L bases, contig ids first_contig..first_contig+n-1; writes the packed stream,

@@ -66,6 +66,8 @@ SIGNATURES = {
     "phk_features_close": (c_int, [c_void_p]),
     "phk_batch_normalized": (c_int, [c_void_p, c_void_p, c_void_p]),
     "phk_batch_select": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, P(c_void_p)]),
+    "phk_batch_column_sums": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "phk_batch_gather_columns": (c_int, [c_void_p, c_void_p, c_void_p, P(c_void_p)]),
     "phk_batch_score": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "phk_batch_free": (c_int, [c_void_p, c_void_p]),
     "phk_kmeans": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_u32, c_u64, c_int, c_void_p, c_void_p, P(c_int)]),
@@ -87,6 +89,7 @@ SIGNATURES = {
     "phk_check_counts_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_u64, c_u64, c_void_p]),
     "phk_score_stats": (c_int, [c_void_p, P(c_u64), P(c_u64)]),
     "phk_score_stats_ex": (c_int, [c_void_p, c_void_p, c_int]),
+    "phk_mfma_f16_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_u64, c_u32, c_void_p]),
     "phk_synth_packed_dev": (c_int, [c_void_p, c_u64, c_u64, c_u64, c_u64, c_u32, c_void_p,
                                      c_void_p, c_void_p]),
     "phk_synth_ragged_dev": (c_int, [c_void_p, c_u64, c_u64, c_u64, c_void_p, c_u64, c_u32, c_u32, c_void_p, c_void_p]),
@@ -335,6 +338,21 @@ class Batch(object):
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
         h = ctypes.c_void_p()
         check(self.ctx.lib.phk_batch_select(self.ctx.handle, self.handle, ptr(rows), rows.shape[0], ctypes.byref(h)))
+        return Batch(self.ctx, h)
+
+    def column_sums(self):
+        """int64 (4^k,): the column sums over the batch's rows, reduced on the device (phk_batch_column_sums)."""
+        out = np.zeros(self.D, dtype=np.int64)
+        check(self.ctx.lib.phk_batch_column_sums(self.ctx.handle, self.handle, ptr(out)))
+        return out
+
+    def gather_columns(self, table):
+        """A new resident batch whose column j is this batch's column table[j] (phk_batch_gather_columns)."""
+        table = np.ascontiguousarray(table, dtype=np.uint32)
+        if table.shape != (self.D,):
+            raise ValueError("gather_columns: the table must have %d entries" % self.D)
+        h = ctypes.c_void_p()
+        check(self.ctx.lib.phk_batch_gather_columns(self.ctx.handle, self.handle, ptr(table), ctypes.byref(h)))
         return Batch(self.ctx, h)
 
     def score(self, model, method="combo"):

@@ -256,6 +256,105 @@ extern "C" int phk_batch_select(phk_ctx *ctx, const phk_batch *b, const uint64_t
     return PHK_OK;
 }
 
+// ---- count-vector transforms and per-file column sums on resident counts ----
+// Column sums of a batch (kmer.count_directory's per-file np.sum(file_counts, axis=0), scripts/kmer.py:170-173): a block
+// sums a stripe of rows with one thread per column (consecutive threads = consecutive columns: coalesced) and adds its
+// partial sums to the [D] result.
+__global__ __launch_bounds__(256) void phk_column_sums_kernel(const uint32_t *__restrict__ counts, uint64_t n, uint64_t D,
+                                                              uint64_t rows_per_block, unsigned long long *__restrict__ sums) {
+    const uint64_t col = (uint64_t)blockIdx.y * 256 + threadIdx.x;
+    if (col >= D) return;
+    const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    unsigned long long acc = 0;
+    for (uint64_t r = r0; r < r1; ++r) acc += counts[r * D + col];
+    if (acc) atomicAdd(sums + col, acc);
+}
+
+extern "C" int phk_batch_column_sums(phk_ctx *ctx, const phk_batch *b, int64_t *sums) {
+    PHK_ENTER(ctx, "phk_batch_column_sums");
+    PHK_REQUIRE(b && sums, "phk_batch_column_sums: NULL");
+    const uint64_t D = b->D;
+    void *d_s;
+    PHK_TRY(phk_ws(ctx, WS_WIDE, D * 8, &d_s));
+    PHK_HIP(hipMemsetAsync(d_s, 0, D * 8, ctx->stream));
+    if (b->n) {
+        uint64_t stripes = (uint64_t)ctx->num_cus * 8 / phk_div_up(D, 256);
+        stripes = stripes < 1 ? 1 : (stripes > b->n ? b->n : stripes);
+        const uint64_t rows_per = phk_div_up(b->n, stripes);
+        PHK_LAUNCH(ctx, "phk_column_sums_kernel",
+                   phk_column_sums_kernel<<<dim3((unsigned)phk_div_up(b->n, rows_per), (unsigned)phk_div_up(D, 256)), dim3(256), 0, ctx->stream>>>(
+                       b->d_counts, b->n, D, rows_per, (unsigned long long *)d_s));
+    }
+    PHK_HIP(hipMemcpyAsync(sums, d_s, D * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    return PHK_OK;
+}
+
+// out[r][j] = counts[r][table[j]] for every row of a resident batch, and the new rows' sums (the reference's tables are
+// not permutations, so a row's sum can change): one wave per row, the row read once into LDS.
+__global__ __launch_bounds__(256) void phk_gather_columns_kernel(const uint32_t *__restrict__ counts, uint64_t n, uint64_t D,
+                                                                 const uint32_t *__restrict__ table,
+                                                                 uint32_t *__restrict__ out, uint32_t *__restrict__ out_nwin) {
+    extern __shared__ uint32_t gc_row[];   // one row of D per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t nw = blockDim.x >> 6;
+    uint32_t *row = gc_row + (uint64_t)wave * D;
+    const uint64_t total = (uint64_t)gridDim.x * nw;
+    for (uint64_t r = (uint64_t)blockIdx.x * nw + wave; r < n; r += total) {
+        for (uint64_t j = lane; j < D; j += 64) row[j] = counts[r * D + j];
+        __builtin_amdgcn_wave_barrier();
+        uint32_t s = 0;
+        for (uint64_t j = lane; j < D; j += 64) {
+            const uint32_t v = row[table[j]];
+            out[r * D + j] = v;
+            s += v;
+        }
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+        if (lane == 0) out_nwin[r] = s;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// transform_kmers.transform_kmers (scripts/transform_kmers.py:68-88) on a resident batch: a new batch whose column j is
+// the source's column table[j] (host table, D entries, each < D).
+extern "C" int phk_batch_gather_columns(phk_ctx *ctx, const phk_batch *b, const uint32_t *table, phk_batch **out) {
+    PHK_ENTER(ctx, "phk_batch_gather_columns");
+    PHK_REQUIRE(b && table && out, "phk_batch_gather_columns: NULL");
+    const uint64_t D = b->D;
+    for (uint64_t j = 0; j < D; ++j)
+        PHK_REQUIRE(table[j] < D, "phk_batch_gather_columns: index %u is out of bounds for %llu columns", table[j], (unsigned long long)D);
+    phk_batch *s = new phk_batch();
+    s->n = b->n; s->k = b->k; s->D = D; s->T = b->T; s->any_invalid = b->any_invalid; s->len = b->len;
+    if (b->n == 0) {
+        *out = s;
+        return PHK_OK;
+    }
+    void *d_tab;
+    int rc = phk_ws(ctx, WS_OFFSETS, D * 4, &d_tab);
+    if (rc == PHK_OK && (hipMalloc(&s->d_counts, s->n * D * sizeof(uint32_t)) != hipSuccess ||
+                         hipMalloc(&s->d_nwin, s->n * sizeof(uint32_t)) != hipSuccess))
+        rc = PHK_ERR_NOMEM;
+    auto body = [&]() -> int {
+        PHK_HIP(hipMemcpyAsync(d_tab, table, D * 4, hipMemcpyHostToDevice, ctx->stream));
+        const uint64_t nw = 4 * D * sizeof(uint32_t) <= 65536 ? 4 : 1;   // waves (rows in LDS) per block: 64 KiB of dynamic LDS
+        uint64_t blocks = phk_div_up(s->n, nw);
+        if (blocks > (uint64_t)ctx->num_cus * 16) blocks = (uint64_t)ctx->num_cus * 16;
+        PHK_LAUNCH(ctx, "phk_gather_columns_kernel",
+                   phk_gather_columns_kernel<<<dim3((unsigned)blocks), dim3((unsigned)(64 * nw)), nw * D * sizeof(uint32_t), ctx->stream>>>(
+                       b->d_counts, s->n, D, (const uint32_t *)d_tab, s->d_counts, s->d_nwin));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+        return PHK_OK;
+    };
+    if (rc == PHK_OK) rc = body();
+    if (rc != PHK_OK) {
+        batch_release(s);
+        return rc;
+    }
+    *out = s;
+    return PHK_OK;
+}
+
 // phamer_scorer.score_points on a device-resident batch (scripts/phamer.py:177-195): scores[n] to the host.
 // A zero-count row (the reference's NaN row) makes the call fail with PHK_ERR_NAN, as phk_score does.
 extern "C" int phk_batch_score(phk_ctx *ctx, const phk_model *model, const phk_batch *b, int method, double *scores) {

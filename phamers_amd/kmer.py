@@ -137,19 +137,36 @@ def count_directory(directory, kmer_length, identifier='fna', symbols=DNA, sum_f
     if sample:
         random.shuffle(selected_files)
     ids, rows = [], []
+    sym = _check_symbols(symbols)
     for path in selected_files:
-        file_ids, file_counts = count_file(path, kmer_length, symbols=symbols)
-        if file_ids is None or len(file_ids) == 0 or np.sum(file_counts) == 0:
+        # one file = one device-resident batch; with sum_file its column sums are reduced on the device
+        # (phk_batch_column_sums) and only the 4^k sums come back -- the per-record count matrix never does
+        try:
+            fasta = _lib.Fasta(path)
+        except IOError:
             logger.warning("Could not read file: %s" % os.path.basename(path))
             continue
-        if sum_file and len(file_counts.shape) == 2:
-            # Summing k-mer counts of all sequences within a file
-            file_counts = np.sum(file_counts, axis=0)
-        elif len(file_counts.shape) == 2 and file_counts.shape[0] == 1:
-            file_counts = file_counts[0]
-        elif len(file_counts.shape) == 2:
-            raise ValueError("count_directory(sum_file=False) needs single-record files (%s has %d records)"
-                             % (os.path.basename(path), file_counts.shape[0]))
+        try:
+            file_ids = fasta.phamers_ids()
+            if fasta.n_records == 0:
+                logger.warning("Could not read file: %s" % os.path.basename(path))
+                continue
+            batch = _lib.Batch.from_fasta(_lib.get_context(), fasta, kmer_length, sym)
+        finally:
+            fasta.close()
+        try:
+            if sum_file:
+                file_counts = batch.column_sums()
+            elif batch.n == 1:
+                file_counts = batch.counts()[0]
+            else:
+                raise ValueError("count_directory(sum_file=False) needs single-record files (%s has %d records)"
+                                 % (os.path.basename(path), batch.n))
+        finally:
+            batch.close()
+        if np.sum(file_counts) == 0:
+            logger.warning("Could not read file: %s" % os.path.basename(path))
+            continue
         ids.append(file_ids[0])
         rows.append(file_counts)
         if sample and len(ids) == sample:

@@ -1,6 +1,7 @@
 """
 transform_kmers.py -- count-vector transforms of PhaMers' scripts/transform_kmers.py:68-88 as a device column
-gather (phk_permute_columns_i64).
+gather (host arrays: phk_permute_columns_i64; device-resident batches: phk_batch_gather_columns; SURVEY.md section
+8(f)-4).
 
 Two families of index tables:
 
@@ -49,6 +50,23 @@ def reference_indices(k, reverse=True, complement=False):
     return (d * (k ** np.arange(k))).sum(axis=1).astype(np.int64)
 
 
+def _table(D, reverse, complement, exact):
+    k = int(round(np.log(D) / np.log(4)))
+    table = (exact_indices if exact else reference_indices)(k, reverse, complement)
+    if table.max() >= D:
+        raise IndexError("index %d is out of bounds for axis 0 with size %d" % (int(table.max()), D))
+    return np.ascontiguousarray(table, dtype=np.uint32)
+
+
+def transform_batch(batch, reverse=True, complement=False, exact=False):
+    """transform_kmers on a device-resident batch (``_lib.Batch``): a new resident batch whose counts are the
+    transformed ones -- a device-to-device column gather (phk_batch_gather_columns), nothing crosses the bus but the
+    4^k-entry table.  Same tables, same IndexError as ``transform_kmers``."""
+    if not reverse and not complement:
+        return batch
+    return batch.gather_columns(_table(batch.D, reverse, complement, exact))
+
+
 def transform_kmers(counts, reverse=True, complement=False, symbols='ATGC', exact=False):
     """Counts as though the reverse / complement / reverse-complement k-mers had been counted
     (scripts/transform_kmers.py:68-88).  ``counts``: (n, 4^k) array.  Default: the reference's own table, bug for
@@ -59,11 +77,7 @@ def transform_kmers(counts, reverse=True, complement=False, symbols='ATGC', exac
     if not reverse and not complement:
         return counts
     n, D = counts.shape
-    k = int(round(np.log(D) / np.log(4)))
-    table = (exact_indices if exact else reference_indices)(k, reverse, complement)
-    if table.max() >= D:
-        raise IndexError("index %d is out of bounds for axis 0 with size %d" % (int(table.max()), D))
-    perm = np.ascontiguousarray(table, dtype=np.uint32)
+    perm = _table(D, reverse, complement, exact)
     src = np.ascontiguousarray(counts, dtype=np.int64)
     out = np.empty_like(src)
     ctx = _lib.get_context()

@@ -709,3 +709,171 @@ def test_learning_distances_and_closest_to_match_reference():
         learning.distances(g["queries"][:2], pos)          # the reference's np.repeat form does not broadcast either
     with pytest.raises(ValueError):
         learning.distances(g["queries"][0][:100], pos)
+
+
+def _mfma_probe(ctx, A, B, C):
+    """A [T][S][32][16], B [T][S][16][32] float16, C [T][32][32] float32 -> D [T][S][32][32] float32 (phk_mfma_f16_probe)."""
+    import ctypes
+    from phamers_amd import _lib
+    A = np.ascontiguousarray(A, dtype=np.float16)
+    B = np.ascontiguousarray(B, dtype=np.float16)
+    C = np.ascontiguousarray(C, dtype=np.float32)
+    T, S = A.shape[0], A.shape[1]
+    D = np.empty((T, S, 32, 32), dtype=np.float32)
+    _lib.check(ctx.lib.phk_mfma_f16_probe(ctx.handle, _lib.ptr(A.view(np.uint16)), _lib.ptr(B.view(np.uint16)), _lib.ptr(C),
+                                          T, S, _lib.ptr(D)))
+    return D
+
+
+def _mfma_step_error_ratio(A, B, acc_in, D):
+    """max over elements of |D - exact(acc_in + sum_k A B)| / (u (|acc_in| + sum_k |A B|)), exact sums by math.fsum of
+    float64 terms (a product of two float16 numbers and a float32 are exact in float64)."""
+    import math
+    u = 2.0 ** -24
+    Ad, Bd = A.astype(np.float64), B.astype(np.float64)
+    prod = Ad[:, :, None] * Bd.T[None, :, :]                        # [32][32][16]
+    mag = np.abs(prod).sum(axis=2) + np.abs(acc_in.astype(np.float64))
+    worst = 0.0
+    for i in range(32):
+        for j in range(32):
+            exact = math.fsum(list(prod[i, j]) + [float(acc_in[i, j])])
+            err = abs(float(D[i, j]) - exact)
+            if mag[i, j] > 0:
+                worst = max(worst, err / (u * mag[i, j]))
+            else:
+                assert err == 0.0
+    return worst
+
+
+@pytest.mark.gpu
+def test_mfma_f16_rounding_charge_holds_on_adversarial_tiles():
+    """The certification's one measured constant: every v_mfma_f32_32x32x16_f16 is charged
+    2u (|acc_in| + sum |products|).  Driven here, through the library, with what should break a too-optimistic model:
+    cancellation-heavy tiles (products that cancel to a residue far below their magnitudes, against an accumulator of
+    the opposite sign), fp16 subnormal operands beside normal ones (the low parts of the split reference columns),
+    count operands at the 2048 limit against the largest scaled reference parts, and chains of 16 instructions as the
+    k = 4 kernels issue them (each step checked against the accumulator the device really fed it)."""
+    from phamers_amd import _lib
+    ctx = _lib.get_context()
+    rng = np.random.default_rng(42)
+    tiles = []   # (A [32][16], B [16][32], C [32][32])
+
+    def f16(x):
+        return np.asarray(x, dtype=np.float64).astype(np.float16)
+    for _ in range(24):     # (a) random, wide dynamic range
+        sc = 10.0 ** rng.uniform(-3, 3)
+        tiles.append((f16(rng.standard_normal((32, 16)) * sc), f16(rng.standard_normal((16, 32)) * 100.0),
+                      (rng.standard_normal((32, 32)) * sc * 1e3).astype(np.float32)))
+    for _ in range(24):     # (b) cancellation: pairs of products +X, -X (1 + 2^-10 ..), C opposite to the residue's scale
+        a = rng.integers(1, 2049, (32, 16)).astype(np.float64)
+        b = rng.uniform(200.0, 2000.0, (16, 32))
+        a[:, 1::2] = a[:, 0::2]
+        b[1::2, :] = -b[0::2, :] * (1.0 + rng.choice([0.0, 2.0 ** -10, -2.0 ** -9, 2.0 ** -6], (8, 32)))
+        c = rng.choice([0.0, 1.0, -1.0], (32, 32)) * rng.uniform(0.0, 4e6, (32, 32))
+        tiles.append((f16(a), f16(b), c.astype(np.float32)))
+    for _ in range(16):     # (c) subnormal low parts (2^-24 .. 2^-15) beside counts, alone and mixed with normal terms
+        a = rng.integers(0, 2049, (32, 16)).astype(np.float64)
+        b = rng.choice([-1.0, 1.0], (16, 32)) * 2.0 ** rng.integers(-24, -14, (16, 32)) * rng.integers(1, 64, (16, 32))
+        mix = rng.random((16, 32)) < 0.3
+        b = np.where(mix, rng.uniform(-800, 800, (16, 32)), b)
+        tiles.append((f16(a), f16(b), (rng.standard_normal((32, 32)) * rng.choice([0.0, 1e-3, 1.0])).astype(np.float32)))
+    for _ in range(16):     # (d) counts at the limit x the largest scaled parts, same sign: the accumulator grows to ~2^29
+        a = np.full((32, 16), 2048.0)
+        a[rng.random((32, 16)) < 0.2] = 2047.0
+        b = rng.uniform(1500.0, 2047.0, (16, 32)) * rng.choice([1.0, 1.0, 1.0, -1.0], (16, 32))
+        tiles.append((f16(a), f16(b), (rng.uniform(-1.0, 1.0, (32, 32)) * 2.0 ** 28).astype(np.float32)))
+    A = np.stack([t[0] for t in tiles])[:, None]
+    B = np.stack([t[1] for t in tiles])[:, None]
+    C = np.stack([t[2] for t in tiles])
+    D = _mfma_probe(ctx, A, B, C)
+    worst = max(_mfma_step_error_ratio(A[t, 0], B[t, 0], C[t], D[t, 0]) for t in range(len(tiles)))
+    assert worst <= 2.0, "single instruction: error %.3f u (|acc| + sum |products|), charged 2" % worst
+
+    # chains of 16 (k = 4: D / 16 instructions per value): count rows x high parts, and the cancellation family again
+    S = 16
+    chains_A, chains_B = [], []
+    for c in range(12):
+        counts = rng.poisson(19.5, (32, 256)).astype(np.float64)
+        if c % 3 == 1:
+            counts[:, rng.integers(0, 256, 6)] = 2048.0        # low-complexity contigs: a few bins at the limit
+        if c % 3 == 2:
+            counts = rng.integers(0, 2049, (32, 256)).astype(np.float64)
+        ref = rng.standard_normal((256, 32)) * rng.uniform(5.0, 600.0)   # (r - mu) S, high parts
+        if c % 2:
+            ref[1::2] = -ref[0::2] * (1.0 + 2.0 ** -9)
+            counts[:, 1::2] = counts[:, 0::2]
+        chains_A.append(f16(counts).reshape(32, S, 16).transpose(1, 0, 2))
+        chains_B.append(f16(ref).reshape(S, 16, 32))
+    A = np.stack(chains_A)
+    B = np.stack(chains_B)
+    C = np.zeros((len(chains_A), 32, 32), dtype=np.float32)
+    D = _mfma_probe(ctx, A, B, C)
+    worst_chain = 0.0
+    for t in range(A.shape[0]):
+        for s in (0, 1, 7, 15):    # every step is one instruction fed the accumulator of the step before
+            acc_in = C[t] if s == 0 else D[t, s - 1]
+            worst_chain = max(worst_chain, _mfma_step_error_ratio(A[t, s], B[t, s], acc_in, D[t, s]))
+    assert worst_chain <= 2.0, "chained instruction: error %.3f u (|acc_in| + sum |products|), charged 2" % worst_chain
+    # and the whole chain against the bound the kernels' error model sums up: sum over steps of the charges
+    u = 2.0 ** -24
+    for t in range(0, A.shape[0], 3):
+        Ad = A[t].astype(np.float64).transpose(1, 0, 2).reshape(32, 256)
+        Bd = B[t].astype(np.float64).reshape(256, 32)
+        exact = Ad @ Bd                                           # float64: error far below u of the terms
+        charge = np.zeros((32, 32))
+        for s in range(S):
+            acc_in = np.zeros((32, 32)) if s == 0 else np.abs(D[t, s - 1].astype(np.float64))
+            charge += 2.0 * u * (acc_in + np.abs(Ad[:, 16 * s:16 * s + 16]) @ np.abs(Bd[16 * s:16 * s + 16]))
+        assert np.all(np.abs(D[t, S - 1].astype(np.float64) - exact) <= charge + 1e-9 * np.abs(Ad) @ np.abs(Bd))
+    print("mfma f16 probe: worst single-instruction error %.3f u, worst chained %.3f u (charged 2 u)" % (worst, worst_chain))
+
+
+@pytest.mark.gpu
+def test_transforms_and_column_sums_on_resident_batches(tmp_path):
+    """SURVEY 8(f)-4 on the device: transform_kmers as a device-to-device column gather of a resident batch
+    (phk_batch_gather_columns) against the reference's own outputs (tests/golden/transform.npz) and against counting the
+    transformed sequences; per-file column sums (kmer.count_directory, scripts/kmer.py:170-173) reduced on the device."""
+    from oracle import oracle
+    from phamers_amd import _lib, synth, transform_kmers
+    ctx = _lib.get_context()
+    comp = {"A": "T", "T": "A", "G": "C", "C": "G"}
+    for k in (3, 4, 5):
+        seqs = [synth.synth_contig(31, i, 200 + 113 * i) for i in range(37)]
+        batch = _lib.Batch.from_sequences(ctx, seqs, k)
+        want = oracle.count(seqs, k).reshape(len(seqs), -1)
+        assert np.array_equal(batch.column_sums(), want.sum(axis=0))
+        for rev, cmpl in ((True, False), (False, True), (True, True)):
+            tb = transform_kmers.transform_batch(batch, reverse=rev, complement=cmpl, exact=True)
+            tseqs = ["".join(comp[c] for c in s) if cmpl else s for s in seqs]
+            tseqs = [s[::-1] for s in tseqs] if rev else tseqs
+            assert np.array_equal(tb.counts(), oracle.count(tseqs, k).reshape(len(seqs), -1)), (k, rev, cmpl)
+            assert (tb.n, tb.D, tb.total_bases) == (batch.n, batch.D, batch.total_bases)
+            tb.close()
+        assert transform_kmers.transform_batch(batch, reverse=False, complement=False) is batch
+        if k == 5:
+            with pytest.raises(IndexError):        # the reference's table points past the last column at k >= 5
+                transform_kmers.transform_batch(batch, reverse=True, complement=True)
+        batch.close()
+    # the reference's own (non-permutation) tables at k = 4, on counts as the device holds them
+    z = helpers.load_npz("transform.npz")
+    x = z["in_k4"]
+    seqs = [synth.synth_contig(32, i, 3000) for i in range(24)]
+    batch = _lib.Batch.from_sequences(ctx, seqs, 4)
+    host = batch.counts()
+    for name, rev, cmpl in (("rev", True, False), ("comp", False, True), ("revcomp", True, True)):
+        tb = transform_kmers.transform_batch(batch, reverse=rev, complement=cmpl)
+        assert np.array_equal(tb.counts(), transform_kmers.transform_kmers(host, reverse=rev, complement=cmpl)), name
+        tb.close()
+        # and the table itself is the one the reference built for the fixture's counts
+        assert np.array_equal(transform_kmers.transform_kmers(x, reverse=rev, complement=cmpl), z[name + "_k4"])
+    # a transformed batch scores like the host-transformed rows (row sums recomputed on the device)
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    model = _lib.Model(ctx, pos, neg, g["cpos_full"], g["cneg_full"], 3)
+    tb = transform_kmers.transform_batch(batch, reverse=True, complement=True, exact=True)
+    q = oracle.normalize_counts(tb.counts())
+    want = oracle.score_points(q, pos, neg, "combo", 3, g["cpos_full"], g["cneg_full"])
+    assert helpers.rel_err(tb.score(model, "combo"), want) < RTOL
+    tb.close()
+    batch.close()
+    model.close()
