@@ -65,6 +65,8 @@ struct HiOnlyOut {
     std::vector<float> *betah_all = nullptr;
     std::vector<_Float16> *lo_rows = nullptr;
     std::vector<double> *lonorm = nullptr;
+    std::vector<double> *hsum = nullptr;   // |sum_d r~'_d| per real column (the residue of centring the counts, see ErrBound)
+    std::vector<double> *xmax = nullptr;   // |r~'|_inf per real column
     uint64_t col0 = 0;
 };
 
@@ -86,7 +88,11 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
                 if (ho.betah_all) (*ho.betah_all)[(cb0 + b) * 32 + i] = -PAD_V;
                 continue;
             }
-            double nrm2 = 0.0, mudot = 0.0, mulo = 0.0, lo2 = 0.0;
+            // The count-exact kernels multiply the column by the counts MINUS their centre c0 ~ T / D (phk_row_center), so
+            // the bias terms are built with mu - 1/D in place of mu: sum_i (c_i - c0) x_i - T [(mu - 1/D).x + ..] =
+            // sum_i c_i x_i - T [mu.x + ..] - (c0 - T/D) sum_i x_i, and the last term is the hsum residue.
+            double nrm2 = 0.0, mudot = 0.0, mulo = 0.0, lo2 = 0.0, xsum = 0.0, xmx = 0.0;
+            const double shift = 1.0 / (double)D;
             for (int c = 0; c < nchunk; ++c)
                 for (int h = 0; h < 2; ++h)
                     for (int s = 0; s < 16; ++s)
@@ -101,13 +107,17 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
                             reinterpret_cast<_Float16 *>(piece + 1024 + lane * 16)[jj] = lo;
                             const double xt = (double)hi + (double)lo;  // the column as the kernel sees it (scaled)
                             nrm2 += xt * xt;
-                            mudot += mu[d] * xt;
-                            mulo += mu[d] * (double)lo;
+                            mudot += (mu[d] - shift) * xt;
+                            mulo += (mu[d] - shift) * (double)lo;
                             lo2 += (double)lo * (double)lo;
+                            xsum += xt;
+                            xmx = std::fabs(xt) > xmx ? std::fabs(xt) : xmx;
                             if (ho.lo_rows) (*ho.lo_rows)[(ho.col0 + r) * D + lo_pos(D, d)] = lo;
                         }
             if (ho.betah_all) (*ho.betah_all)[(cb0 + b) * 32 + i] = (float)(mudot - mulo + 0.5 * nrm2 / (double)F16_SCALE);
             if (ho.lonorm) (*ho.lonorm)[ho.col0 + r] = std::sqrt(lo2) / (double)F16_SCALE;
+            if (ho.hsum) (*ho.hsum)[ho.col0 + r] = std::fabs(xsum) / (double)F16_SCALE;
+            if (ho.xmax) (*ho.xmax)[ho.col0 + r] = xmx / (double)F16_SCALE;
             // count-exact kernel: S beta = S (mu.r~' + |r~'|^2 / 2), the bias per unit of row sum
             cn[32 + i] = (float)(mudot + 0.5 * nrm2 / (double)F16_SCALE);
             beta_all[(cb0 + b) * 32 + i] = cn[32 + i];
@@ -131,8 +141,10 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
     std::vector<uint8_t> rec((nblk + 1) * rec_bytes, 0);  // + one block: the DMA prefetch runs one past the end
     std::vector<float> cn_all((nblk + 1) * 32, PAD_V), beta_all((nblk + 1) * 32, -PAD_V), betah_all;
     std::vector<_Float16> lo_rows;
-    std::vector<double> lonorm;
+    std::vector<double> lonorm, hsum(ncols, 0.0), xmax(ncols, 0.0);
     HiOnlyOut ho;
+    ho.hsum = &hsum;
+    ho.xmax = &xmax;
     if (hi_only) {
         betah_all.assign((nblk + 1) * 32, -PAD_V);
         lo_rows.assign(ncols * D, (_Float16)0.0f);
@@ -152,6 +164,15 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
     if (m->n_cpos) pack_segment_f16(cpos, m->n_cpos, D, mu, rec, rec_bytes, m->n_rblk_ref, cn_all, beta_all, ho);
     ho.col0 = m->M + m->n_cpos;
     if (m->n_cneg) pack_segment_f16(cneg, m->n_cneg, D, mu, rec, rec_bytes, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, cn_all, beta_all, ho);
+    m->hsum_train = m->hsum_cen = m->rho_train = m->rho_cen = 0.0;
+    for (uint64_t c = 0; c < ncols; ++c) {
+        double &dst = c < m->M ? m->hsum_train : m->hsum_cen;
+        dst = hsum[c] > dst ? hsum[c] : dst;
+        double &rd = c < m->M ? m->rho_train : m->rho_cen;
+        const double rr = colnorm[c] > 0.0 ? xmax[c] / colnorm[c] : (xmax[c] > 0.0 ? 1.0 : 0.0);
+        rd = rr > rd ? rr : rd;
+    }
+    m->rho_inf = (m->rho_train > m->rho_cen ? m->rho_train : m->rho_cen) * (1.0 + 1e-6);
     if (hipMalloc(&m->d_Af16, rec.size()) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMemcpy(m->d_Af16, rec.data(), rec.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     if (hipMalloc(&m->d_cn16, cn_all.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
@@ -221,8 +242,10 @@ int phk_model_update_centroids_f16(phk_model *m, const double *cpos, const doubl
     std::vector<uint8_t> rec(nbc * rec_bytes, 0);
     std::vector<float> cn_all(nbc * 32, PAD_V), beta_all(nbc * 32, -PAD_V), betah_all(nbc * 32, -PAD_V);
     std::vector<_Float16> lo_rows;
-    std::vector<double> lonorm;
+    std::vector<double> lonorm, hsum(ncc, 0.0), xmax(ncc, 0.0);
     HiOnlyOut ho;
+    ho.hsum = &hsum;
+    ho.xmax = &xmax;
     if (hi_only) {
         lo_rows.assign(ncc * D, (_Float16)0.0f);
         lonorm.assign(ncc, 0.0);
@@ -234,6 +257,13 @@ int phk_model_update_centroids_f16(phk_model *m, const double *cpos, const doubl
     pack_segment_f16(cpos, m->n_cpos, D, m->h_mu.data(), rec, rec_bytes, 0, cn_all, beta_all, ho);
     ho.col0 = m->n_cpos;
     pack_segment_f16(cneg, m->n_cneg, D, m->h_mu.data(), rec, rec_bytes, m->n_rblk_pos, cn_all, beta_all, ho);
+    m->hsum_cen = m->rho_cen = 0.0;
+    for (uint64_t c = 0; c < ncc; ++c) {
+        m->hsum_cen = hsum[c] > m->hsum_cen ? hsum[c] : m->hsum_cen;
+        const double rr = colnorm_c[c] > 0.0 ? xmax[c] / colnorm_c[c] : (xmax[c] > 0.0 ? 1.0 : 0.0);
+        m->rho_cen = rr > m->rho_cen ? rr : m->rho_cen;
+    }
+    m->rho_inf = (m->rho_train > m->rho_cen ? m->rho_train : m->rho_cen) * (1.0 + 1e-6);
     const uint64_t b0 = m->n_rblk_ref;
     if (hipMemcpy((uint8_t *)m->d_Af16 + b0 * rec_bytes, rec.data(), rec.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(m->d_cn16 + b0 * 32, cn_all.data(), cn_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
@@ -493,9 +523,12 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
         dma_block(blk + 1, (blk + 1) & 1);  // one past the end on the last block: the record array is padded
         const uint8_t *buf = smem + (blk & 1) * F16_BLOCK_BYTES;
 
-        f32x16 acc;
+        // Two accumulators: the hi.hi chain, and the two cross terms (hi.lo + lo.hi), whose running sums are 2^-10 of the
+        // first one's.  Every instruction of a chain is charged on that chain's running sum (ErrBound), so the 32 cross
+        // instructions cost next to nothing there instead of as much as the 16 hi.hi ones.
+        f32x16 acc, accx;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[r] = accx[r] = 0.0f;
         const half8 *fr = reinterpret_cast<const half8 *>(buf) + lane;
         // fragments are read one k-step ahead of their MFMAs (LDS latency ~ one step of MFMA time);
         // the issue order per step is pinned: 2 LDS reads, then MFMA / insertion-VALU interleaved
@@ -509,8 +542,8 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
             }
             __builtin_amdgcn_sched_barrier(0);  // the reads stay up here, one step ahead of their MFMAs
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], accx, 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], accx, 0, 0, 0);
             list_insert(lv, li, ldrop, xs[s], cbase + (uint32_t)((s & 3) + 8 * (s >> 2)));
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // VALU (insertion)
@@ -526,10 +559,10 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) {
             const float4 c4 = cn[2 * m4];
-            xs[4 * m4 + 0] = acc[4 * m4 + 0] + c4.x;
-            xs[4 * m4 + 1] = acc[4 * m4 + 1] + c4.y;
-            xs[4 * m4 + 2] = acc[4 * m4 + 2] + c4.z;
-            xs[4 * m4 + 3] = acc[4 * m4 + 3] + c4.w;
+            xs[4 * m4 + 0] = (acc[4 * m4 + 0] + accx[4 * m4 + 0]) + c4.x;
+            xs[4 * m4 + 1] = (acc[4 * m4 + 1] + accx[4 * m4 + 1]) + c4.y;
+            xs[4 * m4 + 2] = (acc[4 * m4 + 2] + accx[4 * m4 + 2]) + c4.z;
+            xs[4 * m4 + 3] = (acc[4 * m4 + 3] + accx[4 * m4 + 3]) + c4.w;
         }
         cbase = 32u * (blk - seg_first) + 4u * (uint32_t)h;
     }
@@ -654,7 +687,7 @@ __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn
     };
     if (total) dma_block(0, 0);
 
-    // ---- prologue: counts -> fp16 (exact up to 2048), row sum, row maximum ----
+    // ---- prologue: centred counts -> fp16 (exact up to 2048 in magnitude), row sum (from the caller) ----
     half8 bq[NT][16];
     float negT[NT];
     bool big[NT];
@@ -663,19 +696,22 @@ __global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn
         const uint64_t qi = q0 + 32 * t + j;
         const uint64_t qrow = qi < N ? qi : N - 1;
         const uint4 *row = reinterpret_cast<const uint4 *>(counts + qrow * FAST_D + 128 * h);
-        uint32_t sum = 0, mx = 0;
+        // the operand is the count minus the row's centre (phk_row_center): an integer of magnitude <= 2048, exact in fp16
+        const uint32_t tot = rowsum[qrow];
+        const int cen = (int)phk_row_center(tot, FAST_D);
+        uint32_t mx = 0;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const uint4 c0 = row[2 * s], c1 = row[2 * s + 1];
             const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                sum += c[e];
-                mx = mx > c[e] ? mx : c[e];
-                bq[t][s][e] = (_Float16)(float)(c[e] < 2048u ? c[e] : 2048u);
+                const int d = (int)c[e] - cen;           // (a count above 2^31 wraps to a negative d: the row is `big` below)
+                const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+                mx = max(mx, max(ad, c[e] >> 31 ? 0xFFFFFFFFu : 0u));
+                bq[t][s][e] = (_Float16)(float)(d < -2048 ? -2048 : (d > 2048 ? 2048 : d));
             }
         }
-        const uint32_t tot = rowsum ? rowsum[qrow] : sum + __shfl_xor(sum, 32);
         const uint32_t mo = __shfl_xor(mx, 32);
         big[t] = (mx > mo ? mx : mo) > 2048u;
         negT[t] = -(float)tot;
@@ -906,7 +942,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     };
     if (total) dma_block(0, 0);
 
-    // ---- prologue: counts -> fp16 (exact up to 2048), row sum, row maximum ----
+    // ---- prologue: centred counts -> fp16 (exact up to 2048 in magnitude), row sum (from the caller) ----
     half8 bq[NT][16];
     float negT[NT];
     bool big[NT];
@@ -915,19 +951,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
         const uint64_t qi = q0 + 32 * t + j;
         const uint64_t qrow = qi < N ? qi : N - 1;
         const uint4 *row = reinterpret_cast<const uint4 *>(counts + qrow * FAST_D + 128 * h);
-        uint32_t sum = 0, mx = 0;
+        // the operand is the count minus the row's centre (phk_row_center): an integer of magnitude <= 2048, exact in fp16
+        const uint32_t tot = rowsum[qrow];
+        const int cen = (int)phk_row_center(tot, FAST_D);
+        uint32_t mx = 0;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const uint4 c0 = row[2 * s], c1 = row[2 * s + 1];
             const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                sum += c[e];
-                mx = mx > c[e] ? mx : c[e];
-                bq[t][s][e] = (_Float16)(float)(c[e] < 2048u ? c[e] : 2048u);
+                const int d = (int)c[e] - cen;           // (a count above 2^31 wraps to a negative d: the row is `big` below)
+                const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+                mx = max(mx, max(ad, c[e] >> 31 ? 0xFFFFFFFFu : 0u));
+                bq[t][s][e] = (_Float16)(float)(d < -2048 ? -2048 : (d > 2048 ? 2048 : d));
             }
         }
-        const uint32_t tot = rowsum ? rowsum[qrow] : sum + __shfl_xor(sum, 32);
         const uint32_t mo = __shfl_xor(mx, 32);
         big[t] = (mx > mo ? mx : mo) > 2048u;
         negT[t] = -(float)tot;
@@ -1101,8 +1140,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch before the LDS is released
 }
 
+__global__ void phk_rowsum_kernel(const uint32_t *__restrict__ counts, uint64_t N, uint64_t D, uint32_t *__restrict__ out);
+// the count-exact kernels centre a row by a function of its sum: callers that hold no row sums get them computed here
+static int ensure_rowsum(phk_ctx *ctx, const uint32_t *d_counts, uint64_t nb, uint64_t D, const uint32_t *&d_rowsum) {
+    if (d_rowsum) return PHK_OK;
+    void *rs;
+    PHK_TRY(phk_ws(ctx, WS_NWIN, nb * sizeof(uint32_t), &rs));
+    PHK_LAUNCH(ctx, "phk_rowsum_kernel",
+               phk_rowsum_kernel<<<dim3((unsigned)phk_div_up(nb, 4)), dim3(256), 0, ctx->stream>>>(d_counts, nb, D, (uint32_t *)rs));
+    d_rowsum = (const uint32_t *)rs;
+    return PHK_OK;
+}
+
 int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu) {
+    PHK_TRY(ensure_rowsum(ctx, d_counts, nb, m->D, d_rowsum));
     const size_t lds = 2 * F16_BLOCK_BYTES;
     int nt = 2, nw = 8;
     const char *e = ctx->knobs.cx_cfg;  // "<tiles per wave><waves per workgroup>": 14, 24, 28 (default)
@@ -1127,6 +1179,7 @@ int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d
 
 int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu) {
+    PHK_TRY(ensure_rowsum(ctx, d_counts, nb, m->D, d_rowsum));
     const size_t lds = 2 * F16H_BLOCK_BYTES;
     const uint4 *af = (const uint4 *)m->d_Af16h + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16H_BLOCK_BYTES / 16);
     // Two 4-wave workgroups per CU (default, "24") or one 8-wave workgroup ("28"): with two workgroups the two waves of a
@@ -1153,8 +1206,7 @@ int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d
 // queries' chunk fragments (32 KiB, coalesced) once per (tile, chunk) = once per 192 MFMAs, while
 // the column-chunk records stream through the same LDS double buffer as above.
 // ====================================================================================
-__global__ __launch_bounds__(256) void phk_rowsum_kernel(const uint32_t *__restrict__ counts, uint64_t N, uint64_t D,
-                                                         uint32_t *__restrict__ out) {
+__global__ __launch_bounds__(256) void phk_rowsum_kernel(const uint32_t *__restrict__ counts, uint64_t N, uint64_t D, uint32_t *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const uint64_t r = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= N) return;
@@ -1186,7 +1238,8 @@ __global__ __launch_bounds__(256) void phk_split_queries_kernel(const void *__re
     uint4 *out = Bq + (w * 32) * 64 + lane;
     float inv = 0.f;
     if (SRC == 0) inv = (float)(1.0 / (double)rowsum[qrow]) * F16_SCALE;
-    if (SRC == 2) {
+    if (SRC == 2) {   // the counts minus the row's centre (phk_row_center), exact in fp16 up to 2048 in magnitude
+        const int cen = (int)phk_row_center(rowsum[qrow], (uint32_t)D);
         uint32_t mx = 0;
         for (int s = 0; s < 16; ++s) {
             const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + qrow * D + d0 + 8 * s);
@@ -1195,8 +1248,10 @@ __global__ __launch_bounds__(256) void phk_split_queries_kernel(const void *__re
             half8 hi;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                mx = mx > c[e] ? mx : c[e];
-                hi[e] = (_Float16)(float)(c[e] < 2048u ? c[e] : 2048u);
+                const int d = (int)c[e] - cen;
+                const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+                mx = max(mx, max(ad, c[e] >> 31 ? 0xFFFFFFFFu : 0u));
+                hi[e] = (_Float16)(float)(d < -2048 ? -2048 : (d > 2048 ? 2048 : d));
             }
             out[(2 * s) * 64] = *reinterpret_cast<uint4 *>(&hi);
         }
@@ -1255,7 +1310,8 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
                                                                      uint32_t nblk_neg,
                                                                      float *__restrict__ cand_v,
                                                                      uint32_t *__restrict__ cand_i,
-                                                                     float *__restrict__ cand_u) {
+                                                                     float *__restrict__ cand_u,
+                                                                     float *__restrict__ cand_a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x 32 KiB
     // (a third buffer with the DMA running two items ahead and counted vmcnt waits was measured: 106 instead of 96 ms at
     // config 4 -- the deeper queue does not pay)
@@ -1304,6 +1360,9 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
     }
     float negT = 0.f;
     bool isbig = false;
+    // the largest |accumulator| this lane meets at the (block, chunk) item boundaries: what the chain's rounding and
+    // alignment errors scale with (ErrBound, D > 256); the decision stage reads it from cand_a
+    float amax = 0.f;
     if (CX) {
         const uint64_t qr = (qb < nqb && q0 + j < N) ? q0 + j : N - 1;
         negT = -(float)rowsum[qr];
@@ -1361,6 +1420,8 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
                         acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc[cb], 0, 0, 0);
                     }
                 }
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) amax = fmaxf(amax, fmaxf(fabsf(acc[cb][r]), fabsf(acc[cb][r + 1])));
             }
         }
         // epilogue of the tile: norm terms from global memory, insertion (skipped by the whole wave when no lane can place
@@ -1407,12 +1468,13 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
             cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
         }
     }
+    if (cand_a && qb < nqb && q0 + j < N) cand_a[(uint64_t)h * N + q0 + j] = amax;
 }
 
 // proposal pass for D = 256 * nchunk > 256: row sums (if needed) -> split queries -> sweep
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, bool count_exact,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                                    float *cv, uint32_t *ci, float *cu, bool hi_only) {
+                                    float *cv, uint32_t *ci, float *cu, float *ca, bool hi_only) {
     const uint64_t D = m->D, nchunk = D / 256;
     const uint64_t nqb = phk_div_up(nb, 32);
     void *bq, *rs = nullptr;
@@ -1449,17 +1511,17 @@ int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
                    (phk_knn_f16_general_kernel<true, 8, true><<<dim3((unsigned)phk_div_up(nqb, 8)), dim3(512), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_betah16, d_rowsum,
-                       d_big, blk0, nref, npos, nneg, cv, ci, cu)));
+                       d_big, blk0, nref, npos, nneg, cv, ci, cu, ca)));
     } else if (d_big) {
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
                    (phk_knn_f16_general_kernel<true, 8><<<dim3((unsigned)phk_div_up(nqb, 8)), dim3(512), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, d_rowsum,
-                       d_big, blk0, nref, npos, nneg, cv, ci, cu)));
+                       d_big, blk0, nref, npos, nneg, cv, ci, cu, ca)));
     } else {
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
                    (phk_knn_f16_general_kernel<false, 4><<<dim3((unsigned)phk_div_up(nqb, 8)), dim3(512), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, nullptr,
-                       nullptr, blk0, nref, npos, nneg, cv, ci, cu)));
+                       nullptr, blk0, nref, npos, nneg, cv, ci, cu, ca)));
     }
     return PHK_OK;
 }

@@ -331,13 +331,18 @@ struct RerankParams {
     double rmax, mu_norm;
     double vscale;          // computed values are in units of 1/vscale (split-f16 path: S^2)
     double eb_cA, eb_cP, eb_cR, eb_abs;  // error model of the proposal pass (see ErrBound)
-    double eb_cQ;           // coefficient of |q| (count-exact proposal: accumulation of uncentred products)
+    double eb_cQ;           // coefficient of Q (count-exact proposal: |c - c0| / T, the centred count operand)
+    double eb_cI = 0.0;     // coefficient of I, the maximum norm of the query operand (see ErrBound)
+    double eb_hsum = 0.0;   // max_j |sum_i r~'_ji| (count-exact proposals: the residue of centring the counts)
     int per_row_scale;      // count-exact proposal: computed values are in units of T_q / vscale (T_q = row sum)
     const double *R64, *C64, *mu64, *colnorm;
     const uint8_t *labels;
     const float *cand_v;      // candidate lists, structure of arrays (score_lists.h: cand_at / candu_at)
     const uint32_t *cand_i;
     const float *cand_u;
+    const float *cand_a = nullptr;   // general D: largest |accumulator| a lane saw at the (block, chunk) item boundaries of its
+                                     // sweep, [2 halves][N] (the running sums the chain's charges scale with; see ErrBound)
+    double eb_cAmax = 0.0;           // coefficient of that observed running sum (PHK_MFMA_ACC x instructions per value)
     void *fb_rec;           // fallback partial records
     double *scores;
     uint32_t *status;       // NaN-row counter (may be null)
@@ -391,6 +396,54 @@ __device__ __forceinline__ uint32_t group16_sum(uint32_t x) {
     return x;
 }
 
+__device__ __forceinline__ uint32_t group16_max(uint32_t x) {
+    x = max(x, (uint32_t)row_ror_i32<8>((int)x));
+    x = max(x, (uint32_t)row_ror_i32<4>((int)x));
+    x = max(x, (uint32_t)row_ror_i32<2>((int)x));
+    x = max(x, (uint32_t)row_ror_i32<1>((int)x));
+    return x;
+}
+__device__ __forceinline__ uint32_t group16_min(uint32_t x) {
+    x = min(x, (uint32_t)row_ror_i32<8>((int)x));
+    x = min(x, (uint32_t)row_ror_i32<4>((int)x));
+    x = min(x, (uint32_t)row_ror_i32<2>((int)x));
+    x = min(x, (uint32_t)row_ror_i32<1>((int)x));
+    return x;
+}
+__device__ __forceinline__ double group16_max(double x) {
+    x = fmax(x, row_ror_f64<8>(x));
+    x = fmax(x, row_ror_f64<4>(x));
+    x = fmax(x, row_ror_f64<2>(x));
+    x = fmax(x, row_ror_f64<1>(x));
+    return x;
+}
+__device__ __forceinline__ double wave_max(double x) {
+    x = group16_max(x);
+    x = fmax(x, __shfl_xor(x, 16));
+    x = fmax(x, __shfl_xor(x, 32));
+    return x;
+}
+
+// The query operand of a count-exact MFMA chain: the counts minus their centre c0 = phk_row_center(T, D).  From the row's
+// sum of squares, sum, largest and smallest count: Q = |c - c0| / T, I = |c - c0|_inf / T, and the residue of the centring
+// habs = |c0 - T/D| hsum / T (see ErrBound); also |q' - (c0/T - 1/D) 1|^2 = |q'|^2 + D (c0/T - 1/D)^2, the operand the
+// low parts of a high-parts-only value multiply (sum_i q'_i = 0).
+struct CenteredOperand {
+    double Q, I, habs, shift2;   // shift2 = D (c0 / T - 1 / D)^2
+};
+__device__ __forceinline__ CenteredOperand phk_centered_operand(double sumsq, double T, double cmax, double cmin, double D,
+                                                                double hsum) {
+    const double c0 = (double)phk_row_center((uint32_t)T, (uint32_t)D);
+    CenteredOperand o;
+    const double ss = fmax(sumsq - 2.0 * c0 * T + D * c0 * c0, 0.0);
+    o.Q = sqrt(ss) / T * (1.0 + 1e-12);
+    o.I = fmax(cmax - c0, c0 - cmin) / T;
+    const double dl = c0 / T - 1.0 / D;
+    o.habs = fabs(dl) * hsum;
+    o.shift2 = D * dl * dl;
+    return o;
+}
+
 // Exact squared distance of the group's query to `row`.  The query is held UNNORMALISED: qd = the integer
 // counts (or the float64 row with Tq = 1), Tq = their sum, and
 //     |q - r|^2 = sum_i (c_i - Tq r_i)^2 / Tq^2        (one rounding per difference, inside the fma)
@@ -424,27 +477,34 @@ __device__ __forceinline__ double exact_d2(const double (&qd)[4 * DSUB], const d
     return wave_sum(acc);
 }
 
-// Rigorous bound on |computed v - true v| of the proposal pass for a column with |r'| <= R
-// (derivation: DESIGN.md "proposal error bound").  u = 2^-24; A = |q| + |mu|; P = |q'|:
-//     eps(R) = u R (cA A + cP P + cR R) + c_abs (R + P)
-//   fp32 MFMA  : cA 6, cP 264, cR 4, c_abs 0 -- q' to fp32 (<= 4uA), r' to fp32 (<= uR), 258 fused
-//                roundings each <= u |partial|, product partials <= (P + 4uA) R (Cauchy-Schwarz), the norm
-//                step LAST in the chain.
-//   split f16  : cA 6, cP 0.375 D + 24, cR 6, c_abs sqrt(D) 2^-24/S -- operands carry 22 bits (|x - hi - lo|
-//                <= 2^-22 |x| + one fp16 subnormal quantum), the dropped lo.lo term <= 2^-22 P R, and 3D/16
-//                MFMA instructions each charged 2u (|acc_in| + sum |products|) (measured model of
-//                v_mfma_f32_32x32x16_f16: wide 8-product sub-steps, round to nearest; see probe_mfma_f16).
-//   count-exact: the query operand is the integer count vector itself (exact in fp16 up to 2048), so
-//   f16 (k = 4)  the chain computes T S (q.r~' - beta~), beta = mu.r~' + |r~'|^2/2 (r~' = column as split):
-//                cA 1 (beta -> fp32), cQ 2 (2D/16 + 1) + 1 on Q = |q| (2D/16 instructions, each charged
-//                2u (|acc_in| + sum |products|) <= 2u T S |q| R), cP 4 + 1 + 62, cR 4 + 1 + 31 (r' -> r~':
-//                2^-22; the final fma: u |v|; the 5 index bits embedded in the value: 31 ulp <= 62 u |v|),
-//                c_abs as split f16.
+// Bound on |computed v - true v| of the proposal pass for a column with |r'| <= R.  u = 2^-24;
+// A = |q| + |mu|; P = |q'|; Q, I: Euclidean and maximum norm of the query operand as the MFMA chain sees it:
+//     eps(R) = u R (cA A + cQ Q + cI I + cP P + cR R) + c_abs (R + P) + habs
+//   fp32 MFMA  : cA 6, cP 264, cR 4 -- q' to fp32 (<= 4uA), r' to fp32 (<= uR), 258 fused roundings each <= u |partial|
+//                (the instruction is a k-ordered fmaf chain), product partials <= (P + 4uA) R, the norm step LAST.
+//   f16 MFMA   : a chain of n instructions on operands x (query side) and y (column side) errs by at most
+//                n u (PHK_MFMA_ACC |x| |y| + PHK_MFMA_PROD |x|_inf |y|_inf)  (score_lists.h: two halves of aligned,
+//                truncated terms and one rounding each; running sums <= |x| |y| by Cauchy-Schwarz).
+//     split f16   (n = 3D/16; x = q' S as hi + lo, y = r' S as hi + lo): cA 6, cP 11 n + 24, cI 18 n on I = |q'|_inf,
+//                cR 6, c_abs sqrt(D) 2^-24/S -- operands carry 22 bits (|x - hi - lo| <= 2^-22 |x| + one fp16 subnormal
+//                quantum), the dropped lo.lo term <= 2^-22 P R.
+//     count-exact (n = 2D/16; high parts only: n = D/16; x = the integer counts minus their centre c0 -- exact in fp16 --
+//                y = r~' S): cA 1 (bias -> fp32), cQ 11 n + 3 on Q = |c - c0| / T, cI 18 n on I = |c - c0|_inf / T,
+//                cP 4 + 1 + 62, cR 4 + 1 + 31 (r' -> r~': 2^-22; the final fma: u |v|; the 5 index bits embedded in the
+//                value at k = 4: 31 ulp <= 62 u |v|), c_abs as split f16, habs = |c0 - T/D| max_j |sum_i r~'_ji| / T
+//                (what centring the counts leaves behind; the column sums of r' vanish up to the split's rounding).
+//     D > 256    the sweep runs in chunks of 256 dimensions and the kernel records the largest |accumulator| a lane met at
+//                the chunk boundaries (cand_a): inside a chunk a running sum is within |x_c| |y_c| of the sum at its start,
+//                so Q is the largest CHUNK norm of the query operand and habs gains cAmax u a_observed -- the bound follows
+//                the sums that occurred instead of the Cauchy-Schwarz worst case over all D dimensions.
+//     cI carries rho_inf = max_j |r~'_j|_inf / |r'_j| of the model, so that |x|_inf |y|_inf <= I rho_inf R.
 struct ErrBound {
     double A, P, cA, cP, cR, cabs;
     double Q = 0.0, cQ = 0.0;
+    double I = 0.0, cI = 0.0;
+    double habs = 0.0;
     __device__ double operator()(double R) const {
-        return 5.9604644775390625e-08 * R * (cA * A + cQ * Q + cP * P + cR * R) + cabs * (R + P);
+        return 5.9604644775390625e-08 * R * (cA * A + cQ * Q + cI * I + cP * P + cR * R) + cabs * (R + P) + habs;
     }
 };
 
@@ -552,6 +612,7 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
     double qd[4 * DSUB];
     double vs = p.vscale;
     bool nan_row = false;
+    CenteredOperand cop = {0.0, 0.0, 0.0, 0.0};
     if (SRC == 0) {
         const uint32_t *row = static_cast<const uint32_t *>(src) + q * D;
         uint4 c[DSUB];
@@ -565,12 +626,27 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
         nan_row = s == 0;
         const double ds = (double)s;
         if (p.per_row_scale) vs = p.vscale / ds;
+        uint32_t cmx = 0, cmn = 0xFFFFFFFFu;
+        double sq = 0.0, qc2 = 0.0;
+        const double rcen = (double)phk_row_center(s, D);
 #pragma unroll
         for (int sub = 0; sub < DSUB; ++sub) {
-            qd[4 * sub + 0] = (double)c[sub].x / ds;
-            qd[4 * sub + 1] = (double)c[sub].y / ds;
-            qd[4 * sub + 2] = (double)c[sub].z / ds;
-            qd[4 * sub + 3] = (double)c[sub].w / ds;
+            const double x0 = (double)c[sub].x, x1 = (double)c[sub].y, x2 = (double)c[sub].z, x3 = (double)c[sub].w;
+            qd[4 * sub + 0] = x0 / ds;
+            qd[4 * sub + 1] = x1 / ds;
+            qd[4 * sub + 2] = x2 / ds;
+            qd[4 * sub + 3] = x3 / ds;
+            sq = fma(x0, x0, fma(x1, x1, fma(x2, x2, fma(x3, x3, sq))));
+            cmx = max(max(cmx, max(c[sub].x, c[sub].y)), max(c[sub].z, c[sub].w));
+            cmn = min(min(cmn, min(c[sub].x, c[sub].y)), min(c[sub].z, c[sub].w));
+            if (DSUB > 1 && p.per_row_scale) {   // norm of this 256-dimension chunk of c - c0
+                const double y0 = x0 - rcen, y1 = x1 - rcen, y2 = x2 - rcen, y3 = x3 - rcen;
+                qc2 = fmax(qc2, wave_sum(fma(y0, y0, fma(y1, y1, fma(y2, y2, y3 * y3)))));
+            }
+        }
+        if (p.per_row_scale && !nan_row) {  // the operand of the count-exact chain: the counts minus their centre
+            cop = phk_centered_operand(wave_sum(sq), ds, wave_max((double)cmx), -wave_max(-(double)cmn), (double)D, p.eb_hsum);
+            if (DSUB > 1) cop.Q = sqrt(qc2) / ds * (1.0 + 1e-12);
         }
     } else {
         const double *row = static_cast<const double *>(src) + q * D;
@@ -591,7 +667,7 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
         }
         return;
     }
-    double aq = 0.0, ap = 0.0;
+    double aq = 0.0, ap = 0.0, am = 0.0, pc2 = 0.0;
 #pragma unroll
     for (int sub = 0; sub < DSUB; ++sub) {
         const double2 m0 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane];
@@ -600,15 +676,26 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
         const double c2 = qd[4 * sub + 2] - m1.x, c3 = qd[4 * sub + 3] - m1.y;
         aq = fma(qd[4 * sub + 0], qd[4 * sub + 0], fma(qd[4 * sub + 1], qd[4 * sub + 1],
                  fma(qd[4 * sub + 2], qd[4 * sub + 2], fma(qd[4 * sub + 3], qd[4 * sub + 3], aq))));
-        ap = fma(c0, c0, fma(c1, c1, fma(c2, c2, fma(c3, c3, ap))));
+        const double apc = fma(c0, c0, fma(c1, c1, fma(c2, c2, c3 * c3)));
+        ap += apc;
+        am = fmax(fmax(am, fmax(fabs(c0), fabs(c1))), fmax(fabs(c2), fabs(c3)));
+        if (DSUB > 1 && !p.per_row_scale) pc2 = fmax(pc2, wave_sum(apc));   // norm of this chunk of q'
     }
     const double nq2 = wave_sum(aq);
     const double nqp2 = wave_sum(ap);
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
-    eb.Q = sqrt(nq2);
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ;
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
+    if (SRC == 0 && p.per_row_scale) {   // count-exact lists: the chain's query operand is c - c0
+        eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs;
+        eb.P = sqrt(nqp2 + cop.shift2);   // (high-parts-only lists: what the low parts multiply)
+    } else {                             // split-f16 lists: the chain's query operand is q' (largest chunk norm)
+        eb.Q = DSUB > 1 ? sqrt(pc2) * (1.0 + 1e-12) : eb.P;
+        eb.I = wave_max(am);
+    }
+    if (p.cand_a)   // the running sums this query's sweep met at its chunk boundaries, in v units
+        eb.habs += p.eb_cAmax * 5.9604644775390625e-08 * (double)fmaxf(p.cand_a[q], p.cand_a[p.N + q]) * vs * 1.001;
 
     bool ok = true;
     double knn = 0.0, cen = 0.0;
@@ -860,6 +947,7 @@ __global__ __launch_bounds__(256, 4) void phk_rerank16_kernel(const void *__rest
     double vs = p.vscale;
     bool nan_row = false;
     double Tq = 1.0, invT2 = 1.0;  // row sum and 1 / Tq^2 (counts); 1 for float64 rows
+    uint32_t cmx = 0, cmn = 0xFFFFFFFFu;   // largest / smallest count of the row
     // the query's six half-lists, fetched with the row
     float lv[NSEG], lu[NSEG];
     uint32_t lix[NSEG];
@@ -889,7 +977,11 @@ __global__ __launch_bounds__(256, 4) void phk_rerank16_kernel(const void *__rest
         for (int i = 0; i < 8; ++i) {   // the counts themselves: see exact_d2_g16
             qd[2 * i + 0] = (double)c[i].x;
             qd[2 * i + 1] = (double)c[i].y;
+            cmx = max(cmx, max(c[i].x, c[i].y));
+            cmn = min(cmn, min(c[i].x, c[i].y));
         }
+        cmx = group16_max(cmx);
+        cmn = group16_min(cmn);
     } else {
         const double2 *row = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + q * FAST_D) + t;
         bool bad = false;
@@ -905,7 +997,7 @@ __global__ __launch_bounds__(256, 4) void phk_rerank16_kernel(const void *__rest
         b |= __shfl_xor(b, 8); b |= __shfl_xor(b, 4); b |= __shfl_xor(b, 2); b |= __shfl_xor(b, 1);
         nan_row = b != 0;
     }
-    double aq = 0.0, ap = 0.0;
+    double aq = 0.0, ap = 0.0, am = 0.0;
     {
         const double2 *mp = reinterpret_cast<const double2 *>(p.mu64) + t;
 #pragma unroll
@@ -914,14 +1006,22 @@ __global__ __launch_bounds__(256, 4) void phk_rerank16_kernel(const void *__rest
             const double c0 = fma(-Tq, m.x, qd[2 * i]), c1 = fma(-Tq, m.y, qd[2 * i + 1]);
             aq = fma(qd[2 * i], qd[2 * i], fma(qd[2 * i + 1], qd[2 * i + 1], aq));
             ap = fma(c0, c0, fma(c1, c1, ap));
+            am = fmax(am, fmax(fabs(c0), fabs(c1)));
         }
     }
-    const double nq2 = group16_sum(aq) * invT2, nqp2 = group16_sum(ap) * invT2;
+    const double sumsq = group16_sum(aq);
+    const double nq2 = sumsq * invT2, nqp2 = group16_sum(ap) * invT2;
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
-    eb.Q = sqrt(nq2);
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ;
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
+    if (SRC == 0 && p.per_row_scale) {   // count-exact lists: the chain's query operand is c - c0 (see ErrBound)
+        const CenteredOperand cop = phk_centered_operand(sumsq, nan_row ? 1.0 : Tq, (double)cmx, (double)cmn, (double)FAST_D, p.eb_hsum);
+        eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs;
+        eb.P = sqrt(nqp2 + cop.shift2);   // (high-parts-only lists: what the low parts multiply)
+    } else {                             // split-f16 lists: the chain's query operand is q' (Tq = 1 for float64 rows)
+        eb.Q = 0.0; eb.I = group16_max(am) / Tq;
+    }
 
     bool live = inrange && !nan_row;   // NaN rows: every comparison below is false; they are answered separately
     bool ok = true;
@@ -981,7 +1081,7 @@ __global__ __launch_bounds__(256, 4) void phk_rerank16_kernel(const void *__rest
 template <int SRC>
 __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict__ src, RerankParams p) {
     __shared__ uint32_t s_ix[2][256];
-    __shared__ double s_T[256], s_nq2[256], s_nqp2[256], s_dp2[256], s_dn2[256];
+    __shared__ double s_T[256], s_nq2[256], s_nqp2[256], s_dp2[256], s_dn2[256], s_opQ[256], s_opI[256], s_opH[256];
     const int tid = threadIdx.x, lane = tid & 63, t = lane & 15;
     const int QB = blockDim.x;   // queries per block (64: one wave per block, no cross-wave waiting at the phase changes)
     const uint64_t qb = (uint64_t)blockIdx.x * QB;
@@ -1078,6 +1178,7 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
             const uint64_t q = qb + ql < p.N ? qb + ql : p.N - 1;
             double qd[16], Tq = 1.0, invT2 = 1.0;
             bool bad = false;
+            uint32_t cmx = 0, cmn = 0xFFFFFFFFu;
             if (SRC == 0) {
                 uint2 cur[8];
 #pragma unroll
@@ -1094,8 +1195,12 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
                     sum += c.x + c.y;
                     qd[2 * i + 0] = (double)c.x;
                     qd[2 * i + 1] = (double)c.y;
+                    cmx = max(cmx, max(c.x, c.y));
+                    cmn = min(cmn, min(c.x, c.y));
                 }
                 sum = group16_sum(sum);
+                cmx = group16_max(cmx);
+                cmn = group16_min(cmn);
                 bad = sum == 0;
                 Tq = (double)sum;
                 invT2 = 1.0 / (Tq * Tq);
@@ -1112,14 +1217,22 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
                 bb |= __shfl_xor(bb, 8); bb |= __shfl_xor(bb, 4); bb |= __shfl_xor(bb, 2); bb |= __shfl_xor(bb, 1);
                 bad = bb != 0;
             }
-            double aq = 0.0, ap = 0.0;
+            double aq = 0.0, ap = 0.0, am = 0.0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const double c0 = fma(-Tq, mu[i], qd[i]);
                 aq = fma(qd[i], qd[i], aq);
                 ap = fma(c0, c0, ap);
+                am = fmax(am, fabs(c0));
             }
-            const double nq2 = group16_sum(aq) * invT2, nqp2 = group16_sum(ap) * invT2;
+            const double sumsq = group16_sum(aq);
+            const double nq2 = sumsq * invT2, nqp2 = group16_sum(ap) * invT2;
+            // the query operand of the proposal's MFMA chain (see ErrBound): c - c0 for count-exact lists, q' otherwise
+            double opQ = 0.0, opI = group16_max(am) / Tq, opH = 0.0;
+            if (SRC == 0 && p.per_row_scale && !bad) {
+                const CenteredOperand cop = phk_centered_operand(sumsq, Tq, (double)cmx, (double)cmn, (double)FAST_D, p.eb_hsum);
+                opQ = cop.Q; opI = cop.I; opH = cop.habs;
+            }
             double dp2 = 0.0, dn2 = 0.0;
             if (want_cen) {
                 exact_d2_pair_g16(qd, Tq, invT2, p.C64 + (uint64_t)s_ix[0][ql] * FAST_D,
@@ -1127,6 +1240,9 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
             }
             if (t == 0) {
                 s_T[ql] = bad ? 0.0 : Tq;   // 0 marks a NaN row
+                s_opQ[ql] = opQ;
+                s_opI[ql] = opI;
+                s_opH[ql] = opH;
                 s_nq2[ql] = nq2;
                 s_nqp2[ql] = nqp2;
                 s_dp2[ql] = dp2;
@@ -1149,8 +1265,8 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
-    eb.Q = sqrt(nq2);
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ;
+    eb.Q = s_opQ[tid]; eb.I = s_opI[tid]; eb.habs = s_opH[tid];
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
     const double nqp = eb.P;
     const double eps_g = eb(p.rmax);
     auto certify = [&](int sg, int need, const double *cnorms) {   // resolve_segment_g16's margin test
@@ -1222,7 +1338,7 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
     __shared__ float s_v8[8][64], s_u0[64], s_ch[4][64];
     __shared__ double s_cn[5][64];
     __shared__ uint32_t s_flags[64];
-    __shared__ double s_T[64], s_nq2[64], s_nqp2[64], s_dp2[64], s_dn2[64];
+    __shared__ double s_T[64], s_nq2[64], s_nqp2[64], s_dp2[64], s_dn2[64], s_opQ[64], s_opI[64], s_opH[64], s_sh2[64];
     __shared__ double s_mu[FAST_D];         // the training mean (LDS reads keep vmcnt for the row / column loads)
     const int tid = threadIdx.x, t = tid & 15;
     const uint64_t qb = (uint64_t)blockIdx.x * 64;
@@ -1382,15 +1498,19 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
         }
         __builtin_amdgcn_sched_barrier(0);
         double qd[16];
-        uint32_t sum = 0;
+        uint32_t sum = 0, cmx = 0, cmn = 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const uint2 c = cur[i];
             sum += c.x + c.y;
+            cmx = max(cmx, max(c.x, c.y));
+            cmn = min(cmn, min(c.x, c.y));
             qd[2 * i + 0] = (double)c.x;
             qd[2 * i + 1] = (double)c.y;
         }
         sum = group16_sum(sum);
+        cmx = group16_max(cmx);
+        cmn = group16_min(cmn);
         const bool bad = sum == 0;
         const double Tq = (double)sum, invT2 = 1.0 / (Tq * Tq);
         double dp2 = 0.0, dn2 = 0.0;
@@ -1415,13 +1535,20 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
             qd[2 * i + 1] = fma(-Tq, m2.y, qd[2 * i + 1]);
             ap = fma(qd[2 * i], qd[2 * i], fma(qd[2 * i + 1], qd[2 * i + 1], ap));
         }
-        const double nq2 = group16_sum(aq) * invT2, nqp2 = group16_sum(ap) * invT2;
+        const double sumsq = group16_sum(aq);
+        const double nq2 = sumsq * invT2, nqp2 = group16_sum(ap) * invT2;
+        // The proposal kernel's query operand is c - c0 (phk_row_center), so its value is the high product of the
+        // UNcentred counts minus (c0 - T/D) sum_i hi_ji; the low product that completes it is therefore taken with
+        // c - T mu - (c0 - T/D): sum_i (c_i - T mu_i - dlt) lo_ji = sum_i (c_i - T mu_i) lo_ji + dlt sum_i hi_ji - dlt sum_i r~'_ji,
+        // the last term being the model's hsum residue (see ErrBound).
+        const CenteredOperand cop = phk_centered_operand(sumsq, bad ? 1.0 : Tq, (double)cmx, (double)cmn, (double)FAST_D, p.eb_hsum);
         if (KNN) {
             // float32 products (v_fma_mix takes the half operand as it is): 16 + 4 roundings per sum, bounded in
-            // phase C by 2^-19 |q'| lam* -- 1e-6 of the low product's own bound
+            // phase C by 2^-19 |x| lam* -- 1e-6 of the low product's own bound
+            const double dlt = (double)phk_row_center(sum, FAST_D) - Tq * (1.0 / FAST_D);
             float qf[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) qf[i] = (float)qd[i];
+            for (int i = 0; i < 16; ++i) qf[i] = (float)(qd[i] - dlt);
 #pragma unroll
             for (int r = 0; r < PHK_HI_REFINE; ++r) {
                 const _Float16 *lh0 = reinterpret_cast<const _Float16 *>(&l0[r]), *lh1 = reinterpret_cast<const _Float16 *>(&l1[r]);
@@ -1441,6 +1568,10 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
             s_nqp2[ql] = nqp2;
             s_dp2[ql] = dp2;
             s_dn2[ql] = dn2;
+            s_opQ[ql] = cop.Q;
+            s_opI[ql] = cop.I;
+            s_opH[ql] = cop.habs;
+            s_sh2[ql] = cop.shift2;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
@@ -1475,10 +1606,11 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
-    eb.Q = sqrt(nq2);
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ;
+    eb.Q = s_opQ[tid]; eb.I = s_opI[tid]; eb.habs = s_opH[tid];
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
     const double nqp = eb.P;
-    auto e_hi = [&](int sg, double R) { return nqp * phk_lam_of(hp, sg, R) + eb(R); };
+    const double nqx = sqrt(nqp2 + s_sh2[tid]);   // |q' - (c0/T - 1/D) 1|: what the low parts multiply (see phase B)
+    auto e_hi = [&](int sg, double R) { return nqx * phk_lam_of(hp, sg, R) + eb(R); };
     bool cert = true;      // the k-NN part
     bool cert_c = true;    // the centroid part
     double knn = 0.0, cen = 0.0;
@@ -1495,7 +1627,7 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
             for (int r = 0; r < need; ++r) near = near && cn0[r] <= R0;
             const double Rw = near ? R0 : p.rmax;
             // count-exact error model + the float32 rounding of the low products (22 roundings x 2^-24 < 2^-19)
-            const double eh = near ? e_hi(0, R0) : eg, e22 = eb(Rw) + 0x1p-19 * nqp * phk_lam_of(hp, 0, Rw);
+            const double eh = near ? e_hi(0, R0) : eg, e22 = eb(Rw) + 0x1p-19 * nqx * phk_lam_of(hp, 0, Rw);
             // window members: list positions 0 .. nw-1 (sorted by high-part value)
             const double thr = (double)v8[need - 1] * vs - 2.0 * eh;
             int nw = 0;
@@ -1597,9 +1729,19 @@ __global__ __launch_bounds__(256) void phk_rerank_h_kernel(const uint32_t *__res
     }
     const double Tq = (double)s;
     double qd[4 * DSUB];   // normalised row (exact distances), then reused
-    double aq = 0.0, ap = 0.0;
+    double aq = 0.0, ap = 0.0, sq = 0.0, qc2 = 0.0;
+    uint32_t cmx = 0, cmn = 0xFFFFFFFFu;
+    const double rcen = (double)phk_row_center(s, D);
 #pragma unroll
     for (int sub = 0; sub < DSUB; ++sub) {
+        const double x0 = (double)c[sub].x, x1 = (double)c[sub].y, x2 = (double)c[sub].z, x3 = (double)c[sub].w;
+        sq = fma(x0, x0, fma(x1, x1, fma(x2, x2, fma(x3, x3, sq))));
+        {   // norm of this 256-dimension chunk of c - c0 (see ErrBound, D > 256)
+            const double y0 = x0 - rcen, y1 = x1 - rcen, y2 = x2 - rcen, y3 = x3 - rcen;
+            qc2 = fmax(qc2, wave_sum(fma(y0, y0, fma(y1, y1, fma(y2, y2, y3 * y3)))));
+        }
+        cmx = max(max(cmx, max(c[sub].x, c[sub].y)), max(c[sub].z, c[sub].w));
+        cmn = min(min(cmn, min(c[sub].x, c[sub].y)), min(c[sub].z, c[sub].w));
         qd[4 * sub + 0] = (double)c[sub].x / Tq;
         qd[4 * sub + 1] = (double)c[sub].y / Tq;
         qd[4 * sub + 2] = (double)c[sub].z / Tq;
@@ -1613,14 +1755,20 @@ __global__ __launch_bounds__(256) void phk_rerank_h_kernel(const uint32_t *__res
     }
     const double nq2 = wave_sum(aq), nqp2 = wave_sum(ap);
     const double vs = p.vscale / Tq;
+    // the proposal's query operand is c - c0 (see phk_decide_h_kernel): Q, I of ErrBound, and the low product is taken
+    // with c - T mu - (c0 - T/D)
+    const CenteredOperand cop = phk_centered_operand(wave_sum(sq), Tq, wave_max((double)cmx), -wave_max(-(double)cmn), (double)D, p.eb_hsum);
+    const double dlt = (double)phk_row_center(s, D) - Tq / (double)D;
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
-    eb.Q = sqrt(nq2);
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ;
+    eb.Q = sqrt(qc2) / Tq * (1.0 + 1e-12); eb.I = cop.I; eb.habs = cop.habs;
+    if (p.cand_a) eb.habs += p.eb_cAmax * 5.9604644775390625e-08 * (double)fmaxf(p.cand_a[q], p.cand_a[p.N + q]) * vs * 1.001;
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
     const double nqp = eb.P;
-    auto e_hi = [&](int sg, double R) { return nqp * phk_lam_of(hp, sg, R) + eb(R); };
-    // low product of column `col` (global column index): sum_i (c_i - T mu_i) lo_i, the whole wave
+    const double nqx = sqrt(nqp2 + cop.shift2);
+    auto e_hi = [&](int sg, double R) { return nqx * phk_lam_of(hp, sg, R) + eb(R); };
+    // low product of column `col` (global column index): sum_i (c_i - T mu_i - dlt) lo_i, the whole wave
     auto low_product = [&](uint64_t col) {
         const _Float16 *lr = hp.lo16 + col * D;
         double acc = 0.0;
@@ -1630,10 +1778,10 @@ __global__ __launch_bounds__(256) void phk_rerank_h_kernel(const uint32_t *__res
             const _Float16 *lh = reinterpret_cast<const _Float16 *>(&l);
             const double2 m0 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane];
             const double2 m1 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane + 1];
-            acc = fma(fma(-Tq, m0.x, (double)c[sub].x), (double)lh[0], acc);
-            acc = fma(fma(-Tq, m0.y, (double)c[sub].y), (double)lh[1], acc);
-            acc = fma(fma(-Tq, m1.x, (double)c[sub].z), (double)lh[2], acc);
-            acc = fma(fma(-Tq, m1.y, (double)c[sub].w), (double)lh[3], acc);
+            acc = fma(fma(-Tq, m0.x, (double)c[sub].x) - dlt, (double)lh[0], acc);
+            acc = fma(fma(-Tq, m0.y, (double)c[sub].y) - dlt, (double)lh[1], acc);
+            acc = fma(fma(-Tq, m1.x, (double)c[sub].z) - dlt, (double)lh[2], acc);
+            acc = fma(fma(-Tq, m1.y, (double)c[sub].w) - dlt, (double)lh[3], acc);
         }
         return wave_sum(acc);
     };
@@ -2000,10 +2148,12 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     void *cv, *fb, *rec;
     // the second chance sweeps the reference in PHK_SECOND_SPLITS column parts, each with a list set of its own
     const uint64_t set2_bytes = per_list2 * list_bytes;
-    PHK_TRY(phk_ws(ctx, WS_CAND, per_list * list_bytes + PHK_SECOND_SPLITS * set2_bytes, &cv));
+    const uint64_t ca_bytes = D != FAST_D ? 2 * nb_max * sizeof(float) : 0;   // general D: observed running sums (cand_a)
+    PHK_TRY(phk_ws(ctx, WS_CAND, per_list * list_bytes + ca_bytes + PHK_SECOND_SPLITS * set2_bytes, &cv));
     uint32_t *ci = (uint32_t *)((char *)cv + per_list * sizeof(float4));
     float *cu = (float *)((char *)ci + per_list * sizeof(uint4));
-    float *cv2 = (float *)((char *)cv + per_list * list_bytes);
+    float *ca = ca_bytes ? (float *)((char *)cv + per_list * list_bytes) : nullptr;
+    float *cv2 = (float *)((char *)cv + per_list * list_bytes + ca_bytes);
     uint32_t *ci2 = (uint32_t *)((char *)cv2 + per_list2 * sizeof(float4));
     float *cu2 = (float *)((char *)ci2 + per_list2 * sizeof(uint4));
     PHK_TRY(phk_ws(ctx, WS_DIST, (3 * nb_max + 32) * sizeof(uint32_t), &fb));
@@ -2037,24 +2187,39 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.counters = fbc;
         p.col_mask = m->has_mask ? m->d_col_mask : nullptr;
         p.slow_cap = nb_max;
-        p.eb_cQ = 0.0; p.per_row_scale = 0;
+        p.eb_cQ = 0.0; p.eb_cI = 0.0; p.eb_hsum = 0.0; p.per_row_scale = 0;
+        p.cand_a = ca; p.eb_cAmax = 0.0;
+        const double rho = m->rho_inf > 0.0 && m->rho_inf < 1.0 ? m->rho_inf : 1.0;   // max_j |r~'_j|_inf / |r'_j|
+        // f16 MFMA chains (see ErrBound): n instructions, each charged u (PHK_MFMA_ACC |x| |y| + PHK_MFMA_PROD |x|_inf |y|_inf)
         auto split_f16_bound = [&](RerankParams &r) {
-            // 3D/16 MFMA instructions, each charged 2u (|acc_in| + sum |products|) <= 2u (P + dq) R -- the
-            // measured accumulation model of v_mfma_f32_32x32x16_f16 (tools/probe_mfma_f16.hip,
-            // profiles/r01/probe_mfma_f16.txt: two wide 8-product sub-steps with round-to-nearest, worst
-            // observed 1.27u) -- plus the input terms (3 * 2^-22 / u = 12); subnormal quantum sqrt(D) 2^-25 / S
+            // n = 3D/16 instructions on (q' S as hi + lo) x (r' S as hi + lo); running sums <= (P + dq) R S^2; plus the
+            // input terms (3 * 2^-22 / u = 12, doubled for dq); subnormal quantum sqrt(D) 2^-25 / S
+            // D = 256 (phk_knn_f16_kernel): the hi.hi chain (D/16 instructions) and the cross terms (2D/16 instructions on
+            // running sums and products 2^-10 of the first chain's: 11 * 32 * 2^-10 < 1, 18 * 32 * 2^-11 < 1) accumulate
+            // separately and meet in two float32 additions (+2 on cP, +1 on cR); the general-D kernel keeps one accumulator
+            // D > 256: Q = the largest chunk norm of q' and the observed running sums carry the chain (see ErrBound)
+            const double n = (D == FAST_D ? 1.0 : 3.0) * (double)D / 16.0, x = D == FAST_D ? 1.0 : 0.0;
             r.vscale = 1.0 / (4096.0 * 4096.0);
-            r.per_row_scale = 0; r.eb_cQ = 0.0;
-            r.eb_cA = 6.0; r.eb_cP = 0.375 * (double)D + 24.0; r.eb_cR = 6.0;
+            r.per_row_scale = 0; r.eb_hsum = 0.0;
+            r.eb_cA = 6.0; r.eb_cI = (PHK_MFMA_PROD * n + x) * rho; r.eb_cR = 6.0 + x;
+            if (D == FAST_D) {
+                r.eb_cQ = 0.0; r.eb_cP = PHK_MFMA_ACC * n + 24.0 + 3.0 * x; r.eb_cAmax = 0.0;
+            } else {
+                r.eb_cQ = PHK_MFMA_ACC * n; r.eb_cP = 24.0; r.eb_cAmax = PHK_MFMA_ACC * n;
+            }
             r.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
         };
         if (use_cx) {
-            // see ErrBound: values are T S v (per row), 2D/16 instructions on uncentred products
-            p.vscale = 1.0 / 4096.0; p.per_row_scale = 1;
+            // values are T S v (per row); n = 2D/16 instructions on (c - c0) x (r~' S as hi, lo), + 3 for the bias -> fp32,
+            // the final fma and slack; the residue of the centring through hsum
             // (general D keeps its indices in registers: no embedded index bits, 62 / 31 less on cP / cR)
-            p.eb_cA = 1.0; p.eb_cQ = 2.0 * (2.0 * (double)D / 16.0 + 1.0) + 1.0;
+            const double n = 2.0 * (double)D / 16.0;
+            p.vscale = 1.0 / 4096.0; p.per_row_scale = 1;
+            p.eb_cA = 1.0; p.eb_cQ = PHK_MFMA_ACC * n + 3.0; p.eb_cI = PHK_MFMA_PROD * n * rho;
+            p.eb_cAmax = D != FAST_D ? PHK_MFMA_ACC * n : 0.0;
             p.eb_cP = D == FAST_D ? 67.0 : 5.0; p.eb_cR = D == FAST_D ? 36.0 : 5.0;
             p.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
+            p.eb_hsum = m->hsum_train > m->hsum_cen ? m->hsum_train : m->hsum_cen;
         } else if (use_f16) {
             split_f16_bound(p);
         } else {
@@ -2063,7 +2228,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         }
         if (D != FAST_D) {
             PHK_TRY(phk_launch_proposal_f16_general(ctx, m, src, d_counts != nullptr, use_cx, rsum, nb, nref, npos, nneg,
-                                                    (float *)cv, ci, cu, hi_gen));
+                                                    (float *)cv, ci, cu, ca, hi_gen));
         } else if (hi_only) {
             PHK_TRY(phk_launch_proposal_f16h(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu));
         } else if (use_cx) {
@@ -2095,10 +2260,11 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             }
             const dim3 dg((unsigned)phk_div_up(nb, 64)), db(64);
             const bool d_knn = (p.method & PHK_METHOD_KNN) != 0, d_cen = (p.method & PHK_METHOD_KMEANS) != 0;
-            // the high-parts-only kernel issues D/16 MFMAs per value, not the count-exact kernel's 2D/16: cQ = 2 (D/16 + 1) + 1
+            // the high-parts-only kernel issues D/16 MFMAs per value, not the count-exact kernel's 2D/16
             // (the low product the decision stage adds has its own term, see phk_decide_h_kernel)
             RerankParams pd = p;
-            pd.eb_cQ = 2.0 * ((double)D / 16.0 + 1.0) + 1.0;
+            pd.eb_cQ = PHK_MFMA_ACC * ((double)D / 16.0) + 3.0;
+            pd.eb_cI = PHK_MFMA_PROD * ((double)D / 16.0) * rho;
             if (d_knn && d_cen) {
                 PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<true, true><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, pd, hp)));
             } else if (d_knn) {
@@ -2147,7 +2313,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             RerankParams p2 = p;
             split_f16_bound(p2);
             p2.N = cap;
-            p2.cand_v = cv2; p2.cand_i = ci2; p2.cand_u = cu2;
+            p2.cand_v = cv2; p2.cand_i = ci2; p2.cand_u = cu2; p2.cand_a = nullptr;
             p2.map = fb_list; p2.map_count = fbc;
             p2.fb_count = fbc + 3; p2.fb_list = fb2_list;
             p2.exact_extra = fbc + 1;

@@ -37,6 +37,9 @@ struct phk_model {
     std::vector<double> h_mu;
     double max_colnorm_train = 0.0;
     uint32_t n_rblk_ref = 0, n_rblk_pos = 0, n_rblk_neg = 0;  // 32-column blocks per segment
+    double rho_inf = 1.0;         // max_j |r~'_j|_inf / |r'_j| over the real columns: |x|_inf |y_j|_inf <= I rho_inf R in ErrBound
+    double rho_train = 0.0, rho_cen = 0.0;
+    double hsum_train = 0.0, hsum_cen = 0.0;   // max_j |sum_i r~'_ji| over the train rows / the centroids (see ErrBound: habs)
     double max_colnorm = 0.0;     // max ||r'|| over real columns (error bound)
     double mu_norm = 0.0;         // ||mu||
 };
@@ -69,6 +72,6 @@ int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu);
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, bool count_exact,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                                    float *cv, uint32_t *ci, float *cu, bool hi_only = false);
+                                    float *cv, uint32_t *ci, float *cu, float *ca, bool hi_only = false);
 int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
                    const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status);
