@@ -1241,19 +1241,28 @@ __global__ __launch_bounds__(256) void phk_split_queries_kernel(const void *__re
     if (SRC == 2) {   // the counts minus the row's centre (phk_row_center), exact in fp16 up to 2048 in magnitude
         const int cen = (int)phk_row_center(rowsum[qrow], (uint32_t)D);
         uint32_t mx = 0;
-        for (int s = 0; s < 16; ++s) {
-            const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + qrow * D + d0 + 8 * s);
-            const uint4 c0 = row[0], c1 = row[1];
-            const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            half8 hi;
+        // a lane owns 128 consecutive counts of its query's row (512 B): fetched as whole 64-byte pieces, four loads in
+        // flight per piece (32-byte pieces, two loads at a time, made the memory system fetch every sector twice)
+        const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + qrow * D + d0);
+#pragma unroll 2
+        for (int s2 = 0; s2 < 8; ++s2) {
+            uint4 v[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int d = (int)c[e] - cen;
-                const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
-                mx = max(mx, max(ad, c[e] >> 31 ? 0xFFFFFFFFu : 0u));
-                hi[e] = (_Float16)(float)(d < -2048 ? -2048 : (d > 2048 ? 2048 : d));
+            for (int e = 0; e < 4; ++e) v[e] = row[4 * s2 + e];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const uint32_t c[8] = {v[2 * half].x, v[2 * half].y, v[2 * half].z, v[2 * half].w,
+                                       v[2 * half + 1].x, v[2 * half + 1].y, v[2 * half + 1].z, v[2 * half + 1].w};
+                half8 hi;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int d = (int)c[e] - cen;
+                    const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+                    mx = max(mx, max(ad, c[e] >> 31 ? 0xFFFFFFFFu : 0u));
+                    hi[e] = (_Float16)(float)(d < -2048 ? -2048 : (d > 2048 ? 2048 : d));
+                }
+                out[(2 * (2 * s2 + half)) * 64] = *reinterpret_cast<uint4 *>(&hi);
             }
-            out[(2 * s) * 64] = *reinterpret_cast<uint4 *>(&hi);
         }
         if (mx > 2048u) atomicOr(big + qrow, 1u);
         return;

@@ -340,6 +340,8 @@ struct RerankParams {
     const float *cand_v;      // candidate lists, structure of arrays (score_lists.h: cand_at / candu_at)
     const uint32_t *cand_i;
     const float *cand_u;
+    uint64_t fb_rec_cap = 0;         // general D: records the brute-force workspace holds (phk_fallback_group_kernel cuts the
+                                     // reference into 64 chunks per query when they fit, else FB_CHUNKS); 0: FB_CHUNKS
     const float *cand_a = nullptr;   // general D: largest |accumulator| a lane saw at the (block, chunk) item boundaries of its
                                      // sweep, [2 halves][N] (the running sums the chain's charges scale with; see ErrBound)
     double eb_cAmax = 0.0;           // coefficient of that observed running sum (PHK_MFMA_ACC x instructions per value)
@@ -2022,6 +2024,134 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
     }
 }
 
+// General D: the same brute force with the queued queries taken EIGHT at a time.  A queued query of the one-query kernel
+// above streams the whole float64 reference through its CU (50 000 x 32 KiB at configs[4]: 1.6 GB per query, 22 ms for
+// a hundred queries); here a workgroup of 8 waves holds 8 queries -- one per wave, the normalised row in registers -- and
+// all of them meet every column of the item's chunk while it passes through the caches once.  Each wave evaluates its
+// query exactly as phk_rerank_kernel does (exact_d2<DSUB>: same operands, element ownership and summation order), so
+// a score does not depend on the route that produced it.  Items are numbered chunk-major: the workgroups that run
+// together share a chunk of the reference.
+__host__ __device__ __forceinline__ uint32_t fb_group_chunks(uint64_t count, uint64_t rec_cap) {
+    return (rec_cap && count * 64 <= rec_cap) ? 64u : (uint32_t)FB_CHUNKS;
+}
+
+template <int SRC, int DSUB>
+__global__ __launch_bounds__(512) void phk_fallback_group_kernel(const void *__restrict__ src, RerankParams p) {
+    constexpr int D = 256 * DSUB;
+    // two reference rows (float64) in LDS: the row every wave works on and the next one on its way in.  Read straight from
+    // memory by eight waves a row crossed the CU's 32 KiB L1 eight times (184 GB of L2 -> L1 traffic for a hundred queries
+    // at configs[4]); through LDS it crosses once.
+    extern __shared__ __attribute__((aligned(16))) uint8_t fbg_lds[];   // 2 x 8 D bytes
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t count = phk_uniform_load(p.fb_count);
+    const uint64_t ncols = p.M + p.n_cpos + p.n_cneg;
+    const uint64_t nch = fb_group_chunks(count, p.fb_rec_cap);
+    const uint64_t cw = (ncols + nch - 1) / nch;
+    const uint64_t ngroups = ((uint64_t)count + 7) / 8;
+    FbRecord *rec = static_cast<FbRecord *>(p.fb_rec);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)fbg_lds;
+    // row `c` -> buffer `buf`: wave w moves the 1 KiB pieces w, w + 8, ..  (LDS-DMA: lane l's 16 bytes land at piece + 16 l)
+    auto stage = [&](uint64_t c, int buf) {
+        const uint8_t *row = reinterpret_cast<const uint8_t *>(c < p.M ? p.R64 + c * D : p.C64 + (c - p.M) * D);
+#pragma unroll
+        for (int pc = 0; pc < (D * 8) / 8192 + 1; ++pc) {
+            const uint32_t piece = (uint32_t)wave + 8u * (uint32_t)pc;
+            if (piece * 1024u < (uint32_t)(D * 8)) {
+                const uint8_t *gp = row + piece * 1024u + (uint32_t)lane * 16u;
+                const uint32_t lp = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)buf * (uint32_t)(D * 8) + piece * 1024u);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
+            }
+        }
+    };
+    for (uint64_t it = blockIdx.x; it < ngroups * nch; it += gridDim.x) {   // (uniform over the workgroup)
+        const uint64_t ch = it / ngroups, g8 = (it % ngroups) * 8;
+        const uint64_t qi = g8 + (uint64_t)wave;
+        const bool active = qi < count;                 // a group's last waves may have no query: they keep the barriers
+        const uint64_t q = p.fb_list[active ? qi : g8];
+        const uint64_t c0 = ch * cw < ncols ? ch * cw : ncols, c1 = (c0 + cw < ncols) ? c0 + cw : ncols;
+        if (c0 >= c1) {   // (more chunks than columns)
+            if (active && lane == 0) {
+                FbRecord e;
+                for (int k = 0; k < 3; ++k) { e.d[k] = INFINITY; e.i[k] = 0xFFFFFFFFu; }
+                e.minpos = e.minneg = INFINITY; e.pad = 0;
+                rec[qi * nch + ch] = e;
+            }
+            continue;
+        }
+        stage(c0, 0);
+        double qd[4 * DSUB];
+        if (SRC == 0) {
+            const uint32_t *row = static_cast<const uint32_t *>(src) + q * D;
+            uint4 c[DSUB];
+            uint32_t sm = 0;
+#pragma unroll
+            for (int sub = 0; sub < DSUB; ++sub) {
+                c[sub] = reinterpret_cast<const uint4 *>(row + 256 * sub)[lane];
+                sm += c[sub].x + c[sub].y + c[sub].z + c[sub].w;
+            }
+            const double ds = (double)wave_sum(sm);
+#pragma unroll
+            for (int sub = 0; sub < DSUB; ++sub) {
+                qd[4 * sub + 0] = (double)c[sub].x / ds;
+                qd[4 * sub + 1] = (double)c[sub].y / ds;
+                qd[4 * sub + 2] = (double)c[sub].z / ds;
+                qd[4 * sub + 3] = (double)c[sub].w / ds;
+            }
+        } else {
+            const double *row = static_cast<const double *>(src) + q * D;
+#pragma unroll
+            for (int sub = 0; sub < DSUB; ++sub) {
+                const double2 a = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane];
+                const double2 b = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane + 1];
+                qd[4 * sub + 0] = a.x; qd[4 * sub + 1] = a.y; qd[4 * sub + 2] = b.x; qd[4 * sub + 3] = b.y;
+            }
+        }
+        FbRecord r;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r.d[k] = INFINITY; r.i[k] = 0xFFFFFFFFu; }
+        r.minpos = r.minneg = INFINITY;
+        r.pad = 0;
+        for (uint64_t c = c0; c < c1; ++c) {
+            const int buf = (int)((c - c0) & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of row c have landed ...
+            __syncthreads();                                   // ... and everybody's; everybody is done with the other buffer
+            if (c + 1 < c1) stage(c + 1, buf ^ 1);
+            // exact_d2<DSUB> with the row read from LDS: same operands, element ownership and summation order
+            const double *row = reinterpret_cast<const double *>(fbg_lds + (size_t)buf * (D * 8));
+            double acc = 0.0;
+#pragma unroll
+            for (int sub = 0; sub < DSUB; ++sub) {
+                const double2 a = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane];
+                const double2 b = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane + 1];
+                const double d0 = qd[4 * sub + 0] - a.x, d1 = qd[4 * sub + 1] - a.y;
+                const double d2 = qd[4 * sub + 2] - b.x, d3 = qd[4 * sub + 3] - b.y;
+                acc = fma(d0, d0, fma(d1, d1, fma(d2, d2, fma(d3, d3, acc))));
+            }
+            double dist = wave_sum(acc);   // the same value on every lane
+            if (c < p.M) {
+                if (p.col_mask && p.col_mask[c]) dist = INFINITY;
+                double d = dist;
+                uint64_t ix = c;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {   // (distance, index)-ordered
+                    const uint64_t cur = r.i[k] == 0xFFFFFFFFu ? ~0ull : (uint64_t)r.i[k];
+                    if (fb_less(d, ix, r.d[k], cur)) {
+                        const double td = r.d[k];
+                        r.d[k] = d; r.i[k] = (uint32_t)ix; d = td; ix = cur;
+                    }
+                }
+            } else if (c < p.M + p.n_cpos) {
+                r.minpos = fmin(r.minpos, dist);
+            } else {
+                r.minneg = fmin(r.minneg, dist);
+            }
+        }
+        __syncthreads();   // the last row is read: the next item's first row may overwrite buffer 0
+        if (active && lane == 0) rec[qi * nch + ch] = r;
+    }
+}
+
 // one thread per queued query: merge its FB_CHUNKS partial records and emit the score
 __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p) {
     const uint32_t count = *p.fb_count;
@@ -2039,8 +2169,9 @@ __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p)
         double bd[3] = {INFINITY, INFINITY, INFINITY};
         uint64_t bi[3] = {~0ull, ~0ull, ~0ull};
         double bp = INFINITY, bn = INFINITY;
-        for (int ch = 0; ch < FB_CHUNKS; ++ch) {
-            const FbRecord r = rec[qi * FB_CHUNKS + ch];
+        const uint32_t nch = fb_group_chunks(count, p.fb_rec_cap);
+        for (uint32_t ch = 0; ch < nch; ++ch) {
+            const FbRecord r = rec[qi * nch + ch];
             for (int k = 0; k < 3; ++k) {
                 if (r.i[k] == 0xFFFFFFFFu) continue;
                 double d = r.d[k];
@@ -2322,12 +2453,26 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             pf = p2;
             pf.N = nb;
         }
-        if (d_counts) {
-            PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
-                       phk_fallback_partial_kernel<0><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, pf));
+        if (D == FAST_D) {
+            if (d_counts) {
+                PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
+                           phk_fallback_partial_kernel<0><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, pf));
+            } else {
+                PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
+                           phk_fallback_partial_kernel<1><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, pf));
+            }
         } else {
-            PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
-                       phk_fallback_partial_kernel<1><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, pf));
+            // general D: the queued queries eight at a time against a chunk of the reference (see the kernel)
+            pf.fb_rec_cap = nb_max * FB_CHUNKS;
+            const dim3 fg((unsigned)ctx->num_cus * 2), fbk(512);
+            const size_t fgl = 2 * D * sizeof(double);   // <= 64 KiB (D <= 4096)
+#define PHK_FBG(DS)                                                                                                        \
+    do {                                                                                                                   \
+        if (d_counts) { PHK_LAUNCH(ctx, "phk_fallback_group_kernel", (phk_fallback_group_kernel<0, DS><<<fg, fbk, fgl, ctx->stream>>>(src, pf))); } \
+        else { PHK_LAUNCH(ctx, "phk_fallback_group_kernel", (phk_fallback_group_kernel<1, DS><<<fg, fbk, fgl, ctx->stream>>>(src, pf))); }          \
+    } while (0)
+            if (D == 512) PHK_FBG(2); else if (D == 1024) PHK_FBG(4); else if (D == 2048) PHK_FBG(8); else PHK_FBG(16);
+#undef PHK_FBG
         }
         PHK_LAUNCH(ctx, "phk_fallback_merge_kernel",
                    phk_fallback_merge_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(pf));

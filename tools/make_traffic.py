@@ -7,7 +7,7 @@ import sys
 
 src, dst, contigs = sys.argv[1], sys.argv[2], float(sys.argv[3])
 pmc = json.load(open(src))
-out = {"contigs": int(contigs), "note": "FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported; one dispatch per kernel, "
+out = {"contigs": int(contigs), "note": "FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported; summed over the dispatches of one bench step, "
                                           "separate rocprofv3 --pmc passes", "kernels": {}}
 for k, v in pmc.items():
     name = k.split("<")[0].replace("void ", "").strip()
