@@ -316,10 +316,9 @@ def _splitmix64(x):
     return z ^ (z >> 31)
 
 
-def kmeans_lloyd(X, k, seed=10, max_iter=300):
-    """k-means++ seeding (inverse CDF in index order, u_j = splitmix64(seed+j)/2^64 on 53 bits) + Lloyd
-    sweeps with ties to the lower index, index-ordered means, farthest-point re-seeding of empty
-    clusters.  Returns (labels, centroids, sweeps)."""
+def kmeans_pp_seeds(X, k, seed=10):
+    """The k initial centres of kmeans_lloyd: k-means++ seeding by inverse CDF in index order,
+    u_j = splitmix64(seed + j) / 2^64 on 53 bits."""
     X = np.asarray(X, dtype=float)
     n, D = X.shape
     u = lambda j: float(_splitmix64(seed + j) >> 11) / 9007199254740992.0
@@ -352,6 +351,15 @@ def kmeans_lloyd(X, k, seed=10, max_iter=300):
                 run += parts[t]
         centres[j] = X[pick]
         mind2 = np.minimum(mind2, ((X - centres[j]) ** 2).sum(axis=1))
+    return centres
+
+
+def kmeans_lloyd(X, k, seed=10, max_iter=300):
+    """k-means++ seeding (kmeans_pp_seeds) + Lloyd sweeps with ties to the lower index, index-ordered means,
+    farthest-point re-seeding of empty clusters.  Returns (labels, centroids, sweeps)."""
+    X = np.asarray(X, dtype=float)
+    n, D = X.shape
+    centres = kmeans_pp_seeds(X, k, seed)
     labels = np.full(n, -1, dtype=np.int64)
     sweeps = 0
     for it in range(max_iter):

@@ -1386,6 +1386,9 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
         if (qb < nqb && q0 + j < N) cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
         ++seg;
     }
+#if defined(PHK_ABL_NOQ)
+    half8 bh[16], bl[16];
+#endif
     for (uint32_t t = 0; t < ntile; ++t) {
         f32x16 acc[GEN_CT];
 #pragma unroll
@@ -1394,8 +1397,13 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
             for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
         for (uint32_t c = 0; c < nchunk; ++c) {
             // this wave's query fragments of chunk c (16 x hi + 16 x lo, 1 KiB coalesced loads)
+#if !defined(PHK_ABL_NOQ)
             half8 bh[16], bl[16];
+#endif
             const uint4 *bq = Bq + ((qbc * nchunk + c) * 32) * 64 + lane;
+#if defined(PHK_ABL_NOQ)   // ablation (timing only, results wrong): the query fragments are fetched for the first chunk alone
+            if (c == 0 && t == 0)
+#endif
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const uint4 uh = bq[(2 * s) * 64];

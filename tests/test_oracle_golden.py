@@ -168,3 +168,22 @@ def test_distances_and_closest_to_golden():
         assert np.array_equal(oracle.closest_to(v, g["picks"]), g["closest_picks"][i])
     assert np.array_equal(oracle.distances(g["queries"][3:4], pos), g["dist_row_2d"])
     assert g["dist_pos"][10, 0] == 0.0 and g["closest_idx"][14] == 43   # a reference row itself; the first of two equal picks
+
+
+def test_oracle_lloyd_kmeans_agrees_with_scikit_learn_from_the_same_seeds():
+    """oracle.kmeans_lloyd (the statement the device k-means phk_kmeans is tested against) is not a reference function:
+    it is checked here against an independent implementation -- scikit-learn's Lloyd iteration started from the same
+    initial centres (oracle.kmeans_pp_seeds), run to a fixed point (tol = 0): same labels, same centroids."""
+    from sklearn.cluster import KMeans
+    from oracle import oracle
+    ref = helpers.load_npz("ref_features.npz")
+    pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))
+    for rows, k, seed in ((700, 12, 10), (2255, 86, 10), (400, 7, 3)):
+        X = pos[:rows]
+        seeds = oracle.kmeans_pp_seeds(X, k, seed)
+        labels, cents, sweeps = oracle.kmeans_lloyd(X, k, seed)
+        sk = KMeans(n_clusters=k, init=seeds, n_init=1, algorithm="lloyd", tol=0.0, max_iter=300).fit(X)
+        assert len(np.unique(labels)) == k                     # no empty cluster on this data: the plain Lloyd iteration
+        assert np.array_equal(sk.labels_, labels), (rows, k)
+        assert np.allclose(sk.cluster_centers_, cents, rtol=1e-10, atol=1e-14)
+        assert 1 < sweeps < 300
