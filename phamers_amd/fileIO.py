@@ -12,6 +12,12 @@ The writers are native (csrc/csvio.cpp: rows formatted on all cores -- the featu
 ~0.7 GB of text); what they must reproduce is the output of the reference's np.savetxt calls, and
 tests/test_file_formats.py compares the bytes with files written by the reference's own functions
 (tests/golden/files.json).
+
+Which runtime that pins: the fixtures were produced by the reference's functions under Python 3 with NumPy >= 1.14,
+where `scores.astype(str)` / `str(numpy.float64)` give the shortest round-trip digits -- the notation the native writer
+reproduces (a 300 000-value fuzz agrees).  The reference itself is a Python 2.7 script; under its era's NumPy the same
+calls print 12 significant digits.  No file the reference ships covers this, so byte compatibility with the ORIGINAL
+runtime's score text is unpinned; `read_phamer_output` parses either form, and the values agree to those 12 digits.
 """
 import numpy as np
 
