@@ -599,17 +599,14 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
     return true;
 }
 
-template <int SRC, int DSUB>
-__global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict__ src, RerankParams p) {
+// one query, one wave (the body of phk_rerank_kernel)
+// MU_LDS: the training mean is read from LDS at byte offset mu_lds (address space 3: a generic pointer would turn every
+// read into a flat load, which also counts on the vector-memory counter and serialises the kernel's other loads)
+template <int SRC, int DSUB, bool MU_LDS>
+__device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, const RerankParams &p, uint64_t q, uint32_t mu_lds,
+                                                 int lane) {
     constexpr int D = 256 * DSUB;
-    const int lane = threadIdx.x & 63;
-    uint64_t q = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (p.slow_back == 2) {   // listed: only the queries phk_rerank_h_kernel passed on (slow_list, fb_count[2] of them)
-        if (q >= phk_uniform_load(p.fb_count + 2)) return;
-        q = p.slow_list[q] & 0x3FFFFFFFu;
-    } else if (q >= p.N) {
-        return;
-    }
+    typedef __attribute__((address_space(3))) const double lds_cdouble;
     // exact float64 query elements of this lane (kmer.normalize_counts arithmetic): dims 256*sub + 4*lane .. +3
     double qd[4 * DSUB];
     double vs = p.vscale;
@@ -672,8 +669,14 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
     double aq = 0.0, ap = 0.0, am = 0.0, pc2 = 0.0;
 #pragma unroll
     for (int sub = 0; sub < DSUB; ++sub) {
-        const double2 m0 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane];
-        const double2 m1 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane + 1];
+        double2 m0, m1;
+        if (MU_LDS) {
+            lds_cdouble *lm = (lds_cdouble *)(uintptr_t)mu_lds + 256 * sub + 4 * lane;
+            m0.x = lm[0]; m0.y = lm[1]; m1.x = lm[2]; m1.y = lm[3];
+        } else {
+            m0 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane];
+            m1 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane + 1];
+        }
         const double c0 = qd[4 * sub + 0] - m0.x, c1 = qd[4 * sub + 1] - m0.y;
         const double c2 = qd[4 * sub + 2] - m1.x, c3 = qd[4 * sub + 3] - m1.y;
         aq = fma(qd[4 * sub + 0], qd[4 * sub + 0], fma(qd[4 * sub + 1], qd[4 * sub + 1],
@@ -729,6 +732,34 @@ __global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict_
             const uint32_t slot = atomicAdd(p.fb_count, 1u);
             p.fb_list[slot] = (uint32_t)q;
         }
+    }
+}
+
+// One wave per query.  D >= 2048: a workgroup walks its share of the queries (grid-stride) with the training mean in LDS,
+// loaded once -- read from memory per query it was 8 D bytes through the vector cache, a quarter of the kernel's traffic
+// (configs[4]: 11.4 -> 9.6 ms).  Smaller D: one query per wave and launch slot, the mean from the cache (the 8 KB of
+// D = 1024 stay resident there, and the walk was measured slower: configs[2] 37.5 -> 44.7 ms).
+template <int SRC, int DSUB>
+__global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict__ src, RerankParams p) {
+    constexpr int D = 256 * DSUB;
+    constexpr bool WALK = DSUB >= 8;
+    const int lane = threadIdx.x & 63;
+    __shared__ double s_mu[WALK ? D : 2];
+    if (WALK) {
+        for (int i = threadIdx.x; i < D / 2; i += 256)
+            reinterpret_cast<double2 *>(s_mu)[i] = reinterpret_cast<const double2 *>(p.mu64)[i];
+        __syncthreads();
+    }
+    // listed (slow_back == 2): only the queries phk_rerank_h_kernel passed on (slow_list, fb_count[2] of them)
+    const uint64_t nq = p.slow_back == 2 ? (uint64_t)phk_uniform_load(p.fb_count + 2) : p.N;
+    const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t mu_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)s_mu;
+    uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (WALK) {
+        for (; w < nq; w += stride)
+            rerank_one_query<SRC, DSUB, true>(src, p, p.slow_back == 2 ? (uint64_t)(p.slow_list[w] & 0x3FFFFFFFu) : w, mu_lds, lane);
+    } else if (w < nq) {   // (no loop: its live state costs the registers that keep four waves per SIMD)
+        rerank_one_query<SRC, DSUB, false>(src, p, p.slow_back == 2 ? (uint64_t)(p.slow_list[w] & 0x3FFFFFFFu) : w, 0u, lane);
     }
 }
 
@@ -2204,11 +2235,14 @@ __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p)
 // ------------------------------------------------------------------------------------
 template <int SRC>
 static int launch_rerank(phk_ctx *ctx, unsigned blocks, const void *src, const RerankParams &p) {
+    // phk_rerank_kernel walks the queries grid-stride (its workgroups keep the training mean in LDS): a few workgroups per CU
+    const unsigned cap = (unsigned)ctx->num_cus * 16u;
+    const unsigned wblocks = (p.D >= 2048 && blocks > cap) ? cap : blocks;
     switch (p.D) {
         case 256: {
             const char rr = ctx->knobs.rerank;
             if (rr == 'w') {  // one wave per query (the general kernel), for A/B comparison
-                PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 1><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+                PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 1><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p));
             } else if (rr == 'g') {  // four queries per wave for every query (the decision kernel off)
                 PHK_LAUNCH(ctx, "phk_rerank16_kernel",
                            (phk_rerank16_kernel<SRC, 0><<<dim3((unsigned)phk_div_up(p.N, 16)), dim3(256), 0, ctx->stream>>>(src, p)));
@@ -2221,16 +2255,16 @@ static int launch_rerank(phk_ctx *ctx, unsigned blocks, const void *src, const R
             break;
         }
         case 512:
-            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 2><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 2><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p));
             break;
         case 1024:
-            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 4><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 4><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p));
             break;
         case 2048:
-            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 8><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 8><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p));
             break;
         case 4096:
-            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 16><<<dim3(blocks), dim3(256), 0, ctx->stream>>>(src, p));
+            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 16><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p));
             break;
         default:
             phk_set_error("phk_score: no decision kernel for D = %llu", (unsigned long long)p.D);
