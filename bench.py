@@ -12,7 +12,10 @@ Workload (--config, phamers_amd/workloads.py; BASELINE.json `configs`):
   3  k=4, 100M x 5 kb contigs split over the ranks (12.5M per GPU at 8), real PhaMers matrix
   4  k=6, 131072 x 10 kb queries per GPU against 50 000 synthetic reference genomes (replicated on every rank)
 For N>1 every rank processes its own shard of contigs / queries against a replicated reference (no data-path
-collective) and the step ends with one RCCL all-gather of the score vectors.
+collective) and every step issues one RCCL all-gather of the score vectors; the gather is asynchronous (it travels while
+the next step computes, two score buffers) and all of them have completed when the timed region closes.
+`python bench.py --gpus N` started plainly launches its own N ranks (one child process per GPU); under
+torch.distributed.run it is one of the ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
 "roofline" (dominant kernel, algorithmic work / HIP-event time measured in this run) and
@@ -252,8 +255,8 @@ def main():
     local_dev = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if args.gpus > 1 or world > 1:
-        import torch.distributed as dist
+    if args.gpus > 1 or world > 1 or os.environ.get("PHK_BENCH_FORCE_DIST") == "1":   # (the last: a 1-rank group, to run
+        import torch.distributed as dist                                                 #  the collective's code path on one GPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         # RCCL over xGMI in production; PHK_BENCH_BACKEND=gloo only to rehearse the multi-rank code path
@@ -304,9 +307,10 @@ def main():
     packed = torch.empty(device.packed_words(T), dtype=torch.int32, device=dev)
     offsets = torch.empty(n + 1, dtype=torch.int64, device=dev)
     counts = torch.empty((n, D), dtype=torch.int32, device=dev)
-    scores = torch.empty(n, dtype=torch.float64, device=dev)
+    scores_buf = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
+    scores = scores_buf[0]
     status = torch.zeros(1, dtype=torch.int32, device=dev)
-    gathered = torch.empty(world * n, dtype=torch.float64, device=dev) if dist else None
+    gathered_buf = [torch.empty(world * n, dtype=torch.float64, device=dev) for _ in range(2)] if dist else None
     first = rank * n
     mask = None
     if ragged:
@@ -321,19 +325,38 @@ def main():
         device.synth_packed(ctx, 0, first, n, L, packed.data_ptr(), offsets.data_ptr())
     mask_ptr = mask.data_ptr() if mask is not None else None
 
+    # The only collective of the path: the final gather of the score vectors (RCCL all-gather over xGMI).  It is issued
+    # asynchronously, so the gather of step i travels while step i + 1 computes (two score / gather buffers; a buffer's
+    # pending gather is waited for before the buffer is written again), and every gather has completed before the timed
+    # region closes.
+    pending = [None, None]
+    nstep = [0]
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
     def step():
+        b = nstep[0] & 1
+        nstep[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()       # (stream-level: the compute stream waits for the gather that still reads scores_buf[b])
+            pending[b] = None
         device.count_score(ctx, model, packed.data_ptr(), mask_ptr, T, offsets.data_ptr(), n, k, args.method,
-                           counts.data_ptr(), scores.data_ptr(), status.data_ptr())
+                           counts.data_ptr(), scores_buf[b].data_ptr(), status.data_ptr())
         if dist:
             if dist.get_backend() == "nccl":
-                dist.all_gather_into_tensor(gathered, scores)   # the only collective: final score gather
+                pending[b] = dist.all_gather_into_tensor(gathered_buf[b], scores_buf[b], async_op=True)
             else:
-                host = scores.cpu()
+                host = scores_buf[b].cpu()
                 parts = [torch.empty_like(host) for _ in range(world)]
                 dist.all_gather(parts, host)
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -344,6 +367,7 @@ def main():
         # sustained run: size the timed region from one probe step so that every rank times the same number of steps
         t0 = time.perf_counter()
         step()
+        drain()
         torch.cuda.synchronize()
         one = time.perf_counter() - t0
         if dist:
@@ -359,6 +383,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    drain()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
