@@ -582,15 +582,26 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
 // Folds the list sets 1 .. S-1 of a column-split launch into set 0: per (query, half-list) the 4 S train candidates
 // are re-inserted into one list (the best value dropped = the largest any part dropped or the merge drops); the centroid
 // segments, swept by the last part alone, are copied.
+// qcount == NULL: all Nlist queries (the column groups of the general-D sweep); ca: the sets' observed running sums
+// ([2][Nlist] floats each, ca_set floats apart), folded by maximum.
 __global__ __launch_bounds__(256) void phk_merge_list_sets_kernel(float *__restrict__ cv, uint32_t *__restrict__ ci,
                                                                   float *__restrict__ cu, uint64_t Nlist, uint64_t set_bytes,
-                                                                  int S, const uint32_t *__restrict__ qcount) {
-    const uint64_t cnt_all = phk_uniform_load(qcount);
-    const uint64_t cnt = cnt_all < PHK_SECOND_MIN ? 0 : (cnt_all < Nlist ? cnt_all : Nlist);
+                                                                  int S, const uint32_t *__restrict__ qcount,
+                                                                  float *__restrict__ ca, uint64_t ca_set) {
+    uint64_t cnt = Nlist;
+    if (qcount) {
+        const uint64_t cnt_all = phk_uniform_load(qcount);
+        cnt = cnt_all < PHK_SECOND_MIN ? 0 : (cnt_all < Nlist ? cnt_all : Nlist);
+    }
     const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t q = id >> 1;
     const int h = (int)(id & 1);
     if (q >= cnt) return;
+    if (ca) {
+        float a = ca[(uint64_t)h * Nlist + q];
+        for (int y = 1; y < S; ++y) a = fmaxf(a, ca[(uint64_t)y * ca_set + (uint64_t)h * Nlist + q]);
+        ca[(uint64_t)h * Nlist + q] = a;
+    }
     auto set_v = [&](int y) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(cv) + (uint64_t)y * set_bytes); };
     auto set_i = [&](int y) { return reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(ci) + (uint64_t)y * set_bytes); };
     auto set_u = [&](int y) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(cu) + (uint64_t)y * set_bytes); };
@@ -637,7 +648,7 @@ int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, b
     if (splits > 1) {
         PHK_LAUNCH(ctx, "phk_merge_list_sets_kernel",
                    phk_merge_list_sets_kernel<<<dim3((unsigned)phk_div_up(2 * nb, 256)), dim3(256), 0, ctx->stream>>>(
-                       cv, ci, cu, nb, set_bytes, splits, qcount));
+                       cv, ci, cu, nb, set_bytes, splits, qcount, nullptr, 0));
     }
     return PHK_OK;
 }
@@ -1320,16 +1331,42 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
                                                                      float *__restrict__ cand_v,
                                                                      uint32_t *__restrict__ cand_i,
                                                                      float *__restrict__ cand_u,
-                                                                     float *__restrict__ cand_a) {
+                                                                     float *__restrict__ cand_a,
+                                                                     uint32_t ngroups,   // column groups (2-D launch), or 1
+                                                                     uint64_t set_bytes, uint64_t ca_set) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x 32 KiB
     // (a third buffer with the DMA running two items ahead and counted vmcnt waits was measured: 106 instead of 96 ms at
     // config 4 -- the deeper queue does not pay)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const uint64_t qb = (uint64_t)blockIdx.x * GEN_NW + wave;
-    const uint64_t q0 = qb * 32;
     const uint64_t nqb = (N + 31) / 32;
+    // 2-D launch (ngroups > 1; D >= 2048): a workgroup sweeps ONE of `ngroups` groups of train blocks for its 256 queries
+    // and writes list set g (set_bytes apart; the last group also sweeps the centroid blocks), phk_merge_list_sets_kernel
+    // folds the sets.  Workgroups are numbered so that the `ngroups` workgroups of a query block have equal
+    // blockIdx.x % 8 and neighbouring numbers: under the dispatcher's round-robin they share an XCD -- and its L2 serves
+    // the query fragments that every one of them re-reads once per 8 column blocks (a speed matter only; nothing
+    // depends on the placement).  With one group per workgroup those fragments came from HBM: 283 GB per configs[4] step.
+    // The number of groups is a balance (score_model.h, PHK_GEN_GROUPS): every group more also splits the column stream
+    // that the workgroups of an XCD otherwise pull through its L2 in step.
+    uint64_t wg = blockIdx.x;
+    uint32_t col0 = 0;
+    if (ngroups > 1) {
+        const uint32_t li = blockIdx.x >> 3, g = li % ngroups;
+        wg = (uint64_t)(li / ngroups) * 8 + (blockIdx.x & 7u);
+        const uint32_t b0 = (uint32_t)((uint64_t)nblk_ref * g / ngroups), b1 = (uint32_t)((uint64_t)nblk_ref * (g + 1) / ngroups);
+        blk0 += b0;
+        col0 = 32u * b0;
+        nblk_ref = b1 - b0;
+        if (g + 1 != ngroups) nblk_pos = nblk_neg = 0;
+        cand_v = reinterpret_cast<float *>(reinterpret_cast<char *>(cand_v) + (uint64_t)g * set_bytes);
+        cand_i = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cand_i) + (uint64_t)g * set_bytes);
+        cand_u = reinterpret_cast<float *>(reinterpret_cast<char *>(cand_u) + (uint64_t)g * set_bytes);
+        if (cand_a) cand_a += (uint64_t)g * ca_set;
+    }
+    if (wg * GEN_NW >= nqb) return;   // padding workgroup of the 2-D numbering (uniform: before any barrier)
+    const uint64_t qb = wg * GEN_NW + wave;
+    const uint64_t q0 = qb * 32;
     const uint64_t qbc = qb < nqb ? qb : nqb - 1;  // padding waves re-read the last block; nothing is written
     const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
     const uint32_t seg_end0 = nblk_ref, seg_end1 = nblk_ref + nblk_pos;
@@ -1463,9 +1500,12 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
                         if (CX && isbig)
                             cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f,
                                        0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 3.0e38f);
-                        else
-                            cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2],
-                                       li[3], ldrop);
+                        else {
+                            const uint32_t o = seg == 0 ? col0 : 0u;   // (a column group: indices relative to the whole train segment)
+                            cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, lv[0], lv[1], lv[2], lv[3],
+                                       li[0] == 0xFFFFFFFFu ? li[0] : li[0] + o, li[1] == 0xFFFFFFFFu ? li[1] : li[1] + o,
+                                       li[2] == 0xFFFFFFFFu ? li[2] : li[2] + o, li[3] == 0xFFFFFFFFu ? li[3] : li[3] + o, ldrop);
+                        }
                     }
 #pragma unroll
                     for (int c = 0; c < CAND; ++c) {
@@ -1491,7 +1531,8 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
 // proposal pass for D = 256 * nchunk > 256: row sums (if needed) -> split queries -> sweep
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, bool count_exact,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                                    float *cv, uint32_t *ci, float *cu, float *ca, bool hi_only) {
+                                    float *cv, uint32_t *ci, float *cu, float *ca, bool hi_only, uint32_t groups,
+                                    uint64_t set_bytes) {
     const uint64_t D = m->D, nchunk = D / 256;
     const uint64_t nqb = phk_div_up(nb, 32);
     void *bq, *rs = nullptr;
@@ -1524,21 +1565,31 @@ int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void
     }
     const uint64_t rec_u4 = (nchunk * 32 + 1) * 64;
     const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
+    // 2-D launch for D >= 2048 (see the kernel): `groups` column groups per query block, list sets set_bytes apart
+    const uint32_t ng = (groups > 1 && nref >= 8u * groups && nqb >= 64) ? groups : 1u;
+    const uint64_t nqg = phk_div_up(nqb, 8);
+    const unsigned gblocks = ng > 1 ? (unsigned)(phk_div_up(nqg, 8) * 8 * ng) : (unsigned)nqg;
+    const uint64_t ca_set = 2 * nb;
     if (d_big && hi_only) {
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
-                   (phk_knn_f16_general_kernel<true, 8, true><<<dim3((unsigned)phk_div_up(nqb, 8)), dim3(512), 65536, ctx->stream>>>(
+                   (phk_knn_f16_general_kernel<true, 8, true><<<dim3(gblocks), dim3(512), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_betah16, d_rowsum,
-                       d_big, blk0, nref, npos, nneg, cv, ci, cu, ca)));
+                       d_big, blk0, nref, npos, nneg, cv, ci, cu, ca, ng, set_bytes, ca_set)));
     } else if (d_big) {
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
-                   (phk_knn_f16_general_kernel<true, 8><<<dim3((unsigned)phk_div_up(nqb, 8)), dim3(512), 65536, ctx->stream>>>(
+                   (phk_knn_f16_general_kernel<true, 8><<<dim3(gblocks), dim3(512), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, d_rowsum,
-                       d_big, blk0, nref, npos, nneg, cv, ci, cu, ca)));
+                       d_big, blk0, nref, npos, nneg, cv, ci, cu, ca, ng, set_bytes, ca_set)));
     } else {
         PHK_LAUNCH(ctx, "phk_knn_f16_general_kernel",
-                   (phk_knn_f16_general_kernel<false, 4><<<dim3((unsigned)phk_div_up(nqb, 8)), dim3(512), 65536, ctx->stream>>>(
+                   (phk_knn_f16_general_kernel<false, 4><<<dim3(gblocks), dim3(512), 65536, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_Af16, rec_u4, m->d_cn16, m->d_beta16, nullptr,
-                       nullptr, blk0, nref, npos, nneg, cv, ci, cu, ca)));
+                       nullptr, blk0, nref, npos, nneg, cv, ci, cu, ca, ng, set_bytes, ca_set)));
+    }
+    if (ng > 1) {
+        PHK_LAUNCH(ctx, "phk_merge_list_sets_kernel",
+                   phk_merge_list_sets_kernel<<<dim3((unsigned)phk_div_up(2 * nb, 256)), dim3(256), 0, ctx->stream>>>(
+                       cv, ci, cu, nb, set_bytes, (int)ng, nullptr, ca, ca_set));
     }
     return PHK_OK;
 }

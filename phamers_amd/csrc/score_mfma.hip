@@ -2313,12 +2313,15 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     void *cv, *fb, *rec;
     // the second chance sweeps the reference in PHK_SECOND_SPLITS column parts, each with a list set of its own
     const uint64_t set2_bytes = per_list2 * list_bytes;
-    const uint64_t ca_bytes = D != FAST_D ? 2 * nb_max * sizeof(float) : 0;   // general D: observed running sums (cand_a)
-    PHK_TRY(phk_ws(ctx, WS_CAND, per_list * list_bytes + ca_bytes + PHK_SECOND_SPLITS * set2_bytes, &cv));
+    // general D: observed running sums (cand_a); D >= 2048: PHK_GEN_GROUPS list sets (the column groups of the 2-D launch)
+    const uint64_t gen_sets = D >= 2048 ? PHK_GEN_GROUPS : 1;
+    const uint64_t set_bytes = per_list * list_bytes;
+    const uint64_t ca_bytes = D != FAST_D ? gen_sets * 2 * nb_max * sizeof(float) : 0;
+    PHK_TRY(phk_ws(ctx, WS_CAND, gen_sets * set_bytes + ca_bytes + PHK_SECOND_SPLITS * set2_bytes, &cv));
     uint32_t *ci = (uint32_t *)((char *)cv + per_list * sizeof(float4));
     float *cu = (float *)((char *)ci + per_list * sizeof(uint4));
-    float *ca = ca_bytes ? (float *)((char *)cv + per_list * list_bytes) : nullptr;
-    float *cv2 = (float *)((char *)cv + per_list * list_bytes + ca_bytes);
+    float *ca = ca_bytes ? (float *)((char *)cv + gen_sets * set_bytes) : nullptr;
+    float *cv2 = (float *)((char *)cv + gen_sets * set_bytes + ca_bytes);
     uint32_t *ci2 = (uint32_t *)((char *)cv2 + per_list2 * sizeof(float4));
     float *cu2 = (float *)((char *)ci2 + per_list2 * sizeof(uint4));
     PHK_TRY(phk_ws(ctx, WS_DIST, (3 * nb_max + 32) * sizeof(uint32_t), &fb));
@@ -2393,7 +2396,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         }
         if (D != FAST_D) {
             PHK_TRY(phk_launch_proposal_f16_general(ctx, m, src, d_counts != nullptr, use_cx, rsum, nb, nref, npos, nneg,
-                                                    (float *)cv, ci, cu, ca, hi_gen));
+                                                    (float *)cv, ci, cu, ca, hi_gen, (uint32_t)gen_sets, set_bytes));
         } else if (hi_only) {
             PHK_TRY(phk_launch_proposal_f16h(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu));
         } else if (use_cx) {

@@ -72,6 +72,12 @@ int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu);
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, bool count_exact,
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
-                                    float *cv, uint32_t *ci, float *cu, float *ca, bool hi_only = false);
+                                    float *cv, uint32_t *ci, float *cu, float *ca, bool hi_only = false, uint32_t groups = 1,
+                                    uint64_t set_bytes = 0);
+// Column groups of the general-D sweep's 2-D launch (D >= 2048).  Measured on configs[4] (kernel ms): 1 group 92.9, 2: 89.8,
+// 4: 86.4, 8: 95.1 (and 3 / 5 / 6: no better) -- more groups share a query block's fragments through one XCD's L2, but
+// split the column stream that ALL workgroups of an XCD otherwise pull through it in step.  D = 1024 (configs[2]): 184 /
+// 185 / 210 ms with 1 / 2 / 4 groups: one group.
+#define PHK_GEN_GROUPS 4
 int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const uint32_t *d_counts,
                    const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status);
