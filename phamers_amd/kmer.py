@@ -10,6 +10,7 @@ Same names, argument meaning, defaults and return shapes as the reference:
     count_directory(directory, kmer_length, identifier='fna', ...)       scripts/kmer.py:143
     normalize_counts(counts)                                            scripts/kmer.py:209
     kmers(k, symbols=DNA), sequence_to_integers, get_kmer_index         scripts/kmer.py:183-251
+    main()   `python -m phamers_amd.kmer <fasta | dir> <out.csv> -k K`     scripts/kmer.py:283-334
 
 Scope notes: only 4-symbol alphabets run on the GPU (the reference's
 integer-replacement branch with DNA/RNA); other alphabets raise NotImplementedError --
@@ -237,3 +238,48 @@ def kmers(k, symbols=DNA):
     for _ in range(k):
         mers = [m + s for m in mers for s in symbols]
     return mers
+
+
+def _parser():
+    """The counting command line of scripts/kmer.py:283-303 (how the reference's data/reference_features CSVs were made:
+    their '#' headers echo this Namespace): positional input (a FASTA file, or a directory of genome files) and output
+    CSV; -k, -s / --sample, -sym / --symbols, -id / --file_identifier, -v, --debug."""
+    import argparse
+    ap = argparse.ArgumentParser(description="This script counts k-mers in sequence data",
+                                 formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    ap.add_argument('input_file', type=str, help='FASTA file, or a directory of FASTA files (one output row per file)')
+    ap.add_argument('-id', '--file_identifier', type=str, default='.fna', help='File identifier if directory')
+    ap.add_argument('output_file', type=str, help='Output CSV file of k-mer counts')
+    ap.add_argument('-k', '--kmer_length', type=int, default=4, help='Length of k-mer to count')
+    ap.add_argument('-s', '--sample', type=int, help='Number of sequences to sample and count')
+    ap.add_argument('-sym', '--symbols', type=str, default=DNA, help='Symbols to use in k-mer counting')
+    ap.add_argument('-v', '--verbose', action='store_true', help='verbose output')
+    ap.add_argument('--debug', action='store_true', help='Debug console')
+    return ap
+
+
+def main(argv=None):
+    """`python -m phamers_amd.kmer <input> <output.csv> [-k K]` (scripts/kmer.py:283-334): a file goes through
+    count_file, a directory through count_directory (column sums per file, reduced on the device); the result is
+    written by fileIO.save_counts with the Namespace stamped into the '#' header, as the reference does."""
+    from . import fileIO
+    args = _parser().parse_args(argv)
+    logger.setLevel(logging.DEBUG if args.debug else logging.INFO if args.verbose else logging.WARNING)
+    logger.info("Counting k-mers...")
+    if args.input_file and os.path.isfile(args.input_file):
+        ids, counts = count_file(args.input_file, args.kmer_length, symbols=args.symbols)
+        if ids is None:
+            raise SystemExit(1)
+    elif args.input_file and os.path.isdir(args.input_file):
+        ids, counts = count_directory(args.input_file, args.kmer_length, symbols=args.symbols,
+                                      identifier=args.file_identifier, sample=args.sample or 0)
+    else:
+        logger.error("%s was not an acceptable file or directory" % args.input_file)
+        raise SystemExit(1)
+    fileIO.save_counts(counts, ids, args.output_file, args=args)
+    logger.info("K-mer counting complete.")
+    return ids, counts
+
+
+if __name__ == '__main__':
+    main()

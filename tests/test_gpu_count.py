@@ -377,3 +377,39 @@ def test_ragged_batch_sorted_slots_and_pieces(ctx, k, masked):
         ctx.set_option("count_sort", "1")
         ctx.set_option("count_lanes", "")
     assert np.array_equal(got["sorted"], got["wave"]) and np.array_equal(got["sorted"], got["standdown"])
+
+
+@pytest.mark.gpu
+def test_kmer_command_line_end_to_end(tmp_path):
+    """`python -m phamers_amd.kmer` (scripts/kmer.py:283-334): a FASTA file -> one row per record; a directory of genome
+    files -> one row per file (column sums); the CSV reads back through read_feature_file and equals the oracle; the
+    '#' header carries the Namespace as the reference's files do."""
+    from oracle import oracle
+    from phamers_amd import fileIO, kmer as pk, synth
+    seqs = [synth.synth_contig(90, r, 700 + 53 * r, 500 if r % 3 == 0 else 0) for r in range(9)]
+    fasta = tmp_path / "contigs.fasta"
+    with open(fasta, "w") as fh:
+        for r, sq in enumerate(seqs):
+            fh.write(">SuperContig_%d_length_%d_ID_%d\n%s\n" % (r, len(sq), r, sq))
+    out = tmp_path / "features.csv"
+    pk.main([str(fasta), str(out), "-k", "4"])
+    ids, counts = fileIO.read_feature_file(str(out))
+    assert [str(x) for x in ids] == [str(r) for r in range(9)]
+    assert np.array_equal(counts, oracle.count(seqs, 4))
+    head = [ln for ln in open(out).read().splitlines() if ln.startswith("#")]
+    assert any("kmer_length:\t4" in ln for ln in head) and any("symbols:\t'ATGC'" in ln for ln in head)
+    gdir = tmp_path / "genomes"
+    gdir.mkdir()
+    want = {}
+    for fi in range(3):
+        recs = [synth.synth_contig(91 + fi, r, 1500 + 11 * r) for r in range(fi + 1)]
+        with open(gdir / ("g%d.fna" % fi), "w") as fh:
+            for r, sq in enumerate(recs):
+                fh.write(">GB%03d%02d.1 genome\n%s\n" % (fi, r, sq))
+        want["GB%03d00.1" % fi] = oracle.count(recs, 5).reshape(len(recs), -1).sum(axis=0)
+    out2 = tmp_path / "ref_features.csv"
+    pk.main([str(gdir), str(out2), "-k", "5", "-id", ".fna"])
+    ids2, counts2 = fileIO.read_feature_file(str(out2))
+    assert sorted(str(x) for x in ids2) == sorted(want)
+    for i, name in enumerate(ids2):
+        assert np.array_equal(counts2[i], want[str(name)])

@@ -117,3 +117,17 @@ def test_failed_features_cache_write_is_an_error_of_the_run(tmp_path):
     sc.finish_io()
     assert os.path.exists(good) and not os.path.exists(good + ".part")
     sc.finish_io()   # nothing pending: a no-op
+
+
+def test_kmer_command_line_parses_like_the_reference():
+    """scripts/kmer.py:283-303: positional input / output, -k, -s, -sym, -id, -v, --debug, same defaults (the Namespace is
+    what save_counts stamps into the features header: tests/golden/files.json holds one)."""
+    from phamers_amd import kmer
+    doc = helpers.load_json("files.json")["args"]
+    a = kmer._parser().parse_args([doc["input_file"], doc["output_file"], "-k", str(doc["kmer_length"])] + (["-v"] if doc["verbose"] else []))
+    for key in ("input_file", "output_file", "kmer_length", "symbols", "verbose", "debug", "sample", "file_identifier"):
+        assert getattr(a, key) == doc[key], key
+    b = kmer._parser().parse_args(["d", "o.csv", "-k", "5", "-s", "10", "-sym", "AUGC", "-id", ".fa", "--debug"])
+    assert (b.kmer_length, b.sample, b.symbols, b.file_identifier, b.debug) == (5, 10, "AUGC", ".fa", True)
+    with pytest.raises(SystemExit):
+        kmer.main([str("/nonexistent/path/x.fasta"), "out.csv"])
