@@ -739,8 +739,11 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
 // loaded once -- read from memory per query it was 8 D bytes through the vector cache, a quarter of the kernel's traffic
 // (configs[4]: 11.4 -> 9.6 ms).  Smaller D: one query per wave and launch slot, the mean from the cache (the 8 KB of
 // D = 1024 stay resident there, and the walk was measured slower: configs[2] 37.5 -> 44.7 ms).
+#ifndef PHK_RERANK_WAVES
+#define PHK_RERANK_WAVES 4
+#endif
 template <int SRC, int DSUB>
-__global__ __launch_bounds__(256) void phk_rerank_kernel(const void *__restrict__ src, RerankParams p) {
+__global__ __launch_bounds__(256, (DSUB <= 4 ? PHK_RERANK_WAVES : 1)) void phk_rerank_kernel(const void *__restrict__ src, RerankParams p) {
     constexpr int D = 256 * DSUB;
     constexpr bool WALK = DSUB >= 8;
     const int lane = threadIdx.x & 63;
