@@ -39,6 +39,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak
 F64_PEAK_TF = 78.6             # fp64 vector / matrix peak
 MFMA_F16_PEAK_TF = 2500.0      # f16/bf16 dense MFMA peak
+MFMA_I8_PEAK_TF = 5000.0       # int8 dense MFMA peak (2 x bf16 per clock: MI355X_MICROARCH.md, MFMA table)
 
 
 def cpu_model_name():
@@ -436,6 +437,7 @@ def main():
         "phk_knn_f16c_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
         "phk_knn_f16h_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
         "phk_knn_f16_general_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
+        "phk_knn_i8_general_kernel": ("mfma", "TFLOP/s", MFMA_I8_PEAK_TF, score_tflop),
         "phk_dist2_f64_kernel": ("mfma", "TFLOP/s", F64_PEAK_TF, score_tflop),
     }
     if "phk_count_slots_kernel" in prof or "phk_count_pairs_kernel" in prof:
@@ -444,7 +446,7 @@ def main():
     # chance of a count-exact first pass it sees the queued rows alone: credit it with those (stats_ex[2] is the
     # last step's queue on this rank), never with the batch
     first_pass = [kname for kname in ("phk_knn_f16h_kernel", "phk_knn_f16c_kernel", "phk_knn_f16_general_kernel",
-                                      "phk_knn_mfma_kernel") if kname in prof]
+                                      "phk_knn_i8_general_kernel", "phk_knn_mfma_kernel") if kname in prof]
     if first_pass and "phk_knn_f16_kernel" in prof:
         bound, unit, peak, _ = alg["phk_knn_f16_kernel"]
         alg["phk_knn_f16_kernel"] = (bound, unit, peak, score_tflop * (stats_ex["second_chance"] / float(n) if n else 0.0))
@@ -471,9 +473,10 @@ def main():
         "algorithmic_bytes_per_contig": count_bytes * 1e9 / n,
         "hbm_bytes_per_contig_all_kernels": round(sum(per_all.values()), 1) if per_all else None}
     # MFMA flops ISSUED per algorithmic flop: 3 (split-query f16: hi.hi + hi.lo + lo.hi), 2 (count-exact: c.r_hi +
-    # c.r_lo), 1 (count-exact, high parts only: the low parts are applied to the few candidates by the decision stage)
+    # c.r_lo), 1 (count-exact, high parts only: the low parts are applied to the few candidates by the decision stage),
+    # 3 (int8: the reference column in three int8 parts of a 24-bit fixed-point value; against the int8 peak)
     issue = {"phk_knn_f16_kernel": 3.0, "phk_knn_f16c_kernel": 2.0, "phk_knn_f16h_kernel": 1.0,
-             "phk_knn_f16_general_kernel": 2.0}.get(dom)
+             "phk_knn_f16_general_kernel": 2.0, "phk_knn_i8_general_kernel": 3.0}.get(dom)
     if issue:
         roofline["mfma_issue_frac"] = issue * kernels[dom]["frac"]
 
@@ -483,7 +486,10 @@ def main():
         "value": world * T * steps / elapsed / 1e9,
         "unit": "Gbases/s", "n_gpus": world, "ranks_seen": seen, "steps": steps, "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
-        "vs_baseline": None, "dtype": "u32 counts + f16 MFMA proposal (exact integer counts x fp16 reference parts, f32 accumulate; k=4: high parts in the sweep, low parts added in f64 to the window's candidates) + f64 decision",
+        "vs_baseline": None,
+        "dtype": ("u32 counts + int8 MFMA proposal (exact integer counts x 24-bit fixed-point reference columns in three int8 "
+                  "parts, exact int32 accumulate) + f64 decision") if "phk_knn_i8_general_kernel" in prof else
+                 "u32 counts + f16 MFMA proposal (exact integer counts x fp16 reference parts, f32 accumulate; k=4: high parts in the sweep, low parts added in f64 to the window's candidates) + f64 decision",
         "data": ("synthetic (seeded, device-generated: heavy-tailed lengths 5-500 kb in arbitrary order, per-contig GC "
                  "0.3-0.7, 0.1 % invalid bases); reference matrix: " if ragged else
                  "synthetic (seeded uniform ATGC contigs, device-generated); reference matrix: ") + ref_name,

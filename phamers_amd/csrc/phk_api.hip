@@ -37,6 +37,7 @@ static int set_knob(PhkKnobs &k, const char *key, const char *value) {
     else if (!strcmp(key, "count_sort")) k.count_sort = v[0] != '0';
     else if (!strcmp(key, "score_batch")) k.score_batch = strtoull(v, nullptr, 10);
     else if (!strcmp(key, "pipeline")) k.pipeline = v[0] ? atoi(v) : 1;
+    else if (!strcmp(key, "gen_groups")) k.gen_groups = v[0] ? atoi(v) : 0;
     else return PHK_ERR_ARG;
     return PHK_OK;
 }
@@ -46,7 +47,8 @@ static void knobs_from_env(PhkKnobs &k) {
                                            {"slot_threads", "PHK_SLOT_THREADS"}, {"force_exact", "PHK_FORCE_EXACT"},
                                            {"proposal", "PHK_PROPOSAL"}, {"cx_cfg", "PHK_CX_CFG"},
                                            {"rerank", "PHK_RERANK"}, {"count_sort", "PHK_COUNT_SORT"},
-                                           {"score_batch", "PHK_SCORE_BATCH"}, {"pipeline", "PHK_PIPELINE"}};
+                                           {"score_batch", "PHK_SCORE_BATCH"}, {"pipeline", "PHK_PIPELINE"},
+                                           {"gen_groups", "PHK_GEN_GROUPS"}};
     for (auto &n : names) {
         const char *e = getenv(n[1]);
         if (e) (void)set_knob(k, n[0], e);
@@ -84,6 +86,7 @@ extern "C" int phk_create(int device_id, void *stream, phk_ctx **out) {
     {
         int rc = phk_count_init_device(ctx);
         if (rc == PHK_OK) rc = phk_score_f16_init_device(ctx);
+        if (rc == PHK_OK) rc = phk_score_i8_init_device(ctx);
         if (rc == PHK_OK) rc = phk_score_mfma_init_device(ctx);
         if (rc != PHK_OK) {
             delete ctx;

@@ -1,0 +1,458 @@
+// score_i8.hip -- int8-MFMA proposal pass for uint32 count rows at general D (k = 5, 6: D = 1024, 4096; gfx950).
+//
+// Replaces, for count inputs, the two-MFMA count-exact f16 sweep of score_f16.hip (phk_knn_f16_general_kernel<CX>) in the
+// candidate search of learning.knn / the nearest-centroid loop (scripts/learning.py:118-128, scripts/phamer.py:250-256).
+// v_mfma_i32_32x32x32_i8 runs at twice the f16 rate per instruction and accumulates in int32 EXACTLY, so
+//   * the query operand is the count row minus its centre c0 (phk_row_center) as int8 -- exact for |c - c0| <= 127, which
+//     at D >= 1024 covers every contig whose bins hold a few dozen windows (rows beyond it get empty lists and take the
+//     brute-force queue, as rows above 2048 do in the f16 kernels);
+//   * a reference column x_j = r_j - mu is held in 24-bit fixed point with a per-column quantum g_j, as THREE int8 parts
+//     n = 65536 H + 256 M + L (balanced digits in [-128, 127]) -- the precision of the f16 kernel's hi + lo pair
+//     (2^-22 |x|) -- so a value costs 3 MFMAs per 32 dimensions where the f16 kernel issues 4 (measured bare-loop rates
+//     on this chip: 19.0 ns per i8 MFMA, 20.2 ns per f16 MFMA per SIMD; tools/micro/mfma_i8_vs_f16.hip);
+//   * the three part sums are exact integers; the value  T v_j = g_j (65536 S_H + 256 S_M + S_L) - T b_j  is formed once
+//     per (query, column) in float32 in the tile epilogue.  No rounding model of the matrix pipe enters the error bound:
+//     what is left is the quantisation of the column (kappa = max_j |x_j - x~_j| / |x_j|, computed at build), three
+//     int -> float conversions and three fused multiply-adds (phk_score_fast: i8 coefficients).
+// The lane map of the instruction (row / column = lane & 31, k = 16 (lane >> 5) + byte; C/D as the f32 forms) is checked
+// with exact integer data by tools/micro/mfma_i8_vs_f16.hip and, through the whole path, by the parity tests.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "phk_common.h"
+#include "score_lists.h"
+#include "score_model.h"
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+#define I8_NMAX 8300000.0      // |n| <= this: H = n / 65536 (balanced) stays within [-127, 127]
+#define I8_KS 2                // k-steps (32 dimensions each) per chunk of the sweep: chunks of 64 dimensions
+#define I8_APIECES (3 * I8_KS) // 1 KiB pieces per (block, chunk): 3 parts x I8_KS k-steps
+#define I8_CT 4                // column blocks per tile: 4 x 3 int32 accumulators per wave
+#ifndef I8_NW
+#define I8_NW 8                // waves per workgroup (they share the step sets streamed into LDS)
+#endif
+
+// ------------------------------------------------------------------------------------
+// host: 24-bit fixed-point columns in MFMA fragment order.  Block record: D / 64 chunks of 6 pieces
+// [part][k-step s < 2][lane (column i, half h)][16 bytes = dimensions 64 c + 32 s + 16 h + 0..15]; beside the records, 64
+// floats per block: the 32 quanta g_j and the 32 bias terms b_j = (mu - 1/D).x~_j + |x~_j|^2 / 2 (x~ = the column as
+// quantised; see score_lists.h on the centred counts).
+// ------------------------------------------------------------------------------------
+static void pack_segment_i8(const double *rows, uint64_t n, uint64_t D, const double *mu, const double *colnorm,
+                            std::vector<uint8_t> &rec, std::vector<float> &term, uint64_t rec_bytes, uint64_t cb0,
+                            std::vector<double> &kappa, std::vector<double> &hsum, uint64_t col0) {
+    const uint64_t nblk = phk_div_up(n, 32);
+    const int nchunk = (int)(D / (32 * I8_KS));
+    const double shift = 1.0 / (double)D;
+    phk_parallel_for(nblk, [&, nchunk](uint64_t b) {
+        uint8_t *blk = rec.data() + (cb0 + b) * rec_bytes;
+        float *terms = term.data() + (cb0 + b) * 64;
+        for (int i = 0; i < 32; ++i) {
+            const uint64_t r = b * 32 + i;
+            if (r >= n) {   // padding column: zero operand, never selectable
+                terms[i] = 0.0f;
+                terms[32 + i] = 1.0e30f;
+                continue;
+            }
+            double xmax = 0.0;
+            for (uint64_t d = 0; d < D; ++d) {
+                const double x = std::fabs(rows[r * D + d] - mu[d]);
+                xmax = x > xmax ? x : xmax;
+            }
+            const float gf = xmax > 0.0 ? (float)(xmax / I8_NMAX) : 1.0e-30f;
+            const double g = (double)gf;   // the kernel multiplies by the float: quantise against exactly that value
+            double mudot = 0.0, nrm2 = 0.0, xsum = 0.0, d2 = 0.0;
+            for (int c = 0; c < nchunk; ++c)
+                for (int s = 0; s < I8_KS; ++s)
+                    for (int h = 0; h < 2; ++h)
+                        for (int e = 0; e < 16; ++e) {
+                            const uint64_t d = 32 * I8_KS * c + 32 * s + 16 * h + e;
+                            const double x = rows[r * D + d] - mu[d];
+                            long long q = std::llround(x / g);
+                            q = q > (long long)I8_NMAX ? (long long)I8_NMAX : (q < -(long long)I8_NMAX ? -(long long)I8_NMAX : q);
+                            const long long L = ((q + 128) % 256 + 256) % 256 - 128;
+                            const long long q1 = (q - L) / 256;
+                            const long long M = ((q1 + 128) % 256 + 256) % 256 - 128;
+                            const long long H = (q1 - M) / 256;
+                            const int lane = h * 32 + i;
+                            const long long part[3] = {H, M, L};
+                            for (int p = 0; p < 3; ++p)
+                                reinterpret_cast<int8_t *>(blk + ((uint64_t)c * I8_APIECES + p * I8_KS + s) * 1024 + lane * 16)[e] = (int8_t)part[p];
+                            const double xt = g * (double)q;   // the column as the kernel sees it
+                            mudot += (mu[d] - shift) * xt;
+                            nrm2 += xt * xt;
+                            xsum += xt;
+                            d2 += (x - xt) * (x - xt);
+                        }
+            terms[i] = gf;
+            terms[32 + i] = (float)(mudot + 0.5 * nrm2);
+            kappa[col0 + r] = colnorm[col0 + r] > 0.0 ? std::sqrt(d2) / colnorm[col0 + r] : (d2 > 0.0 ? 1.0 : 0.0);
+            hsum[col0 + r] = std::fabs(xsum);
+        }
+    });
+}
+
+int phk_model_build_i8(phk_model *m, const double *pos, const double *neg, const double *cpos, const double *cneg,
+                       const double *mu, const double *colnorm) {
+    const uint64_t D = m->D;
+    if (D == FAST_D || D % 256 != 0) return PHK_OK;
+    const uint64_t nblk = (uint64_t)m->n_rblk_ref + m->n_rblk_pos + m->n_rblk_neg;
+    const uint64_t rec_bytes = D / (32 * I8_KS) * I8_APIECES * 1024;
+    const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
+    std::vector<uint8_t> rec((nblk + 2 * I8_CT) * rec_bytes, 0);   // padding blocks: the sweep's prefetch runs past the end unchecked
+    std::vector<float> term((nblk + I8_CT) * 64, 0.0f);   // a tile's I8_CT blocks are fetched as one piece: padding blocks
+    for (uint64_t b = nblk; b < nblk + I8_CT; ++b)
+        for (int i = 0; i < 32; ++i) term[b * 64 + 32 + i] = 1.0e30f;
+    std::vector<double> kappa(ncols, 0.0), hsum(ncols, 0.0);
+    {
+        std::vector<double> train(m->M * D);
+        std::copy(pos, pos + m->n_pos * D, train.begin());
+        std::copy(neg, neg + m->n_neg * D, train.begin() + m->n_pos * D);
+        pack_segment_i8(train.data(), m->M, D, mu, colnorm, rec, term, rec_bytes, 0, kappa, hsum, 0);
+    }
+    if (m->n_cpos) pack_segment_i8(cpos, m->n_cpos, D, mu, colnorm, rec, term, rec_bytes, m->n_rblk_ref, kappa, hsum, m->M);
+    if (m->n_cneg)
+        pack_segment_i8(cneg, m->n_cneg, D, mu, colnorm, rec, term, rec_bytes, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, kappa,
+                        hsum, m->M + m->n_cpos);
+    m->kappa8 = m->hsum8 = 0.0;
+    for (uint64_t c = 0; c < ncols; ++c) {
+        m->kappa8 = kappa[c] > m->kappa8 ? kappa[c] : m->kappa8;
+        m->hsum8 = hsum[c] > m->hsum8 ? hsum[c] : m->hsum8;
+    }
+    if (hipMalloc(&m->d_A8, rec.size()) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMemcpy(m->d_A8, rec.data(), rec.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    if (hipMalloc(&m->d_T8, term.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMemcpy(m->d_T8, term.data(), term.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    m->rec8_bytes = rec_bytes;
+    return PHK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// counts -> int8 query fragments: one wave per (query block of 32, 256 dimensions); Bq8[(qb D/32 + s) 64 + lane] holds the 16
+// centred counts of query j = lane & 31, dimensions 32 s + 16 (lane >> 5) + 0..15.  Rows with |c - c0| > 127 are
+// flagged in `big`.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_t *__restrict__ counts,
+                                                                   const uint32_t *__restrict__ rowsum, uint64_t N, uint64_t D,
+                                                                   uint4 *__restrict__ Bq, uint32_t *__restrict__ big) {
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    const uint64_t nchunk = D / 256;
+    const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t nqb = (N + 31) / 32;
+    if (w >= nqb * nchunk) return;
+    const uint64_t qb = w / nchunk, c = w % nchunk;
+    const uint64_t qrow = (qb * 32 + j < N) ? qb * 32 + j : N - 1;
+    const int cen = (int)phk_row_center(rowsum[qrow], (uint32_t)D);
+    uint4 *out = Bq + (w * 8) * 64 + lane;
+    uint32_t mx = 0;
+#pragma unroll 2
+    for (int s = 0; s < 8; ++s) {
+        // 16 consecutive counts = one 64-byte piece of the row
+        const uint4 *row = reinterpret_cast<const uint4 *>(counts + qrow * D + 256 * c + 32 * s + 16 * h);
+        uint4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = row[e];
+        uint32_t pk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t cc[4] = {v[e].x, v[e].y, v[e].z, v[e].w};
+            uint32_t word = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int d = (int)cc[b] - cen;
+                const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+                mx = max(mx, max(ad, cc[b] >> 31 ? 0xFFFFFFFFu : 0u));
+                const int q = d < -127 ? -127 : (d > 127 ? 127 : d);
+                word |= ((uint32_t)q & 0xFFu) << (8 * b);
+            }
+            pk[e] = word;
+        }
+        out[s * 64] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    }
+    if (mx > 127u) atomicOr(big + qrow, 1u);
+}
+
+// ------------------------------------------------------------------------------------
+// the sweep: a wave keeps 32 queries x I8_CT column blocks x 3 parts in int32 accumulators (192 registers) and walks the
+// dimensions in chunks of 64.  Everything a workgroup needs for one (tile, chunk) step -- the 3 x 2 fragments of each of
+// the tile's I8_CT column blocks AND the 2 query fragments of each of its 8 waves, 40 pieces of 1 KiB -- is one "step
+// set" in LDS, filled by LDS-DMA (5 pieces per wave) and kept in a ring of I8_NBUF sets: the set of step i + 2 is
+// requested while step i computes (24 MFMAs, ~460 ns, per wave and step: two steps cover an L2 / fabric round trip), and
+// a wave waits with s_waitcnt vmcnt(5) for ITS pieces of the current set only.  No vector-memory instruction other than
+// those DMAs is issued inside a tile, so the count is exact; the query fragments go through LDS for that reason and
+// because 192 accumulators leave no room for a chunk's fragments in registers.  Segment handling, candidate lists,
+// column groups (2-D launch) as phk_knn_f16_general_kernel.
+// ------------------------------------------------------------------------------------
+#define I8_SET_PIECES (I8_CT * I8_APIECES + I8_NW * I8_KS)   // 40
+#define I8_SET_BYTES (I8_SET_PIECES * 1024)
+#ifndef I8_NBUF
+#define I8_NBUF 3
+#endif
+#define I8_PER_WAVE (I8_SET_PIECES / I8_NW)                   // 5 (8 waves), 8 (4 waves)
+#define I8_REQ_STRIDE (3 * I8_KS * I8_CT / I8_PER_WAVE)       // one request every so many MFMAs
+static_assert(I8_SET_PIECES % I8_NW == 0 && (I8_CT * I8_APIECES) % I8_NW == 0 && I8_NBUF >= 2, "pieces per wave");
+
+__global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kernel(
+    const uint4 *__restrict__ Bq, uint64_t N, uint32_t nchunk, const uint4 *__restrict__ A8, uint64_t rec_u4,
+    const uint4 *__restrict__ T8, const uint32_t *__restrict__ rowsum, const uint32_t *__restrict__ big, uint32_t blk0, uint32_t nblk_ref, uint32_t nblk_pos,
+    uint32_t nblk_neg, float *__restrict__ cand_v, uint32_t *__restrict__ cand_i, float *__restrict__ cand_u, uint32_t ngroups,
+    uint64_t set_bytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // I8_NBUF step sets + 1 KiB: the tile's column terms
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const uint64_t nqb = (N + 31) / 32;
+    uint64_t wg = blockIdx.x;
+    uint32_t col0 = 0;
+    if (ngroups > 1) {   // 2-D launch: see phk_knn_f16_general_kernel
+        const uint32_t li = blockIdx.x >> 3, g = li % ngroups;
+        wg = (uint64_t)(li / ngroups) * 8 + (blockIdx.x & 7u);
+        const uint32_t b0 = (uint32_t)((uint64_t)nblk_ref * g / ngroups), b1 = (uint32_t)((uint64_t)nblk_ref * (g + 1) / ngroups);
+        blk0 += b0;
+        col0 = 32u * b0;
+        nblk_ref = b1 - b0;
+        if (g + 1 != ngroups) nblk_pos = nblk_neg = 0;
+        cand_v = reinterpret_cast<float *>(reinterpret_cast<char *>(cand_v) + (uint64_t)g * set_bytes);
+        cand_i = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cand_i) + (uint64_t)g * set_bytes);
+        cand_u = reinterpret_cast<float *>(reinterpret_cast<char *>(cand_u) + (uint64_t)g * set_bytes);
+    }
+    if (wg * I8_NW >= nqb) return;   // padding workgroup of the 2-D numbering (uniform: before any barrier)
+    const uint64_t qb = wg * I8_NW + wave;
+    const uint64_t q0 = qb * 32;
+    const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
+    const uint32_t seg_end0 = nblk_ref, seg_end1 = nblk_ref + nblk_pos;
+    const uint32_t ntile = (total + I8_CT - 1) / I8_CT;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
+
+    // The prefetch head.  Piece i of this wave (piece p = wave + I8_NW i of the set) has a running scalar pointer: a column
+    // fragment (block cb = p / 6 of the tile, piece r = p % 6 of its chunk) advances by one chunk of its block's record per
+    // step and, after the last chunk, to chunk 0 of the block I8_CT further on (records are contiguous: 3 nchunk + 1 chunks
+    // ahead); a query fragment (wave w's block, k-step s) advances by one chunk and wraps.  No bounds are applied: a
+    // partial last tile and the I8_NBUF - 1 sets requested past the end read the records' padding blocks
+    // (phk_model_build_i8) or the next segment's columns, and those results are never used.
+    constexpr int NA = (I8_CT * I8_APIECES) / I8_NW;   // column fragments per wave and set
+    const char *pp[I8_PER_WAVE];
+    uint32_t pl[I8_PER_WAVE];                          // LDS offset of the piece within its set
+#pragma unroll
+    for (int i = 0; i < I8_PER_WAVE; ++i) {
+        const uint32_t p = (uint32_t)wave + I8_NW * i;
+        if (i < NA) {
+            const uint32_t cb = p / I8_APIECES, r = p % I8_APIECES;
+            pp[i] = reinterpret_cast<const char *>(A8) + ((uint64_t)(blk0 + cb) * nchunk * I8_APIECES + r) * 1024;
+        } else {
+            const uint32_t w = (p - I8_CT * I8_APIECES) / I8_KS, s = (p - I8_CT * I8_APIECES) % I8_KS;
+            uint64_t qw = wg * I8_NW + w;
+            qw = qw < nqb ? qw : nqb - 1;              // padding waves re-read the last block; nothing is written
+            pp[i] = reinterpret_cast<const char *>(Bq) + (qw * nchunk * I8_KS + s) * 1024;
+        }
+        pl[i] = lds_base + p * 1024u;
+    }
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    uint32_t pc = 0;                                   // chunk of the set requested next
+    const int64_t a_step = I8_APIECES * 1024, a_wrap = (int64_t)((I8_CT - 1) * nchunk + 1) * I8_APIECES * 1024;
+    const int64_t b_step = I8_KS * 1024, b_wrap = -(int64_t)(nchunk - 1) * I8_KS * 1024;
+    auto request_piece = [&](uint32_t buf, int i) {
+        const uint32_t lp = pl[i] + buf * (uint32_t)I8_SET_BYTES;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(pp[i]), "s"(lp) : "memory");
+        const bool last = pc + 1 == nchunk;
+        pp[i] += i < NA ? (last ? a_wrap : a_step) : (last ? b_wrap : b_step);
+        if (i + 1 == I8_PER_WAVE) pc = last ? 0 : pc + 1;
+    };
+    auto request_set = [&](uint32_t buf) {
+#pragma unroll
+        for (int i = 0; i < I8_PER_WAVE; ++i) request_piece(buf, i);
+    };
+
+    float lv[CAND];
+    uint32_t li[CAND];
+    float ldrop = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < CAND; ++c) {
+        lv[c] = -3.0e38f;
+        li[c] = 0xFFFFFFFFu;
+    }
+    const uint64_t qr = (qb < nqb && q0 + j < N) ? q0 + j : N - 1;
+    const float negT = -(float)rowsum[qr];
+    const bool isbig = big[qr] != 0;
+    int seg = 0;
+    uint32_t seg_first = 0;
+    while (seg < NSEG && (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total) == 0) {   // leading segments without columns
+        if (qb < nqb && q0 + j < N) cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
+        ++seg;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads above: from here on the DMAs are counted
+    if (ntile) {
+#pragma unroll
+        for (int b = 0; b + 1 < I8_NBUF; ++b) request_set(b);
+    }
+    uint32_t cur = 0, nxt = I8_NBUF - 1;
+#ifdef I8_TIMERS   // diagnostic build: cycles per phase, printed by two workgroups (tools/diag/sweep_i8_build.sh "-DI8_TIMERS")
+    uint64_t tm_wait = 0, tm_bar = 0, tm_body = 0, tm_epi = 0, tm_mark = 0;
+    const uint64_t tm_start = __builtin_readcyclecounter();
+#define I8_TM(acc) do { const uint64_t now_ = __builtin_readcyclecounter(); acc += now_ - tm_mark; tm_mark = now_; } while (0)
+    tm_mark = tm_start;
+#else
+#define I8_TM(acc) do { } while (0)
+#endif   // ring positions of the set being read / requested
+    for (uint32_t t = 0; t < ntile; ++t) {
+        i32x16 acc[I8_CT][3];
+#pragma unroll
+        for (int cb = 0; cb < I8_CT; ++cb)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][p][r] = 0;
+        for (uint32_t c = 0; c < nchunk; ++c) {
+            // this wave's 5 pieces of the current set have landed once at most the 5 of the next set are outstanding
+            I8_TM(tm_epi);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(I8_PER_WAVE * (I8_NBUF - 2)) : "memory");
+            I8_TM(tm_wait);
+            __syncthreads();
+            I8_TM(tm_bar);   // ... and everybody's; the set read one step ago is free
+            if (c == 0 && wave == 0) {   // the tile's column terms (I8_CT blocks x 64 floats): older than the pieces requested below,
+                                         // so the vmcnt(5) of the next step covers it; read in the epilogue, many barriers on
+                const uint4 *g = T8 + ((uint64_t)blk0 + (uint64_t)t * I8_CT) * 16 + lane;
+                const uint32_t lp = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(I8_NBUF * I8_SET_BYTES));
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lp) : "memory");
+            }
+            // 24 column fragments in sequence (k-step, column block, part), read from LDS three MFMAs ahead of their use
+            // through a ring of four fragment registers.  Written with explicit ds_read / s_waitcnt: left to the compiler,
+            // each fragment is read right before its MFMA (it minimises live registers here) and the LDS latency shows.
+            const uint32_t la = lds_base + cur * (uint32_t)I8_SET_BYTES + (uint32_t)lane * 16u;
+            i32x4 fa[4], fb[2];
+#define I8_A_OFF(x) ((((x) / 3 % I8_CT) * I8_APIECES + ((x) % 3) * I8_KS + (x) / (3 * I8_CT)) * 1024)
+#define I8_DS_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(la), "n"(off))
+            const uint32_t lb = la + (uint32_t)(I8_CT * I8_APIECES + I8_KS * wave) * 1024u;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0]) : "v"(lb));
+            asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(fb[1]) : "v"(lb));
+            I8_DS_READ(fa[0], I8_A_OFF(0));
+            I8_DS_READ(fa[1], I8_A_OFF(1));
+            I8_DS_READ(fa[2], I8_A_OFF(2));
+#pragma unroll
+            for (int x = 0; x < 3 * I8_KS * I8_CT; ++x) {
+                const int s = x / (3 * I8_CT), cb = x / 3 % I8_CT, p = x % 3;
+                if (x + 3 < 3 * I8_KS * I8_CT) {
+                    I8_DS_READ(fa[(x + 3) & 3], I8_A_OFF(x + 3));
+                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[x & 3]), "+v"(fb[0]), "+v"(fb[1]));
+                } else if (x + 3 == 3 * I8_KS * I8_CT) {
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[x & 3]));
+                } else if (x + 2 == 3 * I8_KS * I8_CT) {
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[x & 3]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[x & 3]));
+                }
+                acc[cb][p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[x & 3], fb[s], acc[cb][p], 0, 0, 0);
+                // the set two steps ahead is requested here, one piece every fourth MFMA: the address arithmetic and the
+                // DMA issue run under the matrix pipe's shadow instead of between the barrier and the first MFMA
+                if (x % I8_REQ_STRIDE == 1 && x / I8_REQ_STRIDE < I8_PER_WAVE) request_piece(nxt, x / I8_REQ_STRIDE);
+            }
+#undef I8_DS_READ
+#undef I8_A_OFF
+            I8_TM(tm_body);
+            cur = cur + 1 == I8_NBUF ? 0 : cur + 1;
+            nxt = nxt + 1 == I8_NBUF ? 0 : nxt + 1;
+        }
+        // epilogue of the tile: T v = g (65536 S_H + 256 S_M + S_L) - T b, insertion, segment flushes
+#pragma unroll
+        for (int cb = 0; cb < I8_CT; ++cb) {
+            const uint32_t blk = t * I8_CT + cb;
+            if (blk < total) {
+                const float4 *gp = reinterpret_cast<const float4 *>(smem + I8_NBUF * I8_SET_BYTES) + cb * 16 + h, *bp = gp + 8;
+                const uint32_t cbase = 32u * (blk - seg_first) + 4u * (uint32_t)h;
+#pragma unroll
+                for (int m4 = 0; m4 < 4; ++m4) {
+                    const float4 g4 = gp[2 * m4], b4 = bp[2 * m4];
+                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * m4 + e;
+                        const float sf = fmaf(65536.0f, (float)acc[cb][0][r], fmaf(256.0f, (float)acc[cb][1][r], (float)acc[cb][2][r]));
+                        list_insert_needed(lv, li, ldrop, fmaf(sf, gg[e], negT * bb[e]), cbase + 8u * m4 + (uint32_t)e);
+                    }
+                }
+                while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
+                    if (qb < nqb && q0 + j < N) {
+                        if (isbig) {
+                            cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f,
+                                       0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 3.0e38f);
+                        } else {
+                            const uint32_t o = seg == 0 ? col0 : 0u;   // (a column group: indices relative to the whole train segment)
+                            cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, lv[0], lv[1], lv[2], lv[3],
+                                       li[0] == 0xFFFFFFFFu ? li[0] : li[0] + o, li[1] == 0xFFFFFFFFu ? li[1] : li[1] + o,
+                                       li[2] == 0xFFFFFFFFu ? li[2] : li[2] + o, li[3] == 0xFFFFFFFFu ? li[3] : li[3] + o, ldrop);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < CAND; ++c) {
+                        lv[c] = -3.0e38f;
+                        li[c] = 0xFFFFFFFFu;
+                    }
+                    ldrop = -3.0e38f;
+                    ++seg;
+                    seg_first = blk + 1;
+                }
+            }
+        }
+    }
+#ifdef I8_TIMERS
+    I8_TM(tm_epi);
+    if (lane == 0 && (blockIdx.x == 8 || blockIdx.x == 1001))
+        printf("i8 timers wg %u wave %d: total %llu wait %llu barrier %llu body %llu epilogue+loop %llu (shader clock ticks)\n", blockIdx.x, wave,
+               (unsigned long long)(tm_mark - tm_start), (unsigned long long)tm_wait, (unsigned long long)tm_bar,
+               (unsigned long long)tm_body, (unsigned long long)tm_epi);
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two sets requested past the end
+    for (; seg < NSEG; ++seg) {
+        if (qb < nqb && q0 + j < N) cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
+    }
+}
+
+__global__ void phk_rowsum_kernel(const uint32_t *__restrict__ counts, uint64_t N, uint64_t D, uint32_t *__restrict__ out);
+__global__ void phk_merge_list_sets_kernel(float *__restrict__ cv, uint32_t *__restrict__ ci, float *__restrict__ cu, uint64_t Nlist,
+                                           uint64_t set_bytes, int S, const uint32_t *__restrict__ qcount, float *__restrict__ ca,
+                                           uint64_t ca_set);
+
+// proposal pass for uint32 counts at D = 512 .. 4096: row sums (if needed) -> int8 query fragments -> sweep (-> merge)
+int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum, uint64_t nb,
+                                   uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu, uint32_t groups,
+                                   uint64_t set_bytes) {
+    const uint64_t D = m->D, nchunk = D / (32 * I8_KS), nchunk256 = D / 256;
+    const uint64_t nqb = phk_div_up(nb, 32);
+    void *bq, *rs = nullptr, *bg;
+    PHK_TRY(phk_ws(ctx, WS_Q64, nqb * (D / 32) * 1024, &bq));
+    if (!d_rowsum) {
+        PHK_TRY(phk_ws(ctx, WS_NWIN, nb * sizeof(uint32_t), &rs));
+        PHK_LAUNCH(ctx, "phk_rowsum_kernel",
+                   phk_rowsum_kernel<<<dim3((unsigned)phk_div_up(nb, 4)), dim3(256), 0, ctx->stream>>>(d_counts, nb, D, (uint32_t *)rs));
+        d_rowsum = (const uint32_t *)rs;
+    }
+    PHK_TRY(phk_ws(ctx, WS_LONG, nb * sizeof(uint32_t), &bg));
+    PHK_HIP(hipMemsetAsync(bg, 0, nb * sizeof(uint32_t), ctx->stream));
+    PHK_LAUNCH(ctx, "phk_split_queries_i8_kernel",
+               phk_split_queries_i8_kernel<<<dim3((unsigned)phk_div_up(nqb * nchunk256, 4)), dim3(256), 0, ctx->stream>>>(
+                   d_counts, d_rowsum, nb, D, (uint4 *)bq, (uint32_t *)bg));
+    const uint64_t rec_u4 = m->rec8_bytes / 16;
+    const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
+    const uint32_t ng = (groups > 1 && nref >= 8u * groups && nqb >= 64) ? groups : 1u;
+    const uint64_t nqg = phk_div_up(nqb, I8_NW);
+    const unsigned gblocks = ng > 1 ? (unsigned)(phk_div_up(nqg, 8) * 8 * ng) : (unsigned)nqg;
+    PHK_LAUNCH(ctx, "phk_knn_i8_general_kernel",
+               (phk_knn_i8_general_kernel<<<dim3(gblocks), dim3(64 * I8_NW), I8_NBUF * I8_SET_BYTES + 1024, ctx->stream>>>(
+                   (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_A8, rec_u4, (const uint4 *)m->d_T8, d_rowsum, (const uint32_t *)bg, blk0, nref,
+                   npos, nneg, cv, ci, cu, ng, set_bytes)));
+    if (ng > 1) {
+        PHK_LAUNCH(ctx, "phk_merge_list_sets_kernel",
+                   phk_merge_list_sets_kernel<<<dim3((unsigned)phk_div_up(2 * nb, 256)), dim3(256), 0, ctx->stream>>>(
+                       cv, ci, cu, nb, set_bytes, (int)ng, nullptr, nullptr, 0));
+    }
+    return PHK_OK;
+}
+
+int phk_score_i8_init_device(phk_ctx *ctx) {
+    (void)ctx;
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_i8_general_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, I8_NBUF * I8_SET_BYTES + 1024));
+    return PHK_OK;
+}

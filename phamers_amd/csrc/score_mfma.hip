@@ -151,6 +151,7 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
         hipMemcpy(m->d_mu64, mu.data(), D * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         return PHK_ERR_HIP;
     PHK_TRY(phk_model_build_f16(m, pos, neg, cpos, cneg, mu.data(), colnorm.data()));
+    PHK_TRY(phk_model_build_i8(m, pos, neg, cpos, cneg, mu.data(), colnorm.data()));
     m->h_mu = mu;
     m->max_colnorm_train = 0.0;
     for (uint64_t c = 0; c < m->M; ++c)
@@ -166,6 +167,10 @@ void phk_model_free_fast(phk_model *m) {
     if (m->d_colnorm) (void)hipFree(m->d_colnorm);
     if (m->d_Af16) (void)hipFree(m->d_Af16);
     m->d_Af16 = nullptr;
+    if (m->d_A8) (void)hipFree(m->d_A8);
+    if (m->d_T8) (void)hipFree(m->d_T8);
+    m->d_A8 = nullptr;
+    m->d_T8 = nullptr;
     if (m->d_term_orig) (void)hipFree(m->d_term_orig);
     if (m->d_col_mask) (void)hipFree(m->d_col_mask);
     m->d_term_orig = nullptr;
@@ -499,6 +504,11 @@ __device__ __forceinline__ double exact_d2(const double (&qd)[4 * DSUB], const d
 //                the chunk boundaries (cand_a): inside a chunk a running sum is within |x_c| |y_c| of the sum at its start,
 //                so Q is the largest CHUNK norm of the query operand and habs gains cAmax u a_observed -- the bound follows
 //                the sums that occurred instead of the Cauchy-Schwarz worst case over all D dimensions.
+//     int8       (score_i8.hip; x = c - c0 as int8, y = r' in 24-bit fixed point, three int8 parts): the part sums are exact
+//                integers, so no chain term: cQ 4 on the full |c - c0| / T (three int -> float conversions and two fused
+//                multiply-adds on sums <= 1.26 / 0.26 / 0.27 / 1.0 |x| |y|: |x|_1 <= sqrt(D) |x|, 2^15 g <= |y|_inf / 253),
+//                cA 2 (bias -> fp32, T b), cP kappa/u + 2, cR kappa (1 + kappa)/u + 3 with kappa = max_j |r'_j - r~'_j| / |r'_j| of
+//                the quantisation (computed at build; the final fma: u |v|), c_abs 0, habs as count-exact.
 //     cI carries rho_inf = max_j |r~'_j|_inf / |r'_j| of the model, so that |x|_inf |y|_inf <= I rho_inf R.
 struct ErrBound {
     double A, P, cA, cP, cR, cabs;
@@ -645,7 +655,7 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         }
         if (p.per_row_scale && !nan_row) {  // the operand of the count-exact chain: the counts minus their centre
             cop = phk_centered_operand(wave_sum(sq), ds, wave_max((double)cmx), -wave_max(-(double)cmn), (double)D, p.eb_hsum);
-            if (DSUB > 1) cop.Q = sqrt(qc2) / ds * (1.0 + 1e-12);
+            if (DSUB > 1 && p.eb_cAmax > 0.0) cop.Q = sqrt(qc2) / ds * (1.0 + 1e-12);   // (with the observed running sums)
         }
     } else {
         const double *row = static_cast<const double *>(src) + q * D;
@@ -2310,6 +2320,10 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // query, the high-part windows are wide -- 20 % of config 4's queries fell through to the brute force -- and the
     // kernel time saved (111 -> 72 ms) is lost in the tail (profiles/r02/README.md)
     const bool hi_gen = use_cx && D != FAST_D && m->d_lo16 && m->d_betah16 && prop[0] == 'h' && prop[1] == 'i';
+    // general D, count rows: the int8 sweep (score_i8.hip; 3 exact-integer MFMAs per 32 dimensions where the f16 count-exact
+    // kernel issues 4) unless the model's centroids were replaced or a column mask is set (its records are not updated by
+    // the cross-validation service); proposal=cxf keeps the f16 count-exact kernel
+    const bool use_i8 = use_cx && D != FAST_D && m->d_A8 && !m->bf_stale && !hi_gen && !(prop[0] == 'c' && prop[1] == 'x' && prop[2] == 'f');
     const uint64_t cap2 = second ? (nb_max / 8 > 4096 ? nb_max / 8 : (nb_max < 4096 ? nb_max : 4096)) : 0;
     const uint64_t per_list = nb_max * NSEG * 2, per_list2 = cap2 * NSEG * 2;
     const uint64_t list_bytes = sizeof(float4) + sizeof(uint4) + sizeof(float);
@@ -2317,7 +2331,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // the second chance sweeps the reference in PHK_SECOND_SPLITS column parts, each with a list set of its own
     const uint64_t set2_bytes = per_list2 * list_bytes;
     // general D: observed running sums (cand_a); D >= 2048: PHK_GEN_GROUPS list sets (the column groups of the 2-D launch)
-    const uint64_t gen_sets = D >= 2048 ? PHK_GEN_GROUPS : 1;
+    const uint64_t gen_sets = ctx->knobs.gen_groups > 0 ? (uint64_t)(ctx->knobs.gen_groups < 16 ? ctx->knobs.gen_groups : 16)
+                                                        : (D >= 2048 ? PHK_GEN_GROUPS : 1);
     const uint64_t set_bytes = per_list * list_bytes;
     const uint64_t ca_bytes = D != FAST_D ? gen_sets * 2 * nb_max * sizeof(float) : 0;
     PHK_TRY(phk_ws(ctx, WS_CAND, gen_sets * set_bytes + ca_bytes + PHK_SECOND_SPLITS * set2_bytes, &cv));
@@ -2380,7 +2395,14 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             }
             r.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
         };
-        if (use_cx) {
+        if (use_i8) {
+            // values are T v (per row), from exact integer sums (see ErrBound: int8)
+            const double ku = m->kappa8 / 5.9604644775390625e-08;
+            p.vscale = 1.0; p.per_row_scale = 1; p.cand_a = nullptr;
+            p.eb_cA = 2.0; p.eb_cQ = 4.0; p.eb_cI = 0.0; p.eb_cAmax = 0.0;
+            p.eb_cP = ku + 2.0; p.eb_cR = ku * (1.0 + m->kappa8) + 3.0; p.eb_abs = 0.0;
+            p.eb_hsum = m->hsum8;
+        } else if (use_cx) {
             // values are T S v (per row); n = 2D/16 instructions on (c - c0) x (r~' S as hi, lo), + 3 for the bias -> fp32,
             // the final fma and slack; the residue of the centring through hsum
             // (general D keeps its indices in registers: no embedded index bits, 62 / 31 less on cP / cR)
@@ -2397,7 +2419,10 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             p.vscale = 1.0;
             p.eb_cA = 6.0; p.eb_cP = 264.0; p.eb_cR = 4.0; p.eb_abs = 0.0;
         }
-        if (D != FAST_D) {
+        if (use_i8) {
+            PHK_TRY(phk_launch_proposal_i8_general(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu,
+                                                   (uint32_t)gen_sets, set_bytes));
+        } else if (D != FAST_D) {
             PHK_TRY(phk_launch_proposal_f16_general(ctx, m, src, d_counts != nullptr, use_cx, rsum, nb, nref, npos, nneg,
                                                     (float *)cv, ci, cu, ca, hi_gen, (uint32_t)gen_sets, set_bytes));
         } else if (hi_only) {

@@ -25,6 +25,12 @@ struct phk_model {
     _Float16 *d_lo16 = nullptr;   // [M + n_cpos + n_cneg][D]
     double lam_tab[3][65] = {{0}};     // per segment (train rows, positive centroids, negative centroids)
     double lam_r0[3] = {0, 0, 0}, lam_step[3] = {1, 1, 1};
+    // int8 proposal for count rows at D >= 512 (score_i8.hip): block records of 24-bit fixed-point columns in three int8
+    // parts + (quantum, bias) per column; kappa8 = max_j |r'_j - r~'_j| / |r'_j| of that quantisation, hsum8 as hsum_*
+    void *d_A8 = nullptr;
+    float *d_T8 = nullptr;        // [blocks + padding][64]: quanta and bias terms
+    uint64_t rec8_bytes = 0;
+    double kappa8 = 0.0, hsum8 = 0.0;
     float *d_mu32 = nullptr;      // centring vector, fp32
     double *d_mu64 = nullptr;     // centring vector, fp64
     // cross-validation service (phk_model_set_centroids / phk_model_set_column_mask): the train segment's column terms as
@@ -74,6 +80,13 @@ int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void
                                     const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
                                     float *cv, uint32_t *ci, float *cu, float *ca, bool hi_only = false, uint32_t groups = 1,
                                     uint64_t set_bytes = 0);
+// int8 proposal (score_i8.hip): count rows, D >= 512, models without a column mask / replaced centroids
+int phk_model_build_i8(phk_model *m, const double *pos, const double *neg, const double *cpos, const double *cneg,
+                       const double *mu, const double *colnorm);
+int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum, uint64_t nb,
+                                   uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu,
+                                   uint32_t groups = 1, uint64_t set_bytes = 0);
+int phk_score_i8_init_device(phk_ctx *ctx);
 // Column groups of the general-D sweep's 2-D launch (D >= 2048).  Measured on configs[4] (kernel ms): 1 group 92.9, 2: 89.8,
 // 4: 86.4, 8: 95.1 (and 3 / 5 / 6: no better) -- more groups share a query block's fragments through one XCD's L2, but
 // split the column stream that ALL workgroups of an XCD otherwise pull through it in step.  D = 1024 (configs[2]): 184 /

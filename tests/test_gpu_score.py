@@ -246,27 +246,37 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
     cpos = np.stack([pos[i::12].mean(axis=0) for i in range(12)])
     cneg = np.stack([neg[i::12].mean(axis=0) for i in range(12)])
     model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
-    d_q = device_counts(90 + k, n_q, 10000)
+    # rows 0 .. 7: the counts of a 40 x longer contig of the same composition (bins far beyond the int8 kernel's +-127 and
+    # rows 4 .. 7 beyond the f16 kernels' 2048 around the row's centre): such rows take the brute-force queue
+    hq = device_counts(90 + k, n_q, 10000).to_host()
+    hq[:4] *= 40
+    hq[4:8] *= 1000
+    d_q = device.DeviceArray.from_host(ctx, hq)
     out = {}
-    for path in ("f16", "hi", "exact"):   # count-exact general-D kernel (default), its high-parts-only flavour (opt-in), float64
+    # int8 MFMA sweep (default for counts), count-exact f16 general-D kernel, its high-parts-only flavour (opt-in), float64
+    for path in ("i8", "cxf", "hi", "exact"):
         ctx.set_option("force_exact", "1" if path == "exact" else "0")
-        ctx.set_option("proposal", "hi" if path == "hi" else "")
+        ctx.set_option("proposal", {"cxf": "cxf", "hi": "hi"}.get(path, ""))
         for method in ("knn", "kmeans", "combo"):
             d_scores = device.DeviceArray(ctx, n_q, np.float64)
             d_status = device.DeviceArray(ctx, 1, np.uint32)
             device.score_counts(ctx, model, d_q, n_q, method, d_scores, d_status)
             out[(path, method)] = d_scores.to_host()
             assert d_status.to_host()[0] == 0
-        if path == "f16":
+        if path in ("i8", "cxf"):
             n_fallback, _ = ctx.score_stats()
-            assert n_fallback < max(n_q // 20, 8)
+            assert 4 <= n_fallback < max(n_q // 20, 16), (path, n_fallback)
     ctx.set_option("proposal", "")
     for method in ("knn", "kmeans", "combo"):
         assert np.array_equal(np.sign(out[("hi", method)]), np.sign(out[("exact", method)])), method
         assert helpers.rel_err(out[("hi", method)], out[("exact", method)]) < 1e-9, method
-    assert np.array_equal(out[("f16", "knn")], out[("exact", "knn")])
-    assert helpers.rel_err(out[("f16", "kmeans")], out[("exact", "kmeans")]) < 1e-9
-    assert helpers.rel_err(out[("f16", "combo")], out[("exact", "combo")]) < 1e-9
+    for path in ("i8", "cxf"):
+        assert np.array_equal(out[(path, "knn")], out[("exact", "knn")]), path
+        assert helpers.rel_err(out[(path, "kmeans")], out[("exact", "kmeans")]) < 1e-9, path
+        assert helpers.rel_err(out[(path, "combo")], out[("exact", "combo")]) < 1e-9, path
+    for method in ("knn", "kmeans", "combo"):   # the decision stage's exact distances are one canonical form: bit-equal
+        assert np.array_equal(out[("i8", method)], out[("cxf", method)]), method
+    out.update({("f16", m): out[("i8", m)] for m in ("knn", "kmeans", "combo")})
     # float64-row entry point on a slice, against the oracle
     ctx.set_option("force_exact", "0")
     qc = d_q.to_host()[:64].astype(np.int64)

@@ -15,7 +15,7 @@ ARGS="--config $CFG --no-cpu-baseline --min-seconds 0"
 cd /tmp && export TMPDIR=/tmp
 echo "== kernel trace + stats"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ROOT/bench.py --steps 3 --warmup 1 $ARGS > "$OUT/bench_under_trace.json" 2> "$OUT/trace.err" || echo "trace run failed"
-for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES"; do
   name=$(echo $pass | tr ' ' '_' | cut -c1-30)
   echo "== pmc $pass"
   timeout -k 10 500 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OUT/pmc_$name" -- python3 $ROOT/bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2> "$OUT/pmc_$name.err" || echo "pmc pass failed: $pass"
