@@ -26,6 +26,8 @@
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 
 #define I8_NMAX 8300000.0      // |n| <= this: H = n / 65536 (balanced) stays within [-127, 127]
 #define I8_KS 2                // k-steps (32 dimensions each) per chunk of the sweep: chunks of 64 dimensions
@@ -180,11 +182,21 @@ __global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_
 // dimensions in chunks of 64.  Everything a workgroup needs for one (tile, chunk) step -- the 3 x 2 fragments of each of
 // the tile's I8_CT column blocks AND the 2 query fragments of each of its 8 waves, 40 pieces of 1 KiB -- is one "step
 // set" in LDS, filled by LDS-DMA (5 pieces per wave) and kept in a ring of I8_NBUF sets: the set of step i + 2 is
-// requested while step i computes (24 MFMAs, ~460 ns, per wave and step: two steps cover an L2 / fabric round trip), and
-// a wave waits with s_waitcnt vmcnt(5) for ITS pieces of the current set only.  No vector-memory instruction other than
-// those DMAs is issued inside a tile, so the count is exact; the query fragments go through LDS for that reason and
-// because 192 accumulators leave no room for a chunk's fragments in registers.  Segment handling, candidate lists,
-// column groups (2-D launch) as phk_knn_f16_general_kernel.
+// requested while step i computes (24 MFMAs per wave and step, ~1 us: two steps cover an L2 / fabric round trip), and
+// a wave waits with s_waitcnt vmcnt(5) for ITS pieces of the current set only, then the barrier.  No vector-memory
+// instruction other than those DMAs is issued inside a tile, so the count is exact; the query fragments go through LDS
+// for that reason and because 192 accumulators leave no room for a chunk's fragments in registers.
+//
+// What the shape is tuned against (profiles/r03/README.md, int8 section; timers: -DI8_TIMERS): a wave issues about one
+// instruction per 5 cycles, an MFMA of this shape occupies the pipe for 32, and two waves share a SIMD -- so the step is
+// issue-bound as soon as a wave spends more than ~12 instructions per MFMA.  Hence: DMA addresses are running scalar
+// pointers (2 scalar adds per piece; the first version's 64-bit address arithmetic per piece made the step 285
+// instructions long, now 138), the requests sit between the MFMAs, not between the barrier and the first one, and the
+// fragment reads are written out as ds_read / s_waitcnt lgkmcnt pairs three MFMAs ahead of their use.  LDS bandwidth is
+// not the limit (tools/micro/lds_per_mfma.hip: 13 fragment reads per 12 MFMAs cost 12 % of the bare MFMA rate), nor
+// is the ring depth (4 sets: same time) or the column-group count (1 / 2 / 4 groups within 4 %).  Two 4-wave workgroups
+// per CU (-DI8_NW=4 -DI8_NBUF=2) are 25 % slower: twice the column bytes per MFMA through L2 and a one-step prefetch.
+// Segment handling, candidate lists, column groups (2-D launch) as phk_knn_f16_general_kernel.
 // ------------------------------------------------------------------------------------
 #define I8_SET_PIECES (I8_CT * I8_APIECES + I8_NW * I8_KS)   // 40
 #define I8_SET_BYTES (I8_SET_PIECES * 1024)
@@ -276,6 +288,9 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
     }
     const uint64_t qr = (qb < nqb && q0 + j < N) ? q0 + j : N - 1;
     const float negT = -(float)rowsum[qr];
+    const f32x2 negT2 = {negT, negT}, c65536 = {65536.0f, 65536.0f}, c256 = {256.0f, 256.0f};
+    float pend_v = -3.0e38f;     // the lane's parked candidate (see the epilogue): value, position in the tile
+    uint32_t pend_i = 0;
     const bool isbig = big[qr] != 0;
     int seg = 0;
     uint32_t seg_first = 0;
@@ -306,14 +321,20 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[cb][p][r] = 0;
         for (uint32_t c = 0; c < nchunk; ++c) {
-            // this wave's 5 pieces of the current set have landed once at most the 5 of the next set are outstanding
+            // this wave's pieces of the current set have landed once at most those of the I8_NBUF - 2 later sets are outstanding
+#if defined(I8_TIMERS) && I8_TIMERS == 2   // fine timers: four counter reads per step
             I8_TM(tm_epi);
+#endif
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(I8_PER_WAVE * (I8_NBUF - 2)) : "memory");
+#if defined(I8_TIMERS) && I8_TIMERS == 2
             I8_TM(tm_wait);
+#endif
             __syncthreads();
-            I8_TM(tm_bar);   // ... and everybody's; the set read one step ago is free
+#if defined(I8_TIMERS) && I8_TIMERS == 2
+            I8_TM(tm_bar);
+#endif   // ... and everybody's; the set read one step ago is free
             if (c == 0 && wave == 0) {   // the tile's column terms (I8_CT blocks x 64 floats): older than the pieces requested below,
-                                         // so the vmcnt(5) of the next step covers it; read in the epilogue, many barriers on
+                                         // so the next step's vmcnt wait covers it; read in the epilogue, many barriers on
                 const uint4 *g = T8 + ((uint64_t)blk0 + (uint64_t)t * I8_CT) * 16 + lane;
                 const uint32_t lp = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(I8_NBUF * I8_SET_BYTES));
                 asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lp) : "memory");
@@ -351,27 +372,55 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
             }
 #undef I8_DS_READ
 #undef I8_A_OFF
+#if defined(I8_TIMERS) && I8_TIMERS == 2
             I8_TM(tm_body);
+#endif
             cur = cur + 1 == I8_NBUF ? 0 : cur + 1;
             nxt = nxt + 1 == I8_NBUF ? 0 : nxt + 1;
         }
+        I8_TM(tm_body);   // (coarse timers: the whole step loop of the tile)
         // epilogue of the tile: T v = g (65536 S_H + 256 S_M + S_L) - T b, insertion, segment flushes
 #pragma unroll
         for (int cb = 0; cb < I8_CT; ++cb) {
             const uint32_t blk = t * I8_CT + cb;
             if (blk < total) {
                 const float4 *gp = reinterpret_cast<const float4 *>(smem + I8_NBUF * I8_SET_BYTES) + cb * 16 + h, *bp = gp + 8;
-                const uint32_t cbase = 32u * (blk - seg_first) + 4u * (uint32_t)h;
+                // column of the tile's first row of this lane, relative to the segment's first column (wraps below zero for the
+                // blocks of a segment that ended inside this tile: their values were inserted when it ended)
+                const uint32_t tbase = 32u * (t * I8_CT - seg_first) + 4u * (uint32_t)h;
 #pragma unroll
                 for (int m4 = 0; m4 < 4; ++m4) {
                     const float4 g4 = gp[2 * m4], b4 = bp[2 * m4];
-                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                    const f32x2 gg[2] = {{g4.x, g4.y}, {g4.z, g4.w}}, bb[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * m4 + e;
-                        const float sf = fmaf(65536.0f, (float)acc[cb][0][r], fmaf(256.0f, (float)acc[cb][1][r], (float)acc[cb][2][r]));
-                        list_insert_needed(lv, li, ldrop, fmaf(sf, gg[e], negT * bb[e]), cbase + 8u * m4 + (uint32_t)e);
+                    for (int e2 = 0; e2 < 2; ++e2) {   // two values per packed float32 instruction
+                        const int r = 4 * m4 + 2 * e2;
+                        const f32x2 fh = {(float)acc[cb][0][r], (float)acc[cb][0][r + 1]}, fm = {(float)acc[cb][1][r], (float)acc[cb][1][r + 1]},
+                                    fl = {(float)acc[cb][2][r], (float)acc[cb][2][r + 1]};
+                        const f32x2 sf = __builtin_elementwise_fma(c65536, fh, __builtin_elementwise_fma(c256, fm, fl));
+                        const f32x2 val = __builtin_elementwise_fma(sf, gg[e2], negT2 * bb[e2]);
+                        // A value that can enter the list (> everything the list dropped) is parked in the lane's pending slot
+                        // with its position in the tile (a compile-time constant); the 4-deep sorted insert -- 20 instructions
+                        // for the whole wave -- runs when some lane would park a second one, an order of magnitude less often
+                        // than "some lane of the 64 has a candidate", and once at the end of the tile / segment.  The pair is
+                        // looked at only if its larger value is a candidate in some lane.
+                        if (__builtin_amdgcn_ballot_w64(fmaxf(val[0], val[1]) > ldrop) != 0) {
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const bool needs = val[e] > ldrop;
+                                if (__builtin_expect(__builtin_amdgcn_ballot_w64(needs && pend_v > -3.0e38f) != 0, 0)) {
+                                    list_insert(lv, li, ldrop, pend_v, tbase + pend_i);   // (lanes without a parked value insert -3e38: no change)
+                                    pend_v = -3.0e38f;
+                                }
+                                pend_v = needs ? val[e] : pend_v;
+                                pend_i = needs ? (uint32_t)(32 * cb + ((r + e) & 3) + 8 * ((r + e) >> 2)) : pend_i;
+                            }
+                        }
                     }
+                }
+                if (cb + 1 == I8_CT || (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total))) {
+                    if (__builtin_amdgcn_ballot_w64(pend_v > -3.0e38f) != 0) list_insert(lv, li, ldrop, pend_v, tbase + pend_i);
+                    pend_v = -3.0e38f;
                 }
                 while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
                     if (qb < nqb && q0 + j < N) {
@@ -396,15 +445,15 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
                 }
             }
         }
+        I8_TM(tm_epi);
     }
 #ifdef I8_TIMERS
-    I8_TM(tm_epi);
     if (lane == 0 && (blockIdx.x == 8 || blockIdx.x == 1001))
         printf("i8 timers wg %u wave %d: total %llu wait %llu barrier %llu body %llu epilogue+loop %llu (shader clock ticks)\n", blockIdx.x, wave,
                (unsigned long long)(tm_mark - tm_start), (unsigned long long)tm_wait, (unsigned long long)tm_bar,
                (unsigned long long)tm_body, (unsigned long long)tm_epi);
 #endif
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the two sets requested past the end
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sets requested past the end
     for (; seg < NSEG; ++seg) {
         if (qb < nqb && q0 + j < N) cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
     }
