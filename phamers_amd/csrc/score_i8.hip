@@ -312,6 +312,19 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
 #else
 #define I8_TM(acc) do { } while (0)
 #endif   // ring positions of the set being read / requested
+    // The step loop is rotated by three MFMAs: the last three of a step (their fragments already in registers) are issued
+    // AFTER the next step's barrier, between that step's first fragment reads -- the matrix pipe has work while the first
+    // LDS reads of a step are in flight, the one stretch it would otherwise idle through in every step (both waves of a
+    // SIMD stand at the same barrier).  At the first step of a tile those three run on stale fragments into accumulators
+    // that are cleared right after; after the last step they are issued before the epilogue.
+    constexpr int NX = 3 * I8_KS * I8_CT;   // 24 MFMAs per step: x = (k-step, column block, part)
+    i32x4 fa[4], fb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fa[i] = i32x4{0, 0, 0, 0};
+    fb[0] = fb[1] = i32x4{0, 0, 0, 0};
+#define I8_A_OFF(x) ((((x) / 3 % I8_CT) * I8_APIECES + ((x) % 3) * I8_KS + (x) / (3 * I8_CT)) * 1024)
+#define I8_DS_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(la), "n"(off))
+#define I8_MFMA(x) acc[(x) / 3 % I8_CT][(x) % 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[(x) & 3], fb[(x) / (3 * I8_CT)], acc[(x) / 3 % I8_CT][(x) % 3], 0, 0, 0)
     for (uint32_t t = 0; t < ntile; ++t) {
         i32x16 acc[I8_CT][3];
 #pragma unroll
@@ -329,55 +342,59 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
 #if defined(I8_TIMERS) && I8_TIMERS == 2
             I8_TM(tm_wait);
 #endif
-            __syncthreads();
+            __syncthreads();   // ... and everybody's; the set read one step ago is free
 #if defined(I8_TIMERS) && I8_TIMERS == 2
             I8_TM(tm_bar);
-#endif   // ... and everybody's; the set read one step ago is free
+#endif
             if (c == 0 && wave == 0) {   // the tile's column terms (I8_CT blocks x 64 floats): older than the pieces requested below,
                                          // so the next step's vmcnt wait covers it; read in the epilogue, many barriers on
-                const uint4 *g = T8 + ((uint64_t)blk0 + (uint64_t)t * I8_CT) * 16 + lane;
+                const uint4 *g = T8 + ((uint64_t)blk0 + (uint64_t)t * I8_CT) * 16;
                 const uint32_t lp = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(I8_NBUF * I8_SET_BYTES));
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lp) : "memory");
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(g), "s"(lp) : "memory");
             }
-            // 24 column fragments in sequence (k-step, column block, part), read from LDS three MFMAs ahead of their use
-            // through a ring of four fragment registers.  Written with explicit ds_read / s_waitcnt: left to the compiler,
-            // each fragment is read right before its MFMA (it minimises live registers here) and the LDS latency shows.
+            // 24 column fragments in sequence, read from LDS four MFMAs ahead of their use through a ring of four fragment
+            // registers.  Written with explicit ds_read / s_waitcnt: left to the compiler, each fragment is read right before
+            // its MFMA (it minimises live registers here) and the LDS latency shows.
             const uint32_t la = lds_base + cur * (uint32_t)I8_SET_BYTES + (uint32_t)lane * 16u;
-            i32x4 fa[4], fb[2];
-#define I8_A_OFF(x) ((((x) / 3 % I8_CT) * I8_APIECES + ((x) % 3) * I8_KS + (x) / (3 * I8_CT)) * 1024)
-#define I8_DS_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(la), "n"(off))
             const uint32_t lb = la + (uint32_t)(I8_CT * I8_APIECES + I8_KS * wave) * 1024u;
             asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0]) : "v"(lb));
-            asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(fb[1]) : "v"(lb));
             I8_DS_READ(fa[0], I8_A_OFF(0));
+            I8_MFMA(NX - 3);   // the previous step's last three, on fa[1..3] and the old fb[1]
             I8_DS_READ(fa[1], I8_A_OFF(1));
+            I8_MFMA(NX - 2);
             I8_DS_READ(fa[2], I8_A_OFF(2));
+            I8_MFMA(NX - 1);
+            I8_DS_READ(fa[3], I8_A_OFF(3));
+            asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(fb[1]) : "v"(lb));
+            if (c == 0) {   // (first step of the tile: those three ran on stale fragments)
 #pragma unroll
-            for (int x = 0; x < 3 * I8_KS * I8_CT; ++x) {
-                const int s = x / (3 * I8_CT), cb = x / 3 % I8_CT, p = x % 3;
-                if (x + 3 < 3 * I8_KS * I8_CT) {
-                    I8_DS_READ(fa[(x + 3) & 3], I8_A_OFF(x + 3));
-                    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[x & 3]), "+v"(fb[0]), "+v"(fb[1]));
-                } else if (x + 3 == 3 * I8_KS * I8_CT) {
-                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[x & 3]));
-                } else if (x + 2 == 3 * I8_KS * I8_CT) {
-                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fa[x & 3]));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[x & 3]));
-                }
-                acc[cb][p] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[x & 3], fb[s], acc[cb][p], 0, 0, 0);
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[I8_CT - 1][p][r] = 0;
+            }
+#pragma unroll
+            for (int x = 0; x < NX - 3; ++x) {
+                // reads in flight behind fragment x: x + 1 .. x + 3 (and the second query fragment while x < 4)
+                if (x < 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[x & 3]), "+v"(fb[0]));
+                else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[x & 3]), "+v"(fb[1]));
+                I8_MFMA(x);
+                if (x + 4 < NX) I8_DS_READ(fa[x & 3], I8_A_OFF(x + 4));
                 // the set two steps ahead is requested here, one piece every fourth MFMA: the address arithmetic and the
                 // DMA issue run under the matrix pipe's shadow instead of between the barrier and the first MFMA
                 if (x % I8_REQ_STRIDE == 1 && x / I8_REQ_STRIDE < I8_PER_WAVE) request_piece(nxt, x / I8_REQ_STRIDE);
             }
-#undef I8_DS_READ
-#undef I8_A_OFF
+            // fragments NX - 3 .. NX - 1 stay in fa[1..3] for the next step; their reads are done before this wave reaches the
+            // barrier behind which the set may be overwritten
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]));
 #if defined(I8_TIMERS) && I8_TIMERS == 2
             I8_TM(tm_body);
 #endif
             cur = cur + 1 == I8_NBUF ? 0 : cur + 1;
             nxt = nxt + 1 == I8_NBUF ? 0 : nxt + 1;
         }
+        I8_MFMA(NX - 3);
+        I8_MFMA(NX - 2);
+        I8_MFMA(NX - 1);
         I8_TM(tm_body);   // (coarse timers: the whole step loop of the tile)
         // epilogue of the tile: T v = g (65536 S_H + 256 S_M + S_L) - T b, insertion, segment flushes
 #pragma unroll
@@ -447,6 +464,9 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
         }
         I8_TM(tm_epi);
     }
+#undef I8_MFMA
+#undef I8_DS_READ
+#undef I8_A_OFF
 #ifdef I8_TIMERS
     if (lane == 0 && (blockIdx.x == 8 || blockIdx.x == 1001))
         printf("i8 timers wg %u wave %d: total %llu wait %llu barrier %llu body %llu epilogue+loop %llu (shader clock ticks)\n", blockIdx.x, wave,
