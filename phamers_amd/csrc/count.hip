@@ -1055,8 +1055,8 @@ __global__ __launch_bounds__(256) void phk_normalize_int_kernel(const T *__restr
         for (uint64_t j = lane; j < D; j += 64) s += (long long)row[j];
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
-        const double ds = (double)s;
-        for (uint64_t j = lane; j < D; j += 64) out[r * D + j] = (double)row[j] / ds;
+        const double ds = (double)s, ry = 1.0 / ds;
+        for (uint64_t j = lane; j < D; j += 64) out[r * D + j] = phk_div_row((double)row[j], ds, ry);
     }
 }
 

@@ -149,6 +149,19 @@ static inline void phk_parallel_for(uint64_t n, F fn) {
     for (auto &th : pool) th.join();
 }
 
+// x / T for the elements of ONE count row: T and y = 1.0 / T (one IEEE division) are shared by the row, each element costs
+// two Newton steps on the quotient -- 5 multiply-adds instead of the ~35 instructions of a float64 division (the general-D
+// decision kernel spent a third of its vector instructions dividing).  The result IS the correctly rounded quotient, bit
+// for bit what `x / T` returns: with y the correctly rounded reciprocal and q within one ulp of x / T,
+// RN(q + (x - T q) y) = RN(x / T) (Markstein's theorem; fma makes the residual exact), and the first step brings
+// q = RN(x y) within one ulp.  0 / 0 stays NaN (y = inf).  Checked on the device by the normalise kernel's bit-exact
+// tests against NumPy's division (tests/test_gpu_count.py), and in exact rational arithmetic by tools/diag/div_exact_check.py.
+__device__ __forceinline__ double phk_div_row(double x, double T, double y) {
+    const double q0 = x * y;
+    const double q1 = __builtin_fma(__builtin_fma(-q0, T, x), y, q0);
+    return __builtin_fma(__builtin_fma(-q1, T, x), y, q1);
+}
+
 static inline uint64_t phk_pow4(int k) { return 1ull << (2 * k); }
 static inline uint64_t phk_div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 

@@ -530,20 +530,16 @@ template <int DSUB>
 __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
                                 const double (&qd)[4 * DSUB], double nqp2, const ErrBound &eb, const double vs,
                                 const double *rows, const double *colnorm, bool want_d2, int lane,
-                                uint32_t (&out_idx)[3], double &out_d2) {
-    // lanes 0..7 hold the 8 candidates (half = lane>>2, slot = lane&3)
-    float v = -3.0e38f;
-    uint32_t ix = 0xFFFFFFFFu;
-    if (lane < 8) {
-        const uint64_t o = cand_at(seg, lane >> 2, lane & 3, q, p.N);
-        v = p.cand_v[o];
-        ix = p.cand_i[o];
-        if (ix >= ncols) v = -3.0e38f;  // padding / empty slot
-    }
+                                uint32_t (&out_idx)[3], double &out_d2, float pre_v, uint32_t pre_i, float pre_u) {
+    // lanes 0..7 hold the 8 candidates (half = lane>>2, slot = lane&3), out of the lists the caller loaded up front
+    float v = __shfl(pre_v, seg * 8 + (lane & 7));
+    uint32_t ix = __shfl(pre_i, seg * 8 + (lane & 7));
+    if (lane >= 8 || ix >= ncols) v = -3.0e38f;  // padding / empty slot
+    if (lane >= 8) ix = 0xFFFFFFFFu;
     // vs: computed values -> v units (a power of two, divided by the row sum for the count-exact proposal)
     // every column the two half-lists dropped has a computed value <= the larger of their
     // best-dropped values (-3e38 when nothing real was dropped)
-    const double U = fmax((double)p.cand_u[candu_at(seg, 0, q, p.N)], (double)p.cand_u[candu_at(seg, 1, q, p.N)]) * vs;
+    const double U = fmax((double)__shfl(pre_u, seg * 2), (double)__shfl(pre_u, seg * 2 + 1)) * vs;
     // rank of each candidate among the 8 (descending v, ties by lane)
     int rank = 0;
 #pragma unroll
@@ -621,7 +617,19 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     double qd[4 * DSUB];
     double vs = p.vscale;
     bool nan_row = false;
+    double ssq = 0.0, tq = 1.0;   // count rows: sum of squares, row sum
     CenteredOperand cop = {0.0, 0.0, 0.0, 0.0};
+    // The candidate lists of all three segments are requested first, beside the query row: lane l < 24 holds candidate l & 7
+    // of segment l >> 3, lane l < 6 the best dropped value of half-list l.  Loaded where they are used, each segment's
+    // lists were one more dependent round trip in a kernel that is a chain of them (10 M queries at configs[2]).
+    float pre_v = -3.0e38f, pre_u = -3.0e38f;
+    uint32_t pre_i = 0xFFFFFFFFu;
+    if (lane < 24) {
+        const uint64_t o = cand_at(lane >> 3, (lane & 7) >> 2, lane & 3, q, p.N);
+        pre_v = p.cand_v[o];
+        pre_i = p.cand_i[o];
+    }
+    if (lane < 6) pre_u = p.cand_u[candu_at(lane >> 1, lane & 1, q, p.N)];
     if (SRC == 0) {
         const uint32_t *row = static_cast<const uint32_t *>(src) + q * D;
         uint4 c[DSUB];
@@ -633,28 +641,32 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         }
         s = wave_sum(s);
         nan_row = s == 0;
-        const double ds = (double)s;
+        const double ds = (double)s, ry = 1.0 / ds;
         if (p.per_row_scale) vs = p.vscale / ds;
         uint32_t cmx = 0, cmn = 0xFFFFFFFFu;
         double sq = 0.0, qc2 = 0.0;
         const double rcen = (double)phk_row_center(s, D);
+        tq = ds;
 #pragma unroll
         for (int sub = 0; sub < DSUB; ++sub) {
             const double x0 = (double)c[sub].x, x1 = (double)c[sub].y, x2 = (double)c[sub].z, x3 = (double)c[sub].w;
-            qd[4 * sub + 0] = x0 / ds;
-            qd[4 * sub + 1] = x1 / ds;
-            qd[4 * sub + 2] = x2 / ds;
-            qd[4 * sub + 3] = x3 / ds;
+            qd[4 * sub + 0] = phk_div_row(x0, ds, ry);   // = x / ds, bit for bit
+            qd[4 * sub + 1] = phk_div_row(x1, ds, ry);
+            qd[4 * sub + 2] = phk_div_row(x2, ds, ry);
+            qd[4 * sub + 3] = phk_div_row(x3, ds, ry);
             sq = fma(x0, x0, fma(x1, x1, fma(x2, x2, fma(x3, x3, sq))));
             cmx = max(max(cmx, max(c[sub].x, c[sub].y)), max(c[sub].z, c[sub].w));
             cmn = min(min(cmn, min(c[sub].x, c[sub].y)), min(c[sub].z, c[sub].w));
-            if (DSUB > 1 && p.per_row_scale) {   // norm of this 256-dimension chunk of c - c0
+            if (DSUB > 1 && p.per_row_scale && p.eb_cAmax > 0.0) {   // norm of this 256-dimension chunk of c - c0 (f16 chains)
                 const double y0 = x0 - rcen, y1 = x1 - rcen, y2 = x2 - rcen, y3 = x3 - rcen;
                 qc2 = fmax(qc2, wave_sum(fma(y0, y0, fma(y1, y1, fma(y2, y2, y3 * y3)))));
             }
         }
+        ssq = wave_sum(sq);   // sum of squared counts, exact: |q|^2 = ssq / T^2
         if (p.per_row_scale && !nan_row) {  // the operand of the count-exact chain: the counts minus their centre
-            cop = phk_centered_operand(wave_sum(sq), ds, wave_max((double)cmx), -wave_max(-(double)cmn), (double)D, p.eb_hsum);
+            // (largest / smallest count: only where the bound has a maximum-norm term -- the f16 chains)
+            const double cmax = p.eb_cI > 0.0 ? wave_max((double)cmx) : rcen, cmin = p.eb_cI > 0.0 ? -wave_max(-(double)cmn) : rcen;
+            cop = phk_centered_operand(ssq, ds, cmax, cmin, (double)D, p.eb_hsum);
             if (DSUB > 1 && p.eb_cAmax > 0.0) cop.Q = sqrt(qc2) / ds * (1.0 + 1e-12);   // (with the observed running sums)
         }
     } else {
@@ -689,14 +701,18 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         }
         const double c0 = qd[4 * sub + 0] - m0.x, c1 = qd[4 * sub + 1] - m0.y;
         const double c2 = qd[4 * sub + 2] - m1.x, c3 = qd[4 * sub + 3] - m1.y;
-        aq = fma(qd[4 * sub + 0], qd[4 * sub + 0], fma(qd[4 * sub + 1], qd[4 * sub + 1],
-                 fma(qd[4 * sub + 2], qd[4 * sub + 2], fma(qd[4 * sub + 3], qd[4 * sub + 3], aq))));
+        if (SRC != 0)
+            aq = fma(qd[4 * sub + 0], qd[4 * sub + 0], fma(qd[4 * sub + 1], qd[4 * sub + 1],
+                     fma(qd[4 * sub + 2], qd[4 * sub + 2], fma(qd[4 * sub + 3], qd[4 * sub + 3], aq))));
         const double apc = fma(c0, c0, fma(c1, c1, fma(c2, c2, c3 * c3)));
         ap += apc;
-        am = fmax(fmax(am, fmax(fabs(c0), fabs(c1))), fmax(fabs(c2), fabs(c3)));
-        if (DSUB > 1 && !p.per_row_scale) pc2 = fmax(pc2, wave_sum(apc));   // norm of this chunk of q'
+        if (!(SRC == 0 && p.per_row_scale)) {   // split-f16 lists only: maximum norm and chunk norms of q'
+            am = fmax(fmax(am, fmax(fabs(c0), fabs(c1))), fmax(fabs(c2), fabs(c3)));
+            if (DSUB > 1) pc2 = fmax(pc2, wave_sum(apc));
+        }
     }
-    const double nq2 = wave_sum(aq);
+    // |q|^2 enters the error bound only: for count rows from the exact sum of squares (+ slack for the two roundings)
+    const double nq2 = SRC == 0 ? ssq / (tq * tq) * (1.0 + 1e-12) : wave_sum(aq);
     const double nqp2 = wave_sum(ap);
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
@@ -717,7 +733,7 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     uint32_t idx[3];
     double d2;
     if (p.method & PHK_METHOD_KNN) {
-        ok = resolve_segment<DSUB>(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, lane, idx, d2);
+        ok = resolve_segment<DSUB>(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, lane, idx, d2, pre_v, pre_i, pre_u);
         if (ok) {
             int votes = 0;
             for (int r = 0; r < p.kn; ++r) votes += p.labels[idx[r]] ? 1 : 0;
@@ -726,10 +742,10 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     }
     if (ok && (p.method & PHK_METHOD_KMEANS)) {
         double dp2 = 0.0, dn2 = 0.0;
-        ok = resolve_segment<DSUB>(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, vs, p.C64, p.colnorm + p.M, true, lane, idx, dp2);
+        ok = resolve_segment<DSUB>(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, vs, p.C64, p.colnorm + p.M, true, lane, idx, dp2, pre_v, pre_i, pre_u);
         if (ok)
             ok = resolve_segment<DSUB>(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, vs, p.C64 + p.n_cpos * D,
-                                 p.colnorm + p.M + p.n_cpos, true, lane, idx, dn2);
+                                 p.colnorm + p.M + p.n_cpos, true, lane, idx, dn2, pre_v, pre_i, pre_u);
         if (ok) {
             const double ep = sqrt(dp2), en = sqrt(dn2);
             cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
@@ -2134,13 +2150,13 @@ __global__ __launch_bounds__(512) void phk_fallback_group_kernel(const void *__r
                 c[sub] = reinterpret_cast<const uint4 *>(row + 256 * sub)[lane];
                 sm += c[sub].x + c[sub].y + c[sub].z + c[sub].w;
             }
-            const double ds = (double)wave_sum(sm);
+            const double ds = (double)wave_sum(sm), ry = 1.0 / ds;
 #pragma unroll
             for (int sub = 0; sub < DSUB; ++sub) {
-                qd[4 * sub + 0] = (double)c[sub].x / ds;
-                qd[4 * sub + 1] = (double)c[sub].y / ds;
-                qd[4 * sub + 2] = (double)c[sub].z / ds;
-                qd[4 * sub + 3] = (double)c[sub].w / ds;
+                qd[4 * sub + 0] = phk_div_row((double)c[sub].x, ds, ry);
+                qd[4 * sub + 1] = phk_div_row((double)c[sub].y, ds, ry);
+                qd[4 * sub + 2] = phk_div_row((double)c[sub].z, ds, ry);
+                qd[4 * sub + 3] = phk_div_row((double)c[sub].w, ds, ry);
             }
         } else {
             const double *row = static_cast<const double *>(src) + q * D;
