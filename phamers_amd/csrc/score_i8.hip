@@ -135,7 +135,7 @@ int phk_model_build_i8(phk_model *m, const double *pos, const double *neg, const
 // ------------------------------------------------------------------------------------
 // counts -> int8 query fragments: one wave per (query block of 32, 256 dimensions); Bq8[(qb D/32 + s) 64 + lane] holds the 16
 // centred counts of query j = lane & 31, dimensions 32 s + 16 (lane >> 5) + 0..15.  Rows with |c - c0| > 127 are
-// flagged in `big`.
+// flagged in `big` (N + 1 words: the last one counts them).
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_t *__restrict__ counts,
                                                                    const uint32_t *__restrict__ rowsum, uint64_t N, uint64_t D,
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_
         }
         out[s * 64] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }
-    if (mx > 127u) atomicOr(big + qrow, 1u);
+    if (mx > 127u && atomicOr(big + qrow, 1u) == 0u) atomicAdd(big + N, 1u);   // word N: how many rows are flagged
 }
 
 // ------------------------------------------------------------------------------------
@@ -487,7 +487,7 @@ __global__ void phk_merge_list_sets_kernel(float *__restrict__ cv, uint32_t *__r
 // proposal pass for uint32 counts at D = 512 .. 4096: row sums (if needed) -> int8 query fragments -> sweep (-> merge)
 int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum, uint64_t nb,
                                    uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu, uint32_t groups,
-                                   uint64_t set_bytes) {
+                                   uint64_t set_bytes, bool *accepted) {
     const uint64_t D = m->D, nchunk = D / (32 * I8_KS), nchunk256 = D / 256;
     const uint64_t nqb = phk_div_up(nb, 32);
     void *bq, *rs = nullptr, *bg;
@@ -498,11 +498,20 @@ int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint3
                    phk_rowsum_kernel<<<dim3((unsigned)phk_div_up(nb, 4)), dim3(256), 0, ctx->stream>>>(d_counts, nb, D, (uint32_t *)rs));
         d_rowsum = (const uint32_t *)rs;
     }
-    PHK_TRY(phk_ws(ctx, WS_LONG, nb * sizeof(uint32_t), &bg));
-    PHK_HIP(hipMemsetAsync(bg, 0, nb * sizeof(uint32_t), ctx->stream));
+    PHK_TRY(phk_ws(ctx, WS_LONG, (nb + 1) * sizeof(uint32_t), &bg));
+    PHK_HIP(hipMemsetAsync(bg, 0, (nb + 1) * sizeof(uint32_t), ctx->stream));
     PHK_LAUNCH(ctx, "phk_split_queries_i8_kernel",
                phk_split_queries_i8_kernel<<<dim3((unsigned)phk_div_up(nqb * nchunk256, 4)), dim3(256), 0, ctx->stream>>>(
                    d_counts, d_rowsum, nb, D, (uint4 *)bq, (uint32_t *)bg));
+    // Rows that do not fit the int8 operand (a bin more than 127 away from the row's centre: long or compositionally
+    // skewed contigs) would all take the float64 brute force.  A batch with more than a handful of them goes through the
+    // f16 kernel instead, whose operand reaches 2048: the caller is told so.  One 4-byte read-back per batch of <= 2^20
+    // rows (the sweep that follows takes tens of milliseconds).
+    uint32_t nbig = 0;
+    PHK_HIP(hipMemcpyAsync(&nbig, (const uint32_t *)bg + nb, sizeof(nbig), hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    *accepted = nbig <= (nb / 256 > 16 ? nb / 256 : 16);
+    if (!*accepted) return PHK_OK;
     const uint64_t rec_u4 = m->rec8_bytes / 16;
     const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
     const uint32_t ng = (groups > 1 && nref >= 8u * groups && nqb >= 64) ? groups : 1u;

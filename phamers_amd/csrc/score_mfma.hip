@@ -2411,7 +2411,12 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             }
             r.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
         };
-        if (use_i8) {
+        // the int8 sweep goes first: it declines a batch with too many rows beyond its operand range (-> the f16 kernel)
+        bool i8_now = false;
+        if (use_i8)
+            PHK_TRY(phk_launch_proposal_i8_general(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu,
+                                                   (uint32_t)gen_sets, set_bytes, &i8_now));
+        if (i8_now) {
             // values are T v (per row), from exact integer sums (see ErrBound: int8)
             const double ku = m->kappa8 / 5.9604644775390625e-08;
             p.vscale = 1.0; p.per_row_scale = 1; p.cand_a = nullptr;
@@ -2435,9 +2440,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             p.vscale = 1.0;
             p.eb_cA = 6.0; p.eb_cP = 264.0; p.eb_cR = 4.0; p.eb_abs = 0.0;
         }
-        if (use_i8) {
-            PHK_TRY(phk_launch_proposal_i8_general(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu,
-                                                   (uint32_t)gen_sets, set_bytes));
+        if (i8_now) {
+            // (launched above)
         } else if (D != FAST_D) {
             PHK_TRY(phk_launch_proposal_f16_general(ctx, m, src, d_counts != nullptr, use_cx, rsum, nb, nref, npos, nneg,
                                                     (float *)cv, ci, cu, ca, hi_gen, (uint32_t)gen_sets, set_bytes));

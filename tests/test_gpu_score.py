@@ -277,6 +277,22 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
     for method in ("knn", "kmeans", "combo"):   # the decision stage's exact distances are one canonical form: bit-equal
         assert np.array_equal(out[("i8", method)], out[("cxf", method)]), method
     out.update({("f16", m): out[("i8", m)] for m in ("knn", "kmeans", "combo")})
+    # a batch in which many rows exceed the int8 operand (every 8th row 40 x): the int8 sweep declines it, the f16 kernel
+    # takes the whole batch -- same scores, and the 40 x rows are NOT brute-forced
+    hq2 = hq.copy()
+    hq2[8::8] *= 40
+    d_q2 = device.DeviceArray.from_host(ctx, hq2)
+    res = {}
+    for path in ("default", "exact"):
+        ctx.set_option("force_exact", "1" if path == "exact" else "0")
+        d_scores = device.DeviceArray(ctx, n_q, np.float64)
+        device.score_counts(ctx, model, d_q2, n_q, "combo", d_scores, None)
+        res[path] = d_scores.to_host()
+        if path == "default":
+            n_fallback, _ = ctx.score_stats()
+            assert 4 <= n_fallback < 32, n_fallback
+    ctx.set_option("force_exact", "0")
+    assert helpers.rel_err(res["default"], res["exact"]) < 1e-9
     # float64-row entry point on a slice, against the oracle
     ctx.set_option("force_exact", "0")
     qc = d_q.to_host()[:64].astype(np.int64)
