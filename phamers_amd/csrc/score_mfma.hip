@@ -605,6 +605,59 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
     return true;
 }
 
+// An upper bound of sqrt(x) from the float32 instruction (1 instruction, |error| < 2e-7 relative with the conversion) --
+// for norms and radii that only enter the error bound or the triangle radius, where larger is the safe side; a float64
+// square root is ~30 instructions of this kernel's budget.
+__device__ __forceinline__ double phk_sqrt_up(double x) { return (double)__builtin_sqrtf((float)x) * (1.0 + 1.0e-6); }
+
+// The margin test of resolve_segment for the three segments AT ONCE: lanes 8 g .. 8 g + 7 hold segment g's candidates and
+// carry out its ranking, its triangle radius and its margin test side by side (the conditions are resolve_segment's, word
+// for word; what differs per segment -- columns, `need`, the norms' base -- is per-lane data).  One after the other the
+// three tests were two thirds of the decision kernel's per-query instructions, every lane of the wave computing the same
+// scalars.  Returns bit 8 g set where segment g is certified; ri[0..2] = the lane's segment's best columns.
+// A segment that is not certified goes through resolve_segment (exact candidate distances) as before.
+__device__ __forceinline__ uint64_t certify_segments(const RerankParams &p, double nqp2, double nqp, const ErrBound &eb, double vs,
+                                                     int lane, float pre_v, uint32_t pre_i, uint32_t (&ri)[3]) {
+    const int g = lane >> 3, gb = lane & 56;
+    const uint32_t ncols = g == 0 ? (uint32_t)p.M : g == 1 ? (uint32_t)p.n_cpos : g == 2 ? (uint32_t)p.n_cneg : 0u;
+    const int need = g == 0 ? p.kn : 1;
+    const double *colnorm = p.colnorm + (g == 0 ? 0 : g == 1 ? p.M : p.M + p.n_cpos);
+    float v = pre_v;
+    const uint32_t ix = pre_i;
+    if (ix >= ncols) v = -3.0e38f;  // padding / empty slot (and lanes >= 24)
+    int rank = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const float ov = __shfl(v, gb | m);
+        rank += (ov > v || (ov == v && m < (lane & 7))) ? 1 : 0;
+    }
+    float rv[4];
+    uint32_t rx[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const unsigned long long bal = __ballot(rank == r);
+        const int srcl = gb + __ffsll((long long)((bal >> gb) & 0xFFull)) - 1;
+        rv[r] = __shfl(v, srcl);
+        rx[r] = __shfl(ix, srcl);
+    }
+    ri[0] = rx[0]; ri[1] = rx[1]; ri[2] = rx[2];
+    const double eps_g = eb(p.rmax);  // holds for every column
+    const float rvn1 = need == 1 ? rv[0] : need == 2 ? rv[1] : rv[2], rvn = need == 1 ? rv[1] : need == 2 ? rv[2] : rv[3];
+    const uint32_t rxn1 = need == 1 ? rx[0] : need == 2 ? rx[1] : rx[2];
+    bool cert = false;
+    if (rxn1 < ncols) {
+        const double d2up = fmax(nqp2 - 2.0 * ((double)rvn1 * vs - eps_g), 0.0);
+        const double R0 = fmin(p.rmax, (nqp + phk_sqrt_up(d2up)) * (1.0 + 1e-6));
+        bool near = true;  // the top `need` computed candidates all lie within R0
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            if (r < need) near = near && colnorm[rx[r]] <= R0;
+        const double eps_m = near ? eb(R0) : eps_g;
+        cert = ((double)rvn1 - (double)rvn) * vs > 2.0 * eps_m;
+    }
+    return __ballot(cert && (lane & 7) == 0 && lane < 24);
+}
+
 // one query, one wave (the body of phk_rerank_kernel)
 // MU_LDS: the training mean is read from LDS at byte offset mu_lds (address space 3: a generic pointer would turn every
 // read into a flat load, which also counts on the vector-memory counter and serialises the kernel's other loads)
@@ -714,13 +767,14 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     // |q|^2 enters the error bound only: for count rows from the exact sum of squares (+ slack for the two roundings)
     const double nq2 = SRC == 0 ? ssq / (tq * tq) * (1.0 + 1e-12) : wave_sum(aq);
     const double nqp2 = wave_sum(ap);
-    ErrBound eb;
-    eb.A = sqrt(nq2) + p.mu_norm;
-    eb.P = sqrt(nqp2);
+    ErrBound eb;   // (its norms: upper bounds, phk_sqrt_up)
+    eb.A = phk_sqrt_up(nq2) + p.mu_norm;
+    const double nqp_up = phk_sqrt_up(nqp2);
+    eb.P = nqp_up;
     eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
     if (SRC == 0 && p.per_row_scale) {   // count-exact lists: the chain's query operand is c - c0
         eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs;
-        eb.P = sqrt(nqp2 + cop.shift2);   // (high-parts-only lists: what the low parts multiply)
+        eb.P = phk_sqrt_up(nqp2 + cop.shift2);   // (high-parts-only lists: what the low parts multiply)
     } else {                             // split-f16 lists: the chain's query operand is q' (largest chunk norm)
         eb.Q = DSUB > 1 ? sqrt(pc2) * (1.0 + 1e-12) : eb.P;
         eb.I = wave_max(am);
@@ -732,8 +786,16 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     double knn = 0.0, cen = 0.0;
     uint32_t idx[3];
     double d2;
+    // all three margin tests side by side; what they certify needs no further list work
+    uint32_t cri[3];
+    const uint64_t certified = certify_segments(p, nqp2, nqp_up, eb, vs, lane, pre_v, pre_i, cri);
     if (p.method & PHK_METHOD_KNN) {
-        ok = resolve_segment<DSUB>(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, lane, idx, d2, pre_v, pre_i, pre_u);
+        if (certified & 1ull) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) idx[r] = __shfl(cri[r], 0);
+        } else {
+            ok = resolve_segment<DSUB>(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, lane, idx, d2, pre_v, pre_i, pre_u);
+        }
         if (ok) {
             int votes = 0;
             for (int r = 0; r < p.kn; ++r) votes += p.labels[idx[r]] ? 1 : 0;
@@ -742,8 +804,13 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     }
     if (ok && (p.method & PHK_METHOD_KMEANS)) {
         double dp2 = 0.0, dn2 = 0.0;
-        ok = resolve_segment<DSUB>(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, vs, p.C64, p.colnorm + p.M, true, lane, idx, dp2, pre_v, pre_i, pre_u);
-        if (ok)
+        if (certified & (1ull << 8))
+            dp2 = exact_d2<DSUB>(qd, p.C64 + (uint64_t)__shfl(cri[0], 8) * D, lane);
+        else
+            ok = resolve_segment<DSUB>(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, vs, p.C64, p.colnorm + p.M, true, lane, idx, dp2, pre_v, pre_i, pre_u);
+        if (ok && (certified & (1ull << 16)))
+            dn2 = exact_d2<DSUB>(qd, p.C64 + (p.n_cpos + (uint64_t)__shfl(cri[0], 16)) * D, lane);
+        else if (ok)
             ok = resolve_segment<DSUB>(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, vs, p.C64 + p.n_cpos * D,
                                  p.colnorm + p.M + p.n_cpos, true, lane, idx, dn2, pre_v, pre_i, pre_u);
         if (ok) {
