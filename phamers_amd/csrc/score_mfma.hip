@@ -451,6 +451,22 @@ __device__ __forceinline__ CenteredOperand phk_centered_operand(double sumsq, do
     return o;
 }
 
+// The same from the row's reciprocal sum rT = RN(1 / T), with float32 square root: every output is an upper bound with
+// slack, at a fifth of the instructions (three float64 divisions and a float64 square root otherwise) -- for the
+// wave-per-query decision kernel, whose per-query scalar arithmetic is what bounds it.
+__device__ __forceinline__ CenteredOperand phk_centered_operand_fast(double sumsq, double T, double rT, double cmax, double cmin,
+                                                                     double D, double hsum) {
+    const double c0 = (double)phk_row_center((uint32_t)T, (uint32_t)D);
+    CenteredOperand o;
+    const double ss = fmax(sumsq - 2.0 * c0 * T + D * c0 * c0, 0.0);
+    o.Q = (double)__builtin_sqrtf((float)ss) * rT * (1.0 + 1.0e-6);
+    o.I = fmax(cmax - c0, c0 - cmin) * rT * (1.0 + 1.0e-9);
+    const double dl = fabs(c0 * rT - 1.0 / D) * (1.0 + 1.0e-9) + 1.0e-18;
+    o.habs = dl * hsum;
+    o.shift2 = D * dl * dl;
+    return o;
+}
+
 // Exact squared distance of the group's query to `row`.  The query is held UNNORMALISED: qd = the integer
 // counts (or the float64 row with Tq = 1), Tq = their sum, and
 //     |q - r|^2 = sum_i (c_i - Tq r_i)^2 / Tq^2        (one rounding per difference, inside the fma)
@@ -670,7 +686,7 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     double qd[4 * DSUB];
     double vs = p.vscale;
     bool nan_row = false;
-    double ssq = 0.0, tq = 1.0;   // count rows: sum of squares, row sum
+    double ssq = 0.0, rtq = 1.0;   // count rows: sum of squares, reciprocal of the row sum
     CenteredOperand cop = {0.0, 0.0, 0.0, 0.0};
     // The candidate lists of all three segments are requested first, beside the query row: lane l < 24 holds candidate l & 7
     // of segment l >> 3, lane l < 6 the best dropped value of half-list l.  Loaded where they are used, each segment's
@@ -695,11 +711,11 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         s = wave_sum(s);
         nan_row = s == 0;
         const double ds = (double)s, ry = 1.0 / ds;
-        if (p.per_row_scale) vs = p.vscale / ds;
+        if (p.per_row_scale) vs = p.vscale * ry;   // (= vscale / ds up to the reciprocal's rounding; vs scales margins and bounds, never a score)
         uint32_t cmx = 0, cmn = 0xFFFFFFFFu;
         double sq = 0.0, qc2 = 0.0;
         const double rcen = (double)phk_row_center(s, D);
-        tq = ds;
+        rtq = ry;
 #pragma unroll
         for (int sub = 0; sub < DSUB; ++sub) {
             const double x0 = (double)c[sub].x, x1 = (double)c[sub].y, x2 = (double)c[sub].z, x3 = (double)c[sub].w;
@@ -719,8 +735,8 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         if (p.per_row_scale && !nan_row) {  // the operand of the count-exact chain: the counts minus their centre
             // (largest / smallest count: only where the bound has a maximum-norm term -- the f16 chains)
             const double cmax = p.eb_cI > 0.0 ? wave_max((double)cmx) : rcen, cmin = p.eb_cI > 0.0 ? -wave_max(-(double)cmn) : rcen;
-            cop = phk_centered_operand(ssq, ds, cmax, cmin, (double)D, p.eb_hsum);
-            if (DSUB > 1 && p.eb_cAmax > 0.0) cop.Q = sqrt(qc2) / ds * (1.0 + 1e-12);   // (with the observed running sums)
+            cop = phk_centered_operand_fast(ssq, ds, ry, cmax, cmin, (double)D, p.eb_hsum);
+            if (DSUB > 1 && p.eb_cAmax > 0.0) cop.Q = phk_sqrt_up(qc2) * ry * (1.0 + 1e-9);   // (with the observed running sums)
         }
     } else {
         const double *row = static_cast<const double *>(src) + q * D;
@@ -765,7 +781,7 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         }
     }
     // |q|^2 enters the error bound only: for count rows from the exact sum of squares (+ slack for the two roundings)
-    const double nq2 = SRC == 0 ? ssq / (tq * tq) * (1.0 + 1e-12) : wave_sum(aq);
+    const double nq2 = SRC == 0 ? ssq * (rtq * rtq) * (1.0 + 1e-12) : wave_sum(aq);
     const double nqp2 = wave_sum(ap);
     ErrBound eb;   // (its norms: upper bounds, phk_sqrt_up)
     eb.A = phk_sqrt_up(nq2) + p.mu_norm;
