@@ -349,6 +349,8 @@ struct RerankParams {
                                      // reference into 64 chunks per query when they fit, else FB_CHUNKS); 0: FB_CHUNKS
     const float *cand_a = nullptr;   // general D: largest |accumulator| a lane saw at the (block, chunk) item boundaries of its
                                      // sweep, [2 halves][N] (the running sums the chain's charges scale with; see ErrBound)
+    double *pend = nullptr;          // general-D decision kernel: [2 N] exact d^2 to the nearest positive / negative centroid of the
+                                     // queries it decided; phk_finish_cen_kernel turns them into the proximity metric
     double eb_cAmax = 0.0;           // coefficient of that observed running sum (PHK_MFMA_ACC x instructions per value)
     void *fb_rec;           // fallback partial records
     double *scores;
@@ -830,13 +832,21 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
             ok = resolve_segment<DSUB>(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, vs, p.C64 + p.n_cpos * D,
                                  p.colnorm + p.M + p.n_cpos, true, lane, idx, dn2, pre_v, pre_i, pre_u);
         if (ok) {
-            const double ep = sqrt(dp2), en = sqrt(dn2);
-            cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
+            if (p.pend) {   // two square roots, a division and a tanh in float64 are ~180 instructions of this wave, for one
+                            // number: left to a lane-per-query kernel (phk_finish_cen_kernel, the same expressions)
+                if (lane == 0) {
+                    p.pend[2 * q] = dp2;
+                    p.pend[2 * q + 1] = dn2;
+                }
+            } else {
+                const double ep = sqrt(dp2), en = sqrt(dn2);
+                cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
+            }
         }
     }
     if (lane == 0) {
         if (ok) {
-            p.scores[p.q_base + q] = knn + cen;  // scripts/phamer.py:313
+            p.scores[p.q_base + q] = knn + cen;  // scripts/phamer.py:313 (cen: see pend)
         } else {
             const uint32_t slot = atomicAdd(p.fb_count, 1u);
             p.fb_list[slot] = (uint32_t)q;
@@ -2342,6 +2352,17 @@ __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p)
     }
 }
 
+// one thread per query: score += tanh((en - ep) / (ep + en)) for the queries whose centroid distances the general-D
+// decision kernel left in `pend` (the rest holds the NaN fill); scripts/phamer.py:206-209, 313
+__global__ __launch_bounds__(256) void phk_finish_cen_kernel(uint64_t N, const double *__restrict__ pend, double *__restrict__ scores) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    const double dp2 = pend[2 * q], dn2 = pend[2 * q + 1];
+    if (!(dp2 >= 0.0)) return;
+    const double ep = sqrt(dp2), en = sqrt(dn2);
+    scores[q] += tanh((en - ep) / (ep + en));
+}
+
 // ------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------
@@ -2434,7 +2455,9 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
                                                         : (D >= 2048 ? PHK_GEN_GROUPS : 1);
     const uint64_t set_bytes = per_list * list_bytes;
     const uint64_t ca_bytes = D != FAST_D ? gen_sets * 2 * nb_max * sizeof(float) : 0;
-    PHK_TRY(phk_ws(ctx, WS_CAND, gen_sets * set_bytes + ca_bytes + PHK_SECOND_SPLITS * set2_bytes, &cv));
+    const uint64_t pend_bytes = (D != FAST_D && (method & PHK_METHOD_KMEANS)) ? nb_max * 2 * sizeof(double) : 0;
+    PHK_TRY(phk_ws(ctx, WS_CAND, gen_sets * set_bytes + ca_bytes + PHK_SECOND_SPLITS * set2_bytes + pend_bytes, &cv));
+    double *pend = pend_bytes ? (double *)((char *)cv + gen_sets * set_bytes + ca_bytes + PHK_SECOND_SPLITS * set2_bytes) : nullptr;
     uint32_t *ci = (uint32_t *)((char *)cv + per_list * sizeof(float4));
     float *cu = (float *)((char *)ci + per_list * sizeof(uint4));
     float *ca = ca_bytes ? (float *)((char *)cv + gen_sets * set_bytes) : nullptr;
@@ -2599,10 +2622,17 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             ph.eb_abs *= 2.0;
             ph.slow_back = 2;
             PHK_TRY(launch_rerank<0>(ctx, rblocks, src, ph));
-        } else if (d_counts) {
-            PHK_TRY(launch_rerank<0>(ctx, rblocks, src, p));
         } else {
-            PHK_TRY(launch_rerank<1>(ctx, rblocks, src, p));
+            RerankParams pr = p;
+            if (pend && ctx->knobs.rerank != 'w') {   // general D: the proximity metric is finished by a lane-per-query kernel
+                PHK_HIP(hipMemsetAsync(pend, 0xFF, nb * 2 * sizeof(double), ctx->stream));   // NaN: not decided here
+                pr.pend = pend;
+            }
+            if (d_counts) PHK_TRY(launch_rerank<0>(ctx, rblocks, src, pr));
+            else PHK_TRY(launch_rerank<1>(ctx, rblocks, src, pr));
+            if (pr.pend)
+                PHK_LAUNCH(ctx, "phk_finish_cen_kernel",
+                           phk_finish_cen_kernel<<<dim3((unsigned)phk_div_up(nb, 256)), dim3(256), 0, ctx->stream>>>(nb, pend, d_scores + s));
         }
         RerankParams pf = p;   // what the brute force works from
         if (second) {
