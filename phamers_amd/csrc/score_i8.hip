@@ -32,6 +32,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define I8_NMAX 8300000.0      // |n| <= this: H = n / 65536 (balanced) stays within [-127, 127]
 #define I8_KS 2                // k-steps (32 dimensions each) per chunk of the sweep: chunks of 64 dimensions
 #define I8_APIECES (3 * I8_KS) // 1 KiB pieces per (block, chunk): 3 parts x I8_KS k-steps
+#define I8_L1_MAX 65000u        // |c - c0|_1 of a row the epilogue's 32-bit fold is exact for: (256 * 127 + 128) * 65000 < 2^31
 #define I8_CT 4                // column blocks per tile: 4 x 3 int32 accumulators per wave
 #ifndef I8_NW
 #define I8_NW 8                // waves per workgroup (they share the step sets streamed into LDS)
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_
     const uint64_t qrow = (qb * 32 + j < N) ? qb * 32 + j : N - 1;
     const int cen = (int)phk_row_center(rowsum[qrow], (uint32_t)D);
     uint4 *out = Bq + (w * 8) * 64 + lane;
-    uint32_t mx = 0;
+    uint32_t mx = 0, l1 = 0;
 #pragma unroll 2
     for (int s = 0; s < 8; ++s) {
         // 16 consecutive counts = one 64-byte piece of the row
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_
                 const int d = (int)cc[b] - cen;
                 const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
                 mx = max(mx, max(ad, cc[b] >> 31 ? 0xFFFFFFFFu : 0u));
+                l1 += min(ad, 127u);
                 const int q = d < -127 ? -127 : (d > 127 ? 127 : d);
                 word |= ((uint32_t)q & 0xFFu) << (8 * b);
             }
@@ -174,7 +176,14 @@ __global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_
         }
         out[s * 64] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }
-    if (mx > 127u && atomicOr(big + qrow, 1u) == 0u) atomicAdd(big + N, 1u);   // word N: how many rows are flagged
+    // bit 31 of a row's word: some bin does not fit the operand; word N counts those rows
+    if (mx > 127u && (atomicOr(big + qrow, 0x80000000u) >> 31) == 0u) atomicAdd(big + N, 1u);
+    // the low bits: |c - c0|_1 of the row, which the sweep's epilogue needs below 65 000 (it folds two exact part sums in one
+    // 32-bit integer).  |c - c0|_1 <= T + D c0, so only rows with a large sum have to be measured: none of a 10 kb batch
+    if (2ull * rowsum[qrow] + D > I8_L1_MAX) {
+        l1 += __shfl_xor(l1, 32);
+        if (h == 0 && qb * 32 + j < N) atomicAdd(big + qrow, l1);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -288,10 +297,11 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
     }
     const uint64_t qr = (qb < nqb && q0 + j < N) ? q0 + j : N - 1;
     const float negT = -(float)rowsum[qr];
-    const f32x2 negT2 = {negT, negT}, c65536 = {65536.0f, 65536.0f}, c256 = {256.0f, 256.0f};
+    const f32x2 negT2 = {negT, negT}, c256 = {256.0f, 256.0f};
     float pend_v = -3.0e38f;     // the lane's parked candidate (see the epilogue): value, position in the tile
     uint32_t pend_i = 0;
-    const bool isbig = big[qr] != 0;
+    const uint32_t bigw = big[qr];
+    const bool isbig = (bigw >> 31) != 0 || (bigw & 0x7FFFFFFFu) > I8_L1_MAX;   // (see phk_split_queries_i8_kernel)
     int seg = 0;
     uint32_t seg_first = 0;
     while (seg < NSEG && (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total) == 0) {   // leading segments without columns
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
         I8_MFMA(NX - 2);
         I8_MFMA(NX - 1);
         I8_TM(tm_body);   // (coarse timers: the whole step loop of the tile)
-        // epilogue of the tile: T v = g (65536 S_H + 256 S_M + S_L) - T b, insertion, segment flushes
+        // epilogue of the tile: T v = g (256 (256 S_H + S_M) + S_L) - T b, insertion, segment flushes
 #pragma unroll
         for (int cb = 0; cb < I8_CT; ++cb) {
             const uint32_t blk = t * I8_CT + cb;
@@ -412,9 +422,10 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
 #pragma unroll
                     for (int e2 = 0; e2 < 2; ++e2) {   // two values per packed float32 instruction
                         const int r = 4 * m4 + 2 * e2;
-                        const f32x2 fh = {(float)acc[cb][0][r], (float)acc[cb][0][r + 1]}, fm = {(float)acc[cb][1][r], (float)acc[cb][1][r + 1]},
+                        // 256 S_H + S_M as one exact 32-bit integer (|c - c0|_1 <= I8_L1_MAX), then two conversions per value
+                        const f32x2 fhm = {(float)(acc[cb][0][r] * 256 + acc[cb][1][r]), (float)(acc[cb][0][r + 1] * 256 + acc[cb][1][r + 1])},
                                     fl = {(float)acc[cb][2][r], (float)acc[cb][2][r + 1]};
-                        const f32x2 sf = __builtin_elementwise_fma(c65536, fh, __builtin_elementwise_fma(c256, fm, fl));
+                        const f32x2 sf = __builtin_elementwise_fma(c256, fhm, fl);
                         const f32x2 val = __builtin_elementwise_fma(sf, gg[e2], negT2 * bb[e2]);
                         // A value that can enter the list (> everything the list dropped) is parked in the lane's pending slot
                         // with its position in the tile (a compile-time constant); the 4-deep sorted insert -- 20 instructions
