@@ -131,3 +131,28 @@ def test_kmer_command_line_parses_like_the_reference():
     assert (b.kmer_length, b.sample, b.symbols, b.file_identifier, b.debug) == (5, 10, "AUGC", ".fa", True)
     with pytest.raises(SystemExit):
         kmer.main([str("/nonexistent/path/x.fasta"), "out.csv"])
+
+
+def test_row_division_by_a_shared_reciprocal_is_the_ieee_quotient():
+    """phk_div_row (csrc/phk_common.h) -- x / T from RN(1 / T) and two fused Newton steps on the quotient -- replayed in
+    exact rational arithmetic: equal to the IEEE quotient for every (count, row sum) tried.  The device side of the same
+    claim is the normalise kernel's bit-exact test against NumPy (tests/test_gpu_count.py)."""
+    import random
+    from fractions import Fraction
+
+    def fma(a, b, c):
+        return float(Fraction(a) * Fraction(b) + Fraction(c))
+
+    def div_row(x, T, y):
+        q0 = x * y
+        q1 = fma(fma(-q0, T, x), y, q0)
+        return fma(fma(-q1, T, x), y, q1)
+
+    rng = random.Random(7)
+    cases = [(x, T) for T in list(range(1, 120)) + [4996, 4997, 9995, 9996, 2 ** 16 - 1, 2 ** 24 + 1, 2 ** 32 - 1]
+             for x in {0, 1, T // 3, T // 2, max(T - 1, 0), T}]
+    cases += [(rng.randrange(0, T + 1), T) for T in (rng.randrange(1, 2 ** 32) for _ in range(4000))]
+    cases += [(rng.randrange(0, min(T, 400) + 1), T) for T in (rng.randrange(1, 200000) for _ in range(4000))]
+    for x, T in cases:
+        xf, Tf = float(x), float(T)
+        assert div_row(xf, Tf, 1.0 / Tf) == xf / Tf, (x, T)
