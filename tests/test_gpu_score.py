@@ -218,7 +218,7 @@ def test_duplicate_train_rows_take_the_certified_or_fallback_route():
     model.close()
 
 
-@pytest.mark.parametrize("k,n_ref,n_q", [(5, 1500, 3000), (6, 700, 1200)])
+@pytest.mark.parametrize("k,n_ref,n_q", [(5, 1500, 3000), (6, 700, 1200), (5, 40, 100)])   # (the last: less than one tile of columns)
 def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q):
     """k = 5 / 6 (D = 1024 / 4096): the general-D split-f16 proposal path against the float64
     brute-force path on synthetic genomes; identical votes, float scores equal to rounding; the
