@@ -31,27 +31,39 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define I8_NMAX 8300000.0      // |n| <= this: H = n / 65536 (balanced) stays within [-127, 127]
 #define I8_KS 2                // k-steps (32 dimensions each) per chunk of the sweep: chunks of 64 dimensions
-#define I8_APIECES (3 * I8_KS) // 1 KiB pieces per (block, chunk): 3 parts x I8_KS k-steps
 #define I8_L1_MAX 65000u        // |c - c0|_1 of a row the epilogue's 32-bit fold is exact for: (256 * 127 + 128) * 65000 < 2^31
-#define I8_CT 4                // column blocks per tile: 4 x 3 int32 accumulators per wave
+#define I8_CT_MAX 6            // most column blocks a tile of any variant holds (padding of the record / term arrays)
+// Two variants of the sweep, <parts NP, column blocks per tile CT> -- both keep 192 int32 accumulator registers per wave and
+// 24 MFMAs + 40 LDS-DMA pieces per 64-dimension step:
+//   <3, 4>  all three parts: the lists carry full-precision values (proposal=i83);
+//   <2, 6>  H and M only (the default): a value is short of the full one by exactly g_j S_L, S_L = sum_i (c_i - c0) L_ji,
+//           |g_j S_L| <= |c - c0| g_j |L_j| (Cauchy-Schwarz) -- 2^-16 of |c - c0| |x_j| where the 8-bit H alone would leave
+//           2^-8.  The decision stage (phk_rerank_kernel<.., I8H>) adds g_j S_L, an exact integer dot product with the
+//           column's L digits (row-major d_L8), to the candidates inside the window that bound opens around the need-th
+//           value; they then carry the three-part value and everything downstream is the three-part path's.  A third fewer
+//           MFMAs per value and six column blocks per query-fragment read instead of four.
 #ifndef I8_NW
 #define I8_NW 8                // waves per workgroup (they share the step sets streamed into LDS)
 #endif
 
 // ------------------------------------------------------------------------------------
-// host: 24-bit fixed-point columns in MFMA fragment order.  Block record: D / 64 chunks of 6 pieces
-// [part][k-step s < 2][lane (column i, half h)][16 bytes = dimensions 64 c + 32 s + 16 h + 0..15]; beside the records, 64
-// floats per block: the 32 quanta g_j and the 32 bias terms b_j = (mu - 1/D).x~_j + |x~_j|^2 / 2 (x~ = the column as
-// quantised; see score_lists.h on the centred counts).
+// host: 24-bit fixed-point columns in MFMA fragment order.  Block record of the <NP, .> sweep: D / 64 chunks of 2 NP pieces
+// [part < NP][k-step s < 2][lane (column i, half h)][16 bytes = dimensions 64 c + 32 s + 16 h + 0..15] (rec3: H, M, L;
+// rec2: H, M); the L digits also row-major, [column][D], for the decision stage of the two-part sweep; beside the records,
+// 64 floats per block: the 32 quanta g_j and the 32 bias terms b_j = (mu - 1/D).x~_j + |x~_j|^2 / 2 (x~ = the column as
+// quantised in all three parts; see score_lists.h on the centred counts).  lam[col] = g_j |L_j|_2: what a two-part value
+// can be short of the full one, per unit of |c - c0| / T.
 // ------------------------------------------------------------------------------------
 static void pack_segment_i8(const double *rows, uint64_t n, uint64_t D, const double *mu, const double *colnorm,
-                            std::vector<uint8_t> &rec, std::vector<float> &term, uint64_t rec_bytes, uint64_t cb0,
-                            std::vector<double> &kappa, std::vector<double> &hsum, uint64_t col0) {
+                            std::vector<uint8_t> &rec3, std::vector<uint8_t> &rec2, std::vector<int8_t> &low,
+                            std::vector<float> &term, uint64_t cb0, std::vector<double> &kappa, std::vector<double> &hsum,
+                            std::vector<double> &lam, uint64_t col0) {
     const uint64_t nblk = phk_div_up(n, 32);
     const int nchunk = (int)(D / (32 * I8_KS));
+    const uint64_t rec3_bytes = (uint64_t)nchunk * 3 * I8_KS * 1024, rec2_bytes = (uint64_t)nchunk * 2 * I8_KS * 1024;
     const double shift = 1.0 / (double)D;
     phk_parallel_for(nblk, [&, nchunk](uint64_t b) {
-        uint8_t *blk = rec.data() + (cb0 + b) * rec_bytes;
+        uint8_t *blk3 = rec3.data() + (cb0 + b) * rec3_bytes, *blk2 = rec2.data() + (cb0 + b) * rec2_bytes;
         float *terms = term.data() + (cb0 + b) * 64;
         for (int i = 0; i < 32; ++i) {
             const uint64_t r = b * 32 + i;
@@ -67,7 +79,8 @@ static void pack_segment_i8(const double *rows, uint64_t n, uint64_t D, const do
             }
             const float gf = xmax > 0.0 ? (float)(xmax / I8_NMAX) : 1.0e-30f;
             const double g = (double)gf;   // the kernel multiplies by the float: quantise against exactly that value
-            double mudot = 0.0, nrm2 = 0.0, xsum = 0.0, d2 = 0.0;
+            double mudot = 0.0, nrm2 = 0.0, xsum = 0.0, d2 = 0.0, l2 = 0.0;
+            int8_t *lrow = low.data() + (col0 + r) * D;
             for (int c = 0; c < nchunk; ++c)
                 for (int s = 0; s < I8_KS; ++s)
                     for (int h = 0; h < 2; ++h)
@@ -83,7 +96,11 @@ static void pack_segment_i8(const double *rows, uint64_t n, uint64_t D, const do
                             const int lane = h * 32 + i;
                             const long long part[3] = {H, M, L};
                             for (int p = 0; p < 3; ++p)
-                                reinterpret_cast<int8_t *>(blk + ((uint64_t)c * I8_APIECES + p * I8_KS + s) * 1024 + lane * 16)[e] = (int8_t)part[p];
+                                reinterpret_cast<int8_t *>(blk3 + ((uint64_t)c * 3 * I8_KS + p * I8_KS + s) * 1024 + lane * 16)[e] = (int8_t)part[p];
+                            for (int p = 0; p < 2; ++p)
+                                reinterpret_cast<int8_t *>(blk2 + ((uint64_t)c * 2 * I8_KS + p * I8_KS + s) * 1024 + lane * 16)[e] = (int8_t)part[p];
+                            lrow[d] = (int8_t)L;
+                            l2 += (double)(L * L);
                             const double xt = g * (double)q;   // the column as the kernel sees it
                             mudot += (mu[d] - shift) * xt;
                             nrm2 += xt * xt;
@@ -94,6 +111,7 @@ static void pack_segment_i8(const double *rows, uint64_t n, uint64_t D, const do
             terms[32 + i] = (float)(mudot + 0.5 * nrm2);
             kappa[col0 + r] = colnorm[col0 + r] > 0.0 ? std::sqrt(d2) / colnorm[col0 + r] : (d2 > 0.0 ? 1.0 : 0.0);
             hsum[col0 + r] = std::fabs(xsum);
+            lam[col0 + r] = g * std::sqrt(l2);
         }
     });
 }
@@ -103,33 +121,44 @@ int phk_model_build_i8(phk_model *m, const double *pos, const double *neg, const
     const uint64_t D = m->D;
     if (D == FAST_D || D % 256 != 0) return PHK_OK;
     const uint64_t nblk = (uint64_t)m->n_rblk_ref + m->n_rblk_pos + m->n_rblk_neg;
-    const uint64_t rec_bytes = D / (32 * I8_KS) * I8_APIECES * 1024;
+    const uint64_t nchunk = D / (32 * I8_KS);
+    const uint64_t rec3_bytes = nchunk * 3 * I8_KS * 1024, rec2_bytes = nchunk * 2 * I8_KS * 1024;
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
-    std::vector<uint8_t> rec((nblk + 2 * I8_CT) * rec_bytes, 0);   // padding blocks: the sweep's prefetch runs past the end unchecked
-    std::vector<float> term((nblk + I8_CT) * 64, 0.0f);   // a tile's I8_CT blocks are fetched as one piece: padding blocks
-    for (uint64_t b = nblk; b < nblk + I8_CT; ++b)
+    // padding blocks: the sweep's prefetch runs past the end unchecked; a tile's terms are fetched as whole 1 KiB pieces
+    std::vector<uint8_t> rec3((nblk + 2 * I8_CT_MAX) * rec3_bytes, 0), rec2((nblk + 2 * I8_CT_MAX) * rec2_bytes, 0);
+    std::vector<int8_t> low(ncols * D, 0);
+    std::vector<float> term((nblk + 2 * I8_CT_MAX + 4) * 64, 0.0f);
+    for (uint64_t b = nblk; b < nblk + 2 * I8_CT_MAX + 4; ++b)
         for (int i = 0; i < 32; ++i) term[b * 64 + 32 + i] = 1.0e30f;
-    std::vector<double> kappa(ncols, 0.0), hsum(ncols, 0.0);
+    std::vector<double> kappa(ncols, 0.0), hsum(ncols, 0.0), lam(ncols, 0.0);
     {
         std::vector<double> train(m->M * D);
         std::copy(pos, pos + m->n_pos * D, train.begin());
         std::copy(neg, neg + m->n_neg * D, train.begin() + m->n_pos * D);
-        pack_segment_i8(train.data(), m->M, D, mu, colnorm, rec, term, rec_bytes, 0, kappa, hsum, 0);
+        pack_segment_i8(train.data(), m->M, D, mu, colnorm, rec3, rec2, low, term, 0, kappa, hsum, lam, 0);
     }
-    if (m->n_cpos) pack_segment_i8(cpos, m->n_cpos, D, mu, colnorm, rec, term, rec_bytes, m->n_rblk_ref, kappa, hsum, m->M);
+    if (m->n_cpos) pack_segment_i8(cpos, m->n_cpos, D, mu, colnorm, rec3, rec2, low, term, m->n_rblk_ref, kappa, hsum, lam, m->M);
     if (m->n_cneg)
-        pack_segment_i8(cneg, m->n_cneg, D, mu, colnorm, rec, term, rec_bytes, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, kappa,
-                        hsum, m->M + m->n_cpos);
+        pack_segment_i8(cneg, m->n_cneg, D, mu, colnorm, rec3, rec2, low, term, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, kappa,
+                        hsum, lam, m->M + m->n_cpos);
     m->kappa8 = m->hsum8 = 0.0;
+    m->lam8[0] = m->lam8[1] = m->lam8[2] = 0.0;
     for (uint64_t c = 0; c < ncols; ++c) {
         m->kappa8 = kappa[c] > m->kappa8 ? kappa[c] : m->kappa8;
         m->hsum8 = hsum[c] > m->hsum8 ? hsum[c] : m->hsum8;
+        const int sg = c < m->M ? 0 : (c < m->M + m->n_cpos ? 1 : 2);
+        m->lam8[sg] = lam[c] > m->lam8[sg] ? lam[c] : m->lam8[sg];
     }
-    if (hipMalloc(&m->d_A8, rec.size()) != hipSuccess) return PHK_ERR_NOMEM;
-    if (hipMemcpy(m->d_A8, rec.data(), rec.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    if (hipMalloc(&m->d_A8, rec3.size()) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMemcpy(m->d_A8, rec3.data(), rec3.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    if (hipMalloc(&m->d_A8h, rec2.size()) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMemcpy(m->d_A8h, rec2.data(), rec2.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    if (hipMalloc((void **)&m->d_L8, low.size() + 64) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMemcpy(m->d_L8, low.data(), low.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     if (hipMalloc(&m->d_T8, term.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMemcpy(m->d_T8, term.data(), term.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
-    m->rec8_bytes = rec_bytes;
+    m->rec8_bytes = rec3_bytes;
+    m->rec8h_bytes = rec2_bytes;
     return PHK_OK;
 }
 
@@ -187,9 +216,9 @@ __global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_
 }
 
 // ------------------------------------------------------------------------------------
-// the sweep: a wave keeps 32 queries x I8_CT column blocks x 3 parts in int32 accumulators (192 registers) and walks the
-// dimensions in chunks of 64.  Everything a workgroup needs for one (tile, chunk) step -- the 3 x 2 fragments of each of
-// the tile's I8_CT column blocks AND the 2 query fragments of each of its 8 waves, 40 pieces of 1 KiB -- is one "step
+// the sweep: a wave keeps 32 queries x CT column blocks x NP parts in int32 accumulators (192 registers) and walks the
+// dimensions in chunks of 64.  Everything a workgroup needs for one (tile, chunk) step -- the NP x 2 fragments of each of
+// the tile's CT column blocks AND the 2 query fragments of each of its 8 waves, 40 pieces of 1 KiB -- is one "step
 // set" in LDS, filled by LDS-DMA (5 pieces per wave) and kept in a ring of I8_NBUF sets: the set of step i + 2 is
 // requested while step i computes (24 MFMAs per wave and step, ~1 us: two steps cover an L2 / fabric round trip), and
 // a wave waits with s_waitcnt vmcnt(5) for ITS pieces of the current set only, then the barrier.  No vector-memory
@@ -207,21 +236,42 @@ __global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_
 // per CU (-DI8_NW=4 -DI8_NBUF=2) are 25 % slower: twice the column bytes per MFMA through L2 and a one-step prefetch.
 // Segment handling, candidate lists, column groups (2-D launch) as phk_knn_f16_general_kernel.
 // ------------------------------------------------------------------------------------
-#define I8_SET_PIECES (I8_CT * I8_APIECES + I8_NW * I8_KS)   // 40
-#define I8_SET_BYTES (I8_SET_PIECES * 1024)
 #ifndef I8_NBUF
 #define I8_NBUF 3
 #endif
-#define I8_PER_WAVE (I8_SET_PIECES / I8_NW)                   // 5 (8 waves), 8 (4 waves)
-#define I8_REQ_STRIDE (3 * I8_KS * I8_CT / I8_PER_WAVE)       // one request every so many MFMAs
-static_assert(I8_SET_PIECES % I8_NW == 0 && (I8_CT * I8_APIECES) % I8_NW == 0 && I8_NBUF >= 2, "pieces per wave");
+template <int NP, int CT>
+struct I8Shape {
+    static constexpr int APIECES = NP * I8_KS;                     // 1 KiB pieces per (block, chunk): NP parts x I8_KS k-steps
+    static constexpr int SET_PIECES = CT * APIECES + I8_NW * I8_KS;   // 40
+    static constexpr int SET_BYTES = SET_PIECES * 1024;
+    static constexpr int PER_WAVE = SET_PIECES / I8_NW;            // 5 (8 waves)
+    static constexpr int NX = NP * I8_KS * CT;                     // 24 MFMAs per step
+    static constexpr int REQ_STRIDE = NX / PER_WAVE;               // one request every so many MFMAs
+    static constexpr int TERM_PIECES = (CT * 256 + 1023) / 1024;   // the tile's column terms: CT blocks x 64 floats
+    static constexpr int LDS_BYTES = I8_NBUF * SET_BYTES + TERM_PIECES * 1024;
+    static_assert(SET_PIECES % I8_NW == 0 && (CT * APIECES) % I8_NW == 0 && I8_NBUF >= 2 && NX % 4 == 0 && CT <= I8_CT_MAX &&
+                      TERM_PIECES <= I8_NW, "pieces per wave");
+};
 
+// a wave-uniform pointer the compiler may have computed in the vector ALU (64-bit multiplies), pinned into scalar registers:
+// the DMA instruction's base operand is an "s" constraint of inline asm, which is not legalised for it
+template <typename T>
+__device__ __forceinline__ const T *i8_uniform_ptr(const T *q) {
+    const uint64_t a = (uint64_t)(uintptr_t)q;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return reinterpret_cast<const T *>((uintptr_t)(((uint64_t)hi << 32) | lo));
+}
+
+template <int NP, int CT>
 __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kernel(
     const uint4 *__restrict__ Bq, uint64_t N, uint32_t nchunk, const uint4 *__restrict__ A8, uint64_t rec_u4,
     const uint4 *__restrict__ T8, const uint32_t *__restrict__ rowsum, const uint32_t *__restrict__ big, uint32_t blk0, uint32_t nblk_ref, uint32_t nblk_pos,
     uint32_t nblk_neg, float *__restrict__ cand_v, uint32_t *__restrict__ cand_i, float *__restrict__ cand_u, uint32_t ngroups,
     uint64_t set_bytes) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // I8_NBUF step sets + 1 KiB: the tile's column terms
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // I8_NBUF step sets + the tile's column terms
+    typedef I8Shape<NP, CT> SH;
+    constexpr int I8_CT = CT, I8_APIECES = SH::APIECES, I8_SET_BYTES = SH::SET_BYTES, I8_PER_WAVE = SH::PER_WAVE,
+                  I8_REQ_STRIDE = SH::REQ_STRIDE;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -250,7 +300,7 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
 
     // The prefetch head.  Piece i of this wave (piece p = wave + I8_NW i of the set) has a running scalar pointer: a column
     // fragment (block cb = p / 6 of the tile, piece r = p % 6 of its chunk) advances by one chunk of its block's record per
-    // step and, after the last chunk, to chunk 0 of the block I8_CT further on (records are contiguous: 3 nchunk + 1 chunks
+    // step and, after the last chunk, to chunk 0 of the block I8_CT further on (records are contiguous: (CT - 1) nchunk + 1 chunks
     // ahead); a query fragment (wave w's block, k-step s) advances by one chunk and wraps.  No bounds are applied: a
     // partial last tile and the I8_NBUF - 1 sets requested past the end read the records' padding blocks
     // (phk_model_build_i8) or the next segment's columns, and those results are never used.
@@ -269,6 +319,7 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
             qw = qw < nqb ? qw : nqb - 1;              // padding waves re-read the last block; nothing is written
             pp[i] = reinterpret_cast<const char *>(Bq) + (qw * nchunk * I8_KS + s) * 1024;
         }
+        pp[i] = i8_uniform_ptr(pp[i]);
         pl[i] = lds_base + p * 1024u;
     }
     const uint32_t lane16 = (uint32_t)lane * 16u;
@@ -327,20 +378,20 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
     // LDS reads of a step are in flight, the one stretch it would otherwise idle through in every step (both waves of a
     // SIMD stand at the same barrier).  At the first step of a tile those three run on stale fragments into accumulators
     // that are cleared right after; after the last step they are issued before the epilogue.
-    constexpr int NX = 3 * I8_KS * I8_CT;   // 24 MFMAs per step: x = (k-step, column block, part)
+    constexpr int NX = SH::NX;   // 24 MFMAs per step: x = (k-step, column block, part)
     i32x4 fa[4], fb[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i] = i32x4{0, 0, 0, 0};
     fb[0] = fb[1] = i32x4{0, 0, 0, 0};
-#define I8_A_OFF(x) ((((x) / 3 % I8_CT) * I8_APIECES + ((x) % 3) * I8_KS + (x) / (3 * I8_CT)) * 1024)
+#define I8_A_OFF(x) ((((x) / NP % I8_CT) * I8_APIECES + ((x) % NP) * I8_KS + (x) / (NP * I8_CT)) * 1024)
 #define I8_DS_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(la), "n"(off))
-#define I8_MFMA(x) acc[(x) / 3 % I8_CT][(x) % 3] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[(x) & 3], fb[(x) / (3 * I8_CT)], acc[(x) / 3 % I8_CT][(x) % 3], 0, 0, 0)
+#define I8_MFMA(x) acc[(x) / NP % I8_CT][(x) % NP] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[(x) & 3], fb[(x) / (NP * I8_CT)], acc[(x) / NP % I8_CT][(x) % NP], 0, 0, 0)
     for (uint32_t t = 0; t < ntile; ++t) {
-        i32x16 acc[I8_CT][3];
+        i32x16 acc[I8_CT][NP];
 #pragma unroll
         for (int cb = 0; cb < I8_CT; ++cb)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[cb][p][r] = 0;
         for (uint32_t c = 0; c < nchunk; ++c) {
@@ -356,10 +407,10 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
 #if defined(I8_TIMERS) && I8_TIMERS == 2
             I8_TM(tm_bar);
 #endif
-            if (c == 0 && wave == 0) {   // the tile's column terms (I8_CT blocks x 64 floats): older than the pieces requested below,
-                                         // so the next step's vmcnt wait covers it; read in the epilogue, many barriers on
-                const uint4 *g = T8 + ((uint64_t)blk0 + (uint64_t)t * I8_CT) * 16;
-                const uint32_t lp = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(I8_NBUF * I8_SET_BYTES));
+            if (c == 0 && wave < SH::TERM_PIECES) {   // the tile's column terms (I8_CT blocks x 64 floats, whole 1 KiB pieces): older than
+                                         // the pieces requested below, so the next step's vmcnt wait covers them; read in the epilogue, many barriers on
+                const uint4 *g = i8_uniform_ptr(T8 + ((uint64_t)blk0 + (uint64_t)t * I8_CT) * 16 + (uint32_t)wave * 64u);
+                const uint32_t lp = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(I8_NBUF * I8_SET_BYTES) + (uint32_t)wave * 1024u);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(g), "s"(lp) : "memory");
             }
             // 24 column fragments in sequence, read from LDS four MFMAs ahead of their use through a ring of four fragment
@@ -378,9 +429,9 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
             asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(fb[1]) : "v"(lb));
             if (c == 0) {   // (first step of the tile: those three ran on stale fragments)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int x = NX - 3; x < NX; ++x)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[I8_CT - 1][p][r] = 0;
+                    for (int r = 0; r < 16; ++r) acc[x / NP % I8_CT][x % NP][r] = 0;
             }
 #pragma unroll
             for (int x = 0; x < NX - 3; ++x) {
@@ -423,9 +474,15 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
                     for (int e2 = 0; e2 < 2; ++e2) {   // two values per packed float32 instruction
                         const int r = 4 * m4 + 2 * e2;
                         // 256 S_H + S_M as one exact 32-bit integer (|c - c0|_1 <= I8_L1_MAX), then two conversions per value
-                        const f32x2 fhm = {(float)(acc[cb][0][r] * 256 + acc[cb][1][r]), (float)(acc[cb][0][r + 1] * 256 + acc[cb][1][r + 1])},
-                                    fl = {(float)acc[cb][2][r], (float)acc[cb][2][r + 1]};
-                        const f32x2 sf = __builtin_elementwise_fma(c256, fhm, fl);
+                        // (two parts: one, and the value is 256 g (256 S_H + S_M) - T b: the full one less g S_L)
+                        const f32x2 fhm = {(float)(acc[cb][0][r] * 256 + acc[cb][1][r]), (float)(acc[cb][0][r + 1] * 256 + acc[cb][1][r + 1])};
+                        f32x2 sf;
+                        if (NP == 3) {
+                            const f32x2 fl = {(float)acc[cb][NP - 1][r], (float)acc[cb][NP - 1][r + 1]};
+                            sf = __builtin_elementwise_fma(c256, fhm, fl);
+                        } else {
+                            sf = c256 * fhm;   // (exact)
+                        }
                         const f32x2 val = __builtin_elementwise_fma(sf, gg[e2], negT2 * bb[e2]);
                         // A value that can enter the list (> everything the list dropped) is parked in the lane's pending slot
                         // with its position in the tile (a compile-time constant); the 4-deep sorted insert -- 20 instructions
@@ -498,7 +555,7 @@ __global__ void phk_merge_list_sets_kernel(float *__restrict__ cv, uint32_t *__r
 // proposal pass for uint32 counts at D = 512 .. 4096: row sums (if needed) -> int8 query fragments -> sweep (-> merge)
 int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum, uint64_t nb,
                                    uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu, uint32_t groups,
-                                   uint64_t set_bytes, bool *accepted) {
+                                   uint64_t set_bytes, bool two_parts, bool *accepted) {
     const uint64_t D = m->D, nchunk = D / (32 * I8_KS), nchunk256 = D / 256;
     const uint64_t nqb = phk_div_up(nb, 32);
     void *bq, *rs = nullptr, *bg;
@@ -523,15 +580,21 @@ int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint3
     PHK_HIP(hipStreamSynchronize(ctx->stream));
     *accepted = nbig <= (nb / 256 > 16 ? nb / 256 : 16);
     if (!*accepted) return PHK_OK;
-    const uint64_t rec_u4 = m->rec8_bytes / 16;
     const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
     const uint32_t ng = (groups > 1 && nref >= 8u * groups && nqb >= 64) ? groups : 1u;
     const uint64_t nqg = phk_div_up(nqb, I8_NW);
     const unsigned gblocks = ng > 1 ? (unsigned)(phk_div_up(nqg, 8) * 8 * ng) : (unsigned)nqg;
-    PHK_LAUNCH(ctx, "phk_knn_i8_general_kernel",
-               (phk_knn_i8_general_kernel<<<dim3(gblocks), dim3(64 * I8_NW), I8_NBUF * I8_SET_BYTES + 1024, ctx->stream>>>(
-                   (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_A8, rec_u4, (const uint4 *)m->d_T8, d_rowsum, (const uint32_t *)bg, blk0, nref,
-                   npos, nneg, cv, ci, cu, ng, set_bytes)));
+    if (two_parts) {
+        PHK_LAUNCH(ctx, "phk_knn_i8_general_kernel",
+                   (phk_knn_i8_general_kernel<2, 6><<<dim3(gblocks), dim3(64 * I8_NW), I8Shape<2, 6>::LDS_BYTES, ctx->stream>>>(
+                       (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_A8h, m->rec8h_bytes / 16, (const uint4 *)m->d_T8, d_rowsum,
+                       (const uint32_t *)bg, blk0, nref, npos, nneg, cv, ci, cu, ng, set_bytes)));
+    } else {
+        PHK_LAUNCH(ctx, "phk_knn_i8_general_kernel",
+                   (phk_knn_i8_general_kernel<3, 4><<<dim3(gblocks), dim3(64 * I8_NW), I8Shape<3, 4>::LDS_BYTES, ctx->stream>>>(
+                       (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_A8, m->rec8_bytes / 16, (const uint4 *)m->d_T8, d_rowsum,
+                       (const uint32_t *)bg, blk0, nref, npos, nneg, cv, ci, cu, ng, set_bytes)));
+    }
     if (ng > 1) {
         PHK_LAUNCH(ctx, "phk_merge_list_sets_kernel",
                    phk_merge_list_sets_kernel<<<dim3((unsigned)phk_div_up(2 * nb, 256)), dim3(256), 0, ctx->stream>>>(
@@ -542,6 +605,7 @@ int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint3
 
 int phk_score_i8_init_device(phk_ctx *ctx) {
     (void)ctx;
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_i8_general_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, I8_NBUF * I8_SET_BYTES + 1024));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_i8_general_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, I8Shape<3, 4>::LDS_BYTES));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_i8_general_kernel<2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, I8Shape<2, 6>::LDS_BYTES));
     return PHK_OK;
 }

@@ -168,8 +168,11 @@ void phk_model_free_fast(phk_model *m) {
     if (m->d_Af16) (void)hipFree(m->d_Af16);
     m->d_Af16 = nullptr;
     if (m->d_A8) (void)hipFree(m->d_A8);
+    if (m->d_A8h) (void)hipFree(m->d_A8h);
+    if (m->d_L8) (void)hipFree(m->d_L8);
     if (m->d_T8) (void)hipFree(m->d_T8);
-    m->d_A8 = nullptr;
+    m->d_A8 = m->d_A8h = nullptr;
+    m->d_L8 = nullptr;
     m->d_T8 = nullptr;
     if (m->d_term_orig) (void)hipFree(m->d_term_orig);
     if (m->d_col_mask) (void)hipFree(m->d_col_mask);
@@ -370,6 +373,12 @@ struct RerankParams {
     uint64_t slow_cap = 0;
     uint32_t *stat_total = nullptr;         // [0] += fallback queue length, [1] += orderings decided by exact distances
     const uint32_t *exact_extra = nullptr;  // exact-distance decisions of an earlier pass of the same batch
+    // lists of the two-part int8 sweep (score_i8.hip; phk_rerank_kernel<.., I8H>): a value lacks g_j S_L, S_L = the exact
+    // integer product of c - c0 with the column's L digits -- |.| <= |c - c0| lam8[segment] per unit of row sum
+    const int8_t *L8 = nullptr;             // [M + n_cpos + n_cneg][D] L digits, row-major
+    const float *T8 = nullptr;              // per 32-column block: 32 quanta g_j (+ 32 bias terms)
+    uint32_t t8_blk[3] = {0, 0, 0};         // first block of each segment
+    double lam8[3] = {0, 0, 0};
 };
 
 // Sums inside each group of 16 lanes = one DPP row: rotations by 8, 4, 2, 1 (row_ror) leave the total on every lane, in
@@ -548,7 +557,8 @@ template <int DSUB>
 __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
                                 const double (&qd)[4 * DSUB], double nqp2, const ErrBound &eb, const double vs,
                                 const double *rows, const double *colnorm, bool want_d2, int lane,
-                                uint32_t (&out_idx)[3], double &out_d2, float pre_v, uint32_t pre_i, float pre_u) {
+                                uint32_t (&out_idx)[3], double &out_d2, float pre_v, uint32_t pre_i, float pre_u,
+                                bool allow_margin = true, double u_extra = 0.0) {
     // lanes 0..7 hold the 8 candidates (half = lane>>2, slot = lane&3), out of the lists the caller loaded up front
     float v = __shfl(pre_v, seg * 8 + (lane & 7));
     uint32_t ix = __shfl(pre_i, seg * 8 + (lane & 7));
@@ -557,7 +567,8 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
     // vs: computed values -> v units (a power of two, divided by the row sum for the count-exact proposal)
     // every column the two half-lists dropped has a computed value <= the larger of their
     // best-dropped values (-3e38 when nothing real was dropped)
-    const double U = fmax((double)__shfl(pre_u, seg * 2), (double)__shfl(pre_u, seg * 2 + 1)) * vs;
+    // (u_extra: lists whose values are short of the true ones by up to that much -- the two-part int8 sweep)
+    const double U = fmax((double)__shfl(pre_u, seg * 2), (double)__shfl(pre_u, seg * 2 + 1)) * vs + u_extra;
     // rank of each candidate among the 8 (descending v, ties by lane)
     int rank = 0;
 #pragma unroll
@@ -576,7 +587,7 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
     }
     const double nqp = sqrt(nqp2);
     const double eps_g = eb(p.rmax);  // holds for every column
-    if (ri[need - 1] < ncols) {
+    if (allow_margin && ri[need - 1] < ncols) {
         // upper bound of the true need-th nearest distance from the computed candidates
         const double d2up = fmax(nqp2 - 2.0 * ((double)rv[need - 1] * vs - eps_g), 0.0);
         const double R0 = fmin(p.rmax, (nqp + sqrt(d2up)) * (1.0 + 1e-6));
@@ -679,7 +690,10 @@ __device__ __forceinline__ uint64_t certify_segments(const RerankParams &p, doub
 // one query, one wave (the body of phk_rerank_kernel)
 // MU_LDS: the training mean is read from LDS at byte offset mu_lds (address space 3: a generic pointer would turn every
 // read into a flat load, which also counts on the vector-memory counter and serialises the kernel's other loads)
-template <int SRC, int DSUB, bool MU_LDS>
+__device__ __forceinline__ int wave_sum_i32(int x) { return (int)wave_sum((uint32_t)x); }
+
+// I8H: the lists come from the two-part int8 sweep (see RerankParams::L8 and the refinement step below)
+template <int SRC, int DSUB, bool MU_LDS, bool I8H>
 __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, const RerankParams &p, uint64_t q, uint32_t mu_lds,
                                                  int lane) {
     constexpr int D = 256 * DSUB;
@@ -690,6 +704,7 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     bool nan_row = false;
     double ssq = 0.0, rtq = 1.0;   // count rows: sum of squares, reciprocal of the row sum
     CenteredOperand cop = {0.0, 0.0, 0.0, 0.0};
+    uint32_t xq[I8H ? DSUB : 1];   // I8H: this lane's centred counts as four int8 per 256-dimension chunk (the sweep's operand)
     // The candidate lists of all three segments are requested first, beside the query row: lane l < 24 holds candidate l & 7
     // of segment l >> 3, lane l < 6 the best dropped value of half-list l.  Loaded where they are used, each segment's
     // lists were one more dependent round trip in a kernel that is a chain of them (10 M queries at configs[2]).
@@ -718,6 +733,13 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         double sq = 0.0, qc2 = 0.0;
         const double rcen = (double)phk_row_center(s, D);
         rtq = ry;
+        if (I8H) {
+            const uint32_t cen = phk_row_center(s, D);
+#pragma unroll
+            for (int sub = 0; sub < DSUB; ++sub)   // (rows beyond the int8 range have empty lists: their bytes are never used)
+                xq[sub] = ((c[sub].x - cen) & 0xFFu) | (((c[sub].y - cen) & 0xFFu) << 8) | (((c[sub].z - cen) & 0xFFu) << 16) |
+                          ((c[sub].w - cen) << 24);
+        }
 #pragma unroll
         for (int sub = 0; sub < DSUB; ++sub) {
             const double x0 = (double)c[sub].x, x1 = (double)c[sub].y, x2 = (double)c[sub].z, x3 = (double)c[sub].w;
@@ -804,15 +826,81 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     double knn = 0.0, cen = 0.0;
     uint32_t idx[3];
     double d2;
+    // Lists of the two-part int8 sweep: a value w^h lacks g_j S_L, at most el = |c - c0| / T * lam8[segment] in v units.  With
+    // h_need the need-th best list value of a segment and e_h = el + eps: every column that can be among the `need` nearest
+    // has w^h >= h_need - 2 e_h (the leaders' true values are >= h_need - e_h; below the window a true value is < that).  The
+    // window's members that are list members get g_j S_L added -- an exact integer dot product with the column's L digits,
+    // 4 DSUB bytes per lane -- and then carry the three-part sweep's value; the window must end above everything the
+    // half-lists dropped (uok), else the segment is left to the exact candidate distances.  Lane l < 24 works for candidate
+    // l & 7 of segment l >> 3, as in certify_segments.
+    uint64_t uok = ~0ull;
+    if (I8H) {
+        const int g3 = lane >> 3, gb = lane & 56;
+        const uint32_t ncols = g3 == 0 ? (uint32_t)p.M : g3 == 1 ? (uint32_t)p.n_cpos : g3 == 2 ? (uint32_t)p.n_cneg : 0u;
+        const int need = g3 == 0 ? p.kn : 1;
+        const bool valid = pre_i < ncols;
+        const float gq = valid ? p.T8[(uint64_t)(p.t8_blk[g3 < 3 ? g3 : 0] + (pre_i >> 5)) * 64 + (pre_i & 31u)] : 0.0f;
+        const uint32_t gcol = pre_i + (g3 == 0 ? 0u : g3 == 1 ? (uint32_t)p.M : (uint32_t)(p.M + p.n_cpos));
+        const float v = valid ? pre_v : -3.0e38f;
+        int rank = 0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const float ov = __shfl(v, gb | m);
+            rank += (ov > v || (ov == v && m < (lane & 7))) ? 1 : 0;
+        }
+        const unsigned long long bal = __ballot(valid && rank == need - 1);
+        const unsigned long long mine = (bal >> gb) & 0xFFull;
+        const float hneed = __shfl(v, gb + (mine ? __ffsll((long long)mine) - 1 : 0));
+        const double el = cop.Q * p.lam8[g3 < 3 ? g3 : 0] * (1.0 + 1.0e-6);
+        const double thr = (double)hneed * vs - 2.0 * (el + eb(p.rmax));
+        const bool inwin = valid && mine != 0 && (double)v * vs >= thr;
+        const double Ug = (double)fmaxf(__shfl(pre_u, 2 * (g3 < 3 ? g3 : 0)), __shfl(pre_u, 2 * (g3 < 3 ? g3 : 0) + 1)) * vs;
+        uok = __ballot(mine != 0 && Ug < thr && (lane & 7) == 0 && lane < 24);
+        // a window of exactly `need` members is decided as it stands (the members ARE the nearest; the margin test below
+        // passes on the list values, the next one lying 2 e_h lower): only wider windows are refined
+        unsigned long long wm = __ballot(inwin && lane < 24);
+        const bool wide = __popcll((wm >> gb) & 0xFFull) > need;
+        wm = __ballot(inwin && wide && lane < 24);
+        while (wm) {   // wave-uniform; two members per round trip
+            const int m0 = __ffsll((long long)wm) - 1;
+            wm &= wm - 1;
+            const int m1 = wm ? __ffsll((long long)wm) - 1 : m0;
+            wm &= wm - 1;
+            const uint32_t *r0 = reinterpret_cast<const uint32_t *>(p.L8 + (uint64_t)__shfl(gcol, m0) * D) + lane;
+            const uint32_t *r1 = reinterpret_cast<const uint32_t *>(p.L8 + (uint64_t)__shfl(gcol, m1) * D) + lane;
+            uint32_t w0[DSUB], w1[DSUB];
+#pragma unroll
+            for (int sub = 0; sub < DSUB; ++sub) {
+                w0[sub] = r0[64 * sub];
+                w1[sub] = r1[64 * sub];
+            }
+            int a0 = 0, a1 = 0;
+#pragma unroll
+            for (int sub = 0; sub < DSUB; ++sub) {
+                a0 = __builtin_amdgcn_sdot4((int)xq[sub], (int)w0[sub], a0, false);
+                a1 = __builtin_amdgcn_sdot4((int)xq[sub], (int)w1[sub], a1, false);
+            }
+            a0 = wave_sum_i32(a0);
+            a1 = wave_sum_i32(a1);
+            if (lane == m0) pre_v = fmaf((float)a0, gq, pre_v);
+            if (lane == m1 && m1 != m0) pre_v = fmaf((float)a1, gq, pre_v);
+        }
+    }
     // all three margin tests side by side; what they certify needs no further list work
     uint32_t cri[3];
-    const uint64_t certified = certify_segments(p, nqp2, nqp_up, eb, vs, lane, pre_v, pre_i, cri);
+    uint64_t certified = certify_segments(p, nqp2, nqp_up, eb, vs, lane, pre_v, pre_i, cri);
+    if (I8H) {
+        certified &= uok;
+        if (lane == 0 && (uok & 0x010101ull) != 0x010101ull && p.counters) atomicAdd(p.counters + 9, 1u);   // statistics: a window reached past the lists
+    }
+    const double uex0 = I8H ? cop.Q * p.lam8[0] * (1.0 + 1.0e-6) : 0.0, uex1 = I8H ? cop.Q * p.lam8[1] * (1.0 + 1.0e-6) : 0.0,
+                 uex2 = I8H ? cop.Q * p.lam8[2] * (1.0 + 1.0e-6) : 0.0;
     if (p.method & PHK_METHOD_KNN) {
         if (certified & 1ull) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) idx[r] = __shfl(cri[r], 0);
         } else {
-            ok = resolve_segment<DSUB>(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, lane, idx, d2, pre_v, pre_i, pre_u);
+            ok = resolve_segment<DSUB>(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, lane, idx, d2, pre_v, pre_i, pre_u, !I8H, uex0);
         }
         if (ok) {
             int votes = 0;
@@ -825,12 +913,12 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         if (certified & (1ull << 8))
             dp2 = exact_d2<DSUB>(qd, p.C64 + (uint64_t)__shfl(cri[0], 8) * D, lane);
         else
-            ok = resolve_segment<DSUB>(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, vs, p.C64, p.colnorm + p.M, true, lane, idx, dp2, pre_v, pre_i, pre_u);
+            ok = resolve_segment<DSUB>(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, vs, p.C64, p.colnorm + p.M, true, lane, idx, dp2, pre_v, pre_i, pre_u, !I8H, uex1);
         if (ok && (certified & (1ull << 16)))
             dn2 = exact_d2<DSUB>(qd, p.C64 + (p.n_cpos + (uint64_t)__shfl(cri[0], 16)) * D, lane);
         else if (ok)
             ok = resolve_segment<DSUB>(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, vs, p.C64 + p.n_cpos * D,
-                                 p.colnorm + p.M + p.n_cpos, true, lane, idx, dn2, pre_v, pre_i, pre_u);
+                                 p.colnorm + p.M + p.n_cpos, true, lane, idx, dn2, pre_v, pre_i, pre_u, !I8H, uex2);
         if (ok) {
             if (p.pend) {   // two square roots, a division and a tanh in float64 are ~180 instructions of this wave, for one
                             // number: left to a lane-per-query kernel (phk_finish_cen_kernel, the same expressions)
@@ -861,7 +949,7 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
 #ifndef PHK_RERANK_WAVES
 #define PHK_RERANK_WAVES 4
 #endif
-template <int SRC, int DSUB>
+template <int SRC, int DSUB, bool I8H = false>
 __global__ __launch_bounds__(256, (DSUB <= 4 ? PHK_RERANK_WAVES : 1)) void phk_rerank_kernel(const void *__restrict__ src, RerankParams p) {
     constexpr int D = 256 * DSUB;
     constexpr bool WALK = DSUB >= 8;
@@ -879,9 +967,9 @@ __global__ __launch_bounds__(256, (DSUB <= 4 ? PHK_RERANK_WAVES : 1)) void phk_r
     uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (WALK) {
         for (; w < nq; w += stride)
-            rerank_one_query<SRC, DSUB, true>(src, p, p.slow_back == 2 ? (uint64_t)(p.slow_list[w] & 0x3FFFFFFFu) : w, mu_lds, lane);
+            rerank_one_query<SRC, DSUB, true, I8H>(src, p, p.slow_back == 2 ? (uint64_t)(p.slow_list[w] & 0x3FFFFFFFu) : w, mu_lds, lane);
     } else if (w < nq) {   // (no loop: its live state costs the registers that keep four waves per SIMD)
-        rerank_one_query<SRC, DSUB, false>(src, p, p.slow_back == 2 ? (uint64_t)(p.slow_list[w] & 0x3FFFFFFFu) : w, 0u, lane);
+        rerank_one_query<SRC, DSUB, false, I8H>(src, p, p.slow_back == 2 ? (uint64_t)(p.slow_list[w] & 0x3FFFFFFFu) : w, 0u, lane);
     }
 }
 
@@ -2388,16 +2476,20 @@ static int launch_rerank(phk_ctx *ctx, unsigned blocks, const void *src, const R
             break;
         }
         case 512:
-            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 2><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p));
+            if (SRC == 0 && p.L8) { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<0, 2, true><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
+            else { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<SRC, 2><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             break;
         case 1024:
-            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 4><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p));
+            if (SRC == 0 && p.L8) { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<0, 4, true><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
+            else { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<SRC, 4><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             break;
         case 2048:
-            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 8><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p));
+            if (SRC == 0 && p.L8) { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<0, 8, true><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
+            else { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<SRC, 8><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             break;
         case 4096:
-            PHK_LAUNCH(ctx, "phk_rerank_kernel", phk_rerank_kernel<SRC, 16><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p));
+            if (SRC == 0 && p.L8) { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<0, 16, true><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
+            else { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<SRC, 16><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             break;
         default:
             phk_set_error("phk_score: no decision kernel for D = %llu", (unsigned long long)p.D);
@@ -2444,6 +2536,9 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // kernel issues 4) unless the model's centroids were replaced or a column mask is set (its records are not updated by
     // the cross-validation service); proposal=cxf keeps the f16 count-exact kernel
     const bool use_i8 = use_cx && D != FAST_D && m->d_A8 && !m->bf_stale && !hi_gen && !(prop[0] == 'c' && prop[1] == 'x' && prop[2] == 'f');
+    // its two-part form (H and M digits in the sweep, the L product added by the decision kernel to the window's members) is
+    // the default; proposal=i83 keeps all three parts in the sweep
+    const bool i8_two = use_i8 && m->d_A8h && m->d_L8 && !(prop[0] == 'i' && prop[1] == '8' && prop[2] == '3');
     const uint64_t cap2 = second ? (nb_max / 8 > 4096 ? nb_max / 8 : (nb_max < 4096 ? nb_max : 4096)) : 0;
     const uint64_t per_list = nb_max * NSEG * 2, per_list2 = cap2 * NSEG * 2;
     const uint64_t list_bytes = sizeof(float4) + sizeof(uint4) + sizeof(float);
@@ -2521,7 +2616,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         bool i8_now = false;
         if (use_i8)
             PHK_TRY(phk_launch_proposal_i8_general(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu,
-                                                   (uint32_t)gen_sets, set_bytes, &i8_now));
+                                                   (uint32_t)gen_sets, set_bytes, i8_two, &i8_now));
         if (i8_now) {
             // values are T v (per row), from exact integer sums (see ErrBound: int8)
             const double ku = m->kappa8 / 5.9604644775390625e-08;
@@ -2529,6 +2624,13 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             p.eb_cA = 2.0; p.eb_cQ = 4.0; p.eb_cI = 0.0; p.eb_cAmax = 0.0;
             p.eb_cP = ku + 2.0; p.eb_cR = ku * (1.0 + m->kappa8) + 3.0; p.eb_abs = 0.0;
             p.eb_hsum = m->hsum8;
+            if (i8_two) {   // a refined value: one more fused multiply-add on |v| (u |v| <= u (P R + R^2 / 2)); the conversion of S_L
+                            // (|g S_L| <= 2^-15 |x| |y|) is inside cQ, which the two-part value's single conversion leaves room in
+                p.eb_cP += 1.0; p.eb_cR += 1.0;
+                p.L8 = m->d_L8; p.T8 = m->d_T8;
+                p.t8_blk[0] = 0; p.t8_blk[1] = m->n_rblk_ref; p.t8_blk[2] = m->n_rblk_ref + m->n_rblk_pos;
+                for (int sg = 0; sg < 3; ++sg) p.lam8[sg] = m->lam8[sg];
+            }
         } else if (use_cx) {
             // values are T S v (per row); n = 2D/16 instructions on (c - c0) x (r~' S as hi, lo), + 3 for the bias -> fp32,
             // the final fma and slack; the residue of the centring through hsum

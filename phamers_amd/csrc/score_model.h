@@ -31,6 +31,12 @@ struct phk_model {
     float *d_T8 = nullptr;        // [blocks + padding][64]: quanta and bias terms
     uint64_t rec8_bytes = 0;
     double kappa8 = 0.0, hsum8 = 0.0;
+    // two-part sweep (the default): records of the H and M parts only; the L digits row-major for the decision stage,
+    // [M + n_cpos + n_cneg][D]; lam8[s] = max_j g_j |L_j|_2 over segment s's columns (what a two-part value can lack)
+    void *d_A8h = nullptr;
+    int8_t *d_L8 = nullptr;
+    uint64_t rec8h_bytes = 0;
+    double lam8[3] = {0, 0, 0};
     float *d_mu32 = nullptr;      // centring vector, fp32
     double *d_mu64 = nullptr;     // centring vector, fp64
     // cross-validation service (phk_model_set_centroids / phk_model_set_column_mask): the train segment's column terms as
@@ -85,7 +91,7 @@ int phk_model_build_i8(phk_model *m, const double *pos, const double *neg, const
                        const double *mu, const double *colnorm);
 int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum, uint64_t nb,
                                    uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu,
-                                   uint32_t groups, uint64_t set_bytes, bool *accepted);
+                                   uint32_t groups, uint64_t set_bytes, bool two_parts, bool *accepted);
 int phk_score_i8_init_device(phk_ctx *ctx);
 // Column groups of the general-D sweep's 2-D launch (D >= 2048).  Measured on configs[4] (kernel ms): 1 group 92.9, 2: 89.8,
 // 4: 86.4, 8: 95.1 (and 3 / 5 / 6: no better) -- more groups share a query block's fragments through one XCD's L2, but

@@ -253,29 +253,31 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
     hq[4:8] *= 1000
     d_q = device.DeviceArray.from_host(ctx, hq)
     out = {}
-    # int8 MFMA sweep (default for counts), count-exact f16 general-D kernel, its high-parts-only flavour (opt-in), float64
-    for path in ("i8", "cxf", "hi", "exact"):
+    # int8 MFMA sweep (default for counts: two parts in the sweep, the third added by the decision kernel), the same with all
+    # three parts in the sweep, count-exact f16 general-D kernel, its high-parts-only flavour (opt-in), float64
+    for path in ("i8", "i83", "cxf", "hi", "exact"):
         ctx.set_option("force_exact", "1" if path == "exact" else "0")
-        ctx.set_option("proposal", {"cxf": "cxf", "hi": "hi"}.get(path, ""))
+        ctx.set_option("proposal", {"cxf": "cxf", "hi": "hi", "i83": "i83"}.get(path, ""))
         for method in ("knn", "kmeans", "combo"):
             d_scores = device.DeviceArray(ctx, n_q, np.float64)
             d_status = device.DeviceArray(ctx, 1, np.uint32)
             device.score_counts(ctx, model, d_q, n_q, method, d_scores, d_status)
             out[(path, method)] = d_scores.to_host()
             assert d_status.to_host()[0] == 0
-        if path in ("i8", "cxf"):
+        if path in ("i8", "i83", "cxf"):
             n_fallback, _ = ctx.score_stats()
             assert 4 <= n_fallback < max(n_q // 20, 16), (path, n_fallback)
     ctx.set_option("proposal", "")
     for method in ("knn", "kmeans", "combo"):
         assert np.array_equal(np.sign(out[("hi", method)]), np.sign(out[("exact", method)])), method
         assert helpers.rel_err(out[("hi", method)], out[("exact", method)]) < 1e-9, method
-    for path in ("i8", "cxf"):
+    for path in ("i8", "i83", "cxf"):
         assert np.array_equal(out[(path, "knn")], out[("exact", "knn")]), path
         assert helpers.rel_err(out[(path, "kmeans")], out[("exact", "kmeans")]) < 1e-9, path
         assert helpers.rel_err(out[(path, "combo")], out[("exact", "combo")]) < 1e-9, path
     for method in ("knn", "kmeans", "combo"):   # the decision stage's exact distances are one canonical form: bit-equal
         assert np.array_equal(out[("i8", method)], out[("cxf", method)]), method
+        assert np.array_equal(out[("i8", method)], out[("i83", method)]), method
     out.update({("f16", m): out[("i8", m)] for m in ("knn", "kmeans", "combo")})
     # a batch in which many rows exceed the int8 operand (every 8th row 40 x): the int8 sweep declines it, the f16 kernel
     # takes the whole batch -- same scores, and the 40 x rows are NOT brute-forced
