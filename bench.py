@@ -474,9 +474,11 @@ def main():
         "hbm_bytes_per_contig_all_kernels": round(sum(per_all.values()), 1) if per_all else None}
     # MFMA flops ISSUED per algorithmic flop: 3 (split-query f16: hi.hi + hi.lo + lo.hi), 2 (count-exact: c.r_hi +
     # c.r_lo), 1 (count-exact, high parts only: the low parts are applied to the few candidates by the decision stage),
-    # 3 (int8: the reference column in three int8 parts of a 24-bit fixed-point value; against the int8 peak)
+    # int8 (against the int8 peak): the reference column is a 24-bit fixed-point value in three int8 parts; the default sweep
+    # issues the upper two (the third is applied to the window's candidates by the decision stage), proposal=i83 all three
+    i8_parts = 3.0 if os.environ.get("PHK_PROPOSAL", "") == "i83" else 2.0
     issue = {"phk_knn_f16_kernel": 3.0, "phk_knn_f16c_kernel": 2.0, "phk_knn_f16h_kernel": 1.0,
-             "phk_knn_f16_general_kernel": 2.0, "phk_knn_i8_general_kernel": 3.0}.get(dom)
+             "phk_knn_f16_general_kernel": 2.0, "phk_knn_i8_general_kernel": i8_parts}.get(dom)
     if issue:
         roofline["mfma_issue_frac"] = issue * kernels[dom]["frac"]
 
@@ -488,7 +490,8 @@ def main():
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None,
         "dtype": ("u32 counts + int8 MFMA proposal (exact integer counts x 24-bit fixed-point reference columns in three int8 "
-                  "parts, exact int32 accumulate) + f64 decision") if "phk_knn_i8_general_kernel" in prof else
+                  "parts, exact int32 accumulate; the upper two parts in the sweep, the third added as an exact integer product "
+                  "to the window's candidates) + f64 decision") if "phk_knn_i8_general_kernel" in prof else
                  "u32 counts + f16 MFMA proposal (exact integer counts x fp16 reference parts, f32 accumulate; k=4: high parts in the sweep, low parts added in f64 to the window's candidates) + f64 decision",
         "data": ("synthetic (seeded, device-generated: heavy-tailed lengths 5-500 kb in arbitrary order, per-contig GC "
                  "0.3-0.7, 0.1 % invalid bases); reference matrix: " if ragged else

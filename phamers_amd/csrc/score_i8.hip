@@ -18,6 +18,7 @@
 // with exact integer data by tools/micro/mfma_i8_vs_f16.hip and, through the whole path, by the parity tests.
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "phk_common.h"
@@ -386,15 +387,17 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
 #define I8_A_OFF(x) ((((x) / NP % I8_CT) * I8_APIECES + ((x) % NP) * I8_KS + (x) / (NP * I8_CT)) * 1024)
 #define I8_DS_READ(dst, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(la), "n"(off))
 #define I8_MFMA(x) acc[(x) / NP % I8_CT][(x) % NP] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[(x) & 3], fb[(x) / (NP * I8_CT)], acc[(x) / NP % I8_CT][(x) % NP], 0, 0, 0)
+#define I8_MFMA0(x) acc[(x) / NP % I8_CT][(x) % NP] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[(x) & 3], fb[(x) / (NP * I8_CT)], zero16, 0, 0, 0)
+    i32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0;
     for (uint32_t t = 0; t < ntile; ++t) {
         i32x16 acc[I8_CT][NP];
-#pragma unroll
-        for (int cb = 0; cb < I8_CT; ++cb)
-#pragma unroll
-            for (int p = 0; p < NP; ++p)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[cb][p][r] = 0;
-        for (uint32_t c = 0; c < nchunk; ++c) {
+        // One (tile, chunk) step.  FIRST (chunk 0 of a tile): the accumulators are not cleared -- 192 v_mov per tile and wave,
+        // 6 % of a D = 1024 tile's issue slots -- but written by the first k-step's MFMAs from a zero C operand, and the three
+        // rotated MFMAs at the head (the previous tile's were issued before its epilogue) are left out.
+        auto step = [&](auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             // this wave's pieces of the current set have landed once at most those of the I8_NBUF - 2 later sets are outstanding
 #if defined(I8_TIMERS) && I8_TIMERS == 2   // fine timers: four counter reads per step
             I8_TM(tm_epi);
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
 #if defined(I8_TIMERS) && I8_TIMERS == 2
             I8_TM(tm_bar);
 #endif
-            if (c == 0 && wave < SH::TERM_PIECES) {   // the tile's column terms (I8_CT blocks x 64 floats, whole 1 KiB pieces): older than
+            if (FIRST && wave < SH::TERM_PIECES) {   // the tile's column terms (I8_CT blocks x 64 floats, whole 1 KiB pieces): older than
                                          // the pieces requested below, so the next step's vmcnt wait covers them; read in the epilogue, many barriers on
                 const uint4 *g = i8_uniform_ptr(T8 + ((uint64_t)blk0 + (uint64_t)t * I8_CT) * 16 + (uint32_t)wave * 64u);
                 const uint32_t lp = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(I8_NBUF * I8_SET_BYTES) + (uint32_t)wave * 1024u);
@@ -420,25 +423,20 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
             const uint32_t lb = la + (uint32_t)(I8_CT * I8_APIECES + I8_KS * wave) * 1024u;
             asm volatile("ds_read_b128 %0, %1" : "=v"(fb[0]) : "v"(lb));
             I8_DS_READ(fa[0], I8_A_OFF(0));
-            I8_MFMA(NX - 3);   // the previous step's last three, on fa[1..3] and the old fb[1]
+            if (!FIRST) I8_MFMA(NX - 3);   // the previous step's last three, on fa[1..3] and the old fb[1]
             I8_DS_READ(fa[1], I8_A_OFF(1));
-            I8_MFMA(NX - 2);
+            if (!FIRST) I8_MFMA(NX - 2);
             I8_DS_READ(fa[2], I8_A_OFF(2));
-            I8_MFMA(NX - 1);
+            if (!FIRST) I8_MFMA(NX - 1);
             I8_DS_READ(fa[3], I8_A_OFF(3));
             asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(fb[1]) : "v"(lb));
-            if (c == 0) {   // (first step of the tile: those three ran on stale fragments)
-#pragma unroll
-                for (int x = NX - 3; x < NX; ++x)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[x / NP % I8_CT][x % NP][r] = 0;
-            }
 #pragma unroll
             for (int x = 0; x < NX - 3; ++x) {
                 // reads in flight behind fragment x: x + 1 .. x + 3 (and the second query fragment while x < 4)
                 if (x < 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[x & 3]), "+v"(fb[0]));
                 else asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[x & 3]), "+v"(fb[1]));
-                I8_MFMA(x);
+                if (FIRST && x < NP * I8_CT) I8_MFMA0(x);   // (k-step 0: the first touch of each accumulator)
+                else I8_MFMA(x);
                 if (x + 4 < NX) I8_DS_READ(fa[x & 3], I8_A_OFF(x + 4));
                 // the set two steps ahead is requested here, one piece every fourth MFMA: the address arithmetic and the
                 // DMA issue run under the matrix pipe's shadow instead of between the barrier and the first MFMA
@@ -452,7 +450,9 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
 #endif
             cur = cur + 1 == I8_NBUF ? 0 : cur + 1;
             nxt = nxt + 1 == I8_NBUF ? 0 : nxt + 1;
-        }
+        };
+        step(std::true_type{});
+        for (uint32_t c = 1; c < nchunk; ++c) step(std::false_type{});
         I8_MFMA(NX - 3);
         I8_MFMA(NX - 2);
         I8_MFMA(NX - 1);
@@ -466,39 +466,61 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
                 // column of the tile's first row of this lane, relative to the segment's first column (wraps below zero for the
                 // blocks of a segment that ended inside this tile: their values were inserted when it ended)
                 const uint32_t tbase = 32u * (t * I8_CT - seg_first) + 4u * (uint32_t)h;
+                // Eight values at a time, without a branch between them: the LDS reads of their column terms and the conversion /
+                // multiply chains of the four pairs overlap (with a test after every pair each pair waited for its own term
+                // reads and its own dependent chain: by the phase timers the epilogue was 37 % of the D = 1024 sweep, ~18
+                // cycles per instruction).  Then one test for the eight -- late in a long sweep most hold no candidate in any
+                // lane -- and the tests per pair.
 #pragma unroll
-                for (int m4 = 0; m4 < 4; ++m4) {
-                    const float4 g4 = gp[2 * m4], b4 = bp[2 * m4];
-                    const f32x2 gg[2] = {{g4.x, g4.y}, {g4.z, g4.w}}, bb[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
+                for (int hb = 0; hb < 2; ++hb) {   // (half a block at a time: the terms of all 16 values at once cost spilled registers)
+                    float4 g4[2], b4[2];
 #pragma unroll
-                    for (int e2 = 0; e2 < 2; ++e2) {   // two values per packed float32 instruction
-                        const int r = 4 * m4 + 2 * e2;
-                        // 256 S_H + S_M as one exact 32-bit integer (|c - c0|_1 <= I8_L1_MAX), then two conversions per value
-                        // (two parts: one, and the value is 256 g (256 S_H + S_M) - T b: the full one less g S_L)
-                        const f32x2 fhm = {(float)(acc[cb][0][r] * 256 + acc[cb][1][r]), (float)(acc[cb][0][r + 1] * 256 + acc[cb][1][r + 1])};
-                        f32x2 sf;
-                        if (NP == 3) {
-                            const f32x2 fl = {(float)acc[cb][NP - 1][r], (float)acc[cb][NP - 1][r + 1]};
-                            sf = __builtin_elementwise_fma(c256, fhm, fl);
-                        } else {
-                            sf = c256 * fhm;   // (exact)
+                    for (int m = 0; m < 2; ++m) {
+                        g4[m] = gp[2 * (2 * hb + m)];
+                        b4[m] = bp[2 * (2 * hb + m)];
+                    }
+                    f32x2 val[4];
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const f32x2 gg[2] = {{g4[m].x, g4[m].y}, {g4[m].z, g4[m].w}}, bb[2] = {{b4[m].x, b4[m].y}, {b4[m].z, b4[m].w}};
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {   // two values per packed float32 instruction
+                            const int r = 4 * (2 * hb + m) + 2 * e2;
+                            // 256 S_H + S_M as one exact 32-bit integer (|c - c0|_1 <= I8_L1_MAX), then two conversions per value
+                            // (two parts: one, and the value is 256 g (256 S_H + S_M) - T b: the full one less g S_L)
+                            const f32x2 fhm = {(float)(acc[cb][0][r] * 256 + acc[cb][1][r]), (float)(acc[cb][0][r + 1] * 256 + acc[cb][1][r + 1])};
+                            f32x2 sf;
+                            if (NP == 3) {
+                                const f32x2 fl = {(float)acc[cb][NP - 1][r], (float)acc[cb][NP - 1][r + 1]};
+                                sf = __builtin_elementwise_fma(c256, fhm, fl);
+                            } else {
+                                sf = c256 * fhm;   // (exact)
+                            }
+                            val[2 * m + e2] = __builtin_elementwise_fma(sf, gg[e2], negT2 * bb[e2]);
                         }
-                        const f32x2 val = __builtin_elementwise_fma(sf, gg[e2], negT2 * bb[e2]);
-                        // A value that can enter the list (> everything the list dropped) is parked in the lane's pending slot
-                        // with its position in the tile (a compile-time constant); the 4-deep sorted insert -- 20 instructions
-                        // for the whole wave -- runs when some lane would park a second one, an order of magnitude less often
-                        // than "some lane of the 64 has a candidate", and once at the end of the tile / segment.  The pair is
-                        // looked at only if its larger value is a candidate in some lane.
-                        if (__builtin_amdgcn_ballot_w64(fmaxf(val[0], val[1]) > ldrop) != 0) {
+                    }
+                    const float vmax = fmaxf(fmaxf(fmaxf(val[0][0], val[0][1]), fmaxf(val[1][0], val[1][1])),
+                                             fmaxf(fmaxf(val[2][0], val[2][1]), fmaxf(val[3][0], val[3][1])));
+                    if (__builtin_amdgcn_ballot_w64(vmax > ldrop) != 0) {
 #pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const bool needs = val[e] > ldrop;
-                                if (__builtin_expect(__builtin_amdgcn_ballot_w64(needs && pend_v > -3.0e38f) != 0, 0)) {
-                                    list_insert(lv, li, ldrop, pend_v, tbase + pend_i);   // (lanes without a parked value insert -3e38: no change)
-                                    pend_v = -3.0e38f;
+                        for (int pr = 0; pr < 4; ++pr) {
+                            // A value that can enter the list (> everything the list dropped) is parked in the lane's pending slot
+                            // with its position in the tile (a compile-time constant); the 4-deep sorted insert -- 20 instructions
+                            // for the whole wave -- runs when some lane would park a second one, an order of magnitude less often
+                            // than "some lane of the 64 has a candidate", and once at the end of the tile / segment.  The pair is
+                            // looked at only if its larger value is a candidate in some lane.
+                            if (__builtin_amdgcn_ballot_w64(fmaxf(val[pr][0], val[pr][1]) > ldrop) != 0) {
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    const int r = 8 * hb + 2 * pr + e;
+                                    const bool needs = val[pr][e] > ldrop;
+                                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(needs && pend_v > -3.0e38f) != 0, 0)) {
+                                        list_insert(lv, li, ldrop, pend_v, tbase + pend_i);   // (lanes without a parked value insert -3e38: no change)
+                                        pend_v = -3.0e38f;
+                                    }
+                                    pend_v = needs ? val[pr][e] : pend_v;
+                                    pend_i = needs ? (uint32_t)(32 * cb + (r & 3) + 8 * (r >> 2)) : pend_i;
                                 }
-                                pend_v = needs ? val[e] : pend_v;
-                                pend_i = needs ? (uint32_t)(32 * cb + ((r + e) & 3) + 8 * ((r + e) >> 2)) : pend_i;
                             }
                         }
                     }
@@ -525,7 +547,7 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
                         li[c] = 0xFFFFFFFFu;
                     }
                     ldrop = -3.0e38f;
-                    ++seg;
+                    seg = __builtin_amdgcn_readfirstlane(seg + 1);   // (wave-uniform by construction: keeps the tests on it scalar)
                     seg_first = blk + 1;
                 }
             }
@@ -533,6 +555,7 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
         I8_TM(tm_epi);
     }
 #undef I8_MFMA
+#undef I8_MFMA0
 #undef I8_DS_READ
 #undef I8_A_OFF
 #ifdef I8_TIMERS

@@ -2615,8 +2615,11 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         // the int8 sweep goes first: it declines a batch with too many rows beyond its operand range (-> the f16 kernel)
         bool i8_now = false;
         if (use_i8)
+            // (column groups: the int8 sweep's optimum is 2 at D >= 2048 -- configs[4], two-part kernel: 40.1 / 38.5 / 42.3 / 40.3 /
+            // 44.2 ms with 1 / 2 / 3 / 4 / 6 groups; the f16 kernel's is PHK_GEN_GROUPS)
             PHK_TRY(phk_launch_proposal_i8_general(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu,
-                                                   (uint32_t)gen_sets, set_bytes, i8_two, &i8_now));
+                                                   ctx->knobs.gen_groups > 0 ? (uint32_t)gen_sets : (gen_sets > 2 ? 2u : (uint32_t)gen_sets),
+                                                   set_bytes, i8_two, &i8_now));
         if (i8_now) {
             // values are T v (per row), from exact integer sums (see ErrBound: int8)
             const double ku = m->kappa8 / 5.9604644775390625e-08;
