@@ -462,6 +462,80 @@ def test_count_exact_path_adversarial_queries():
 
 
 @pytest.mark.gpu
+def test_two_digit_int8_sweep_adversarial_queries_and_batch_split():
+    """k = 5 (D = 1024), the default general-D path: the int8 sweep carries two of the reference's three int8 digits and the
+    decision kernel adds the third to the candidates inside the window.  Queries built to make those windows wide: thinned
+    reference genomes (nearest neighbour at sampling-noise distance), mixtures of a positive and a negative genome (two
+    near-equidistant neighbours with opposite labels), and a reference with DUPLICATED rows of mixed labels (exact ties:
+    the refined values cannot separate them, the exact candidate distances decide, ties to the lower index) -- bit-equal to
+    the three-digit sweep and the f16 sweep, equal to the float64 brute force, and independent of the scoring-batch split."""
+    from phamers_amd import _lib, device
+    ctx = _lib.get_context()
+    k, D, n_ref = 5, 1024, 600
+
+    def device_counts(seed, n, L):
+        T = n * L
+        d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+        d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+        device.synth_packed(ctx, seed, 0, n, L, d_packed, d_off)
+        d_counts = device.DeviceArray(ctx, (n, D), np.uint32)
+        device.count(ctx, d_packed, None, T, d_off, n, k, d_counts)
+        return d_counts.to_host()
+
+    rc = device_counts(71, n_ref, 30000).astype(np.int64)
+    w = 1.0 + 0.25 * np.sin(np.arange(D) * 0.61)
+    rc[: n_ref // 2] = np.rint(rc[: n_ref // 2] * w).astype(np.int64)
+    # duplicated genomes with mixed labels: rows 0..19 of the positive class reappear as rows 0..19 of the negative class
+    rc[n_ref // 2: n_ref // 2 + 20] = rc[:20]
+    ref = rc / rc.sum(axis=1, keepdims=True)
+    pos, neg = ref[: n_ref // 2], ref[n_ref // 2:]
+    cpos = np.stack([pos[i::9].mean(axis=0) for i in range(9)])
+    cneg = np.stack([neg[i::9].mean(axis=0) for i in range(9)])
+    model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
+    rng = np.random.default_rng(17)
+    ia, ib = rng.integers(0, n_ref // 2, 300), rng.integers(n_ref // 2, n_ref, 300)
+    rows = [rc[ia] // 3, rc[ib] // 3,                         # contig-sized versions of reference genomes (incl. the duplicated ones)
+            rc[:20] // 3, rc[:20] // 4 + 1,                    # ... of the duplicated genomes, twice
+            rc[ia] // 6 + rc[ib] // 6,                         # between a positive and a negative genome
+            device_counts(72, 400, 10000).astype(np.int64)]   # ordinary contigs
+    counts = np.vstack(rows).astype(np.uint32)
+    n_q = len(counts)
+    d_q = device.DeviceArray.from_host(ctx, counts)
+    out = {}
+    for path in ("i8", "i8_batches", "i83", "cxf", "exact"):
+        ctx.set_option("force_exact", "1" if path == "exact" else "0")
+        ctx.set_option("proposal", {"cxf": "cxf", "i83": "i83"}.get(path, ""))
+        ctx.set_option("score_batch", "192" if path == "i8_batches" else "0")
+        for method in ("knn", "kmeans", "combo"):
+            d_scores = device.DeviceArray(ctx, n_q, np.float64)
+            d_status = device.DeviceArray.from_host(ctx, np.zeros(1, np.uint32))
+            device.score_counts(ctx, model, d_q, n_q, method, d_scores, d_status)
+            out[(path, method)] = d_scores.to_host()
+            assert d_status.to_host()[0] == 0
+        if path == "i8":
+            n_fallback, n_exact = ctx.score_stats()
+            assert n_exact > 0               # the tied / near-tied queries were decided by exact candidate distances
+            assert n_fallback < n_q // 4, n_fallback
+    ctx.set_option("proposal", "")
+    ctx.set_option("score_batch", "0")
+    ctx.set_option("force_exact", "0")
+    for method in ("knn", "kmeans", "combo"):
+        for path in ("i8_batches", "i83", "cxf"):
+            assert np.array_equal(out[("i8", method)], out[(path, method)]), (path, method)
+    # against the float64 brute force: votes where the 3rd and 4th neighbour are distinguishable, floats everywhere
+    q = counts.astype(np.float64) / counts.sum(axis=1, keepdims=True)
+    train = np.vstack([pos, neg])
+    d2 = (q * q).sum(axis=1)[:, None] - 2.0 * q @ train.T + (train * train).sum(axis=1)[None, :]
+    srt = np.sort(d2, axis=1)
+    clear = (srt[:, 3] - srt[:, 2]) > 1e-9 * np.maximum(srt[:, 3], 1e-300)
+    assert clear.sum() > n_q // 2
+    assert np.array_equal(out[("i8", "knn")][clear], out[("exact", "knn")][clear])
+    assert helpers.rel_err(out[("i8", "kmeans")], out[("exact", "kmeans")]) < 1e-9
+    assert np.array_equal(out[("i8", "knn")], out[("exact", "knn")])   # (ties go to the lower index on both paths)
+    model.close()
+
+
+@pytest.mark.gpu
 def test_scoring_in_several_batches_matches_one_batch_and_exact_path():
     """N slightly above the scoring batch (option score_batch): the per-batch offsets of queries, row sums and
     workspaces, and the statistics summed over the batches -- against one batch and against the float64 path."""
