@@ -891,7 +891,9 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     uint64_t certified = certify_segments(p, nqp2, nqp_up, eb, vs, lane, pre_v, pre_i, cri);
     if (I8H) {
         certified &= uok;
-        if (lane == 0 && (uok & 0x010101ull) != 0x010101ull && p.counters) atomicAdd(p.counters + 9, 1u);   // statistics: a window reached past the lists
+        // statistics: a window of a segment the method uses reached past the lists (rare: one atomic per such query)
+        const uint64_t used = ((p.method & PHK_METHOD_KNN) ? 0x01ull : 0ull) | ((p.method & PHK_METHOD_KMEANS) ? 0x010100ull : 0ull);
+        if (lane == 0 && (uok & used) != used && p.counters) atomicAdd(p.counters + 9, 1u);
     }
     const double uex0 = I8H ? cop.Q * p.lam8[0] * (1.0 + 1.0e-6) : 0.0, uex1 = I8H ? cop.Q * p.lam8[1] * (1.0 + 1.0e-6) : 0.0,
                  uex2 = I8H ? cop.Q * p.lam8[2] * (1.0 + 1.0e-6) : 0.0;
