@@ -1064,6 +1064,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
             const half8 ah = ahn;
             if (s < 15) ahn = fr[(s + 1) * 64];
             __builtin_amdgcn_sched_barrier(0);  // the reads stay up here, one step ahead of their MFMAs (two steps ahead: 4 spilled registers, 2.17 ms instead of 2.10)
+            // (also measured and not kept: s_setprio 2 around the two MFMAs, 2.42 ms against 2.21 on the same box; the first
+            // tile's insertion between the two MFMAs instead of behind them, 2.19 against 2.21: within the noise)
             if (s == 0) {
                 f32x16 z;
 #pragma unroll
