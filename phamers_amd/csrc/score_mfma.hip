@@ -2573,7 +2573,14 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + D) * sizeof(double);
     PHK_REQUIRE(fb_lds <= FB_LDS_MAX, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);  // phk_model_build_fast keeps such models off this path
     if (!ctx->keep_score_state) PHK_HIP(hipMemsetAsync(fbc, 0, 128, ctx->stream));   // incl. the totals of this call
+    // Safety valve of the two-digit int8 sweep: its windows are 2^-16 of |c - c0| |x_j| wide, and a reference with many
+    // near-duplicate columns can put more of them inside a window than the lists hold -- such queries end in the float64
+    // brute force, which is sized for a handful per batch.  When a batch leaves more than max(64, nb / 256) queries there,
+    // it is swept again with all three digits (windows 2^-24 wide), and so is the rest of the call.
+    bool two_ok = i8_two;
     for (uint64_t s = 0; s < N; s += BATCH) {
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool i8_two = two_ok;   // (shadows the call-wide setting: what this attempt runs)
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
         const void *src = d_counts ? (const void *)(d_counts + s * D) : (const void *)(d_Q + s * D);
         const uint32_t *rsum = d_rowsum ? d_rowsum + s : nullptr;
@@ -2587,7 +2594,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
         p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.colnorm = m->d_colnorm; p.labels = m->d_labels;
         p.cand_v = (const float *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
-        p.scores = d_scores; p.status = d_status; p.fb_count = fbc; p.fb_list = fb_list; p.slow_list = slow_list; p.q_base = s;
+        p.scores = d_scores; p.status = attempt == 0 ? d_status : nullptr;   // (a second attempt must not count the NaN rows again)
+        p.fb_count = fbc; p.fb_list = fb_list; p.slow_list = slow_list; p.q_base = s;
         p.stat_total = fbc + 16;
         p.counters = fbc;
         p.col_mask = m->has_mask ? m->d_col_mask : nullptr;
@@ -2741,7 +2749,17 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
                 PHK_LAUNCH(ctx, "phk_finish_cen_kernel",
                            phk_finish_cen_kernel<<<dim3((unsigned)phk_div_up(nb, 256)), dim3(256), 0, ctx->stream>>>(nb, pend, d_scores + s));
         }
+        if (attempt == 0 && i8_now && i8_two) {   // the safety valve (one 4-byte read-back per batch, like the sweep's own)
+            uint32_t queued = 0;
+            PHK_HIP(hipMemcpyAsync(&queued, fbc, sizeof(queued), hipMemcpyDeviceToHost, ctx->stream));
+            PHK_HIP(hipStreamSynchronize(ctx->stream));
+            if (queued > (nb / 256 > 64 ? nb / 256 : 64)) {
+                two_ok = false;
+                continue;   // the same batch again, three digits in the sweep
+            }
+        }
         RerankParams pf = p;   // what the brute force works from
+        pf.status = d_status;
         if (second) {
             const uint64_t cap = nb < cap2 ? nb : cap2;
             PHK_TRY(phk_launch_proposal_f16(ctx, m, src, true, rsum, cap, nref, npos, nneg, cv2, ci2, cu2, fb_list, fbc,
@@ -2781,6 +2799,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         }
         PHK_LAUNCH(ctx, "phk_fallback_merge_kernel",
                    phk_fallback_merge_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(pf));
+        break;
+      }
     }
     return PHK_OK;
 }

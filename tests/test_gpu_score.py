@@ -536,6 +536,73 @@ def test_two_digit_int8_sweep_adversarial_queries_and_batch_split():
 
 
 @pytest.mark.gpu
+def test_two_digit_sweep_safety_valve_on_near_duplicate_references():
+    """A reference whose genomes come in clusters of twelve near-duplicates (one count apart in 300 000): more columns fall
+    inside the two-digit sweep's window than the candidate lists hold, its queries pile up in the brute-force queue, and
+    phk_score_fast sweeps the batch again with all three digits, which tells the copies apart.  Scores equal the float64
+    path's; after the call only a few queries were brute-forced."""
+    from phamers_amd import _lib, device
+    ctx = _lib.get_context()
+    k, D, n_base, copies = 5, 1024, 24, 12
+
+    def device_counts(seed, n, L):
+        T = n * L
+        d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+        d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+        device.synth_packed(ctx, seed, 0, n, L, d_packed, d_off)
+        d_counts = device.DeviceArray(ctx, (n, D), np.uint32)
+        device.count(ctx, d_packed, None, T, d_off, n, k, d_counts)
+        return d_counts.to_host()
+
+    base = device_counts(81, n_base, 300000).astype(np.int64)
+    w = 1.0 + 0.3 * np.sin(np.arange(D) * 0.43)
+    base[: n_base // 2] = np.rint(base[: n_base // 2] * w).astype(np.int64)
+    rows, labels = [], []
+    for b in range(n_base):
+        for c in range(copies):
+            r = base[b].copy()
+            r[(37 * c + 11 * b) % D] += c          # copy c: c more windows of one k-mer
+            rows.append(r)
+            labels.append((b < n_base // 2) ^ (c % 5 == 4))   # mostly the cluster's class, every fifth copy the other
+    rows = np.array(rows, dtype=np.float64)
+    labels = np.array(labels)
+    ref = rows / rows.sum(axis=1, keepdims=True)
+    pos, neg = ref[labels], ref[~labels]
+    cpos = np.stack([pos[i::6].mean(axis=0) for i in range(6)])
+    cneg = np.stack([neg[i::6].mean(axis=0) for i in range(6)])
+    model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
+    rng = np.random.default_rng(23)
+    n_q = 1536
+    pick = rng.integers(0, n_base, n_q)
+    counts = rng.binomial(base[pick], 1.0 / 30.0).astype(np.uint32)   # 10 kb contigs drawn from the base genomes
+    d_q = device.DeviceArray.from_host(ctx, counts)
+    out, stats, sweeps = {}, {}, {}
+    for path in ("i8", "i83", "exact"):
+        ctx.set_option("force_exact", "1" if path == "exact" else "0")
+        ctx.set_option("proposal", "i83" if path == "i83" else "")
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for method in ("knn", "combo"):
+            d_scores = device.DeviceArray(ctx, n_q, np.float64)
+            device.score_counts(ctx, model, d_q, n_q, method, d_scores, None)
+            out[(path, method)] = d_scores.to_host()
+        ctx.profile_enable(False)
+        stats[path] = ctx.score_stats()
+        sweeps[path] = ctx.profile().get("phk_knn_i8_general_kernel", (0.0, 0))[1]
+    ctx.set_option("proposal", "")
+    ctx.set_option("force_exact", "0")
+    # the valve fired (two sweeps per call on the default path, one with proposal=i83): what is left in the brute-force queue
+    # is the three-digit sweep's, not hundreds of queries
+    assert sweeps["i8"] == 4 and sweeps["i83"] == 2, sweeps
+    assert stats["i8"][0] == stats["i83"][0] and stats["i8"][0] < n_q // 10, stats
+    for method in ("knn", "combo"):
+        assert np.array_equal(out[("i8", method)], out[("i83", method)]), method
+    assert np.array_equal(out[("i8", "knn")], out[("exact", "knn")])
+    assert helpers.rel_err(out[("i8", "combo")], out[("exact", "combo")]) < 1e-9
+    model.close()
+
+
+@pytest.mark.gpu
 def test_scoring_in_several_batches_matches_one_batch_and_exact_path():
     """N slightly above the scoring batch (option score_batch): the per-batch offsets of queries, row sums and
     workspaces, and the statistics summed over the batches -- against one batch and against the float64 path."""
