@@ -536,6 +536,49 @@ def test_two_digit_int8_sweep_adversarial_queries_and_batch_split():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", [512, 2048])
+def test_int8_sweep_at_the_other_supported_dimensions(D):
+    """D = 512 and 2048 (no k of a 4-letter alphabet gives them, but the scoring entry points take any supported D): count
+    rows through the default two-digit int8 sweep, the three-digit one and the float64 path -- the shapes of the sweep
+    (chunks per tile, column groups at D >= 2048) and of the decision kernel's L products that the k = 5 / 6 tests do not reach."""
+    from phamers_amd import _lib, device
+    ctx = _lib.get_context()
+    rng = np.random.default_rng(100 + D)
+    n_ref, n_q = 900, 700
+    prof = rng.gamma(4.0, 1.0, (n_ref, D))
+    prof[: n_ref // 2] *= 1.0 + 0.3 * np.sin(np.arange(D) * 0.29)
+    ref = prof / prof.sum(axis=1, keepdims=True)
+    pos, neg = ref[: n_ref // 2], ref[n_ref // 2:]
+    cpos = np.stack([pos[i::7].mean(axis=0) for i in range(7)])
+    cneg = np.stack([neg[i::7].mean(axis=0) for i in range(7)])
+    model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
+    # contigs drawn from the reference profiles (8 windows per bin on average), a few of them from one profile twice
+    pick = rng.integers(0, n_ref, n_q)
+    pick[1::50] = pick[0::50][: len(pick[1::50])]
+    counts = rng.multinomial(8 * D, ref[pick]).astype(np.uint32)
+    d_q = device.DeviceArray.from_host(ctx, counts)
+    out = {}
+    for path in ("i8", "i83", "exact"):
+        ctx.set_option("force_exact", "1" if path == "exact" else "0")
+        ctx.set_option("proposal", "i83" if path == "i83" else "")
+        for method in ("knn", "combo"):
+            d_scores = device.DeviceArray(ctx, n_q, np.float64)
+            d_status = device.DeviceArray.from_host(ctx, np.zeros(1, np.uint32))
+            device.score_counts(ctx, model, d_q, n_q, method, d_scores, d_status)
+            out[(path, method)] = d_scores.to_host()
+            assert d_status.to_host()[0] == 0
+        if path == "i8":
+            assert ctx.score_stats()[0] < n_q // 10
+    ctx.set_option("proposal", "")
+    ctx.set_option("force_exact", "0")
+    for method in ("knn", "combo"):
+        assert np.array_equal(out[("i8", method)], out[("i83", method)]), method
+    assert np.array_equal(out[("i8", "knn")], out[("exact", "knn")])
+    assert helpers.rel_err(out[("i8", "combo")], out[("exact", "combo")]) < 1e-9
+    model.close()
+
+
+@pytest.mark.gpu
 def test_two_digit_sweep_safety_valve_on_near_duplicate_references():
     """A reference whose genomes come in clusters of twelve near-duplicates (one count apart in 300 000): more columns fall
     inside the two-digit sweep's window than the candidate lists hold, its queries pile up in the brute-force queue, and
