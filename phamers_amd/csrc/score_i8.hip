@@ -9,7 +9,9 @@
 //   * a reference column x_j = r_j - mu is held in 24-bit fixed point with a per-column quantum g_j, as THREE int8 parts
 //     n = 65536 H + 256 M + L (balanced digits in [-128, 127]) -- the precision of the f16 kernel's hi + lo pair
 //     (2^-22 |x|) -- so a value costs 3 MFMAs per 32 dimensions where the f16 kernel issues 4 (measured bare-loop rates
-//     on this chip: 19.0 ns per i8 MFMA, 20.2 ns per f16 MFMA per SIMD; tools/micro/mfma_i8_vs_f16.hip);
+//     on this chip: 19.0 ns per i8 MFMA, 20.2 ns per f16 MFMA per SIMD; tools/micro/mfma_i8_vs_f16.hip) -- and by default
+//     only TWO: the sweep multiplies H and M, and the decision kernel adds g_j S_L, an exact integer product with the
+//     column's L digits, to the candidates inside the window the missing part opens (see below and phk_rerank_kernel);
 //   * the three part sums are exact integers; the value  T v_j = g_j (65536 S_H + 256 S_M + S_L) - T b_j  is formed once
 //     per (query, column) in float32 in the tile epilogue.  No rounding model of the matrix pipe enters the error bound:
 //     what is left is the quantisation of the column (kappa = max_j |x_j - x~_j| / |x_j|, computed at build), three
