@@ -1583,7 +1583,12 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
     __shared__ float s_v8[8][64], s_u0[64], s_ch[4][64];
     __shared__ double s_cn[5][64];
     __shared__ uint32_t s_flags[64];
-    __shared__ double s_T[64], s_nq2[64], s_nqp2[64], s_dp2[64], s_dn2[64], s_opQ[64], s_opI[64], s_opH[64], s_sh2[64];
+    // phase B leaves the row's RAW sums here; everything one lane per query can finish -- the division by T^2, the centred
+    // operand's norms (a float64 square root and three divisions) -- is phase C's: in phase B the 16 lanes of a query, 64 lanes of
+    // a wave, each repeated it in every pass (a fifth of that phase's instructions, and the kernel is bound by its own
+    // instruction stream at two waves per SIMD)
+    __shared__ double s_T[64], s_sumsq[64], s_apsum[64], s_dp2[64], s_dn2[64];
+    __shared__ uint32_t s_cmx[64], s_cmn[64];
     __shared__ double s_mu[FAST_D];         // the training mean (LDS reads keep vmcnt for the row / column loads)
     const int tid = threadIdx.x, t = tid & 15;
     const uint64_t qb = (uint64_t)blockIdx.x * 64;
@@ -1757,8 +1762,8 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
         cmx = group16_max(cmx);
         cmn = group16_min(cmn);
         const bool bad = sum == 0;
-        const double Tq = (double)sum, invT2 = 1.0 / (Tq * Tq);
-        double dp2 = 0.0, dn2 = 0.0;
+        const double Tq = (double)sum;
+        double dp2 = 0.0, dn2 = 0.0;   // (the sums; phase C multiplies by 1 / T^2)
         if (CEN) {   // exact float64 distances to the two leading centroids (as exact_d2_g16)
             double acca = 0.0, accb = 0.0;
 #pragma unroll
@@ -1768,8 +1773,8 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
                 acca = fma(a0, a0, fma(a1, a1, acca));
                 accb = fma(b0, b0, fma(b1, b1, accb));
             }
-            dp2 = group16_sum(acca) * invT2;
-            dn2 = group16_sum(accb) * invT2;
+            dp2 = group16_sum(acca);
+            dn2 = group16_sum(accb);
         }
         double aq = 0.0, ap = 0.0;
 #pragma unroll
@@ -1780,13 +1785,11 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
             qd[2 * i + 1] = fma(-Tq, m2.y, qd[2 * i + 1]);
             ap = fma(qd[2 * i], qd[2 * i], fma(qd[2 * i + 1], qd[2 * i + 1], ap));
         }
-        const double sumsq = group16_sum(aq);
-        const double nq2 = sumsq * invT2, nqp2 = group16_sum(ap) * invT2;
+        const double sumsq = group16_sum(aq), apsum = group16_sum(ap);
         // The proposal kernel's query operand is c - c0 (phk_row_center), so its value is the high product of the
         // UNcentred counts minus (c0 - T/D) sum_i hi_ji; the low product that completes it is therefore taken with
         // c - T mu - (c0 - T/D): sum_i (c_i - T mu_i - dlt) lo_ji = sum_i (c_i - T mu_i) lo_ji + dlt sum_i hi_ji - dlt sum_i r~'_ji,
         // the last term being the model's hsum residue (see ErrBound).
-        const CenteredOperand cop = phk_centered_operand(sumsq, bad ? 1.0 : Tq, (double)cmx, (double)cmn, (double)FAST_D, p.eb_hsum);
         if (KNN) {
             // float32 products (v_fma_mix takes the half operand as it is): 16 + 4 roundings per sum, bounded in
             // phase C by 2^-19 |x| lam* -- 1e-6 of the low product's own bound
@@ -1809,14 +1812,12 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
         }
         if (t == 0) {
             s_T[ql] = bad ? 0.0 : Tq;   // 0 marks a NaN row
-            s_nq2[ql] = nq2;
-            s_nqp2[ql] = nqp2;
+            s_sumsq[ql] = sumsq;
+            s_apsum[ql] = apsum;
             s_dp2[ql] = dp2;
             s_dn2[ql] = dn2;
-            s_opQ[ql] = cop.Q;
-            s_opI[ql] = cop.I;
-            s_opH[ql] = cop.habs;
-            s_sh2[ql] = cop.shift2;
+            s_cmx[ql] = cmx;
+            s_cmn[ql] = cmn;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
@@ -1831,7 +1832,9 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
         if (p.status) atomicAdd(p.status, 1u);
         return;
     }
-    const double nq2 = s_nq2[tid], nqp2 = s_nqp2[tid];
+    const double invT2 = 1.0 / (Tq * Tq);
+    const double nq2 = s_sumsq[tid] * invT2, nqp2 = s_apsum[tid] * invT2;
+    const CenteredOperand cop = phk_centered_operand(s_sumsq[tid], Tq, (double)s_cmx[tid], (double)s_cmn[tid], (double)FAST_D, p.eb_hsum);
     const double vs = p.vscale / Tq;
     double cn0[3];
     uint32_t labbits;
@@ -1851,10 +1854,10 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
-    eb.Q = s_opQ[tid]; eb.I = s_opI[tid]; eb.habs = s_opH[tid];
+    eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs;
     eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
     const double nqp = eb.P;
-    const double nqx = sqrt(nqp2 + s_sh2[tid]);   // |q' - (c0/T - 1/D) 1|: what the low parts multiply (see phase B)
+    const double nqx = sqrt(nqp2 + cop.shift2);   // |q' - (c0/T - 1/D) 1|: what the low parts multiply (see phase B)
     auto e_hi = [&](int sg, double R) { return nqx * phk_lam_of(hp, sg, R) + eb(R); };
     bool cert = true;      // the k-NN part
     bool cert_c = true;    // the centroid part
@@ -1925,7 +1928,7 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
         };
         cert_c = leader_ok(0, cnp2) && leader_ok(1, cnn2);
         if (!cert_c) atomicAdd(p.counters + 11, 1u);   // diagnostics: centroid leader not certified
-        const double ep = sqrt(s_dp2[tid]), en = sqrt(s_dn2[tid]);
+        const double ep = sqrt(s_dp2[tid] * invT2), en = sqrt(s_dn2[tid] * invT2);   // (the squared distances as exact_d2_g16 forms them)
         cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
     }
     if (cert && cert_c) {
