@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
 // ------------------------------------------------------------------------------------
 // 2. certify / exact re-rank: one wavefront per query, lane = 4 dimensions
 // ------------------------------------------------------------------------------------
+#define PHK_STRIPES 256
 struct RerankParams {
     uint64_t N, M, n_cpos, n_cneg, D;
     int kn, method;
@@ -368,6 +369,12 @@ struct RerankParams {
     const uint32_t *map = nullptr;
     const uint32_t *map_count = nullptr;
     uint32_t *counters = nullptr;           // the batch's counter words (see phk_score_fast)
+    // Statistics that most waves of a large grid increment -- decisions by exact distances, the reasons a query is handed on --
+    // are counted in PHK_STRIPES copies of the counter words, each in a cache line of its own, chosen by the workgroup number,
+    // and summed by phk_fallback_merge_kernel.  As atomics on the batch's ONE line of counters they were a serial resource the
+    // whole grid queued for: ~9 ns apiece, 0.31 ms of phk_decide_h_kernel's 0.79 and 0.19 ms of phk_rerank16_kernel's 0.35 on
+    // configs[1] (end of round 3; profiles/r03/README.md).
+    uint32_t *stripes = nullptr;            // [PHK_STRIPES][32] words, or null: count in `counters` / `fb_count`
     int slow_back = 0;                      // phk_rerank16_kernel MODE 1: 3 = both of the following in one launch; 0 = slow_list[0 ..) counted by fb_count[2],
                                             // 1 = the list that grows down from slow_list[slow_cap - 1], counted by counters[12]
     uint64_t slow_cap = 0;
@@ -380,6 +387,11 @@ struct RerankParams {
     uint32_t t8_blk[3] = {0, 0, 0};         // first block of each segment
     double lam8[3] = {0, 0, 0};
 };
+
+// the counter word `k` of this workgroup's stripe (see RerankParams::stripes)
+__device__ __forceinline__ uint32_t *phk_stat_word(const RerankParams &p, uint32_t *plain, int k) {
+    return p.stripes ? p.stripes + (blockIdx.x & (PHK_STRIPES - 1)) * 32u + (uint32_t)k : plain;
+}
 
 // Sums inside each group of 16 lanes = one DPP row: rotations by 8, 4, 2, 1 (row_ror) leave the total on every lane, in
 // the VALU (a __shfl_xor butterfly is 4 dependent ds_bpermute round trips per sum -- with eleven sums per pass that chain
@@ -602,7 +614,7 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
             return true;
         }
     }
-    if (lane == 0) atomicAdd(p.fb_count + 1, 1u);  // statistics: resolved by exact distances
+    if (lane == 0) atomicAdd(phk_stat_word(p, p.fb_count + 1, 1), 1u);  // statistics: resolved by exact distances
     // not certified: exact float64 distances for all (valid) candidates
     double best[3] = {INFINITY, INFINITY, INFINITY};
     uint32_t bidx[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
@@ -1092,7 +1104,7 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
     uint32_t bidx[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     const bool need_exact = live && !certified;
     if (__any(need_exact)) {  // wave-uniform: some group must decide by exact float64 distances
-        if (need_exact && t == 0) atomicAdd(p.fb_count + 1, 1u);
+        if (need_exact && t == 0) atomicAdd(phk_stat_word(p, p.fb_count + 1, 1), 1u);
         // only candidates inside the window can be among the `need` nearest: one whose computed value lies more than
         // 2 eps below the need-th best has a true value below the true need-th best (same argument as the margin test).
         // The lists are sorted within each half, so the late slots are skipped by whole waves most of the time.
@@ -1885,8 +1897,8 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
             cert = nw <= PHK_HI_REFINE && (double)U0 * vs < thr;
             // diagnostics: window too wide / reaches past the lists (one uniform address per statement, so that the
             // compiler folds a wave's increments into one atomic; a per-lane address costs ~10 ns per lane)
-            if (!cert && nw > PHK_HI_REFINE) atomicAdd(p.counters + 8, 1u);
-            if (!cert && nw <= PHK_HI_REFINE) atomicAdd(p.counters + 9, 1u);
+            if (!cert && nw > PHK_HI_REFINE) atomicAdd(phk_stat_word(p, p.counters + 8, 8), 1u);
+            if (!cert && nw <= PHK_HI_REFINE) atomicAdd(phk_stat_word(p, p.counters + 9, 9), 1u);
             if (cert) {
                 // refined values of the window's members, descending
                 double rv[PHK_HI_REFINE];
@@ -1910,7 +1922,7 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
                 const double hi_v = need == 1 ? rv[0] : need == 2 ? rv[1] : rv[2];
                 const double lo_v = need == 1 ? rv[1] : need == 2 ? rv[2] : rv[3];
                 cert = nw == need || hi_v - lo_v > 2.0 * e22;
-                if (!cert) atomicAdd(p.counters + 10, 1u);   // diagnostics: refined values too close
+                if (!cert) atomicAdd(phk_stat_word(p, p.counters + 10, 10), 1u);   // diagnostics: refined values too close
                 int votes = 0;
                 for (int r = 0; r < need; ++r) votes += (int)rl[r];
                 knn = (2 * votes > need) ? 1.0 : -1.0;
@@ -1927,7 +1939,7 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
             return ((double)ch1[k2] - (double)ch2[k2]) * vs > 2.0 * eh;
         };
         cert_c = leader_ok(0, cnp2) && leader_ok(1, cnn2);
-        if (!cert_c) atomicAdd(p.counters + 11, 1u);   // diagnostics: centroid leader not certified
+        if (!cert_c) atomicAdd(phk_stat_word(p, p.counters + 11, 11), 1u);   // diagnostics: centroid leader not certified
         const double ep = sqrt(s_dp2[tid] * invT2), en = sqrt(s_dn2[tid] * invT2);   // (the squared distances as exact_d2_g16 forms them)
         cen = tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209
     }
@@ -2402,11 +2414,20 @@ __global__ __launch_bounds__(512) void phk_fallback_group_kernel(const void *__r
 __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p) {
     const uint32_t count = *p.fb_count;
     if (blockIdx.x == 0 && threadIdx.x == 0 && p.stat_total) {   // statistics: this batch's counters into the call's totals
-        p.stat_total[0] += p.fb_count[0];
-        p.stat_total[1] += p.fb_count[1] + (p.exact_extra ? *p.exact_extra : 0u);
-        if (p.map_count) p.stat_total[2] += *p.map_count;   // queries that took the second chance
+        // (atomic: the striped copies are added by another workgroup of this launch)
+        atomicAdd(p.stat_total + 0, p.fb_count[0]);
+        atomicAdd(p.stat_total + 1, p.fb_count[1] + (p.exact_extra ? *p.exact_extra : 0u));
+        if (p.map_count) atomicAdd(p.stat_total + 2, *p.map_count);   // queries that took the second chance
         if (p.counters)                                      // why the high-parts-only decision stage passed them on
-            for (int i = 0; i < 4; ++i) p.stat_total[3 + i] += p.counters[8 + i];
+            for (int i = 0; i < 4; ++i) atomicAdd(p.stat_total + 3 + i, p.counters[8 + i]);
+    }
+    if (blockIdx.x == 1 && p.stat_total && p.stripes) {          // ... and the striped copies of the same words
+        for (uint32_t sidx = threadIdx.x; sidx < PHK_STRIPES; sidx += blockDim.x) {
+            const uint32_t *w = p.stripes + sidx * 32u;
+            if (w[1]) atomicAdd(p.stat_total + 1, w[1]);
+            for (int i = 0; i < 4; ++i)
+                if (w[8 + i]) atomicAdd(p.stat_total + 3 + i, w[8 + i]);
+        }
     }
     const FbRecord *rec = static_cast<const FbRecord *>(p.fb_rec);
     for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < count;
@@ -2564,7 +2585,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     float *cv2 = (float *)((char *)cv + gen_sets * set_bytes + ca_bytes);
     uint32_t *ci2 = (uint32_t *)((char *)cv2 + per_list2 * sizeof(float4));
     float *cu2 = (float *)((char *)ci2 + per_list2 * sizeof(uint4));
-    PHK_TRY(phk_ws(ctx, WS_DIST, (3 * nb_max + 32) * sizeof(uint32_t), &fb));
+    PHK_TRY(phk_ws(ctx, WS_DIST, (3 * nb_max + 32 + PHK_STRIPES * 32) * sizeof(uint32_t), &fb));
     PHK_TRY(phk_ws(ctx, WS_QF32, nb_max * FB_CHUNKS * sizeof(FbRecord), &rec));
     // counter words, per batch: [0] first-pass queue length, [1] exact-distance decisions, [2] decide kernel's hand-over
     // count, [3] brute-force queue length after the second chance, [4] its exact-distance decisions, [8..11] why the
@@ -2572,6 +2593,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // lists, refined values too close, centroid leader not certified); [16 ..] totals of the call: brute-forced queries,
     // exact-distance decisions, second-chance queries, the four reasons
     uint32_t *fbc = (uint32_t *)fb, *fb_list = fbc + 32, *slow_list = fb_list + nb_max, *fb2_list = slow_list + nb_max;
+    uint32_t *stripes = fb2_list + nb_max;   // striped statistics words (RerankParams::stripes)
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
     const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + D) * sizeof(double);
     PHK_REQUIRE(fb_lds <= FB_LDS_MAX, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);  // phk_model_build_fast keeps such models off this path
@@ -2592,6 +2614,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         const uint32_t npos = (method & PHK_METHOD_KMEANS) ? m->n_rblk_pos : 0;
         const uint32_t nneg = (method & PHK_METHOD_KMEANS) ? m->n_rblk_neg : 0;
         PHK_HIP(hipMemsetAsync(fbc, 0, 64, ctx->stream));
+        PHK_HIP(hipMemsetAsync(stripes, 0, PHK_STRIPES * 32 * sizeof(uint32_t), ctx->stream));
         RerankParams p;
         p.N = nb; p.M = m->M; p.n_cpos = m->n_cpos; p.n_cneg = m->n_cneg; p.D = D;
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
@@ -2601,6 +2624,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.fb_count = fbc; p.fb_list = fb_list; p.slow_list = slow_list; p.q_base = s;
         p.stat_total = fbc + 16;
         p.counters = fbc;
+        p.stripes = stripes;
         p.col_mask = m->has_mask ? m->d_col_mask : nullptr;
         p.slow_cap = nb_max;
         p.eb_cQ = 0.0; p.eb_cI = 0.0; p.eb_hsum = 0.0; p.per_row_scale = 0;
