@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
 // 2. certify / exact re-rank: one wavefront per query, lane = 4 dimensions
 // ------------------------------------------------------------------------------------
 #define PHK_STRIPES 256
+#define PHK_SUB_LISTS 16   // pairs of hand-over lists between phk_decide_h_kernel and phk_rerank16_kernel (<= PHK_STRIPES)
 struct RerankParams {
     uint64_t N, M, n_cpos, n_cneg, D;
     int kn, method;
@@ -378,6 +379,13 @@ struct RerankParams {
     int slow_back = 0;                      // phk_rerank16_kernel MODE 1: 3 = both of the following in one launch; 0 = slow_list[0 ..) counted by fb_count[2],
                                             // 1 = the list that grows down from slow_list[slow_cap - 1], counted by counters[12]
     uint64_t slow_cap = 0;
+    // phk_decide_h_kernel -> phk_rerank16_kernel (MODE 1, slow_back == 3): the hand-over lists as `sub_lists` separate pairs of
+    // lists, workgroup b of the decision kernel appending to pair b % sub_lists.  Pair s owns slow_list[s sub_cap, (s + 1) sub_cap)
+    // (front list up from its start, back list down from its end; sub_cap = 64 ceil(workgroups / sub_lists) bounds what its
+    // workgroups can hand over) and counts in words 2 / 12 of stripe s -- a cache line of its own, where the two returning
+    // atomics per wave of the decision kernel no longer queue behind every other wave's (0: the single pair of lists above)
+    uint32_t sub_lists = 0;
+    uint64_t sub_cap = 0;
     uint32_t *stat_total = nullptr;         // [0] += fallback queue length, [1] += orderings decided by exact distances
     const uint32_t *exact_extra = nullptr;  // exact-distance decisions of an earlier pass of the same batch
     // lists of the two-part int8 sweep (score_i8.hip; phk_rerank_kernel<.., I8H>): a value lacks g_j S_L, S_L = the exact
@@ -1166,20 +1174,42 @@ __global__ __launch_bounds__(256, 4) void phk_rerank16_kernel(const void *__rest
         // fb_count[2]), waves from its end the back list (counters[12]); front + back <= N, so the two never meet, and a
         // wave serves one kind of list.  (Two launches, each over the whole grid, spent 0.09 ms apiece on waves that
         // read a count and left.)
-        uint64_t cnt = phk_uniform_load(p.slow_back == 1 ? p.counters + 12 : p.fb_count + 2);
+        uint64_t cnt, base = 0, cap = p.slow_cap;
         bool back = p.slow_back == 1;
-        if (p.slow_back == 3 && (qraw & ~3ull) >= cnt) {
-            const uint64_t nwave4 = (((uint64_t)gridDim.x * blockDim.x) >> 6) * 4;
-            qraw = nwave4 - 4 - (qraw & ~3ull) + (qraw & 3ull);   // wave k from the end, same lane group
-            cnt = phk_uniform_load(p.counters + 12);
-            back = true;
+        if (p.slow_back == 3 && p.sub_lists) {
+            // the grid's waves in sub_lists runs of nlw: run s serves pair s, wave lw of the run from the front of its numbering
+            // the pair's front list, from its end the back list (front + back <= sub_cap <= 4 (nlw - 2): the two never meet);
+            // neighbouring waves work on neighbouring queries of one list
+            const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+            const uint64_t nlw = ((((uint64_t)gridDim.x * blockDim.x) >> 6)) / p.sub_lists;
+            if (wave_id >= nlw * p.sub_lists) return;   // (the waves beyond a whole number of runs)
+            const uint32_t sl = __builtin_amdgcn_readfirstlane((uint32_t)(wave_id / nlw));   // (wave-uniform: scalar loads below)
+            const uint64_t lw = wave_id % nlw;
+            base = (uint64_t)sl * p.sub_cap;
+            cap = p.sub_cap;
+            uint64_t q4 = lw * 4;
+            cnt = phk_uniform_load(p.stripes + sl * 32u + 2u);
+            if (q4 >= cnt) {
+                q4 = (nlw - 1 - lw) * 4;
+                cnt = phk_uniform_load(p.stripes + sl * 32u + 12u);
+                back = true;
+            }
+            qraw = q4 + (uint64_t)(lane >> 4);
+        } else {
+            cnt = phk_uniform_load(p.slow_back == 1 ? p.counters + 12 : p.fb_count + 2);
+            if (p.slow_back == 3 && (qraw & ~3ull) >= cnt) {
+                const uint64_t nwave4 = (((uint64_t)gridDim.x * blockDim.x) >> 6) * 4;
+                qraw = nwave4 - 4 - (qraw & ~3ull) + (qraw & 3ull);   // wave k from the end, same lane group
+                cnt = phk_uniform_load(p.counters + 12);
+                back = true;
+            }
         }
         if ((qraw & ~3ull) >= cnt) return;
         inrange = qraw < cnt;
         // entry = query | todo << 30: which parts are still open (bit 0 the k-NN vote, bit 1 the centroid metric; 0 = both).
         // A part the sender has decided already sits in scores[q] and is only added to.
         const uint64_t pos = inrange ? qraw : cnt - 1;
-        const uint32_t entry = p.slow_list[back ? p.slow_cap - 1 - pos : pos];
+        const uint32_t entry = p.slow_list[base + (back ? cap - 1 - pos : pos)];
         q = ql = entry & 0x3FFFFFFFu;
         todo = entry >> 30 ? entry >> 30 : 3u;
     } else if (MODE == 2) {
@@ -1953,7 +1983,13 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
         const uint32_t open_parts = ((want_knn && !cert) ? 1u : 0u) | ((want_cen && !cert_c) ? 2u : 0u);
         // two lists in one array, so that a wave of the next kernel works on one kind of segment: queries with the k-NN
         // part open from the front, those with only the centroid part open from the back
-        if (open_parts == 2u) p.slow_list[p.slow_cap - 1 - atomicAdd(p.counters + 12, 1u)] = (uint32_t)qa | (open_parts << 30);
+        if (p.sub_lists) {   // this workgroup's pair of lists (see RerankParams::sub_lists)
+            const uint32_t sl = blockIdx.x % p.sub_lists;
+            uint32_t *cw = p.stripes + sl * 32u;
+            const uint64_t base = (uint64_t)sl * p.sub_cap;
+            if (open_parts == 2u) p.slow_list[base + p.sub_cap - 1 - atomicAdd(cw + 12, 1u)] = (uint32_t)qa | (open_parts << 30);
+            else p.slow_list[base + atomicAdd(cw + 2, 1u)] = (uint32_t)qa | (open_parts << 30);
+        } else if (open_parts == 2u) p.slow_list[p.slow_cap - 1 - atomicAdd(p.counters + 12, 1u)] = (uint32_t)qa | (open_parts << 30);
         else p.slow_list[atomicAdd(p.fb_count + 2, 1u)] = (uint32_t)qa | (open_parts << 30);
     }
 }
@@ -2585,14 +2621,14 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     float *cv2 = (float *)((char *)cv + gen_sets * set_bytes + ca_bytes);
     uint32_t *ci2 = (uint32_t *)((char *)cv2 + per_list2 * sizeof(float4));
     float *cu2 = (float *)((char *)ci2 + per_list2 * sizeof(uint4));
-    PHK_TRY(phk_ws(ctx, WS_DIST, (3 * nb_max + 32 + PHK_STRIPES * 32) * sizeof(uint32_t), &fb));
+    PHK_TRY(phk_ws(ctx, WS_DIST, (3 * nb_max + 32 + 64 * PHK_SUB_LISTS + PHK_STRIPES * 32) * sizeof(uint32_t), &fb));
     PHK_TRY(phk_ws(ctx, WS_QF32, nb_max * FB_CHUNKS * sizeof(FbRecord), &rec));
     // counter words, per batch: [0] first-pass queue length, [1] exact-distance decisions, [2] decide kernel's hand-over
     // count, [3] brute-force queue length after the second chance, [4] its exact-distance decisions, [8..11] why the
     // high-parts-only decision stage passed a query on (window wider than the refined set, window reaching past the
     // lists, refined values too close, centroid leader not certified); [16 ..] totals of the call: brute-forced queries,
     // exact-distance decisions, second-chance queries, the four reasons
-    uint32_t *fbc = (uint32_t *)fb, *fb_list = fbc + 32, *slow_list = fb_list + nb_max, *fb2_list = slow_list + nb_max;
+    uint32_t *fbc = (uint32_t *)fb, *fb_list = fbc + 32, *slow_list = fb_list + nb_max, *fb2_list = slow_list + nb_max + 64 * PHK_SUB_LISTS;
     uint32_t *stripes = fb2_list + nb_max;   // striped statistics words (RerankParams::stripes)
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
     const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + D) * sizeof(double);
@@ -2727,6 +2763,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             // the high-parts-only kernel issues D/16 MFMAs per value, not the count-exact kernel's 2D/16
             // (the low product the decision stage adds has its own term, see phk_decide_h_kernel)
             RerankParams pd = p;
+            pd.sub_lists = PHK_SUB_LISTS;
+            pd.sub_cap = 64 * phk_div_up(phk_div_up(nb, 64), PHK_SUB_LISTS);
             pd.eb_cQ = PHK_MFMA_ACC * ((double)D / 16.0) + 3.0;
             pd.eb_cI = PHK_MFMA_PROD * ((double)D / 16.0) * rho;
             if (d_knn && d_cen) {
@@ -2744,8 +2782,9 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             ph.eb_cP += 8192.0 * (1.0 + 1.0 / 2048.0) + 1.0;
             ph.eb_abs *= 2.0;
             ph.slow_back = 3;   // front and back list in one launch
+            // (waves: sub_lists x (sub_cap / 4 + 2) local ones, four per workgroup)
             PHK_LAUNCH(ctx, "phk_rerank16_kernel",
-                       (phk_rerank16_kernel<0, 1><<<dim3((unsigned)phk_div_up(nb, 16) + 1), dim3(256), 0, ctx->stream>>>(src, ph)));
+                       (phk_rerank16_kernel<0, 1><<<dim3((unsigned)phk_div_up((uint64_t)PHK_SUB_LISTS * (pd.sub_cap / 4 + 2), 4)), dim3(256), 0, ctx->stream>>>(src, ph)));
         } else if (hi_gen) {
             HiParams hp;
             hp.lo16 = m->d_lo16;
