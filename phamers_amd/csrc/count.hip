@@ -406,9 +406,20 @@ __global__ __launch_bounds__(256) void phk_count_stats_kernel(const uint64_t *__
         pad += __shfl_xor(pad, sft);
         used += __shfl_xor(used, sft);
     }
-    if ((threadIdx.x & 63) == 0 && pad) {
-        atomicAdd(stats, pad);
-        atomicAdd(stats + 1, used);
+    // one pair of atomics per workgroup, not per wave: they all land on one cache line and retire one after the other
+    __shared__ unsigned long long s_pad[4], s_used[4];
+    if ((threadIdx.x & 63) == 0) {
+        s_pad[threadIdx.x >> 6] = pad;
+        s_used[threadIdx.x >> 6] = used;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        pad = s_pad[0] + s_pad[1] + s_pad[2] + s_pad[3];
+        used = s_used[0] + s_used[1] + s_used[2] + s_used[3];
+        if (pad) {
+            atomicAdd(stats, pad);
+            atomicAdd(stats + 1, used);
+        }
     }
 }
 
