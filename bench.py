@@ -193,7 +193,7 @@ def main():
                     help="uniform: the BASELINE configuration (fixed-length, uniform i.i.d. contigs; the headline). "
                          "ragged: heavy-tailed lengths 5-500 kb in arbitrary order, per-contig GC 0.3-0.7, 0.1 %% N -- "
                          "a second, separately labelled workload; --contigs defaults to 200000 there")
-    ap.add_argument("--min-seconds", type=float, default=3.0,
+    ap.add_argument("--min-seconds", type=float, default=8.0,
                     help="time at least this long: the timed region is max(--steps, enough steps to fill it), so that a "
                          "millisecond-scale step is measured at the sustained clock (and is visible to an outside "
                          "GPU-activity sampler); 0 = exactly --steps")
@@ -203,7 +203,7 @@ def main():
     args = ap.parse_args()
 
     # `python bench.py --gpus N` started plainly (no RANK in the environment): this process becomes the launcher.  It
-    # starts the N ranks as CHILD processes before anything here touches the GPU (counting devices does not), hands
+    # starts the N ranks as CHILD processes before anything here touches the GPU (the devices are counted in sysfs, not through the runtime), hands
     # through rank 0's JSON line and exits with the ranks' status.  Under torch.distributed.run RANK is set and this
     # branch is not taken.  With fewer than N devices visible nothing is measured (exit code 2); PHK_BENCH_BACKEND=gloo
     # lifts that check to rehearse the multi-rank code path with several ranks on one device (or, with
@@ -311,7 +311,7 @@ def main():
     scores_buf = [torch.empty(n, dtype=torch.float64, device=dev) for _ in range(2)]
     scores = scores_buf[0]
     status = torch.zeros(1, dtype=torch.int32, device=dev)
-    gathered_buf = [torch.empty(world * n, dtype=torch.float64, device=dev) for _ in range(2)] if dist else None
+    gathered_buf = [torch.full((world * n,), float("nan"), dtype=torch.float64, device=dev) for _ in range(2)] if dist else None
     first = rank * n
     mask = None
     if ragged:
@@ -397,6 +397,20 @@ def main():
     prof = ctx.profile()
     n_fallback, n_exact = ctx.score_stats()
     stats_ex = ctx.score_stats_ex()
+    # the collective, checked after the timed region: this rank's slice of the last step's gathered vector is its score
+    # vector bit for bit, and every rank's slice arrived (a score is never NaN for these synthetic contigs; the gather
+    # buffers start out as NaN)
+    gather_info = None
+    if dist:
+        gather_info = {"backend": dist.get_backend(), "async": dist.get_backend() == "nccl",
+                       "bytes_per_rank_per_step": n * 8}
+        if gathered_buf is not None and dist.get_backend() == "nccl":
+            b = (nstep[0] - 1) & 1
+            mine = gathered_buf[b][rank * n:(rank + 1) * n]
+            gather_info["gathered_equals_scores"] = bool(torch.equal(mine, scores_buf[b]))
+            gather_info["slices_arrived"] = int(sum(
+                bool(torch.isfinite(gathered_buf[b][r * n:(r + 1) * n]).all().item()) for r in range(world)))
+    scores = scores_buf[(nstep[0] - 1) & 1]
 
     if rank != 0:
         if dist:
@@ -464,7 +478,10 @@ def main():
                 "peak": kernels[dom]["peak"], "unit": kernels[dom]["unit"], "frac": kernels[dom]["frac"],
                 "traffic": per_contig * n if per_contig else None}
     if tsrc:
+        # the PMC passes are separate rocprofv3 runs of this same command (counters cannot be read from inside it):
+        # the figure is quoted from the newest committed measurement, not measured by the run that prints this line
         roofline["traffic_source"] = tsrc
+        roofline["traffic_measured_in_this_run"] = False
     # the whole step against both roofs: every algorithmic flop / byte of the step over the step's wall time, and the
     # HBM bytes all of its kernels moved (PMC, same source) beside the algorithmic bytes
     step_s = elapsed / steps
@@ -486,7 +503,8 @@ def main():
         "metric": ("Gbases/s k-mer-count+score, k=%d, ragged 5-500 kb contigs" % k) if ragged else
                   "Gbases/s k-mer-count+score, k=%d, %d kb contigs" % (k, L // 1000),
         "value": world * T * steps / elapsed / 1e9,
-        "unit": "Gbases/s", "n_gpus": world, "ranks_seen": seen, "steps": steps, "warmup": args.warmup,
+        "unit": "Gbases/s", "n_gpus": world, "ranks_seen": seen, "steps": steps, "steps_requested": args.steps,
+        "warmup": args.warmup,
         "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None,
         "dtype": ("u32 counts + int8 MFMA proposal (exact integer counts x 24-bit fixed-point reference columns in three int8 "
@@ -508,6 +526,8 @@ def main():
         "parity": parity,
         "timed_region_s": elapsed,
     }
+    if gather_info:
+        out["gather"] = gather_info
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(k, L if not ragged else int(T // n), pos, neg, cpos, cneg, pool=pool)
     if pool is not None:

@@ -18,6 +18,7 @@ PHK_ERR_ARG, PHK_ERR_HIP, PHK_ERR_NOMEM, PHK_ERR_UNSUPPORTED, PHK_ERR_NAN, PHK_E
 METHOD_KNN, METHOD_KMEANS, METHOD_COMBO = 1, 2, 3
 METHODS = {"knn": METHOD_KNN, "kmeans": METHOD_KMEANS, "combo": METHOD_COMBO}
 MAX_K = 7
+ABI_VERSION = 1
 
 c_void_p, c_int, c_u32, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
 c_char_p, c_double = ctypes.c_char_p, ctypes.c_double
@@ -125,6 +126,14 @@ def load():
                     fn = getattr(lib, name)
                     fn.restype = res
                     fn.argtypes = args
+                ver = lib.phk_abi_version()
+                if ver != ABI_VERSION and not (ver == (ABI_VERSION | 0x40000000)
+                                               and os.environ.get("PHK_ALLOW_DIAGNOSTIC_BUILD") == "1"):
+                    raise ImportError(
+                        "%s reports ABI version %#x, this binding is for %d%s" % (
+                            LIB_PATH, ver, ABI_VERSION,
+                            " (a -DPHK_DIAGNOSTIC_BUILD library: timing only, never for results; tools/diag scripts "
+                            "load it with PHK_ALLOW_DIAGNOSTIC_BUILD=1)" if ver & 0x40000000 else ""))
                 _lib = lib
     return _lib
 

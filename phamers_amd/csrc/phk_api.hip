@@ -16,7 +16,13 @@ void phk_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *phk_last_error(void) { return g_err; }
+// A diagnostic build (-DPHK_DIAGNOSTIC_BUILD: the only switch under which the timer / probe code of the kernels compiles)
+// reports a different version, so such a library cannot pass __graft_entry__.build() or be loaded by phamers_amd._lib.
+#ifdef PHK_DIAGNOSTIC_BUILD
+extern "C" int phk_abi_version(void) { return PHK_ABI_VERSION | 0x40000000; }
+#else
 extern "C" int phk_abi_version(void) { return PHK_ABI_VERSION; }
+#endif
 
 extern "C" int phk_device_count(int *count) {
     PHK_REQUIRE(count, "phk_device_count: NULL");

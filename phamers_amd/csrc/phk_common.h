@@ -13,6 +13,13 @@
 
 #define PHK_WAVE 64
 
+// Diagnostic code (phase timers, tuning overrides of the kernels' shape macros) compiles only in a build that says so;
+// such a build reports another ABI version (phk_api.hip) and is refused by the loader.
+#if (defined(I8_TIMERS) || defined(I8_NW) || defined(I8_NBUF) || defined(SLOT_LINES) || defined(PHK_HI_REFINE) || \
+     defined(PHK_RERANK_WAVES)) && !defined(PHK_DIAGNOSTIC_BUILD)
+#error "kernel tuning / timer macros need -DPHK_DIAGNOSTIC_BUILD (make EXTRA_CXXFLAGS='-DPHK_DIAGNOSTIC_BUILD -D...')"
+#endif
+
 void phk_set_error(const char *fmt, ...);
 
 #define PHK_HIP(call)                                                                      \

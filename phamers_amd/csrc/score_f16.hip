@@ -408,9 +408,6 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
     // front of the barrier below (M0 = LDS byte address of the piece, written in the same statement).
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
     auto dma_block = [&](uint32_t blk, int buf) {
-#if defined(PHK_ABL) && (PHK_ABL == 3 || PHK_ABL == 4)
-        if (blk > 1) return;
-#endif
         const uint4 *g = Af + (uint64_t)blk * (F16_BLOCK_BYTES / 16) + lane;
         const uint32_t l = lds_base + (uint32_t)buf * F16_BLOCK_BYTES;
         for (int p = wave; p < F16_PIECES; p += F16_WAVES) {
@@ -1428,9 +1425,6 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
         if (qb < nqb && q0 + j < N) cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
         ++seg;
     }
-#if defined(PHK_ABL_NOQ)
-    half8 bh[16], bl[16];
-#endif
     for (uint32_t t = 0; t < ntile; ++t) {
         f32x16 acc[GEN_CT];
 #pragma unroll
@@ -1439,13 +1433,8 @@ __global__ __launch_bounds__(64 * GEN_NW, GEN_NW == 8 ? 1 : 2) void phk_knn_f16_
             for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
         for (uint32_t c = 0; c < nchunk; ++c) {
             // this wave's query fragments of chunk c (16 x hi + 16 x lo, 1 KiB coalesced loads)
-#if !defined(PHK_ABL_NOQ)
             half8 bh[16], bl[16];
-#endif
             const uint4 *bq = Bq + ((qbc * nchunk + c) * 32) * 64 + lane;
-#if defined(PHK_ABL_NOQ)   // ablation (timing only, results wrong): the query fragments are fetched for the first chunk alone
-            if (c == 0 && t == 0)
-#endif
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const uint4 uh = bq[(2 * s) * 64];

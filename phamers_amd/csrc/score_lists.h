@@ -76,22 +76,10 @@ __device__ __forceinline__ uint32_t phk_bfi_hw(uint32_t m, uint32_t a, uint32_t 
 // into divergent branches (s_and_saveexec + register moves, ~10x the instructions).  Values move with
 // v_max / v_med3 (the list is sorted, so the new k-th value is med3(v[k-1], v[k], x)); indices move with
 // bitfield inserts under sign-replicated masks m_k = (x > v[k]) ? ~0 : 0 taken from the sign of v[k] - x.
-#if defined(PHK_ABL) && PHK_ABL == 1
-__device__ __forceinline__ uint32_t phk_bfi(uint32_t m, uint32_t a, uint32_t b) {
-    uint32_t r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
-    return r;
-}
-#else
 __device__ __forceinline__ uint32_t phk_bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
-#endif
 
 __device__ __forceinline__ void list_insert(float (&v)[CAND], uint32_t (&ix)[CAND], float &drop, float x,
                                             uint32_t c) {
-#if defined(PHK_ABL) && (PHK_ABL == 2 || PHK_ABL == 4)
-    drop = fmaxf(drop, x);
-    return;
-#endif
     const uint32_t m0 = (uint32_t)(__float_as_int(v[0] - x) >> 31);
     const uint32_t m1 = (uint32_t)(__float_as_int(v[1] - x) >> 31);
     const uint32_t m2 = (uint32_t)(__float_as_int(v[2] - x) >> 31);

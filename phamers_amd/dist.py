@@ -16,11 +16,42 @@ import sys
 import numpy as np
 
 
-def visible_gpus():
-    """Number of GPUs this process may use.  Counting devices does not initialise the GPU (so a launcher may call
-    this and still start its ranks as children)."""
-    import torch
-    return int(torch.cuda.device_count())
+def _parse_visible(value, have):
+    """Entries of a *_VISIBLE_DEVICES list that name one of `have` devices by index (the runtime stops at the first
+    entry it cannot resolve; UUID entries are taken as present)."""
+    n = 0
+    for item in value.split(","):
+        item = item.strip()
+        if not item:
+            break
+        if item.lstrip("-").isdigit():
+            if not 0 <= int(item) < have:
+                break
+        n += 1
+    return n
+
+
+def visible_gpus(topology="/sys/class/kfd/kfd/topology/nodes"):
+    """Number of GPUs this process may use, counted WITHOUT the HIP / HSA runtime: the KFD topology in sysfs lists
+    one node per agent, and a GPU is a node with a non-zero simd_count (CPU nodes have 0); ROCR_VISIBLE_DEVICES /
+    HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow the count as they would narrow the runtime's.  A launcher may
+    therefore call this and still start its ranks as children that are the first to touch the GPU."""
+    import glob
+    have = 0
+    for props in glob.glob(os.path.join(topology, "*", "properties")):
+        try:
+            with open(props) as f:
+                for line in f:
+                    if line.startswith("simd_count"):
+                        have += int(line.split()[1]) > 0
+                        break
+        except (OSError, ValueError, IndexError):
+            continue
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            have = min(have, _parse_visible(v, have))
+    return have
 
 
 def free_port():

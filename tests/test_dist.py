@@ -195,3 +195,23 @@ def test_launch_ranks_env_and_failure(tmp_path):
     t0 = time.monotonic()
     assert pdist.launch_ranks(2, [sys.executable, str(script), str(tmp_path), "fail"], require_gpus=False, timeout=120) == 7
     assert time.monotonic() - t0 < 30        # rank 0 was terminated, not waited for
+
+
+def test_visible_gpus_counts_kfd_nodes_without_the_runtime(tmp_path, monkeypatch):
+    """The launcher counts GPUs from the KFD topology in sysfs (a node with simd_count > 0), narrowed by the
+    *_VISIBLE_DEVICES variables -- no HIP / HSA call, so its children are the first to touch the device."""
+    from phamers_amd import dist as pdist
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):       # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if not simd else 0, simd))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert pdist.visible_gpus(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert pdist.visible_gpus(str(tmp_path)) == 2
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,7,0")        # the runtime stops at the entry it cannot resolve
+    assert pdist.visible_gpus(str(tmp_path)) == 1
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert pdist.visible_gpus(str(tmp_path)) == 0
+    assert pdist.visible_gpus(str(tmp_path / "absent")) == 0

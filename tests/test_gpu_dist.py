@@ -1,6 +1,8 @@
 """The sharded path on the GPU: shard-count invariance of the device scorer (scores bit-identical for
 1 / 2 / 4 / 8 shards) and the product-level sharded entry points with their default (GPU) scorer under a 2-rank gloo
-group on one device (RCCL needs a device per rank; the collective itself is covered by the driver's multi-GPU run)."""
+group on one device (RCCL needs a device per rank), and -- as 1-rank `nccl` groups in fresh child processes -- the RCCL
+code path itself: init_process_group(device_id=...), the asynchronous double-buffered all_gather_into_tensor of
+bench.py against the library's stream, gather_variable on device tensors, destroy_process_group."""
 import json
 import os
 import subprocess
@@ -116,3 +118,91 @@ def test_sharded_entry_points_with_the_gpu_scorer_two_ranks(tmp_path):
     assert np.array_equal(got[0], want)
     assert np.array_equal(got[1], want)
     assert json.load(open(outp + ".ids.json")) == ["0", "1", "2", "3", "4"]
+
+
+def _rccl_env(**extra):
+    from phamers_amd import dist as pdist
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(pdist.free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS="4")
+    env.update(extra)
+    return env
+
+
+def test_bench_runs_the_rccl_gather_as_a_one_rank_group():
+    """bench.py with PHK_BENCH_FORCE_DIST=1 in a fresh child process: a 1-rank RCCL group on the one GPU of the box --
+    init_process_group("nccl", device_id=...), the rank-id all-gather, the per-step asynchronous
+    all_gather_into_tensor on two buffers beside the library's stream, the closing barrier, destroy_process_group.
+    The line must report one rank seen, green parity, and a gathered vector equal to the score vector."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--config", "1", "--contigs", "65536",
+                        "--no-cpu-baseline", "--min-seconds", "0", "--steps", "3", "--warmup", "1"],
+                       env=_rccl_env(PHK_BENCH_FORCE_DIST="1", PHK_BENCH_BACKEND="nccl"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["steps"] == 3 and line["steps_requested"] == 3
+    g = line["gather"]
+    assert g["backend"] == "nccl" and g["async"] is True
+    assert g["gathered_equals_scores"] is True and g["slices_arrived"] == 1
+    par = line["parity"]
+    assert par["counts_bit_exact"] is True and par["max_rel_score_err"] < 1e-6 and par["nan_rows"] == 0
+    assert line["value"] > 0 and line["config"]["contigs_per_gpu"] == 65536
+
+
+RCCL_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["PHK_REPO"])
+import torch
+import torch.distributed as dist
+from phamers_amd import dist as pdist
+from tests import test_gpu_dist as T, helpers
+from oracle import oracle
+
+dev = pdist.rank_device()
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev))
+assert pdist.ranks_seen(device=torch.device("cuda", dev)) == 1
+g = helpers.load_npz("scoring_k4.npz")
+ref = helpers.load_npz("ref_features.npz")
+pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))[:2255]
+neg = oracle.normalize_counts(ref["neg_counts"].astype(np.int64))[:2255]
+seqs = T._contigs()
+full = pdist.score_contigs_distributed(seqs, pos, neg, g["cpos_eq"], g["cneg_eq"], 4, "combo", 3)
+ids, full_f = pdist.score_fasta_distributed(os.environ["PHK_FASTA"], pos, neg, g["cpos_eq"], g["cneg_eq"], 4, "combo", 3)
+# gather_variable on device tensors of different lengths is what N > 1 ranks run; with one rank: identity
+t = torch.arange(7, dtype=torch.float64, device="cuda:%d" % dev)
+assert torch.equal(pdist.gather_variable(t), t)
+np.save(os.environ["PHK_OUT"], np.stack([full, full_f]))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_entry_points_under_a_one_rank_rccl_group(tmp_path):
+    """dist.score_contigs_distributed / score_fasta_distributed under the `nccl` backend (the scores travel as DEVICE
+    tensors through RCCL's all-gather) in a fresh child process: equal to the single-process device result."""
+    from oracle import oracle
+    from phamers_amd import dist as pdist
+    seqs = _contigs()
+    fasta = tmp_path / "contigs.fasta"
+    with open(fasta, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(">SuperContig_%d_length_%d_ID_%d\n" % (i, len(s), i))
+            for j in range(0, len(s), 70):
+                f.write(s[j:j + 70] + "\n")
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    outp = str(tmp_path / "out.npy")
+    r = subprocess.run([sys.executable, str(script)], env=_rccl_env(PHK_REPO=REPO, PHK_OUT=outp, PHK_FASTA=str(fasta)),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-4000:]
+    got = np.load(outp)
+    g = helpers.load_npz("scoring_k4.npz")
+    ref = helpers.load_npz("ref_features.npz")
+    pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))[:2255]
+    neg = oracle.normalize_counts(ref["neg_counts"].astype(np.int64))[:2255]
+    want = pdist.default_scorer()(seqs, 4, "combo", pos, neg, g["cpos_eq"], g["cneg_eq"], 3)
+    assert np.array_equal(got[0], want)
+    assert np.array_equal(got[1], want)
