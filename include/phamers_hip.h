@@ -307,7 +307,9 @@ int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_exact_resolv
 /* the same and more, out[0 .. n_out): [0] brute-forced queries, [1] orderings decided by exact distances, [2] queries
  * that took the second chance (split-query MFMA pass), [3..6] why the high-parts-only decision stage passed them on:
  * window wider than the refined candidates, window reaching past the lists, refined values too close, centroid
- * leader not certified */
+ * leader not certified; general D (k = 5, 6), int8 sweep: [7] rows re-swept alone with all three digits (the two-digit
+ * window held more columns than the lists), [8] rows beyond the int8 operand, swept by the f16 count-exact kernel
+ * (both are also counted in [2]) */
 int phk_score_stats_ex(phk_ctx *ctx, uint64_t *out, int n_out);
 
 /* Diagnostic of the arithmetic the MFMA proposal rests on: chains of v_mfma_f32_32x32x16_f16 on caller tiles.  Per tile

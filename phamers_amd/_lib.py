@@ -212,10 +212,11 @@ class Context(object):
 
     def score_stats_ex(self):
         """Diagnostics of the most recent scoring call (phk_score_stats_ex) as a dict."""
-        out = np.zeros(7, dtype=np.uint64)
-        check(self.lib.phk_score_stats_ex(self.handle, ptr(out), 7))
+        out = np.zeros(9, dtype=np.uint64)
+        check(self.lib.phk_score_stats_ex(self.handle, ptr(out), 9))
         names = ("brute_forced", "exact_distance_decisions", "second_chance", "window_wider_than_refined",
-                 "window_past_lists", "refined_values_too_close", "centroid_leader_uncertified")
+                 "window_past_lists", "refined_values_too_close", "centroid_leader_uncertified",
+                 "reswept_three_digits", "swept_f16_beyond_int8")
         return {k: int(v) for k, v in zip(names, out)}
 
     # ---- timing ----

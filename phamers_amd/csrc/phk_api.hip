@@ -522,12 +522,12 @@ extern "C" int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_e
 extern "C" int phk_score_stats_ex(phk_ctx *ctx, uint64_t *out, int n_out) {
     PHK_ENTER(ctx, "phk_score_stats_ex");
     PHK_REQUIRE(out && n_out >= 0, "phk_score_stats_ex: NULL");
-    uint32_t c[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (ctx->last_score_fast && ctx->ws[WS_DIST].ptr) {
         PHK_HIP(hipMemcpyAsync(c, (const uint32_t *)ctx->ws[WS_DIST].ptr + 16, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         PHK_HIP(hipStreamSynchronize(ctx->stream));
     }
-    for (int i = 0; i < n_out; ++i) out[i] = i < 7 ? c[i] : 0;
+    for (int i = 0; i < n_out; ++i) out[i] = i < 9 ? c[i] : 0;
     return PHK_OK;
 }
 

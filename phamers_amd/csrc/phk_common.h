@@ -70,6 +70,8 @@ enum PhkSlot {
     WS_NWIN,        // row sums
     WS_LONG,        // counting: contigs handed from the lane-pair kernel to the wave-per-contig kernel
     WS_OUT,         // batch API: scores on their way to the host
+    WS_SUB,         // scoring at general D: dense count rows (+ row sums) of a second pass's sub-batch
+    WS_QUEUE,       // scoring at general D: the two hand-over queues of the first pass
     WS_SLOTS
 };
 

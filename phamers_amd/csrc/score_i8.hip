@@ -580,7 +580,7 @@ __global__ void phk_merge_list_sets_kernel(float *__restrict__ cv, uint32_t *__r
 // proposal pass for uint32 counts at D = 512 .. 4096: row sums (if needed) -> int8 query fragments -> sweep (-> merge)
 int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum, uint64_t nb,
                                    uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu, uint32_t groups,
-                                   uint64_t set_bytes, bool two_parts, bool *accepted) {
+                                   uint64_t set_bytes, bool two_parts) {
     const uint64_t D = m->D, nchunk = D / (32 * I8_KS), nchunk256 = D / 256;
     const uint64_t nqb = phk_div_up(nb, 32);
     void *bq, *rs = nullptr, *bg;
@@ -597,14 +597,8 @@ int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint3
                phk_split_queries_i8_kernel<<<dim3((unsigned)phk_div_up(nqb * nchunk256, 4)), dim3(256), 0, ctx->stream>>>(
                    d_counts, d_rowsum, nb, D, (uint4 *)bq, (uint32_t *)bg));
     // Rows that do not fit the int8 operand (a bin more than 127 away from the row's centre: long or compositionally
-    // skewed contigs) would all take the float64 brute force.  A batch with more than a handful of them goes through the
-    // f16 kernel instead, whose operand reaches 2048: the caller is told so.  One 4-byte read-back per batch of <= 2^20
-    // rows (the sweep that follows takes tens of milliseconds).
-    uint32_t nbig = 0;
-    PHK_HIP(hipMemcpyAsync(&nbig, (const uint32_t *)bg + nb, sizeof(nbig), hipMemcpyDeviceToHost, ctx->stream));
-    PHK_HIP(hipStreamSynchronize(ctx->stream));
-    *accepted = nbig <= (nb / 256 > 16 ? nb / 256 : 16);
-    if (!*accepted) return PHK_OK;
+    // skewed contigs) are flagged in `big`: the sweep stores sentinel lists for them and the decision kernel hands them to
+    // the f16 count-exact sweep, row by row (phk_score_fast).
     const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
     const uint32_t ng = (groups > 1 && nref >= 8u * groups && nqb >= 64) ? groups : 1u;
     const uint64_t nqg = phk_div_up(nqb, I8_NW);

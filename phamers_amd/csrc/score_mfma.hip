@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__rest
 // 2. certify / exact re-rank: one wavefront per query, lane = 4 dimensions
 // ------------------------------------------------------------------------------------
 #define PHK_STRIPES 256
+#define PHK_SUBPASS_MIN 32 // general D: a hand-over queue shorter than this is brute-forced, not swept (phk_score_fast)
 #define PHK_SUB_LISTS 16   // pairs of hand-over lists between phk_decide_h_kernel and phk_rerank16_kernel (<= PHK_STRIPES)
 struct RerankParams {
     uint64_t N, M, n_cpos, n_cneg, D;
@@ -343,6 +344,7 @@ struct RerankParams {
     double eb_cA, eb_cP, eb_cR, eb_abs;  // error model of the proposal pass (see ErrBound)
     double eb_cQ;           // coefficient of Q (count-exact proposal: |c - c0| / T, the centred count operand)
     double eb_cI = 0.0;     // coefficient of I, the maximum norm of the query operand (see ErrBound)
+    double eb_cIf = 0.0;    // the same without rho_inf: the floor term of the nominal products (float16 subnormals, see ErrBound)
     double eb_hsum = 0.0;   // max_j |sum_i r~'_ji| (count-exact proposals: the residue of centring the counts)
     int per_row_scale;      // count-exact proposal: computed values are in units of T_q / vscale (T_q = row sum)
     const double *R64, *C64, *mu64, *colnorm;
@@ -390,6 +392,16 @@ struct RerankParams {
     const uint32_t *exact_extra = nullptr;  // exact-distance decisions of an earlier pass of the same batch
     // lists of the two-part int8 sweep (score_i8.hip; phk_rerank_kernel<.., I8H>): a value lacks g_j S_L, S_L = the exact
     // integer product of c - c0 with the column's L digits -- |.| <= |c - c0| lam8[segment] per unit of row sum
+    // Per-row routing at general D (phk_score_fast): a pass over a SUB-BATCH -- rows of the batch gathered into a dense
+    // count matrix -- works on dense indices; out_map[i] is row i's index within the batch, used wherever a result
+    // leaves the pass: the score, the centroid distances in `pend`, the brute-force queue.  In the first pass (q2_count
+    // set) a row the lists cannot decide is handed on instead of brute-forced: a row beyond the int8 operand (sentinel
+    // lists) to q2_big, counted by q2_count[1] -- the f16 count-exact sweep takes it -- any other to q2_wide, counted by
+    // q2_count[0] -- re-swept with all three digits (null: straight to the brute-force queue).
+    const uint32_t *out_map = nullptr;
+    uint32_t *q2_count = nullptr;
+    uint32_t *q2_wide = nullptr;
+    uint32_t *q2_big = nullptr;
     const int8_t *L8 = nullptr;             // [M + n_cpos + n_cneg][D] L digits, row-major
     const float *T8 = nullptr;              // per 32-column block: 32 quanta g_j (+ 32 bias terms)
     uint32_t t8_blk[3] = {0, 0, 0};         // first block of each segment
@@ -557,13 +569,22 @@ __device__ __forceinline__ double exact_d2(const double (&qd)[4 * DSUB], const d
 //                cA 2 (bias -> fp32, T b), cP kappa/u + 2, cR kappa (1 + kappa)/u + 3 with kappa = max_j |r'_j - r~'_j| / |r'_j| of
 //                the quantisation (computed at build; the final fma: u |v|), c_abs 0, habs as count-exact.
 //     cI carries rho_inf = max_j |r~'_j|_inf / |r'_j| of the model, so that |x|_inf |y|_inf <= I rho_inf R.
+//     Subnormal float16 operands (round 4; found by the bulk fuzz of tests/mfma_fuzz_worker.py, confirmed by the probe in
+//     tools/diag/mfma_emulate.py): the instruction aligns a term by the operands' exponent FIELDS, so a non-zero subnormal
+//     (|x| < 2^-14: the low parts of small reference elements) counts as 2^-14 whatever its leading zeros, and the `p` of
+//     the per-instruction charge u (11 A + 18 p) is the largest NOMINAL product:  p <= (|x|_inf + 2^-14)(|y|_inf + 2^-14).
+//     In v units, with f = 2^-14 / S:  p <= (I + f)(rho_inf R + f), i.e. the chain is charged cIf u f (I + R + f) on top of
+//     the cI term (cIf = 18 n) -- six orders of magnitude below it for any real reference (f = 1.5e-8 against R ~ 1e-3), but
+//     without it the bound is not a bound.
 struct ErrBound {
     double A, P, cA, cP, cR, cabs;
     double Q = 0.0, cQ = 0.0;
     double I = 0.0, cI = 0.0;
     double habs = 0.0;
+    double cIf = 0.0;   // f16 chains: PHK_MFMA_PROD x instructions, WITHOUT rho_inf -- the floor of the nominal products, see above
     __device__ double operator()(double R) const {
-        return 5.9604644775390625e-08 * R * (cA * A + cQ * Q + cI * I + cP * P + cR * R) + cabs * (R + P) + habs;
+        const double f = 1.4901161193847656e-08;   // 2^-14 / S, S = 2^12: a float16 subnormal's nominal magnitude in operand units
+        return 5.9604644775390625e-08 * (R * (cA * A + cQ * Q + cI * I + cP * P + cR * R) + cIf * f * (I + R + f)) + cabs * (R + P) + habs;
     }
 };
 
@@ -831,7 +852,7 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     eb.A = phk_sqrt_up(nq2) + p.mu_norm;
     const double nqp_up = phk_sqrt_up(nqp2);
     eb.P = nqp_up;
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI; eb.cIf = p.eb_cIf;
     if (SRC == 0 && p.per_row_scale) {   // count-exact lists: the chain's query operand is c - c0
         eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs;
         eb.P = phk_sqrt_up(nqp2 + cop.shift2);   // (high-parts-only lists: what the low parts multiply)
@@ -854,6 +875,8 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     // half-lists dropped (uok), else the segment is left to the exact candidate distances.  Lane l < 24 works for candidate
     // l & 7 of segment l >> 3, as in certify_segments.
     uint64_t uok = ~0ull;
+    // (a row beyond the int8 operand: the sweep stored its sentinel, 3e38 as the best dropped value)
+    const bool big_row = p.q2_count ? __any(lane < 6 && pre_u > 1.0e38f) != 0 : false;
     if (I8H) {
         const int g3 = lane >> 3, gb = lane & 56;
         const uint32_t ncols = g3 == 0 ? (uint32_t)p.M : g3 == 1 ? (uint32_t)p.n_cpos : g3 == 2 ? (uint32_t)p.n_cneg : 0u;
@@ -913,7 +936,7 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         certified &= uok;
         // statistics: a window of a segment the method uses reached past the lists (rare: one atomic per such query)
         const uint64_t used = ((p.method & PHK_METHOD_KNN) ? 0x01ull : 0ull) | ((p.method & PHK_METHOD_KMEANS) ? 0x010100ull : 0ull);
-        if (lane == 0 && (uok & used) != used && p.counters) atomicAdd(p.counters + 9, 1u);
+        if (lane == 0 && (uok & used) != used && p.counters && !big_row) atomicAdd(p.counters + 9, 1u);
     }
     const double uex0 = I8H ? cop.Q * p.lam8[0] * (1.0 + 1.0e-6) : 0.0, uex1 = I8H ? cop.Q * p.lam8[1] * (1.0 + 1.0e-6) : 0.0,
                  uex2 = I8H ? cop.Q * p.lam8[2] * (1.0 + 1.0e-6) : 0.0;
@@ -945,8 +968,9 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
             if (p.pend) {   // two square roots, a division and a tanh in float64 are ~180 instructions of this wave, for one
                             // number: left to a lane-per-query kernel (phk_finish_cen_kernel, the same expressions)
                 if (lane == 0) {
-                    p.pend[2 * q] = dp2;
-                    p.pend[2 * q + 1] = dn2;
+                    const uint64_t oq = p.out_map ? (uint64_t)p.out_map[q] : q;
+                    p.pend[2 * oq] = dp2;
+                    p.pend[2 * oq + 1] = dn2;
                 }
             } else {
                 const double ep = sqrt(dp2), en = sqrt(dn2);
@@ -955,11 +979,16 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         }
     }
     if (lane == 0) {
+        const uint64_t oq = p.out_map ? (uint64_t)p.out_map[q] : q;
         if (ok) {
-            p.scores[p.q_base + q] = knn + cen;  // scripts/phamer.py:313 (cen: see pend)
+            p.scores[p.q_base + oq] = knn + cen;  // scripts/phamer.py:313 (cen: see pend)
+        } else if (p.q2_count && big_row) {
+            p.q2_big[atomicAdd(p.q2_count + 1, 1u)] = (uint32_t)q;
+        } else if (p.q2_count && p.q2_wide) {
+            p.q2_wide[atomicAdd(p.q2_count, 1u)] = (uint32_t)q;
         } else {
             const uint32_t slot = atomicAdd(p.fb_count, 1u);
-            p.fb_list[slot] = (uint32_t)q;
+            p.fb_list[slot] = (uint32_t)oq;
         }
     }
 }
@@ -1301,7 +1330,7 @@ __global__ __launch_bounds__(256, 4) void phk_rerank16_kernel(const void *__rest
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI; eb.cIf = p.eb_cIf;
     if (SRC == 0 && p.per_row_scale) {   // count-exact lists: the chain's query operand is c - c0 (see ErrBound)
         const CenteredOperand cop = phk_centered_operand(sumsq, nan_row ? 1.0 : Tq, (double)cmx, (double)cmn, (double)FAST_D, p.eb_hsum);
         eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs;
@@ -1553,7 +1582,7 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
     eb.Q = s_opQ[tid]; eb.I = s_opI[tid]; eb.habs = s_opH[tid];
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI; eb.cIf = p.eb_cIf;
     const double nqp = eb.P;
     const double eps_g = eb(p.rmax);
     auto certify = [&](int sg, int need, const double *cnorms) {   // resolve_segment_g16's margin test
@@ -1897,7 +1926,7 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
     eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs;
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI; eb.cIf = p.eb_cIf;
     const double nqp = eb.P;
     const double nqx = sqrt(nqp2 + cop.shift2);   // |q' - (c0/T - 1/D) 1|: what the low parts multiply (see phase B)
     auto e_hi = [&](int sg, double R) { return nqx * phk_lam_of(hp, sg, R) + eb(R); };
@@ -2060,7 +2089,7 @@ __global__ __launch_bounds__(256) void phk_rerank_h_kernel(const uint32_t *__res
     eb.P = sqrt(nqp2);
     eb.Q = sqrt(qc2) / Tq * (1.0 + 1e-12); eb.I = cop.I; eb.habs = cop.habs;
     if (p.cand_a) eb.habs += p.eb_cAmax * 5.9604644775390625e-08 * (double)fmaxf(p.cand_a[q], p.cand_a[p.N + q]) * vs * 1.001;
-    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI;
+    eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI; eb.cIf = p.eb_cIf;
     const double nqp = eb.P;
     const double nqx = sqrt(nqp2 + cop.shift2);
     auto e_hi = [&](int sg, double R) { return nqx * phk_lam_of(hp, sg, R) + eb(R); };
@@ -2454,6 +2483,11 @@ __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p)
         atomicAdd(p.stat_total + 0, p.fb_count[0]);
         atomicAdd(p.stat_total + 1, p.fb_count[1] + (p.exact_extra ? *p.exact_extra : 0u));
         if (p.map_count) atomicAdd(p.stat_total + 2, *p.map_count);   // queries that took the second chance
+        if (p.q2_count) {   // general D: rows re-swept with three digits / swept by the f16 kernel (both are second chances)
+            atomicAdd(p.stat_total + 2, p.q2_count[0] + p.q2_count[1]);
+            atomicAdd(p.stat_total + 7, p.q2_count[0]);
+            atomicAdd(p.stat_total + 8, p.q2_count[1]);
+        }
         if (p.counters)                                      // why the high-parts-only decision stage passed them on
             for (int i = 0; i < 4; ++i) atomicAdd(p.stat_total + 3 + i, p.counters[8 + i]);
     }
@@ -2511,6 +2545,32 @@ __global__ __launch_bounds__(256) void phk_finish_cen_kernel(uint64_t N, const d
     if (!(dp2 >= 0.0)) return;
     const double ep = sqrt(dp2), en = sqrt(dn2);
     scores[q] += tanh((en - ep) / (ep + en));
+}
+
+// rows list[0 .. n) of a count matrix -> a dense matrix (+ their row sums): the sub-batch of a second pass.  One wave per row.
+__global__ __launch_bounds__(256) void phk_gather_rows_kernel(const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rowsum,
+                                                              const uint32_t *__restrict__ list, uint64_t n, uint64_t D,
+                                                              uint32_t *__restrict__ out, uint32_t *__restrict__ out_sum) {
+    const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= n) return;
+    const uint64_t r = list[w];
+    const uint4 *src = reinterpret_cast<const uint4 *>(counts + r * D);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + w * D);
+    for (uint64_t i = lane; i < D / 4; i += 64) dst[i] = src[i];
+    if (lane == 0 && rowsum) out_sum[w] = rowsum[r];
+}
+
+// a short hand-over queue goes straight to the brute force: its rows are appended to that queue
+__global__ __launch_bounds__(256) void phk_append_queue_kernel(const uint32_t *__restrict__ list, uint32_t n, uint32_t *__restrict__ fb_list,
+                                                               uint32_t *__restrict__ fb_count, uint32_t *__restrict__ q_count) {
+    __shared__ uint32_t base;
+    if (threadIdx.x == 0) {
+        base = atomicAdd(fb_count, n);
+        *q_count = 0;   // (statistics: these rows are brute-forced, not swept again)
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) fb_list[base + i] = list[i];
 }
 
 // ------------------------------------------------------------------------------------
@@ -2634,14 +2694,24 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + D) * sizeof(double);
     PHK_REQUIRE(fb_lds <= FB_LDS_MAX, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);  // phk_model_build_fast keeps such models off this path
     if (!ctx->keep_score_state) PHK_HIP(hipMemsetAsync(fbc, 0, 128, ctx->stream));   // incl. the totals of this call
-    // Safety valve of the two-digit int8 sweep: its windows are 2^-16 of |c - c0| |x_j| wide, and a reference with many
-    // near-duplicate columns can put more of them inside a window than the lists hold -- such queries end in the float64
-    // brute force, which is sized for a handful per batch.  When a batch leaves more than max(64, nb / 256) queries there,
-    // it is swept again with all three digits (windows 2^-24 wide), and so is the rest of the call.
-    bool two_ok = i8_two;
+    // General D, count rows (the int8 sweep): routing is PER ROW, never per batch.  The first pass sweeps the whole batch with two
+    // digits; its decision kernel hands on what the lists cannot decide -- rows beyond the int8 operand (a bin more than 127
+    // from the row's centre: long or compositionally skewed contigs) to one device queue, rows whose two-digit window holds
+    // more columns than the lists (references with clusters of near-duplicate genomes) or whose candidates' exact distances
+    // do not certify to another.  One 8-byte read-back per batch tells the host the two lengths; each queue's rows are
+    // gathered into a dense sub-batch and swept ALONE -- the first by the f16 count-exact kernel, whose operand reaches
+    // +-2048, the second by the three-digit int8 sweep, whose windows are 2^-24 wide -- and decided from those lists; only
+    // what these passes cannot certify either is brute-forced.  (Round 3 declined a whole batch to the f16 kernel when more
+    // than max(16, n / 256) of its rows were beyond the operand, and re-swept a whole batch -- and the rest of the call --
+    // with three digits when its brute-force queue grew past max(64, n / 256).)
+    uint32_t *q2c = fbc + 5, *q2_wide = nullptr, *q2_big = nullptr;
+    if (use_i8) {
+        void *q2;
+        PHK_TRY(phk_ws(ctx, WS_QUEUE, 2 * nb_max * sizeof(uint32_t), &q2));
+        q2_wide = (uint32_t *)q2;
+        q2_big = q2_wide + nb_max;
+    }
     for (uint64_t s = 0; s < N; s += BATCH) {
-      for (int attempt = 0; attempt < 2; ++attempt) {
-        const bool i8_two = two_ok;   // (shadows the call-wide setting: what this attempt runs)
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
         const void *src = d_counts ? (const void *)(d_counts + s * D) : (const void *)(d_Q + s * D);
         const uint32_t *rsum = d_rowsum ? d_rowsum + s : nullptr;
@@ -2656,7 +2726,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
         p.R64 = m->d_R64; p.C64 = m->d_C64; p.mu64 = m->d_mu64; p.colnorm = m->d_colnorm; p.labels = m->d_labels;
         p.cand_v = (const float *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
-        p.scores = d_scores; p.status = attempt == 0 ? d_status : nullptr;   // (a second attempt must not count the NaN rows again)
+        p.scores = d_scores; p.status = d_status;
         p.fb_count = fbc; p.fb_list = fb_list; p.slow_list = slow_list; p.q_base = s;
         p.stat_total = fbc + 16;
         p.counters = fbc;
@@ -2677,7 +2747,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             const double n = (D == FAST_D ? 1.0 : 3.0) * (double)D / 16.0, x = D == FAST_D ? 1.0 : 0.0;
             r.vscale = 1.0 / (4096.0 * 4096.0);
             r.per_row_scale = 0; r.eb_hsum = 0.0;
-            r.eb_cA = 6.0; r.eb_cI = (PHK_MFMA_PROD * n + x) * rho; r.eb_cR = 6.0 + x;
+            r.eb_cA = 6.0; r.eb_cI = (PHK_MFMA_PROD * n + x) * rho; r.eb_cIf = PHK_MFMA_PROD * n + x; r.eb_cR = 6.0 + x;
             if (D == FAST_D) {
                 r.eb_cQ = 0.0; r.eb_cP = PHK_MFMA_ACC * n + 24.0 + 3.0 * x; r.eb_cAmax = 0.0;
             } else {
@@ -2685,39 +2755,47 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             }
             r.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
         };
-        // the int8 sweep goes first: it declines a batch with too many rows beyond its operand range (-> the f16 kernel)
-        bool i8_now = false;
-        if (use_i8)
-            // (column groups: the int8 sweep's optimum is 2 at D >= 2048 -- configs[4], two-part kernel: 40.1 / 38.5 / 42.3 / 40.3 /
-            // 44.2 ms with 1 / 2 / 3 / 4 / 6 groups; the f16 kernel's is PHK_GEN_GROUPS)
-            PHK_TRY(phk_launch_proposal_i8_general(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu,
-                                                   ctx->knobs.gen_groups > 0 ? (uint32_t)gen_sets : (gen_sets > 2 ? 2u : (uint32_t)gen_sets),
-                                                   set_bytes, i8_two, &i8_now));
-        if (i8_now) {
-            // values are T v (per row), from exact integer sums (see ErrBound: int8)
+        // the error models of the count-exact lists (see ErrBound)
+        auto i8_bound = [&](RerankParams &r, bool two) {
+            // values are T v (per row), from exact integer sums
             const double ku = m->kappa8 / 5.9604644775390625e-08;
-            p.vscale = 1.0; p.per_row_scale = 1; p.cand_a = nullptr;
-            p.eb_cA = 2.0; p.eb_cQ = 4.0; p.eb_cI = 0.0; p.eb_cAmax = 0.0;
-            p.eb_cP = ku + 2.0; p.eb_cR = ku * (1.0 + m->kappa8) + 3.0; p.eb_abs = 0.0;
-            p.eb_hsum = m->hsum8;
-            if (i8_two) {   // a refined value: one more fused multiply-add on |v| (u |v| <= u (P R + R^2 / 2)); the conversion of S_L
-                            // (|g S_L| <= 2^-15 |x| |y|) is inside cQ, which the two-part value's single conversion leaves room in
-                p.eb_cP += 1.0; p.eb_cR += 1.0;
-                p.L8 = m->d_L8; p.T8 = m->d_T8;
-                p.t8_blk[0] = 0; p.t8_blk[1] = m->n_rblk_ref; p.t8_blk[2] = m->n_rblk_ref + m->n_rblk_pos;
-                for (int sg = 0; sg < 3; ++sg) p.lam8[sg] = m->lam8[sg];
+            r.vscale = 1.0; r.per_row_scale = 1; r.cand_a = nullptr;
+            r.eb_cA = 2.0; r.eb_cQ = 4.0; r.eb_cI = 0.0; r.eb_cIf = 0.0; r.eb_cAmax = 0.0;
+            r.eb_cP = ku + 2.0; r.eb_cR = ku * (1.0 + m->kappa8) + 3.0; r.eb_abs = 0.0;
+            r.eb_hsum = m->hsum8;
+            r.L8 = nullptr;
+            if (two) {   // a refined value: one more fused multiply-add on |v| (u |v| <= u (P R + R^2 / 2)); the conversion of S_L
+                         // (|g S_L| <= 2^-15 |x| |y|) is inside cQ, which the two-part value's single conversion leaves room in
+                r.eb_cP += 1.0; r.eb_cR += 1.0;
+                r.L8 = m->d_L8; r.T8 = m->d_T8;
+                r.t8_blk[0] = 0; r.t8_blk[1] = m->n_rblk_ref; r.t8_blk[2] = m->n_rblk_ref + m->n_rblk_pos;
+                for (int sg = 0; sg < 3; ++sg) r.lam8[sg] = m->lam8[sg];
             }
-        } else if (use_cx) {
+        };
+        auto cx_bound = [&](RerankParams &r) {
             // values are T S v (per row); n = 2D/16 instructions on (c - c0) x (r~' S as hi, lo), + 3 for the bias -> fp32,
             // the final fma and slack; the residue of the centring through hsum
             // (general D keeps its indices in registers: no embedded index bits, 62 / 31 less on cP / cR)
             const double n = 2.0 * (double)D / 16.0;
-            p.vscale = 1.0 / 4096.0; p.per_row_scale = 1;
-            p.eb_cA = 1.0; p.eb_cQ = PHK_MFMA_ACC * n + 3.0; p.eb_cI = PHK_MFMA_PROD * n * rho;
-            p.eb_cAmax = D != FAST_D ? PHK_MFMA_ACC * n : 0.0;
-            p.eb_cP = D == FAST_D ? 67.0 : 5.0; p.eb_cR = D == FAST_D ? 36.0 : 5.0;
-            p.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
-            p.eb_hsum = m->hsum_train > m->hsum_cen ? m->hsum_train : m->hsum_cen;
+            r.vscale = 1.0 / 4096.0; r.per_row_scale = 1; r.L8 = nullptr;
+            r.cand_a = ca;
+            r.eb_cA = 1.0; r.eb_cQ = PHK_MFMA_ACC * n + 3.0; r.eb_cI = PHK_MFMA_PROD * n * rho; r.eb_cIf = PHK_MFMA_PROD * n;
+            r.eb_cAmax = D != FAST_D ? PHK_MFMA_ACC * n : 0.0;
+            r.eb_cP = D == FAST_D ? 67.0 : 5.0; r.eb_cR = D == FAST_D ? 36.0 : 5.0;
+            r.eb_abs = std::sqrt((double)D) * 5.9604644775390625e-08 / 4096.0;
+            r.eb_hsum = m->hsum_train > m->hsum_cen ? m->hsum_train : m->hsum_cen;
+        };
+        // column groups of the int8 sweep: its optimum is 2 at D >= 2048 -- configs[4], two-part kernel: 40.1 / 38.5 / 42.3 /
+        // 40.3 / 44.2 ms with 1 / 2 / 3 / 4 / 6 groups; the f16 kernel's is PHK_GEN_GROUPS
+        const uint32_t i8_groups = ctx->knobs.gen_groups > 0 ? (uint32_t)gen_sets : (gen_sets > 2 ? 2u : (uint32_t)gen_sets);
+        const bool i8_now = use_i8;
+        if (i8_now) {
+            PHK_TRY(phk_launch_proposal_i8_general(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu,
+                                                   i8_groups, set_bytes, i8_two));
+            i8_bound(p, i8_two);
+            p.q2_count = q2c; p.q2_big = q2_big; p.q2_wide = i8_two ? q2_wide : nullptr;
+        } else if (use_cx) {
+            cx_bound(p);
         } else if (use_f16) {
             split_f16_bound(p);
         } else {
@@ -2767,6 +2845,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             pd.sub_cap = 64 * phk_div_up(phk_div_up(nb, 64), PHK_SUB_LISTS);
             pd.eb_cQ = PHK_MFMA_ACC * ((double)D / 16.0) + 3.0;
             pd.eb_cI = PHK_MFMA_PROD * ((double)D / 16.0) * rho;
+            pd.eb_cIf = PHK_MFMA_PROD * ((double)D / 16.0);
             if (d_knn && d_cen) {
                 PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<true, true><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, pd, hp)));
             } else if (d_knn) {
@@ -2811,18 +2890,48 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             }
             if (d_counts) PHK_TRY(launch_rerank<0>(ctx, rblocks, src, pr));
             else PHK_TRY(launch_rerank<1>(ctx, rblocks, src, pr));
+            if (i8_now) {
+                // ---- the second passes: each hand-over queue as a dense sub-batch, swept alone ----
+                uint32_t q2n[2] = {0, 0};
+                PHK_HIP(hipMemcpyAsync(q2n, q2c, sizeof(q2n), hipMemcpyDeviceToHost, ctx->stream));
+                PHK_HIP(hipStreamSynchronize(ctx->stream));
+                for (int pass = 0; pass < 2; ++pass) {   // 0: three digits for the wide windows; 1: the f16 kernel for the long rows
+                    const uint64_t nq = q2n[pass];
+                    if (!nq) continue;
+                    const uint32_t *list = pass == 0 ? q2_wide : q2_big;
+                    // A sweep of the whole reference for a handful of rows is one workgroup walking every column block
+                    // (0.5 ms at configs[2], where a batch queues ~7 rows): below PHK_SUBPASS_MIN rows the float64 brute
+                    // force, which takes eight queued rows per workgroup and cuts the reference into chunks, is cheaper.
+                    if (nq < PHK_SUBPASS_MIN) {
+                        PHK_LAUNCH(ctx, "phk_append_queue_kernel",
+                                   phk_append_queue_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(list, (uint32_t)nq, fb_list, fbc, q2c + pass));
+                        continue;
+                    }
+                    void *sub;
+                    PHK_TRY(phk_ws(ctx, WS_SUB, nq * (D + 1) * sizeof(uint32_t), &sub));
+                    uint32_t *sub_counts = (uint32_t *)sub, *sub_sum = sub_counts + nq * D;
+                    PHK_LAUNCH(ctx, "phk_gather_rows_kernel",
+                               phk_gather_rows_kernel<<<dim3((unsigned)phk_div_up(nq, 4)), dim3(256), 0, ctx->stream>>>(
+                                   (const uint32_t *)src, rsum, list, nq, D, sub_counts, sub_sum));
+                    const uint32_t *sub_rs = rsum ? sub_sum : nullptr;
+                    RerankParams p2 = pr;
+                    p2.N = nq; p2.out_map = list; p2.status = nullptr;
+                    p2.q2_count = nullptr; p2.q2_wide = p2.q2_big = nullptr;
+                    if (pass == 0) {
+                        PHK_TRY(phk_launch_proposal_i8_general(ctx, m, sub_counts, sub_rs, nq, nref, npos, nneg, (float *)cv, ci, cu,
+                                                               i8_groups, set_bytes, false));
+                        i8_bound(p2, false);
+                    } else {
+                        PHK_TRY(phk_launch_proposal_f16_general(ctx, m, sub_counts, true, true, sub_rs, nq, nref, npos, nneg,
+                                                                (float *)cv, ci, cu, ca, false, (uint32_t)gen_sets, set_bytes));
+                        cx_bound(p2);
+                    }
+                    PHK_TRY(launch_rerank<0>(ctx, (unsigned)phk_div_up(nq, 4), sub_counts, p2));
+                }
+            }
             if (pr.pend)
                 PHK_LAUNCH(ctx, "phk_finish_cen_kernel",
                            phk_finish_cen_kernel<<<dim3((unsigned)phk_div_up(nb, 256)), dim3(256), 0, ctx->stream>>>(nb, pend, d_scores + s));
-        }
-        if (attempt == 0 && i8_now && i8_two) {   // the safety valve (one 4-byte read-back per batch, like the sweep's own)
-            uint32_t queued = 0;
-            PHK_HIP(hipMemcpyAsync(&queued, fbc, sizeof(queued), hipMemcpyDeviceToHost, ctx->stream));
-            PHK_HIP(hipStreamSynchronize(ctx->stream));
-            if (queued > (nb / 256 > 64 ? nb / 256 : 64)) {
-                two_ok = false;
-                continue;   // the same batch again, three digits in the sweep
-            }
         }
         RerankParams pf = p;   // what the brute force works from
         pf.status = d_status;
@@ -2865,8 +2974,6 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         }
         PHK_LAUNCH(ctx, "phk_fallback_merge_kernel",
                    phk_fallback_merge_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(pf));
-        break;
-      }
     }
     return PHK_OK;
 }

@@ -91,7 +91,7 @@ int phk_model_build_i8(phk_model *m, const double *pos, const double *neg, const
                        const double *mu, const double *colnorm);
 int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum, uint64_t nb,
                                    uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu,
-                                   uint32_t groups, uint64_t set_bytes, bool two_parts, bool *accepted);
+                                   uint32_t groups, uint64_t set_bytes, bool two_parts);
 int phk_score_i8_init_device(phk_ctx *ctx);
 // Column groups of the general-D sweep's 2-D launch (D >= 2048).  Measured on configs[4] (kernel ms): 1 group 92.9, 2: 89.8,
 // 4: 86.4, 8: 95.1 (and 3 / 5 / 6: no better) -- more groups share a query block's fragments through one XCD's L2, but

@@ -1,6 +1,8 @@
 """GPU parity: scoring through the C ABI (facade + device API) against the golden vectors
 produced by the reference's phamer.score_points.  knn scores exact (+-1); float scores within
 1e-6 relative (BASELINE.json north_star tolerance)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -247,7 +249,8 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
     cneg = np.stack([neg[i::12].mean(axis=0) for i in range(12)])
     model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
     # rows 0 .. 7: the counts of a 40 x longer contig of the same composition (bins far beyond the int8 kernel's +-127 and
-    # rows 4 .. 7 beyond the f16 kernels' 2048 around the row's centre): such rows take the brute-force queue
+    # rows 4 .. 7 beyond the f16 kernels' 2048 around the row's centre).  The int8 paths route them PER ROW: all eight go to
+    # the f16 count-exact sweep as a sub-batch of their own, which decides rows 0 .. 3; rows 4 .. 7 are brute-forced
     hq = device_counts(90 + k, n_q, 10000).to_host()
     hq[:4] *= 40
     hq[4:8] *= 1000
@@ -267,6 +270,12 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
         if path in ("i8", "i83", "cxf"):
             n_fallback, _ = ctx.score_stats()
             assert 4 <= n_fallback < max(n_q // 20, 16), (path, n_fallback)
+        if path in ("i8", "i83"):
+            st = ctx.score_stats_ex()      # (of the last call: combo)
+            assert st["swept_f16_beyond_int8"] == 0, (path, st)      # a queue of 8 is below the sub-pass threshold: brute-forced
+            assert st["second_chance"] == st["swept_f16_beyond_int8"] + st["reswept_three_digits"], (path, st)
+            if path == "i83":
+                assert st["reswept_three_digits"] == 0, st
     ctx.set_option("proposal", "")
     for method in ("knn", "kmeans", "combo"):
         assert np.array_equal(np.sign(out[("hi", method)]), np.sign(out[("exact", method)])), method
@@ -279,22 +288,43 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
         assert np.array_equal(out[("i8", method)], out[("cxf", method)]), method
         assert np.array_equal(out[("i8", method)], out[("i83", method)]), method
     out.update({("f16", m): out[("i8", m)] for m in ("knn", "kmeans", "combo")})
-    # a batch in which many rows exceed the int8 operand (every 8th row 40 x): the int8 sweep declines it, the f16 kernel
-    # takes the whole batch -- same scores, and the 40 x rows are NOT brute-forced
+    # a batch in which many rows exceed the int8 operand (every 8th row 40 x): no batch-level decision any more -- the int8
+    # sweep keeps the batch, exactly those rows (and rows 0 .. 7) are swept by the f16 kernel as a sub-batch, they are NOT
+    # brute-forced, and every other row's score is bit for bit what it was in the batch above (route independence)
     hq2 = hq.copy()
     hq2[8::8] *= 40
     d_q2 = device.DeviceArray.from_host(ctx, hq2)
     res = {}
-    for path in ("default", "exact"):
+    for path in ("default", "small_batches", "cxf", "exact"):
         ctx.set_option("force_exact", "1" if path == "exact" else "0")
+        ctx.set_option("proposal", "cxf" if path == "cxf" else "")
+        ctx.set_option("score_batch", "256" if path == "small_batches" else "0")
+        ctx.profile_reset()
+        ctx.profile_enable(True)
         d_scores = device.DeviceArray(ctx, n_q, np.float64)
         device.score_counts(ctx, model, d_q2, n_q, "combo", d_scores, None)
         res[path] = d_scores.to_host()
+        ctx.profile_enable(False)
         if path == "default":
-            n_fallback, _ = ctx.score_stats()
-            assert 4 <= n_fallback < 32, n_fallback
+            st = ctx.score_stats_ex()
+            n_big = 8 + len(range(8, n_q, 8))
+            prof = ctx.profile()
+            assert prof["phk_knn_i8_general_kernel"][1] >= 1, prof
+            if n_big >= 32:      # (a shorter queue goes straight to the brute force)
+                assert 4 <= st["brute_forced"] < 32, st
+                assert st["swept_f16_beyond_int8"] == n_big, st
+                assert prof["phk_knn_f16_general_kernel"][1] == 1, prof
+            else:
+                assert st["swept_f16_beyond_int8"] == 0 and n_big <= st["brute_forced"] < n_big + 8, st
     ctx.set_option("force_exact", "0")
+    ctx.set_option("proposal", "")
+    ctx.set_option("score_batch", "0")
     assert helpers.rel_err(res["default"], res["exact"]) < 1e-9
+    assert np.array_equal(res["default"], res["small_batches"])
+    assert np.array_equal(res["default"], res["cxf"])
+    keep = np.ones(n_q, dtype=bool)
+    keep[8::8] = False
+    assert np.array_equal(res["default"][keep], out[("i8", "combo")][keep])
     # float64-row entry point on a slice, against the oracle
     ctx.set_option("force_exact", "0")
     qc = d_q.to_host()[:64].astype(np.int64)
@@ -581,9 +611,10 @@ def test_int8_sweep_at_the_other_supported_dimensions(D):
 @pytest.mark.gpu
 def test_two_digit_sweep_safety_valve_on_near_duplicate_references():
     """A reference whose genomes come in clusters of twelve near-duplicates (one count apart in 300 000): more columns fall
-    inside the two-digit sweep's window than the candidate lists hold, its queries pile up in the brute-force queue, and
-    phk_score_fast sweeps the batch again with all three digits, which tells the copies apart.  Scores equal the float64
-    path's; after the call only a few queries were brute-forced."""
+    inside the two-digit sweep's window than the candidate lists hold.  Such rows are NOT brute-forced and the batch is not
+    swept again as a whole: the decision kernel queues them, and phk_score_fast sweeps exactly the queued rows, as a dense
+    sub-batch, with all three digits, which tells the copies apart (round 3 re-swept the whole batch and kept three digits for
+    the rest of the call).  Scores equal the three-digit path's and the float64 path's; only a few queries are brute-forced."""
     from phamers_amd import _lib, device
     ctx = _lib.get_context()
     k, D, n_base, copies = 5, 1024, 24, 12
@@ -619,7 +650,7 @@ def test_two_digit_sweep_safety_valve_on_near_duplicate_references():
     pick = rng.integers(0, n_base, n_q)
     counts = rng.binomial(base[pick], 1.0 / 30.0).astype(np.uint32)   # 10 kb contigs drawn from the base genomes
     d_q = device.DeviceArray.from_host(ctx, counts)
-    out, stats, sweeps = {}, {}, {}
+    out, stats, stats_ex, sweeps = {}, {}, {}, {}
     for path in ("i8", "i83", "exact"):
         ctx.set_option("force_exact", "1" if path == "exact" else "0")
         ctx.set_option("proposal", "i83" if path == "i83" else "")
@@ -631,13 +662,16 @@ def test_two_digit_sweep_safety_valve_on_near_duplicate_references():
             out[(path, method)] = d_scores.to_host()
         ctx.profile_enable(False)
         stats[path] = ctx.score_stats()
+        stats_ex[path] = ctx.score_stats_ex()
         sweeps[path] = ctx.profile().get("phk_knn_i8_general_kernel", (0.0, 0))[1]
     ctx.set_option("proposal", "")
     ctx.set_option("force_exact", "0")
-    # the valve fired (two sweeps per call on the default path, one with proposal=i83): what is left in the brute-force queue
-    # is the three-digit sweep's, not hundreds of queries
+    # two sweeps per call on the default path (the batch with two digits, the queued rows alone with three), one with
+    # proposal=i83: what is left in the brute-force queue is the three-digit sweep's, not hundreds of queries
     assert sweeps["i8"] == 4 and sweeps["i83"] == 2, sweeps
     assert stats["i8"][0] == stats["i83"][0] and stats["i8"][0] < n_q // 10, stats
+    assert 0 < stats_ex["i8"]["reswept_three_digits"] <= n_q and stats_ex["i8"]["swept_f16_beyond_int8"] == 0, stats_ex
+    assert stats_ex["i83"]["reswept_three_digits"] == 0, stats_ex
     for method in ("knn", "combo"):
         assert np.array_equal(out[("i8", method)], out[("i83", method)]), method
     assert np.array_equal(out[("i8", "knn")], out[("exact", "knn")])
@@ -940,13 +974,16 @@ def _mfma_probe(ctx, A, B, C):
 def _mfma_step_error_ratio(A, B, acc_in, D):
     """max over the tile's elements of |D - exact(acc_in + sum_k A B)| / (u (11 Amax + 18 pmax)): the charge of one
     v_mfma_f32_32x32x16_f16 in the certification (score_lists.h: PHK_MFMA_ACC / PHK_MFMA_PROD), with Amax = the largest
-    exact running sum (before, after the first 8 products, after all 16) and pmax = the largest product.  Exact sums by
+    exact running sum (before, after the first 8 products, after all 16) and pmax = the largest nominal product.  Exact sums by
     math.fsum of float64 terms (a product of two float16 numbers and a float32 are exact in float64)."""
     import math
     u = 2.0 ** -24
     Ad, Bd = A.astype(np.float64), B.astype(np.float64)
     prod = Ad[:, None, :] * Bd.T[None, :, :]                        # [32][32][16]: A[i][k] B[k][j]
-    pmax = np.abs(prod).max(axis=2)
+    # p: the largest NOMINAL product -- a non-zero float16 subnormal operand counts as 2^-14 (score_lists.h)
+    An = np.where(Ad != 0, np.maximum(np.abs(Ad), 2.0 ** -14), 0.0)
+    Bn = np.where(Bd != 0, np.maximum(np.abs(Bd), 2.0 ** -14), 0.0)
+    pmax = (An[:, None, :] * Bn.T[None, :, :]).max(axis=2)
     worst = 0.0
     for i in range(32):
         for j in range(32):
@@ -1079,146 +1116,30 @@ def test_mfma_f16_rounding_charge_holds_on_adversarial_tiles():
     print("mfma f16 probe: worst single-instruction error %.3f, worst chained %.3f of the charged u (11 A + 18 p)" % (worst, worst_chain))
 
 
-def _mfma_ratios_bulk(A, B, acc_in, D):
-    """Vectorised _mfma_step_error_ratio for many instructions at once, on the device in float64 (test plumbing: torch):
-    A [T][32][16], B [T][16][32] float16, acc_in / D [T][32][32] float32 -> the worst ratio per instruction [T].  A
-    product of two float16 numbers is exact in float64; the float64 sums of 17 terms err by < 2^-48 of the largest term,
-    2^-20 of the smallest possible charge u (11 A + 18 p) -- far inside the margin asserted."""
-    import torch
-    dev = torch.device("cuda", 0)
-    u = 2.0 ** -24
-    out = np.empty(A.shape[0])
-    step = 8192
-    for lo in range(0, A.shape[0], step):
-        a = torch.from_numpy(np.ascontiguousarray(A[lo:lo + step]).view(np.int16)).to(dev).view(torch.float16).double()
-        b = torch.from_numpy(np.ascontiguousarray(B[lo:lo + step]).view(np.int16)).to(dev).view(torch.float16).double()
-        c = torch.from_numpy(np.ascontiguousarray(acc_in[lo:lo + step])).to(dev).double()
-        d = torch.from_numpy(np.ascontiguousarray(D[lo:lo + step])).to(dev).double()
-        prod = a[:, :, None, :] * b.transpose(1, 2)[:, None, :, :]            # [t][i][j][k] = A[i][k] B[k][j]
-        half = c + prod[..., :8].sum(-1)
-        exact = half + prod[..., 8:].sum(-1)
-        amax = torch.maximum(torch.maximum(c.abs(), half.abs()), exact.abs())
-        charge = u * (11.0 * amax + 18.0 * prod.abs().amax(-1))
-        err = (d - exact).abs()
-        assert bool(((charge > 0) | (err == 0)).all())
-        ratio = torch.where(charge > 0, err / charge.clamp_min(1e-300), torch.zeros_like(err))
-        out[lo:lo + step] = ratio.amax(dim=(1, 2)).cpu().numpy()
-        del prod
-    return out
-
-
-def _rand_f16(rng, shape, emin, emax, exps=None):
-    """Random float16 values with exponents drawn uniformly from [emin, emax] (per element, or the given array), a random
-    11-bit significand and a random sign; exponents below -14 give float16 subnormals (fewer significant bits)."""
-    e = rng.integers(emin, emax + 1, shape) if exps is None else exps
-    m = rng.integers(1024, 2048, shape).astype(np.float64) / 1024.0
-    v = np.ldexp(m, e) * rng.choice([-1.0, 1.0], shape)
-    return v.astype(np.float16)
-
-
 @pytest.mark.gpu
 def test_mfma_f16_rounding_charge_bulk_fuzz():
     """Bulk random fuzz of the per-instruction charge u (11 A + 18 p) of v_mfma_f32_32x32x16_f16 (the
-    structured families of the test above are the author's idea of a worst case -- this one is not): >= 10^5
-    instructions per family through phk_mfma_f16_probe, every one of its 1024 results checked against float64.
-    Families: (a) exponents of A, B and C drawn independently per element over the float16 / float32 ranges, random
-    signs; (b) per-tile exponent windows of width 0..6 with C at the scale of the products -- terms of nearly equal
-    magnitude, where the cuts bite most; (c) float16 subnormals mixed into B beside integer A (the low parts of split
-    columns beside counts); (d) chains of 16 instructions (k = 4 kernels); (e) chains of 256 (the D = 4096 f16 kernel),
-    each instruction checked against the accumulator the device really fed it."""
-    import torch
-    from phamers_amd import _lib
-    ctx = _lib.get_context()
-    rng = np.random.default_rng(20261005)
-    n = 1 << 17                                   # 131 072 instructions per family
-    worst = {}
-
-    def run_single(name, gen, chunk=16384):
-        w = 0.0
-        for lo in range(0, n, chunk):
-            A, B, C = gen(chunk)
-            D = _mfma_probe(ctx, A[:, None], B[:, None], C)[:, 0]
-            assert np.isfinite(D).all()
-            r = _mfma_ratios_bulk(A, B, C, D)
-            w = max(w, float(r.max()))
-        worst[name] = w
-
-    def fam_a(t):
-        A = _rand_f16(rng, (t, 32, 16), -24, 15)
-        B = _rand_f16(rng, (t, 16, 32), -24, 15)
-        C = (np.ldexp(rng.uniform(1.0, 2.0, (t, 32, 32)), rng.integers(-50, 41, (t, 32, 32)))
-             * rng.choice([-1.0, 1.0, 0.0], (t, 32, 32), p=[0.45, 0.45, 0.1])).astype(np.float32)
-        return A, B, C
-
-    def fam_b(t):
-        w = rng.integers(0, 7, (t, 1, 1))
-        ea = rng.integers(-12, 10, (t, 1, 1))
-        eb = rng.integers(-12, 10, (t, 1, 1))
-        A = _rand_f16(rng, (t, 32, 16), 0, 0, exps=ea + rng.integers(0, 7, (t, 32, 16)) % (w + 1))
-        B = _rand_f16(rng, (t, 16, 32), 0, 0, exps=eb + rng.integers(0, 7, (t, 16, 32)) % (w + 1))
-        ec = ea + eb + rng.integers(-6, 11, (t, 32, 32))
-        C = (np.ldexp(rng.uniform(1.0, 2.0, (t, 32, 32)), ec)
-             * rng.choice([-1.0, 1.0, 0.0], (t, 32, 32), p=[0.4, 0.4, 0.2])).astype(np.float32)
-        return A, B, C
-
-    def fam_c(t):
-        A = (rng.integers(0, 2049, (t, 32, 16)) * rng.choice([-1.0, 1.0], (t, 32, 16))).astype(np.float16)
-        sub = _rand_f16(rng, (t, 16, 32), -24, -15)
-        nor = _rand_f16(rng, (t, 16, 32), -14, 10)
-        B = np.where(rng.random((t, 16, 32)) < rng.uniform(0.0, 1.0, (t, 1, 1)), sub, nor)
-        C = (rng.standard_normal((t, 32, 32)) * np.ldexp(1.0, rng.integers(-30, 25, (t, 1, 1)))).astype(np.float32)
-        return A, B, C
-
-    run_single("independent exponents", fam_a)
-    run_single("exponent windows", fam_b)
-    run_single("subnormals", fam_c)
-
-    def run_chains(name, S, gen):
-        w, wc = 0.0, 0.0
-        u = 2.0 ** -24
-        chains = n // S
-        per = max(1, 4096 // S)
-        for lo in range(0, chains, per):
-            t = min(per, chains - lo)
-            A, B = gen(t, S)                       # [t][S][32][16], [t][S][16][32]
-            C = np.zeros((t, 32, 32), dtype=np.float32)
-            D = _mfma_probe(ctx, A, B, C)          # [t][S][32][32]
-            assert np.isfinite(D).all()
-            acc_in = np.concatenate((C[:, None], D[:, :-1]), axis=1)
-            r = _mfma_ratios_bulk(A.reshape(t * S, 32, 16), B.reshape(t * S, 16, 32), acc_in.reshape(t * S, 32, 32),
-                                  D.reshape(t * S, 32, 32))
-            w = max(w, float(r.max()))
-            # the whole chain against what the error model sums up: n u (11 |x| |y| + 18 |x|_inf |y|_inf)
-            x = torch.from_numpy(A.view(np.int16)).cuda().view(torch.float16).double().permute(0, 2, 1, 3).reshape(t, 32, S * 16)
-            y = torch.from_numpy(B.view(np.int16)).cuda().view(torch.float16).double().reshape(t, S * 16, 32)
-            exact = x @ y
-            bound = S * u * (11.0 * x.norm(dim=2)[:, :, None] * y.norm(dim=1)[:, None, :]
-                             + 18.0 * x.abs().amax(2)[:, :, None] * y.abs().amax(1)[:, None, :])
-            err = (torch.from_numpy(D[:, -1]).cuda().double() - exact).abs()
-            slack = 1e-12 * (x.abs() @ y.abs())    # float64 rounding of the reference product itself
-            wc = max(wc, float(((err - slack).clamp_min(0) / bound.clamp_min(1e-300)).max()))
-        worst[name] = w
-        worst[name + ", whole chain vs the model's sum"] = wc
-
-    def fam_chain(t, S):
-        kind = rng.integers(0, 3, (t, 1, 1, 1))
-        counts = rng.poisson(rng.uniform(2.0, 40.0, (t, 1, 1, 1)), (t, S, 32, 16)).astype(np.float64)
-        counts = counts - np.rint(counts.mean(axis=(1, 3), keepdims=True))               # centred rows
-        wide = rng.integers(-2048, 2049, (t, S, 32, 16)).astype(np.float64)
-        spike = np.where(rng.random((t, S, 32, 16)) < 0.01, 2048.0, counts)
-        A = np.where(kind == 0, counts, np.where(kind == 1, spike, wide)).astype(np.float16)
-        B = (rng.standard_normal((t, S, 16, 32)) * rng.uniform(1.0, 700.0, (t, 1, 1, 1))).astype(np.float16)
-        pair = rng.random((t, 1, 1, 1)) < 0.3                                             # cancelling column pairs
-        Bp = B.copy()
-        Bp[:, :, 1::2] = -B[:, :, 0::2] * np.float16(1.0 + 2.0 ** -9)
-        Ap = A.copy()
-        Ap[..., 1::2] = A[..., 0::2]
-        return np.where(pair, Ap, A), np.where(pair, Bp, B)
-
-    run_chains("chains of 16", 16, fam_chain)
-    run_chains("chains of 256", 256, fam_chain)
-    print("mfma f16 bulk fuzz, worst error / charge:", {k: round(v, 4) for k, v in worst.items()})
-    for name, w in worst.items():
+    structured families of the test above are the author's idea of a worst case -- this one is not, and its first run
+    found the charge as round 3 stated it -- p = the largest product by value -- exceeded 150-fold by float16 subnormal
+    operands, which the instruction aligns by their exponent field: p is the largest NOMINAL product since): 131 072
+    instructions per family through phk_mfma_f16_probe, every one of their 1024 results checked against float64
+    (tests/mfma_fuzz_worker.py, a child process: its checker runs in torch on the device).  Families: exponents of A, B
+    and C drawn independently per element over the float16 / float32 ranges; per-tile exponent windows with C at the
+    scale of the products; float16 subnormals beside integer counts; chains of 16 and of 256 instructions, each
+    instruction checked against the accumulator the device really fed it, and each whole chain against the sum the error
+    model charges for it."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, "-m", "tests.mfma_fuzz_worker"], cwd=helpers.REPO, env=env, capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print("mfma f16 bulk fuzz:", line)
+    assert line["instructions_per_family"] >= 100000 and line["p"] == "nominal"
+    assert len(line["worst_error_over_charge"]) == 7
+    for name, w in line["worst_error_over_charge"].items():
         assert w <= 1.0, "%s: error %.3f x the charge" % (name, w)
 
 
