@@ -35,6 +35,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define I8_NMAX 8300000.0      // |n| <= this: H = n / 65536 (balanced) stays within [-127, 127]
 #define I8_KS 2                // k-steps (32 dimensions each) per chunk of the sweep: chunks of 64 dimensions
 #define I8_L1_MAX 65000u        // |c - c0|_1 of a row the epilogue's 32-bit fold is exact for: (256 * 127 + 128) * 65000 < 2^31
+#define I8_SENT 0x03FFFFFFu    // id of an empty list slot (two-part sweep)
 #define I8_CT_MAX 6            // most column blocks a tile of any variant holds (padding of the record / term arrays)
 // Two variants of the sweep, <parts NP, column blocks per tile CT> -- both keep 192 int32 accumulator registers per wave and
 // 24 MFMAs + 40 LDS-DMA pieces per 64-dimension step:
@@ -349,6 +350,48 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
         lv[c] = -3.0e38f;
         li[c] = 0xFFFFFFFFu;
     }
+    // Two-part sweep (NP == 2): the list of the k = 4 count-exact kernels (score_f16.hip) instead -- the low 5 mantissa bits
+    // of a value carry (r << 1) | fresh, r = which of the lane's 16 rows of the column block, fresh = inserted during this
+    // block; the sorted 5-deep value list (4 candidates + the best dropped value) moves with 5 v_med3 per value and no
+    // index registers, and after a block the block number is shifted into the id list at the fresh positions (settle).
+    // The classic list above costs ~19 instructions per value on a 4 510-column sweep -- two ballots, a parked candidate
+    // and a 20-instruction sorted insert whenever a lane would park a second one, and on a short sweep nearly every pair of
+    // values holds a candidate in some lane -- which made the tile epilogue a third of the D = 1024 sweep; this one ~11.
+    // The 31-ulp perturbation is part of the two-part lists' error bound (phk_score_fast: +62 on cP, +31 on cR), small
+    // beside the window the missing third part opens anyway.  The three-part sweep keeps exact values.
+    const float vempty = __uint_as_float(__float_as_uint(-3.0e38f) & ~31u);   // empty slot: fresh bit clear
+    const float fbig = 3.3e38f;
+    float l5[5] = {vempty, vempty, vempty, vempty, vempty};
+    uint32_t lb[4] = {I8_SENT, I8_SENT, I8_SENT, I8_SENT};
+    auto insert5 = [&](float w, int r) {
+        const float x = __uint_as_float((__float_as_uint(w) & ~31u) | (uint32_t)(2 * r + 1));
+        const float n4 = __builtin_amdgcn_fmed3f(l5[3], l5[4], x);
+        const float n3 = __builtin_amdgcn_fmed3f(l5[2], l5[3], x);
+        const float n2 = __builtin_amdgcn_fmed3f(l5[1], l5[2], x);
+        const float n1 = __builtin_amdgcn_fmed3f(l5[0], l5[1], x);
+        l5[0] = __builtin_amdgcn_fmed3f(l5[0], x, fbig);
+        l5[1] = n1;
+        l5[2] = n2;
+        l5[3] = n3;
+        l5[4] = n4;
+    };
+    auto settle = [&](uint32_t cur) {
+        uint32_t m[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m[c]) : "v"(l5[c]));   // 0 / ~0 from the fresh bit
+        lb[3] = phk_bfi_hw(m[0], lb[2], lb[3]);
+        lb[2] = phk_bfi_hw(m[0], lb[1], lb[2]);
+        lb[1] = phk_bfi_hw(m[0], lb[0], lb[1]);
+        lb[0] = phk_bfi_hw(m[0], cur, lb[0]);
+        lb[3] = phk_bfi_hw(m[1], lb[2], lb[3]);
+        lb[2] = phk_bfi_hw(m[1], lb[1], lb[2]);
+        lb[1] = phk_bfi_hw(m[1], cur, lb[1]);
+        lb[3] = phk_bfi_hw(m[2], lb[2], lb[3]);
+        lb[2] = phk_bfi_hw(m[2], cur, lb[2]);
+        lb[3] = phk_bfi_hw(m[3], cur, lb[3]);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) l5[c] = __uint_as_float(__float_as_uint(l5[c]) & ~1u);
+    };
     const uint64_t qr = (qb < nqb && q0 + j < N) ? q0 + j : N - 1;
     const float negT = -(float)rowsum[qr];
     const f32x2 negT2 = {negT, negT}, c256 = {256.0f, 256.0f};
@@ -473,6 +516,7 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
                 // reads and its own dependent chain: by the phase timers the epilogue was 37 % of the D = 1024 sweep, ~18
                 // cycles per instruction).  Then one test for the eight -- late in a long sweep most hold no candidate in any
                 // lane -- and the tests per pair.
+                bool touched = false;   // (wave-uniform) a value of this block entered some lane's list
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {   // (half a block at a time: the terms of all 16 values at once cost spilled registers)
                     float4 g4[2], b4[2];
@@ -503,7 +547,18 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
                     }
                     const float vmax = fmaxf(fmaxf(fmaxf(val[0][0], val[0][1]), fmaxf(val[1][0], val[1][1])),
                                              fmaxf(fmaxf(val[2][0], val[2][1]), fmaxf(val[3][0], val[3][1])));
-                    if (__builtin_amdgcn_ballot_w64(vmax > ldrop) != 0) {
+                    if (NP == 2) {
+                        // one test for the eight (late in a long sweep most hold no candidate in any lane), then per value: the
+                        // five v_med3 only when some lane can place it
+                        if (__builtin_amdgcn_ballot_w64(vmax > l5[4]) != 0) {
+                            touched = true;
+#pragma unroll
+                            for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+                                for (int e = 0; e < 2; ++e)
+                                    if (__builtin_amdgcn_ballot_w64(val[pr][e] > l5[4]) != 0) insert5(val[pr][e], 8 * hb + 2 * pr + e);
+                        }
+                    } else if (__builtin_amdgcn_ballot_w64(vmax > ldrop) != 0) {
 #pragma unroll
                         for (int pr = 0; pr < 4; ++pr) {
                             // A value that can enter the list (> everything the list dropped) is parked in the lane's pending slot
@@ -527,7 +582,9 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
                         }
                     }
                 }
-                if (cb + 1 == I8_CT || (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total))) {
+                if (NP == 2) {
+                    if (touched) settle(blk);
+                } else if (cb + 1 == I8_CT || (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total))) {
                     if (__builtin_amdgcn_ballot_w64(pend_v > -3.0e38f) != 0) list_insert(lv, li, ldrop, pend_v, tbase + pend_i);
                     pend_v = -3.0e38f;
                 }
@@ -536,6 +593,17 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
                         if (isbig) {
                             cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f,
                                        0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 3.0e38f);
+                        } else if (NP == 2) {
+                            // column of a slot: its block (id list, relative to the segment's first block) and its row (value bits)
+                            const uint32_t o = (seg == 0 ? col0 : 0u) + 4u * (uint32_t)h - 32u * seg_first;
+                            uint32_t ix[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const uint32_t r = (__float_as_uint(l5[c]) >> 1) & 15u;
+                                ix[c] = lb[c] == I8_SENT ? 0xFFFFFFFFu : lb[c] * 32u + (r & 3u) + 8u * (r >> 2) + o;
+                            }
+                            cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, l5[0], l5[1], l5[2], l5[3], ix[0], ix[1], ix[2], ix[3],
+                                       l5[4]);
                         } else {
                             const uint32_t o = seg == 0 ? col0 : 0u;   // (a column group: indices relative to the whole train segment)
                             cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, lv[0], lv[1], lv[2], lv[3],
@@ -549,6 +617,10 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
                         li[c] = 0xFFFFFFFFu;
                     }
                     ldrop = -3.0e38f;
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) l5[c] = vempty;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) lb[c] = I8_SENT;
                     seg = __builtin_amdgcn_readfirstlane(seg + 1);   // (wave-uniform by construction: keeps the tests on it scalar)
                     seg_first = blk + 1;
                 }

@@ -2767,6 +2767,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             if (two) {   // a refined value: one more fused multiply-add on |v| (u |v| <= u (P R + R^2 / 2)); the conversion of S_L
                          // (|g S_L| <= 2^-15 |x| |y|) is inside cQ, which the two-part value's single conversion leaves room in
                 r.eb_cP += 1.0; r.eb_cR += 1.0;
+                // the two-part sweep's lists carry 5 index bits in the value (score_i8.hip): 31 ulp <= 62 u |v|
+                r.eb_cP += 62.0; r.eb_cR += 31.0;
                 r.L8 = m->d_L8; r.T8 = m->d_T8;
                 r.t8_blk[0] = 0; r.t8_blk[1] = m->n_rblk_ref; r.t8_blk[2] = m->n_rblk_ref + m->n_rblk_pos;
                 for (int sg = 0; sg < 3; ++sg) r.lam8[sg] = m->lam8[sg];
