@@ -456,6 +456,11 @@ def main():
     }
     if "phk_count_slots_kernel" in prof or "phk_count_pairs_kernel" in prof:
         alg.pop("phk_count_kernel", None)   # the wave-per-contig kernel then only serves the hand-over list
+    if "phk_count_slots_kernel" in prof and "phk_count_pairs_kernel" in prof:
+        # both are launched and decide on the device which of them counts the batch (the other returns at once):
+        # the bytes are credited to the one that did the work
+        idle = min(("phk_count_slots_kernel", "phk_count_pairs_kernel"), key=lambda kname: prof[kname][0])
+        alg.pop(idle, None)
     # the split-query kernel is the whole sweep only as a first pass (float64 rows / proposal=f16); as the second
     # chance of a count-exact first pass it sees the queued rows alone: credit it with those (stats_ex[2] is the
     # last step's queue on this rank), never with the batch

@@ -550,6 +550,7 @@ __global__ __launch_bounds__(256) void phk_sort_scatter_kernel(const uint64_t *_
 // longer than the mean are appended to `long_list` for the wave-per-contig kernel, which follows; a ragged batch is
 // walked as a sorted list of (contig, piece) items, a long contig being cut into pieces that are columns like any other.
 // ------------------------------------------------------------------------------------
+#define PHK_PAIRS_DEFAULT 'P'   // count_lanes unset: the two-windows-per-add kernel (1024 threads) for k = 4 batches without a mask; '1' = the slot kernel
 #ifndef SLOT_LINES
 #define SLOT_LINES 2                       // 128-byte lines per contig and stage
 #endif
@@ -578,7 +579,8 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                                                              uint2 *__restrict__ long_list,
                                                              uint32_t *__restrict__ long_count,
                                                              const uint2 *__restrict__ order,      // length-bucketed (contig, piece) items (ragged batches), or NULL
-                                                             uint32_t piece_w) {                    // windows per piece (0: whole contigs)
+                                                             uint32_t piece_w,                     // windows per piece (0: whole contigs)
+                                                             uint32_t skip_plain = 0) {            // 1: a batch that is not ragged was counted by phk_count_pairs_kernel
     constexpr uint32_t D = 1u << (2 * K);
     constexpr int CH = 8 * SLOT_LINES;      // 4-word chunks per contig and stage
     constexpr int PARTS = NTH / SLOTS;      // lanes per contig
@@ -593,8 +595,10 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
     uint32_t *split_s = nwin_s + SLOTS;   // [SLOTS] contig id + 1 of a slot that holds a PIECE (its column is added atomically), else 0
     // a batch in arbitrary order whose groups of SLOTS contigs are ragged is walked in the length-bucketed order the
     // sort kernels prepared; without one (count_sort off) the kernel stands down and the wave-per-contig kernel counts
-    if (phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) order = nullptr;
-    else if (!order) return;
+    if (phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) {
+        if (skip_plain) return;
+        order = nullptr;
+    } else if (!order) return;
     if (order) n = long_count[1];   // the work list of a ragged batch: items, counted by the sort kernels
     const int t = threadIdx.x, lane = t & 63;
     const int slot = t & (SLOTS - 1), part = t / SLOTS;          // counting role: contig slot, chunk (mod PARTS) within the stage
@@ -750,6 +754,7 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                     for (int j = 0; j < 3; ++j) mk[ln][j] = mkn[ln][j];
                 if (s + 1 < smax) mload(s + 1, mkn);
             }
+            bool issued = false;   // (wave-uniform) this wave issued a chunk's 64 adds after its staging writes
             // take delivery of ALL the stage's staging reads here: a read waited for after the first adds have been
             // issued costs a full drain of the add queue (the LDS counter is in order and saturates at 15)
 #pragma unroll
@@ -778,6 +783,7 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                     }
                 }
                 const uint32_t wds[5] = {cw[ln].x, cw[ln].y, cw[ln].z, cw[ln].w, nx[ln]};
+                issued = issued || __any(any);
                 if (!__any(any && !all)) {   // wave-uniform: every lane's chunk is interior to its contig (and all valid) or empty
                     if (all) {
 #pragma unroll
@@ -800,7 +806,10 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
                     }
                 }
             }
-            phk_stage_barrier();
+            // (a wave that issued no adds in this stage -- all its contigs have ended -- has its staging writes among its
+            // youngest LDS operations: it waits for all of them)
+            if (issued) phk_stage_barrier();
+            else phk_lds_barrier();
         }
         if (MASK && cnt_ok) atomicAdd(nwin_s + slot, cnt_ok);
         phk_lds_barrier();  // every wave's adds have landed
@@ -842,6 +851,197 @@ __global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__
         if (MASK && t < SLOTS) nwin_s[t] = 0;
         if (t == 0) *smax_p = 0;
         phk_lds_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// TWO WINDOWS PER ADD (k = 4, no validity mask, batches the statistics do not call ragged; round 4).
+// The slot kernel above is bound by the CU's LDS adder: one conflict-free wave-wide ds_add_u32 per ~4-6 cycles, one add per
+// window (tools/micro/lds_add_rate.hip).  Two consecutive windows -- the 4-mers at bases p and p + 1 -- are
+// one 5-mer (bases p .. p + 4): its upper 8 bits are the first window's code, its lower 8 bits the second's.  So the
+// contig's windows are taken in PAIRS (p = first base, + 2, + 4, ..), each pair is ONE add into a histogram of stride-2
+// 5-mers, and the 4-mer counts are that histogram's two marginals, formed at the flush:
+//     count4[x] = sum_b n5[4 x + b]  +  sum_a n5[256 a + x]          (+ 1 for the last window of a contig with an odd number)
+// The 1024 5-mer bins are 16-bit halves of 512 words -- bins[code5 >> 1][slot], increment 1 << 16 (code5 & 1) -- 64 KiB for
+// 32 contigs; a half holds at most W / 2 <= 65 535 (longer contigs are handed on, as the slot kernel hands on its long
+// ones).  Pairs are aligned to the CONTIG's first base: a contig that starts on an odd base has its words
+// re-aligned by one base (v_alignbit + v_cndmask per word), after which every shift is an immediate as in the slot
+// kernel.  Per add: 2 address operations + 2 for the increment, i.e. the slot kernel's VALU work per window and half its
+// LDS adds; the flush reads every bin word twice (4 LDS reads per 4-mer instead of 1).
+// ------------------------------------------------------------------------------------
+template <int NTH>
+__global__ __launch_bounds__(NTH) void phk_count_pairs_kernel(const uint32_t *__restrict__ packed, const uint64_t *__restrict__ offsets,
+                                                             uint64_t n, uint64_t max_word, uint32_t long_thr,
+                                                             uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin,
+                                                             uint2 *__restrict__ long_list, uint32_t *__restrict__ long_count,
+                                                             uint32_t piece_w) {
+    constexpr int K = 4;
+    constexpr uint32_t D = 256, NWORD = 512;   // 4-mer bins of a row; pair words of a histogram column
+    constexpr int SLOTS = 32;
+    constexpr int PARTS = NTH / SLOTS;      // lanes per contig
+    constexpr int XPT = (int)D / PARTS;     // 4-mer codes a thread flushes
+    static_assert(XPT % 4 == 0, "flush geometry");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [NWORD][SLOTS] | single [SLOTS]
+    uint32_t *single_s = lds + NWORD * SLOTS;
+    if (!phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) return;   // ragged: the sorted slot kernel's
+    const int t = threadIdx.x;
+    const int slot = t & (SLOTS - 1), part = t / SLOTS;
+    for (uint32_t b = t * 4; b < NWORD * SLOTS; b += 4 * NTH) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t colb = (uint32_t)slot * 4u;
+    const uint32_t pthr = long_thr < 131070u ? long_thr : 131070u;   // a 16-bit half holds W / 2
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    // the pair whose 5-mer starts at base o (even, <= 8) of `src`: bin word (code5 >> 1) at bits [15:7] of the byte address,
+    // increment 1 or 65536 by the 5-mer's last bit
+    auto pair_addr = [&](uint32_t src, int o) { return (lds_u32 *)(uintptr_t)(((src >> (16 - 2 * o)) & (0x1FFu << 7)) | colb); };
+    auto pair_inc = [&](uint32_t src, int o) {   // (bfe + mad: hipcc turns the C form into and + compare + select)
+        uint32_t bit, inc;
+        asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(bit) : "v"(src), "n"(22 - 2 * o));
+        asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc) : "v"(bit), "v"(65535u));
+        return inc;
+    };
+#if defined(PHK_DIAGNOSTIC_BUILD) && defined(PAIRS_ABL) && PAIRS_ABL == 1   // timing only: no LDS adds (the operands are kept alive)
+    auto add1 = [&](lds_u32 *p, uint32_t val) { asm volatile("" ::"v"(p), "v"(val)); };
+#else
+    auto add1 = [&](lds_u32 *p, uint32_t val) { __hip_atomic_fetch_add(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+#endif
+    const uint64_t wlast = max_word + 1;   // the pad word: the last one that exists
+
+    for (uint64_t batch = blockIdx.x; batch * SLOTS < n; batch += gridDim.x) {
+        const uint64_t c = batch * SLOTS + slot;
+        const bool have = c < n;
+        const uint64_t st = have ? offsets[c] : 0;
+        const uint64_t en = have ? offsets[c + 1] : 0;
+        const uint64_t len = en - st;
+        uint32_t W = len >= (uint64_t)K ? (uint32_t)((len - K + 1) < 0xFFFFFFFFull ? (len - K + 1) : 0xFFFFFFFFull) : 0;
+        const bool handed_over = W > pthr;
+        if (handed_over) {
+            if (part == 0) {
+                const uint32_t np = piece_w ? (W + piece_w - 1) / piece_w : 1u;
+                const uint32_t base = atomicAdd(long_count, np);
+                for (uint32_t pc = 0; pc < np; ++pc) long_list[base + pc] = make_uint2((uint32_t)c, pc);
+            }
+            W = 0;
+        }
+        const uint32_t par = (uint32_t)st & 1u;
+        const uint32_t npair = W >> 1;
+        // Units of four words (64 bases, 32 pairs), aligned in the stream; lane `part` of the contig takes units part, part +
+        // PARTS, ..  No staging and no barrier until the flush: a lane reads its words straight from memory (the vector
+        // cache serves the other lanes' pieces of a line).  Positions relative to the contig's first unit fit 32 bits
+        // (W <= 131 070).
+        const uint64_t U0 = st >> 6;
+        const uint32_t rst = (uint32_t)(st - (U0 << 6));                 // the contig's first base
+        const uint32_t rPL = rst + 2u * npair - 2u;                      // first base of its last pair (npair > 0)
+        const uint32_t nunit = npair ? (rPL >> 6) + 1u : 0u;
+        const uint32_t *pc = packed + 4 * U0;                            // the contig's first unit
+        // the word after a unit is read only where the stream still has one (its bases are needed only then)
+        const uint32_t wlim = (uint32_t)((wlast - 4 * U0) < 0x7FFFFFFFull ? (wlast - 4 * U0) : 0x7FFFFFFFull);
+        if (part == 0) {   // the unpaired last window of a contig with an odd number of them
+            uint32_t sg = 0xFFFFFFFFu;
+            if (W & 1u) {
+                const uint64_t lb = st + W - 1, wl = lb >> 4;
+                const uint64_t f = ((uint64_t)packed[wl] << 32) | packed[wl + 1];
+                sg = (uint32_t)(f >> (56 - 2 * (uint32_t)(lb & 15))) & 0xFFu;
+            }
+            single_s[slot] = sg;
+        }
+        auto load5 = [&](uint32_t j, uint32_t (&w)[5]) {
+            const uint32_t w0 = 4u * j;
+            if (w0 + 3 <= wlim) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(pc + w0);
+                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+            } else {   // the last words of the whole stream
+                w[0] = pc[w0]; w[1] = pc[w0 + 1 < wlim ? w0 + 1 : wlim]; w[2] = pc[w0 + 2 < wlim ? w0 + 2 : wlim]; w[3] = pc[wlim];
+            }
+            w[4] = pc[w0 + 4 < wlim ? w0 + 4 : wlim];
+        };
+        uint32_t cur[5] = {0, 0, 0, 0, 0}, nxt[5] = {0, 0, 0, 0, 0};
+        uint32_t j = (uint32_t)part;
+        if (j < nunit) load5(j, cur);
+        while (__any(j < nunit)) {
+            const bool live = j < nunit;
+            if (j + PARTS < nunit) load5(j + PARTS, nxt);
+            const uint32_t s0 = 64u * j + par;                            // pair i of the unit starts at s0 + 2 i, i < 32
+            const bool all = live && s0 >= rst && s0 + 62u <= rPL;
+            // the unit's words, re-aligned to the contig's parity (of the fifth only the top bases are used)
+            uint32_t sw[5];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sw[i] = par ? __builtin_amdgcn_alignbit(cur[i], cur[i + 1], 30) : cur[i];
+            sw[4] = par ? cur[4] << 2 : cur[4];
+            if (!__any(live && !all)) {   // wave-uniform: every live lane's unit is interior to its contig
+                if (all) {
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        const uint32_t y = sw[wd], u = __builtin_amdgcn_alignbit(y, sw[wd + 1], 16);
+#pragma unroll
+                        for (int jp = 0; jp < 8; ++jp) {   // pairs at bases 0, 2, .., 8 of y and 10, 12, 14 = 2, 4, 6 of u
+                            const uint32_t src = jp < 5 ? y : u;
+                            const int o = jp < 5 ? 2 * jp : 2 * jp - 8;
+                            add1(pair_addr(src, o), pair_inc(src, o));
+                        }
+                    }
+                }
+            } else if (live) {            // a lane at an edge of its contig: the pair's bit times the increment
+                const uint32_t ilo = rst > s0 ? (rst - s0) >> 1 : 0u;
+                const uint32_t ihi = (rPL - s0) >> 1 < 31u ? (rPL - s0) >> 1 : 31u;
+                const uint32_t pm = (ihi - ilo == 31u) ? ~0u : (((1u << (ihi - ilo + 1)) - 1u) << (31 - ihi));   // bit 31 - i: pair i is counted
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) {
+                    const uint32_t y = sw[wd], u = __builtin_amdgcn_alignbit(y, sw[wd + 1], 16);
+#pragma unroll
+                    for (int jp = 0; jp < 8; ++jp) {
+                        const uint32_t src = jp < 5 ? y : u;
+                        const int o = jp < 5 ? 2 * jp : 2 * jp - 8;
+                        add1(pair_addr(src, o), pair_inc(src, o) * __builtin_amdgcn_ubfe(pm, 31 - (8 * wd + jp), 1));
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) cur[i] = nxt[i];
+            j += PARTS;
+        }
+        phk_lds_barrier();  // every wave's adds (and the single windows) have landed
+        // ---- flush: thread (slot, g) forms the 4-mer counts x in [g XPT, (g + 1) XPT) of contig `slot` from the two marginals ----
+        {
+            const uint32_t x0 = (uint32_t)part * XPT;
+            uint32_t out[XPT];
+            const uint32_t *col = lds + slot;
+            // (v_sad_u16 with a zero operand adds both halves of a word onto an accumulator; v_mad_u32_u16 x 1 one half, chosen
+            // by op_sel: the unpacking costs no instruction of its own)
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) {                    // first window of the pair: 5-mers 4 x .. 4 x + 3 = words 2 x, 2 x + 1
+                const uint32_t w0 = col[(2 * (x0 + i)) * SLOTS], w1 = col[(2 * (x0 + i) + 1) * SLOTS];
+                out[i] = __builtin_amdgcn_sad_u16(w1, 0u, __builtin_amdgcn_sad_u16(w0, 0u, 0u));
+            }
+            const uint32_t one = 1u;
+#pragma unroll
+            for (int mm = 0; mm < XPT / 2; ++mm)               // second window: 5-mers 256 a + x = half x & 1 of word 128 a + x / 2
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const uint32_t w = col[(128 * a + x0 / 2 + mm) * SLOTS];
+                    asm("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(out[2 * mm]) : "v"(w), "v"(one));
+                    asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(out[2 * mm + 1]) : "v"(w), "v"(one));
+                }
+            const uint32_t sg = single_s[slot];
+#pragma unroll
+            for (int i = 0; i < XPT; ++i) out[i] += (sg == x0 + i) ? 1u : 0u;
+            phk_lds_barrier();   // every thread has read what it needs: the columns may be cleared
+            uint32_t *zc = lds + (2 * x0) * SLOTS + slot;
+#pragma unroll
+            for (int i = 0; i < 2 * XPT; ++i) zc[i * SLOTS] = 0;
+            uint32_t *rowo = counts + c * D + x0;
+#if defined(PHK_DIAGNOSTIC_BUILD) && defined(PAIRS_ABL) && PAIRS_ABL == 2   // timing only: rows are stored for one batch in 64
+            if (have && (!handed_over || piece_w) && (batch & 63) == 0) {
+#else
+            if (have && (!handed_over || piece_w)) {           // (a contig handed over in pieces gets its zero row here)
+#endif
+#pragma unroll
+                for (int i = 0; i < XPT / 4; ++i)
+                    *reinterpret_cast<uint4 *>(rowo + 4 * i) = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
+            }
+            if (nwin && have && part == 0 && (!handed_over || piece_w)) nwin[c] = W;
+        }
+        phk_lds_barrier();   // the columns are clear and single_s may be rewritten
     }
 }
 
@@ -916,7 +1116,11 @@ static int slots_instance_ok(Kern kern, bool *ok) {
 int phk_count_init_device(phk_ctx *ctx) {
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     bool ok = true;
+    PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<512>, &ok));
+    PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<1024>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 256, false>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 256, true>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 512, false>, &ok));
@@ -956,7 +1160,10 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
     if (k >= 3 && k <= 5 && max_word >= 64 && n < (1ull << 32) && lanes_knob != '0' && ctx->slots_lds0 &&
         !ctx->knobs.count_cfg[0]) {
         const uint32_t slots = k == 5 ? 16u : 32u;
-        const bool sorted = ctx->knobs.count_sort && lanes_knob != '2';
+        // count_lanes: '2' = slot kernel whatever the batch looks like (tests), 'q' / 'Q' = the same with the two-windows-per-add
+        // kernel (512 / 1024 threads) for k = 4 without a mask; 'p' / 'P' = that kernel where the statistics allow
+        const bool forced = lanes_knob == '2' || lanes_knob == 'q' || lanes_knob == 'Q';
+        const bool sorted = ctx->knobs.count_sort && !forced;
         // contigs much longer than the batch mean leave the slot kernel (a workgroup runs as many stages as its longest
         // contig): with count_sort they go to the wave-per-contig kernel as PIECES of 32768 windows, each its own work
         // item adding onto the zeroed row, so that one 500 kb contig is shared by 15 waves instead of pinning one
@@ -976,7 +1183,7 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         uint32_t *d_cursor = (uint32_t *)ws + 16 + 2 * max_items;
         uint2 *d_order = (uint2 *)(d_cursor + SORT_KEYS);
         PHK_HIP(hipMemsetAsync(d_long_count, 0, 64, ctx->stream));
-        if (lanes_knob != '2')  // count_lanes=2: slot kernel whatever the batch looks like (tests)
+        if (!forced)
         PHK_LAUNCH(ctx, "phk_count_stats_kernel",
                    phk_count_stats_kernel<<<dim3((unsigned)phk_div_up(phk_div_up(n, slots), 256)), dim3(256), 0, ctx->stream>>>(
                        d_offsets, n, k, slots, long_thr, (unsigned long long *)(d_long_count + 2)));
@@ -994,6 +1201,29 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
                                                                                                   d_cursor, d_order, d_counts, d_nwin));
         }
         const uint2 *d_ord = sorted ? d_order : nullptr;
+        // k = 4 without a validity mask: a batch the statistics do not call ragged is counted two windows per add
+        // (phk_count_pairs_kernel); the slot kernel below then only serves the ragged case (both decide on the device)
+        uint32_t skip_plain = 0;
+        const char pk = lanes_knob == 'p' || lanes_knob == 'q' ? 'p' : (lanes_knob == 'P' || lanes_knob == 'Q' ? 'P' : (lanes_knob == 0 ? PHK_PAIRS_DEFAULT : 0));
+        if (k == 4 && !d_mask && pk) {
+            const int nth = pk == 'P' ? 1024 : 512;   // 2 workgroups per CU either way: 32 / 16 waves
+            const size_t plds = (size_t)512 * 32 * 4 + 32 * 4;
+            const unsigned pfit = (unsigned)((160u * 1024u - 1024u) / plds);
+            const unsigned pper = nth == 1024 ? (pfit > 2 ? 2 : pfit) : (pfit > 4 ? 4 : pfit);
+            uint64_t pblocks = phk_div_up(n, 32);
+            const uint64_t pcap = (uint64_t)ctx->num_cus * pper;
+            if (pblocks > pcap) pblocks = pcap;
+            if (nth == 1024) {
+                PHK_LAUNCH(ctx, "phk_count_pairs_kernel",
+                           (phk_count_pairs_kernel<1024><<<dim3((unsigned)pblocks), dim3(1024), plds, ctx->stream>>>(
+                               d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w)));
+            } else {
+                PHK_LAUNCH(ctx, "phk_count_pairs_kernel",
+                           (phk_count_pairs_kernel<512><<<dim3((unsigned)pblocks), dim3(512), plds, ctx->stream>>>(
+                               d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w)));
+            }
+            skip_plain = 1;
+        }
         const size_t lds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * SLOT_ROW * 4 + 16 + 2 * slots * 4;
         // resident blocks per CU: the LDS allocation granule keeps a block that would exactly fill the 160 KiB out
         const unsigned fit = (unsigned)((160u * 1024u - 1024u) / lds);
@@ -1005,11 +1235,11 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         if (d_mask) {                                                                                                       \
             PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                       \
                        (phk_count_slots_kernel<K_, S_, T_, true><<<dim3((unsigned)blocks), dim3(T_), lds, ctx->stream>>>(   \
-                           d_packed, d_mask, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w))); \
+                           d_packed, d_mask, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w, skip_plain))); \
         } else {                                                                                                            \
             PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                       \
                        (phk_count_slots_kernel<K_, S_, T_, false><<<dim3((unsigned)blocks), dim3(T_), lds, ctx->stream>>>(  \
-                           d_packed, nullptr, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w))); \
+                           d_packed, nullptr, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w, skip_plain))); \
         }                                                                                                                   \
         return launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                                    \
             ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count, piece_w)

@@ -207,7 +207,9 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
     want = oracle.count(seqs, k)
     D = 4 ** k
     rows = {}
-    for lanes in ("2", "1", "0"):   # slot kernel forced / chosen by the batch statistics / wave-per-contig kernel only
+    # slot kernel forced / chosen by the batch statistics / wave-per-contig kernel only; at k = 4 also the two-windows-per-add
+    # kernel (5-mer pairs in 16-bit half bins, marginalised at the flush), forced and by the statistics, in both shapes
+    for lanes in ("2", "1", "0") + (("q", "Q", "p", "P") if k == 4 else ()):
         ctx.set_option("count_lanes", lanes)
         try:
             d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 0xABCD, np.uint32))
@@ -218,7 +220,8 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
             assert np.array_equal(d_nwin.to_host().astype(np.int64), want.sum(axis=1)), (k, lanes)
         finally:
             ctx.set_option("count_lanes", "")
-    assert np.array_equal(rows["0"], rows["1"]) and np.array_equal(rows["0"], rows["2"])
+    for lanes in rows:
+        assert np.array_equal(rows["0"], rows[lanes]), lanes
     # the same with invalid bases (validity mask): scattered single characters and long runs
     seqs_n = [synth.synth_contig(9, i, L, invalid_ppm=(30000 if i % 3 else 0)) for i, L in enumerate(lens)]
     seqs_n[16] = seqs_n[16][:300] + "N" * 200 + seqs_n[16][500:]
@@ -274,7 +277,7 @@ def test_slot_count_kernel_random_batches(ctx, seed):
     d_off = device.DeviceArray.from_host(ctx, offsets)
     want = oracle.count(seqs, k)
     D = 4 ** k
-    for lanes in ("2", "1"):
+    for lanes in ("2", "1", "q", "Q", "p"):   # (q / Q / p: the two-windows-per-add kernel where it applies -- k = 4, no mask)
         ctx.set_option("count_lanes", lanes)
         try:
             d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 7, np.uint32))
@@ -284,6 +287,58 @@ def test_slot_count_kernel_random_batches(ctx, seed):
             assert np.array_equal(d_nwin.to_host().astype(np.int64), want.sum(axis=1)), (seed, k, lanes)
         finally:
             ctx.set_option("count_lanes", "")
+
+
+@pytest.mark.gpu
+def test_two_windows_per_add_count_kernel_k4(ctx):
+    """phk_count_pairs_kernel (k = 4, no mask): windows taken in pairs from the contig's first base, one add per pair into
+    stride-2 5-mer bins (16-bit halves), 4-mer counts = the two marginals + the unpaired last window.  Edges: every start
+    parity (contigs of odd and even lengths back to back), 0 .. 4 windows, pairs that straddle a chunk and a stage, a
+    homopolymer whose half bin reaches exactly 65 535 and one a window longer (handed to the wave-per-contig kernel), a
+    stream that ends word-aligned; both shapes of the kernel, forced and chosen by the batch statistics."""
+    from oracle import oracle
+    from phamers_amd import device, synth
+    rng = np.random.default_rng(77)
+    k, D = 4, 256
+    batches = []
+    batches.append([int(x) for x in rng.integers(0, 300, 333)] + [3, 4, 5, 6, 7, 8, 67, 68, 69, 131, 132, 133, 1027, 1028, 16 * 9])
+    batches.append([int(x) for x in rng.integers(2000, 9000, 70)] + [300001, 4999, 5000, 5001, 5002] + [int(x) for x in rng.integers(1, 64, 31)])
+    batches.append(None)   # the 16-bit limit
+    for bi, lens in enumerate(batches):
+        if lens is None:
+            seqs = ["A" * 131073, "A" * 131074, "AT" * 65540, synth.synth_contig(5, 0, 120000), "C" * 131072, synth.synth_contig(5, 1, 140001),
+                    synth.synth_contig(5, 2, 99999), "G" * 7]
+            lens = [len(x) for x in seqs]
+        else:
+            seqs = [synth.synth_contig(40 + bi, i, L) for i, L in enumerate(lens)]
+        T = sum(lens)
+        offsets = np.zeros(len(lens) + 1, dtype=np.uint64)
+        offsets[1:] = np.cumsum(lens)
+        raw = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+        d_raw = device.DeviceArray.from_host(ctx, raw)
+        d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+        d_mask = device.DeviceArray(ctx, device.mask_words(T), np.uint32)
+        device.pack_ascii(ctx, d_raw, T, d_packed, d_mask, None)
+        d_off = device.DeviceArray.from_host(ctx, offsets)
+        want = oracle.count(seqs, k).reshape(len(lens), D)
+        for lanes in ("q", "Q", "p", "P"):
+            ctx.set_option("count_lanes", lanes)
+            try:
+                ctx.profile_reset()
+                ctx.profile_enable(True)
+                d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 0xABCD, np.uint32))
+                d_nwin = device.DeviceArray.from_host(ctx, np.full(len(lens), 0xABCD, np.uint32))
+                device.count(ctx, d_packed, None, T, d_off, len(lens), k, d_counts, d_nwin)
+                got = d_counts.to_host().astype(np.int64)
+                ctx.profile_enable(False)
+                assert "phk_count_pairs_kernel" in ctx.profile(), (bi, lanes)
+                bad = np.flatnonzero((got != want).any(axis=1))
+                assert bad.size == 0, (bi, lanes, bad[:8], [lens[i] for i in bad[:8]])
+                assert np.array_equal(d_nwin.to_host().astype(np.int64), want.sum(axis=1)), (bi, lanes)
+            finally:
+                ctx.set_option("count_lanes", "")
+        for a in (d_raw, d_packed, d_mask, d_off):
+            a.free()
 
 
 @pytest.mark.gpu

@@ -15,8 +15,10 @@ ap.add_argument("--k", type=int, default=4)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--invalid-ppm", type=int, default=0)
 ap.add_argument("--check", type=int, default=64)
+ap.add_argument("--lanes", default="", help="count_lanes knob: '' default, p / P two-windows-per-add kernel (256x1 / 512x2), 2 slot kernel forced, 0 wave kernel")
 a = ap.parse_args()
 ctx = _lib.Context(0)
+ctx.set_option("count_lanes", a.lanes)
 n, L, k = a.contigs, a.length, a.k
 T, D = n * L, 4 ** k
 packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
@@ -31,7 +33,7 @@ for _ in range(a.iters):
     device.count(ctx, packed, mask, T, off, n, k, counts)
 ctx.sync()
 prof = ctx.profile()
-ms = sum(prof[name][0] for name in ("phk_count_slots_kernel", "phk_count_kernel") if name in prof) / a.iters
+ms = sum(prof[name][0] for name in ("phk_count_slots_kernel", "phk_count_kernel", "phk_count_pairs_kernel") if name in prof) / a.iters
 alg = n * ((L + 3) // 4 + 8 + 4 * D) + (n * ((L + 7) // 8) if mask else 0)
 ok = None
 if a.check:
@@ -41,6 +43,6 @@ if a.check:
     want = oracle.count(synth.synth_contigs(0, m, L, a.invalid_ppm), k).reshape(m, D)
     got = counts.to_host()[:m].astype(np.int64)
     ok = bool(np.array_equal(got, want))
-print(json.dumps({"cfg": os.environ.get("PHK_COUNT_CFG", "default"), "kernels": sorted(prof), "k": k, "contigs": n, "length": L,
+print(json.dumps({"cfg": os.environ.get("PHK_COUNT_CFG", "default"), "lanes": a.lanes, "per_kernel_ms": {kn: v[0] / a.iters for kn, v in prof.items()}, "kernels": sorted(prof), "k": k, "contigs": n, "length": L,
                   "ms": ms, "GBps_algorithmic": alg / ms / 1e6, "Gbases_per_s": T / ms / 1e6,
                   "frac_hbm_peak": alg / ms / 1e6 / 8000.0, "bit_exact_vs_oracle": ok}))
