@@ -446,6 +446,7 @@ def main():
         "phk_count_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
         "phk_count_slots_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
         "phk_count_pairs_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
+        "phk_count_direct_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
         "phk_knn_mfma_kernel": ("mfma", "TFLOP/s", MFMA_F32_PEAK_TF, score_tflop),
         "phk_knn_f16_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
         "phk_knn_f16c_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
@@ -454,13 +455,16 @@ def main():
         "phk_knn_i8_general_kernel": ("mfma", "TFLOP/s", MFMA_I8_PEAK_TF, score_tflop),
         "phk_dist2_f64_kernel": ("mfma", "TFLOP/s", F64_PEAK_TF, score_tflop),
     }
-    if "phk_count_slots_kernel" in prof or "phk_count_pairs_kernel" in prof:
+    if "phk_count_slots_kernel" in prof or "phk_count_pairs_kernel" in prof or "phk_count_direct_kernel" in prof:
         alg.pop("phk_count_kernel", None)   # the wave-per-contig kernel then only serves the hand-over list
-    if "phk_count_slots_kernel" in prof and "phk_count_pairs_kernel" in prof:
-        # both are launched and decide on the device which of them counts the batch (the other returns at once):
+    slotk = [kname for kname in ("phk_count_slots_kernel", "phk_count_pairs_kernel", "phk_count_direct_kernel") if kname in prof]
+    if len(slotk) > 1:
+        # two of them are launched and decide on the device which one counts the batch (the other returns at once):
         # the bytes are credited to the one that did the work
-        idle = min(("phk_count_slots_kernel", "phk_count_pairs_kernel"), key=lambda kname: prof[kname][0])
-        alg.pop(idle, None)
+        busy = max(slotk, key=lambda kname: prof[kname][0])
+        for kname in slotk:
+            if kname != busy:
+                alg.pop(kname, None)
     # the split-query kernel is the whole sweep only as a first pass (float64 rows / proposal=f16); as the second
     # chance of a count-exact first pass it sees the queued rows alone: credit it with those (stats_ex[2] is the
     # last step's queue on this rank), never with the batch

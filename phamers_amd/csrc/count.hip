@@ -1045,6 +1045,126 @@ __global__ __launch_bounds__(NTH) void phk_count_pairs_kernel(const uint32_t *__
     }
 }
 
+// ------------------------------------------------------------------------------------
+// The slot kernel WITHOUT staging and stage barriers (k = 5, no validity mask, batches the statistics do not call ragged;
+// round 4): what made the two-windows-per-add kernel above fast was, as much as its halved adds, that a lane reads its
+// words straight from memory and no wave waits for another before the flush.  Same bins as phk_count_slots_kernel
+// (bins[code][slot], 16 contigs per workgroup at k = 5), one add per window, 64 windows per lane and round.
+// ------------------------------------------------------------------------------------
+template <int K, int SLOTS, int NTH>
+__global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *__restrict__ packed, const uint64_t *__restrict__ offsets,
+                                                              uint64_t n, uint64_t max_word, uint32_t long_thr,
+                                                              uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin,
+                                                              uint2 *__restrict__ long_list, uint32_t *__restrict__ long_count,
+                                                              uint32_t piece_w) {
+    constexpr uint32_t D = 1u << (2 * K);
+    constexpr int PARTS = NTH / SLOTS;      // lanes per contig
+    constexpr int XPT = (int)D / PARTS;     // codes a thread flushes
+    constexpr int SHB = SLOTS == 32 ? 7 : 6;  // log2 of a bin row in bytes
+    static_assert(XPT % 4 == 0 && K <= 5, "flush geometry / window fits the funnel");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][SLOTS]
+    if (!phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) return;   // ragged: the sorted slot kernel's
+    const int t = threadIdx.x;
+    const int slot = t & (SLOTS - 1), part = t / SLOTS;
+    for (uint32_t b = t * 4; b < D * SLOTS; b += 4 * NTH) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const uint32_t colb = (uint32_t)slot * 4u;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    auto bin = [&](uint32_t src, int o) {   // the window starting at base o (< 8) of `src`
+        constexpr uint32_t msk = (D - 1u) << SHB;
+        const int sh = 32 - 2 * K - 2 * o - SHB;
+        return (lds_u32 *)(uintptr_t)(((src >> sh) & msk) | colb);
+    };
+    auto add1 = [&](lds_u32 *p, uint32_t val) { __hip_atomic_fetch_add(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    const uint64_t wlast = max_word + 1;   // the pad word: the last one that exists
+
+    for (uint64_t batch = blockIdx.x; batch * SLOTS < n; batch += gridDim.x) {
+        const uint64_t c = batch * SLOTS + slot;
+        const bool have = c < n;
+        const uint64_t st = have ? offsets[c] : 0;
+        const uint64_t en = have ? offsets[c + 1] : 0;
+        const uint64_t len = en - st;
+        uint32_t W = len >= (uint64_t)K ? (uint32_t)((len - K + 1) < 0xFFFFFFFFull ? (len - K + 1) : 0xFFFFFFFFull) : 0;
+        const bool handed_over = W > long_thr;
+        if (handed_over) {
+            if (part == 0) {
+                const uint32_t np = piece_w ? (W + piece_w - 1) / piece_w : 1u;
+                const uint32_t base = atomicAdd(long_count, np);
+                for (uint32_t pc = 0; pc < np; ++pc) long_list[base + pc] = make_uint2((uint32_t)c, pc);
+            }
+            W = 0;
+        }
+        // units of four words (64 windows), aligned in the stream; positions relative to the contig's first unit
+        const uint64_t U0 = st >> 6;
+        const uint32_t rst = (uint32_t)(st - (U0 << 6));
+        const uint64_t rlast64 = (uint64_t)rst + W - 1;                  // the last window (W > 0)
+        const uint32_t rlast = rlast64 < 0xFFFFFFC0ull ? (uint32_t)rlast64 : 0xFFFFFFC0u;   // (long_thr keeps W far below this)
+        const uint32_t nunit = W ? (rlast >> 6) + 1u : 0u;
+        const uint32_t *pc = packed + 4 * U0;
+        const uint32_t wlim = (uint32_t)((wlast - 4 * U0) < 0x7FFFFFFFull ? (wlast - 4 * U0) : 0x7FFFFFFFull);
+        auto load5 = [&](uint32_t j, uint32_t (&w)[5]) {
+            const uint32_t w0 = 4u * j;
+            if (w0 + 3 <= wlim) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(pc + w0);
+                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+            } else {   // the last words of the whole stream
+                w[0] = pc[w0]; w[1] = pc[w0 + 1 < wlim ? w0 + 1 : wlim]; w[2] = pc[w0 + 2 < wlim ? w0 + 2 : wlim]; w[3] = pc[wlim];
+            }
+            w[4] = pc[w0 + 4 < wlim ? w0 + 4 : wlim];
+        };
+        uint32_t cur[5] = {0, 0, 0, 0, 0}, nxt[5] = {0, 0, 0, 0, 0};
+        uint32_t j = (uint32_t)part;
+        if (j < nunit) load5(j, cur);
+        while (__any(j < nunit)) {
+            const bool live = j < nunit;
+            if (j + PARTS < nunit) load5(j + PARTS, nxt);
+            const uint32_t fb = 64u * j;                                  // window i of the unit starts at fb + i
+            const bool all = live && fb >= rst && fb + 63u <= rlast;
+            if (!__any(live && !all)) {   // wave-uniform: every live lane's unit is interior to its contig
+                if (all) {
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        const uint32_t y = cur[wd], u = __builtin_amdgcn_alignbit(y, cur[wd + 1], 16);
+#pragma unroll
+                        for (int jw = 0; jw < 16; ++jw) add1(bin(jw < 8 ? y : u, jw & 7), 1u);
+                    }
+                }
+            } else if (live) {            // a lane at an edge of its contig: the window's bit instead of 1
+                const uint32_t lo = rst > fb ? rst - fb : 0u;
+                const uint32_t hi = rlast - fb < 63u ? rlast - fb : 63u;
+                const uint64_t wv = (hi - lo == 63u) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << (63 - hi));   // bit 63 - i: window i is counted
+                const uint32_t vhi = (uint32_t)(wv >> 32), vlo = (uint32_t)wv;
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) {
+                    const uint32_t y = cur[wd], u = __builtin_amdgcn_alignbit(y, cur[wd + 1], 16);
+#pragma unroll
+                    for (int jw = 0; jw < 16; ++jw) {
+                        const int wi = 16 * wd + jw;
+                        add1(bin(jw < 8 ? y : u, jw & 7), __builtin_amdgcn_ubfe(wi < 32 ? vhi : vlo, 31 - (wi & 31), 1));
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) cur[i] = nxt[i];
+            j += PARTS;
+        }
+        phk_lds_barrier();  // every wave's adds have landed
+        {   // flush: thread (slot, g) writes codes [g XPT, (g + 1) XPT) of contig `slot` and clears them
+            uint32_t *cellb = lds + ((uint32_t)part * XPT) * SLOTS + slot;
+            uint32_t *rowo = counts + c * D + (uint32_t)part * XPT;
+#pragma unroll 8
+            for (uint32_t i = 0; i < XPT / 4; ++i) {
+                uint32_t *cell = cellb + 4 * i * SLOTS;
+                const uint4 o = make_uint4(cell[0], cell[SLOTS], cell[2 * SLOTS], cell[3 * SLOTS]);
+                cell[0] = 0; cell[SLOTS] = 0; cell[2 * SLOTS] = 0; cell[3 * SLOTS] = 0;
+                if (have && (!handed_over || piece_w)) *reinterpret_cast<uint4 *>(rowo + 4 * i) = o;
+            }
+            if (nwin && have && part == 0 && (!handed_over || piece_w)) nwin[c] = W;
+        }
+        phk_lds_barrier();
+    }
+}
+
 // replication / packing per k: keep a wave's bins <= 32 KiB
 template <int K> struct PhkCountCfg {
     static constexpr bool pack16 = K >= 6;
@@ -1119,6 +1239,10 @@ int phk_count_init_device(phk_ctx *ctx) {
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     bool ok = true;
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_direct_kernel<5, 16, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_direct_kernel<5, 16, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+    PHK_TRY(slots_instance_ok(phk_count_direct_kernel<5, 16, 512>, &ok));
+    PHK_TRY(slots_instance_ok(phk_count_direct_kernel<5, 16, 1024>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<512>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<1024>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 256, false>, &ok));
@@ -1220,6 +1344,23 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
             } else {
                 PHK_LAUNCH(ctx, "phk_count_pairs_kernel",
                            (phk_count_pairs_kernel<512><<<dim3((unsigned)pblocks), dim3(512), plds, ctx->stream>>>(
+                               d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w)));
+            }
+            skip_plain = 1;
+        }
+        // k = 5 without a validity mask: the slot kernel's bins without its staging and stage barriers (phk_count_direct_kernel)
+        if (k == 5 && !d_mask && (lanes_knob == 0 || lanes_knob == 'd' || lanes_knob == 'D')) {
+            const size_t dlds = (size_t)1024 * 16 * 4;
+            uint64_t dblocks = phk_div_up(n, 16);
+            const uint64_t dcap = (uint64_t)ctx->num_cus * 2;
+            if (dblocks > dcap) dblocks = dcap;
+            if (lanes_knob == 'd') {
+                PHK_LAUNCH(ctx, "phk_count_direct_kernel",
+                           (phk_count_direct_kernel<5, 16, 512><<<dim3((unsigned)dblocks), dim3(512), dlds, ctx->stream>>>(
+                               d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w)));
+            } else {
+                PHK_LAUNCH(ctx, "phk_count_direct_kernel",
+                           (phk_count_direct_kernel<5, 16, 1024><<<dim3((unsigned)dblocks), dim3(1024), dlds, ctx->stream>>>(
                                d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w)));
             }
             skip_plain = 1;

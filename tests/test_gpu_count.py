@@ -209,7 +209,8 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
     rows = {}
     # slot kernel forced / chosen by the batch statistics / wave-per-contig kernel only; at k = 4 also the two-windows-per-add
     # kernel (5-mer pairs in 16-bit half bins, marginalised at the flush), forced and by the statistics, in both shapes
-    for lanes in ("2", "1", "0") + (("q", "Q", "p", "P") if k == 4 else ()):
+    # ("" = the library's own choice: those kernels where they apply; k = 5: "d" / "D" = the unstaged slot kernel, 512 / 1024 threads)
+    for lanes in ("2", "1", "0", "") + (("q", "Q", "p", "P") if k == 4 else ()) + (("d", "D") if k == 5 else ()):
         ctx.set_option("count_lanes", lanes)
         try:
             d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 0xABCD, np.uint32))
@@ -277,7 +278,7 @@ def test_slot_count_kernel_random_batches(ctx, seed):
     d_off = device.DeviceArray.from_host(ctx, offsets)
     want = oracle.count(seqs, k)
     D = 4 ** k
-    for lanes in ("2", "1", "q", "Q", "p"):   # (q / Q / p: the two-windows-per-add kernel where it applies -- k = 4, no mask)
+    for lanes in ("2", "1", "q", "Q", "p", "d", ""):   # (q / Q / p: the two-windows-per-add kernel where it applies -- k = 4, no mask; d: k = 5)
         ctx.set_option("count_lanes", lanes)
         try:
             d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 7, np.uint32))

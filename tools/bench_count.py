@@ -33,7 +33,7 @@ for _ in range(a.iters):
     device.count(ctx, packed, mask, T, off, n, k, counts)
 ctx.sync()
 prof = ctx.profile()
-ms = sum(prof[name][0] for name in ("phk_count_slots_kernel", "phk_count_kernel", "phk_count_pairs_kernel") if name in prof) / a.iters
+ms = sum(prof[name][0] for name in ("phk_count_slots_kernel", "phk_count_kernel", "phk_count_pairs_kernel", "phk_count_direct_kernel") if name in prof) / a.iters
 alg = n * ((L + 3) // 4 + 8 + 4 * D) + (n * ((L + 7) // 8) if mask else 0)
 ok = None
 if a.check:
