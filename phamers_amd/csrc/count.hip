@@ -1056,14 +1056,19 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
                                                               uint64_t n, uint64_t max_word, uint32_t long_thr,
                                                               uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin,
                                                               uint2 *__restrict__ long_list, uint32_t *__restrict__ long_count,
-                                                              uint32_t piece_w) {
+                                                              uint32_t piece_w,
+                                                              uint4 *__restrict__ frag8,      // the scorer's int8 operand (PhkPrep8), or NULL
+                                                              uint32_t *__restrict__ big8) {
     constexpr uint32_t D = 1u << (2 * K);
     constexpr int PARTS = NTH / SLOTS;      // lanes per contig
     constexpr int XPT = (int)D / PARTS;     // codes a thread flushes
     constexpr int SHB = SLOTS == 32 ? 7 : 6;  // log2 of a bin row in bytes
-    static_assert(XPT % 4 == 0 && K <= 5, "flush geometry / window fits the funnel");
+    static_assert(XPT % 16 == 0 && K <= 5, "flush geometry / window fits the funnel");
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][SLOTS]
-    if (!phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) return;   // ragged: the sorted slot kernel's
+    if (!phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) {   // ragged: the sorted slot kernel's
+        if (big8 && blockIdx.x == 0 && threadIdx.x == 0) big8[n] = 2u;   // (nothing prepared for the scorer)
+        return;
+    }
     const int t = threadIdx.x;
     const int slot = t & (SLOTS - 1), part = t / SLOTS;
     for (uint32_t b = t * 4; b < D * SLOTS; b += 4 * NTH) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
@@ -1152,12 +1157,47 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
         {   // flush: thread (slot, g) writes codes [g XPT, (g + 1) XPT) of contig `slot` and clears them
             uint32_t *cellb = lds + ((uint32_t)part * XPT) * SLOTS + slot;
             uint32_t *rowo = counts + c * D + (uint32_t)part * XPT;
-#pragma unroll 8
-            for (uint32_t i = 0; i < XPT / 4; ++i) {
-                uint32_t *cell = cellb + 4 * i * SLOTS;
-                const uint4 o = make_uint4(cell[0], cell[SLOTS], cell[2 * SLOTS], cell[3 * SLOTS]);
-                cell[0] = 0; cell[SLOTS] = 0; cell[2 * SLOTS] = 0; cell[3 * SLOTS] = 0;
-                if (have && (!handed_over || piece_w)) *reinterpret_cast<uint4 *>(rowo + 4 * i) = o;
+            // ... and, for the scorer's int8 sweep (score_i8.hip), the same 16 codes per piece as int8 around the row's centre in
+            // fragment order: piece (k-step s = dims / 32, half h) of query c at [(c / 32) (D / 32) + s][32 h + c % 32]
+            const int cen = (int)phk_row_center(W, D);
+            uint32_t mx = 0, l1 = 0;
+#pragma unroll
+            for (uint32_t pz = 0; pz < XPT / 16; ++pz) {
+                uint32_t pk[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4; ++i) {
+                    uint32_t *cell = cellb + (16 * pz + 4 * i) * SLOTS;
+                    const uint4 o = make_uint4(cell[0], cell[SLOTS], cell[2 * SLOTS], cell[3 * SLOTS]);
+                    cell[0] = 0; cell[SLOTS] = 0; cell[2 * SLOTS] = 0; cell[3 * SLOTS] = 0;
+                    if (have && (!handed_over || piece_w)) *reinterpret_cast<uint4 *>(rowo + 16 * pz + 4 * i) = o;
+                    const uint32_t cc[4] = {o.x, o.y, o.z, o.w};
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int d = (int)cc[b] - cen;
+                        const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+                        mx = max(mx, ad);
+                        l1 += min(ad, 127u);
+                        const int q = d < -127 ? -127 : (d > 127 ? 127 : d);
+                        word |= ((uint32_t)q & 0xFFu) << (8 * b);
+                    }
+                    pk[i] = word;
+                }
+                if (frag8 && have && !handed_over) {
+                    const uint32_t dim16 = (uint32_t)part * (XPT / 16) + pz;   // which 16 dimensions of the row
+                    frag8[((c >> 5) * (D / 32) + (dim16 >> 1)) * 64 + 32u * (dim16 & 1u) + (uint32_t)(c & 31)] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                }
+            }
+            if (big8 && have) {
+                if (handed_over) {   // counted later, in pieces: the scorer's own fragment kernel takes this row
+                    if (part == 0) {
+                        big8[c] = PHK_PREP8_MISSING;
+                        atomicOr(big8 + n, 1u);
+                    }
+                } else {
+                    if (mx > 127u) atomicOr(big8 + c, 0x80000000u);
+                    if (2ull * W + D > PHK_I8_L1_MAX) atomicAdd(big8 + c, l1);
+                }
             }
             if (nwin && have && part == 0 && (!handed_over || piece_w)) nwin[c] = W;
         }
@@ -1354,16 +1394,24 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
             uint64_t dblocks = phk_div_up(n, 16);
             const uint64_t dcap = (uint64_t)ctx->num_cus * 2;
             if (dblocks > dcap) dblocks = dcap;
+            // the scorer's int8 operand beside the counts, when phk_count_score_dev armed it for exactly this matrix
+            PhkPrep8 &pp = ctx->prep8;
+            const bool prep = pp.armed && pp.counts == d_counts && pp.n == n && pp.D == 1024;
+            uint4 *frag8 = prep ? (uint4 *)pp.frag : nullptr;
+            uint32_t *big8 = prep ? pp.big : nullptr;
             if (lanes_knob == 'd') {
                 PHK_LAUNCH(ctx, "phk_count_direct_kernel",
                            (phk_count_direct_kernel<5, 16, 512><<<dim3((unsigned)dblocks), dim3(512), dlds, ctx->stream>>>(
-                               d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w)));
+                               d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w, frag8, big8)));
             } else {
                 PHK_LAUNCH(ctx, "phk_count_direct_kernel",
                            (phk_count_direct_kernel<5, 16, 1024><<<dim3((unsigned)dblocks), dim3(1024), dlds, ctx->stream>>>(
-                               d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w)));
+                               d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w, frag8, big8)));
             }
+            pp.armed = prep;   // (stays armed only if the kernel that prepares it was launched)
             skip_plain = 1;
+        } else {
+            ctx->prep8.armed = false;
         }
         const size_t lds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * SLOT_ROW * 4 + 16 + 2 * slots * 4;
         // resident blocks per CU: the LDS allocation granule keeps a block that would exactly fill the 160 KiB out

@@ -461,8 +461,23 @@ extern "C" int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const u
     chunks = chunks < 1 ? 1 : (chunks > 8 ? 8 : chunks);
     if (k != 4 || !phk_model_has_fast(model) || ctx->knobs.force_exact || n < 65536ull * (uint64_t)chunks) chunks = 1;
     if (chunks == 1) {
-        PHK_TRY(phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets, n, k, d_counts, nwin));
-        return phk_score_rows(ctx, model, nullptr, d_counts, nwin, n, method, d_scores, d_status);
+        // k = 5: the count kernel's flush also writes the int8 operand of the scorer's sweep (PhkPrep8, phk_common.h)
+        ctx->prep8.armed = false;
+        if (k == 5 && !d_mask && n > 0 && phk_model_has_fast(model) && model->d_A8 && !model->bf_stale && !ctx->knobs.force_exact &&
+            !ctx->knobs.proposal[0] && !ctx->knobs.count_lanes && !ctx->knobs.count_cfg[0]) {
+            const uint64_t D = model->D;
+            void *frag, *big;
+            PHK_TRY(phk_ws(ctx, WS_FRAG8, phk_div_up(n, 32) * 32 * D, &frag));
+            PHK_TRY(phk_ws(ctx, WS_BIG8, (n + 1) * sizeof(uint32_t), &big));
+            PHK_HIP(hipMemsetAsync(big, 0, (n + 1) * sizeof(uint32_t), ctx->stream));
+            ctx->prep8.counts = d_counts; ctx->prep8.n = n; ctx->prep8.D = D;
+            ctx->prep8.frag = frag; ctx->prep8.big = (uint32_t *)big;
+            ctx->prep8.armed = true;
+        }
+        int rc = phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets, n, k, d_counts, nwin);
+        if (rc == PHK_OK) rc = phk_score_rows(ctx, model, nullptr, d_counts, nwin, n, method, d_scores, d_status);
+        ctx->prep8.armed = false;
+        return rc;
     }
     if (!ctx->aux) {
         PHK_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));

@@ -72,6 +72,8 @@ enum PhkSlot {
     WS_OUT,         // batch API: scores on their way to the host
     WS_SUB,         // scoring at general D: dense count rows (+ row sums) of a second pass's sub-batch
     WS_QUEUE,       // scoring at general D: the two hand-over queues of the first pass
+    WS_FRAG8,       // count -> score at k = 5: the int8 query fragments of the whole call, written by the count kernel's flush
+    WS_BIG8,        // ... and their per-row flag words (+ the call's mode word)
     WS_SLOTS
 };
 
@@ -105,8 +107,24 @@ struct PhkKnobs {
                                // measured 5.32 / 5.71 / 6.39 / 7.94 ms per 1M contigs with 1 / 2 / 4 / 8 chunks)
 };
 
+// The int8 operand of the general-D sweep prepared by the count kernel (phk_count_score_dev at k = 5: the flush of
+// phk_count_direct_kernel writes each row's centred int8 fragment pieces beside the counts, which saves the scorer a pass
+// over the 4 KB count rows).  big[n] is the call's mode word: 0 = every row prepared, 1 = rows flagged PHK_PREP8_MISSING
+// are not (contigs handed to the wave-per-contig kernel), 2 = nothing prepared (a ragged batch took the sorted slot
+// kernel); phk_split_queries_i8_kernel completes the operand accordingly.
+#define PHK_PREP8_MISSING 0x40000000u
+#define PHK_I8_L1_MAX 65000u   // |c - c0|_1 of a row the sweep epilogue's 32-bit fold is exact for: (256 * 127 + 128) * 65000 < 2^31
+struct PhkPrep8 {
+    bool armed = false;
+    const uint32_t *counts = nullptr;   // the count matrix the fragments belong to
+    uint64_t n = 0, D = 0;
+    void *frag = nullptr;               // [ceil(n / 32)][D / 32][64 lanes] x 16 bytes
+    uint32_t *big = nullptr;            // [n + 1]
+};
+
 struct phk_ctx {
     int device = 0;
+    PhkPrep8 prep8;
     PhkKnobs knobs;
     bool slots_lds0 = true;        // the slot count kernel's dynamic LDS starts at address 0 (checked at creation)
     hipStream_t stream = nullptr;
@@ -171,6 +189,10 @@ __device__ __forceinline__ double phk_div_row(double x, double T, double y) {
     const double q1 = __builtin_fma(__builtin_fma(-q0, T, x), y, q0);
     return __builtin_fma(__builtin_fma(-q1, T, x), y, q1);
 }
+
+// Count rows enter the count-exact MFMA kernels CENTRED by an integer: c_i - c0 with c0 = the integer nearest to T / D
+// (T = row sum); every kernel derives c0 from T with this one function (see score_lists.h).
+__host__ __device__ __forceinline__ uint32_t phk_row_center(uint32_t T, uint32_t D) { return (T + D / 2) / D; }
 
 static inline uint64_t phk_pow4(int k) { return 1ull << (2 * k); }
 static inline uint64_t phk_div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }

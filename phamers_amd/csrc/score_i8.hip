@@ -34,7 +34,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define I8_NMAX 8300000.0      // |n| <= this: H = n / 65536 (balanced) stays within [-127, 127]
 #define I8_KS 2                // k-steps (32 dimensions each) per chunk of the sweep: chunks of 64 dimensions
-#define I8_L1_MAX 65000u        // |c - c0|_1 of a row the epilogue's 32-bit fold is exact for: (256 * 127 + 128) * 65000 < 2^31
+#define I8_L1_MAX PHK_I8_L1_MAX   // (phk_common.h)
 #define I8_SENT 0x03FFFFFFu    // id of an empty list slot (two-part sweep)
 #define I8_CT_MAX 6            // most column blocks a tile of any variant holds (padding of the record / term arrays)
 // Two variants of the sweep, <parts NP, column blocks per tile CT> -- both keep 192 int32 accumulator registers per wave and
@@ -173,7 +173,12 @@ int phk_model_build_i8(phk_model *m, const double *pos, const double *neg, const
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_t *__restrict__ counts,
                                                                    const uint32_t *__restrict__ rowsum, uint64_t N, uint64_t D,
-                                                                   uint4 *__restrict__ Bq, uint32_t *__restrict__ big) {
+                                                                   uint4 *__restrict__ Bq, uint32_t *__restrict__ big,
+                                                                   const uint32_t *__restrict__ mode_word) {
+    // mode_word: the operand may have been prepared by the count kernel (PhkPrep8): 0 = all of it (nothing to do), 1 = all
+    // but the rows flagged PHK_PREP8_MISSING, 2 (or no word) = none of it
+    const uint32_t mode = mode_word ? phk_uniform_load(mode_word) : 2u;
+    if (mode == 0u) return;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     const uint64_t nchunk = D / 256;
     const uint64_t w = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -181,6 +186,8 @@ __global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_
     if (w >= nqb * nchunk) return;
     const uint64_t qb = w / nchunk, c = w % nchunk;
     const uint64_t qrow = (qb * 32 + j < N) ? qb * 32 + j : N - 1;
+    const bool mine = mode == 2u || (big[qrow] & PHK_PREP8_MISSING) != 0u;   // (patch mode: this lane's row still lacks its fragments)
+    if (mode == 1u && !__any(mine)) return;
     const int cen = (int)phk_row_center(rowsum[qrow], (uint32_t)D);
     uint4 *out = Bq + (w * 8) * 64 + lane;
     uint32_t mx = 0, l1 = 0;
@@ -207,15 +214,15 @@ __global__ __launch_bounds__(256) void phk_split_queries_i8_kernel(const uint32_
             }
             pk[e] = word;
         }
-        out[s * 64] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        if (mine) out[s * 64] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     }
-    // bit 31 of a row's word: some bin does not fit the operand; word N counts those rows
-    if (mx > 127u && (atomicOr(big + qrow, 0x80000000u) >> 31) == 0u) atomicAdd(big + N, 1u);
+    // bit 31 of a row's word: some bin does not fit the operand
+    if (mx > 127u && mine) atomicOr(big + qrow, 0x80000000u);
     // the low bits: |c - c0|_1 of the row, which the sweep's epilogue needs below 65 000 (it folds two exact part sums in one
     // 32-bit integer).  |c - c0|_1 <= T + D c0, so only rows with a large sum have to be measured: none of a 10 kb batch
     if (2ull * rowsum[qrow] + D > I8_L1_MAX) {
         l1 += __shfl_xor(l1, 32);
-        if (h == 0 && qb * 32 + j < N) atomicAdd(big + qrow, l1);
+        if (h == 0 && qb * 32 + j < N && mine) atomicAdd(big + qrow, l1);
     }
 }
 
@@ -398,7 +405,7 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
     float pend_v = -3.0e38f;     // the lane's parked candidate (see the epilogue): value, position in the tile
     uint32_t pend_i = 0;
     const uint32_t bigw = big[qr];
-    const bool isbig = (bigw >> 31) != 0 || (bigw & 0x7FFFFFFFu) > I8_L1_MAX;   // (see phk_split_queries_i8_kernel)
+    const bool isbig = (bigw >> 31) != 0 || (bigw & 0x3FFFFFFFu) > I8_L1_MAX;   // (see phk_split_queries_i8_kernel; bit 30: PHK_PREP8_MISSING)
     int seg = 0;
     uint32_t seg_first = 0;
     while (seg < NSEG && (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total) == 0) {   // leading segments without columns
@@ -656,18 +663,31 @@ int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint3
     const uint64_t D = m->D, nchunk = D / (32 * I8_KS), nchunk256 = D / 256;
     const uint64_t nqb = phk_div_up(nb, 32);
     void *bq, *rs = nullptr, *bg;
+    // the operand the count kernel prepared (phk_count_score_dev), when this batch is a whole-block range of its matrix
+    const PhkPrep8 &pp = ctx->prep8;
+    const uint64_t r0 = pp.armed && d_counts >= pp.counts ? (uint64_t)(d_counts - pp.counts) / D : 0;
+    const bool prepared = pp.armed && pp.D == D && d_counts >= pp.counts && (uint64_t)(d_counts - pp.counts) % D == 0 && r0 % 32 == 0 &&
+                          r0 + nb <= pp.n && (nb % 32 == 0 || r0 + nb == pp.n);
+    if (prepared) {
+        bq = (char *)pp.frag + (r0 / 32) * (D / 32) * 1024;
+        bg = pp.big + r0;
+    } else {
     PHK_TRY(phk_ws(ctx, WS_Q64, nqb * (D / 32) * 1024, &bq));
+    }
     if (!d_rowsum) {
         PHK_TRY(phk_ws(ctx, WS_NWIN, nb * sizeof(uint32_t), &rs));
         PHK_LAUNCH(ctx, "phk_rowsum_kernel",
                    phk_rowsum_kernel<<<dim3((unsigned)phk_div_up(nb, 4)), dim3(256), 0, ctx->stream>>>(d_counts, nb, D, (uint32_t *)rs));
         d_rowsum = (const uint32_t *)rs;
     }
-    PHK_TRY(phk_ws(ctx, WS_LONG, (nb + 1) * sizeof(uint32_t), &bg));
-    PHK_HIP(hipMemsetAsync(bg, 0, (nb + 1) * sizeof(uint32_t), ctx->stream));
+    if (!prepared) {
+        PHK_TRY(phk_ws(ctx, WS_LONG, (nb + 1) * sizeof(uint32_t), &bg));
+        PHK_HIP(hipMemsetAsync(bg, 0, (nb + 1) * sizeof(uint32_t), ctx->stream));
+    }
+    // (prepared: the kernel completes what the count kernel left -- usually nothing: its waves read the mode word and leave)
     PHK_LAUNCH(ctx, "phk_split_queries_i8_kernel",
                phk_split_queries_i8_kernel<<<dim3((unsigned)phk_div_up(nqb * nchunk256, 4)), dim3(256), 0, ctx->stream>>>(
-                   d_counts, d_rowsum, nb, D, (uint4 *)bq, (uint32_t *)bg));
+                   d_counts, d_rowsum, nb, D, (uint4 *)bq, (uint32_t *)bg, prepared ? pp.big + pp.n : nullptr));
     // Rows that do not fit the int8 operand (a bin more than 127 away from the row's centre: long or compositionally
     // skewed contigs) are flagged in `big`: the sweep stores sentinel lists for them and the decision kernel hands them to
     // the f16 count-exact sweep, row by row (phk_score_fast).

@@ -1144,6 +1144,76 @@ def test_mfma_f16_rounding_charge_bulk_fuzz():
 
 
 @pytest.mark.gpu
+def test_count_score_k5_with_the_operand_prepared_by_the_count_kernel():
+    """phk_count_score_dev at k = 5: the flush of the count kernel writes the int8 fragments the scorer's sweep multiplies
+    (PhkPrep8), so the scorer does not read the count rows again.  Three batches, one per mode of the hand-over: uniform
+    contigs (every row prepared), the same with three 200 kb contigs that the count kernel hands to the wave-per-contig
+    kernel in pieces (their rows are completed by the scorer's own fragment kernel), and ragged lengths (the sorted slot
+    kernel counts: nothing prepared).  Counts and scores must equal counting and scoring in two separate calls -- where the
+    scorer builds the operand itself -- bit for bit."""
+    from phamers_amd import _lib, device, synth
+    ctx = _lib.get_context()
+    k, D, n_ref = 5, 1024, 1200
+
+    def device_counts(seed, n, L):
+        T = n * L
+        d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+        d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+        device.synth_packed(ctx, seed, 0, n, L, d_packed, d_off)
+        d_counts = device.DeviceArray(ctx, (n, D), np.uint32)
+        device.count(ctx, d_packed, None, T, d_off, n, k, d_counts)
+        return d_counts.to_host()
+
+    ref = device_counts(61, n_ref, 30000).astype(np.float64)
+    ref[: n_ref // 2] *= 1.0 + 0.3 * np.sin(np.arange(D) * 0.37)
+    ref /= ref.sum(axis=1, keepdims=True)
+    pos, neg = ref[: n_ref // 2], ref[n_ref // 2:]
+    cpos = np.stack([pos[i::12].mean(axis=0) for i in range(12)])
+    cneg = np.stack([neg[i::12].mean(axis=0) for i in range(12)])
+    model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
+    rng = np.random.default_rng(5)
+    uniform = [10000] * 2500 + [9999, 10001, 5, 4, 0, 64, 10000]
+    with_long = list(uniform)
+    for at in (7, 1000, 2400):
+        with_long[at] = 200000 + at
+    ragged = [int(x) for x in np.minimum((rng.pareto(1.1, 1500) * 2000).astype(np.int64) + 5, 150000)]
+    for name, lens in (("uniform", uniform), ("handed over", with_long), ("ragged", ragged)):
+        n = len(lens)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lens)
+        T = int(offs[-1])
+        d_off = device.DeviceArray.from_host(ctx, offs)
+        d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+        d_mask = device.DeviceArray(ctx, device.mask_words(T), np.uint32)
+        device.synth_ragged(ctx, 17, 0, n, d_off, T, d_packed, d_mask, gc_spread_permille=300, invalid_ppm=0)
+        d_counts = device.DeviceArray.from_host(ctx, np.full((n, D), 0xABCD, np.uint32))
+        d_scores = device.DeviceArray(ctx, n, np.float64)
+        d_status = device.DeviceArray.from_host(ctx, np.zeros(1, np.uint32))
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        device.count_score(ctx, model, d_packed, None, T, d_off, n, k, "combo", d_counts, d_scores, d_status)
+        fused_counts, fused = d_counts.to_host(), d_scores.to_host()
+        ctx.profile_enable(False)
+        prof = ctx.profile()
+        assert "phk_count_direct_kernel" in prof and "phk_knn_i8_general_kernel" in prof, (name, sorted(prof))
+        stats = ctx.score_stats_ex()
+        d_counts2 = device.DeviceArray.from_host(ctx, np.full((n, D), 0x1234, np.uint32))
+        d_scores2 = device.DeviceArray(ctx, n, np.float64)
+        device.count(ctx, d_packed, None, T, d_off, n, k, d_counts2)
+        device.score_counts(ctx, model, d_counts2, n, "combo", d_scores2, None)
+        assert np.array_equal(fused_counts, d_counts2.to_host()), name
+        two = d_scores2.to_host()
+        assert np.array_equal(np.isnan(fused), np.isnan(two)), name
+        ok = ~np.isnan(two)
+        assert np.array_equal(fused[ok], two[ok]), (name, int((fused[ok] != two[ok]).sum()))
+        assert stats == ctx.score_stats_ex(), (name, stats, ctx.score_stats_ex())
+        assert d_status.to_host()[0] == int((~ok).sum()), name
+        for a in (d_off, d_packed, d_mask, d_counts, d_scores, d_status, d_counts2, d_scores2):
+            a.free()
+    model.close()
+
+
+@pytest.mark.gpu
 def test_transforms_and_column_sums_on_resident_batches(tmp_path):
     """SURVEY 8(f)-4 on the device: transform_kmers as a device-to-device column gather of a resident batch
     (phk_batch_gather_columns) against the reference's own outputs (tests/golden/transform.npz) and against counting the
