@@ -527,20 +527,24 @@ __device__ __forceinline__ double wave_sum(double x) {   // rows in the VALU, th
     return x;
 }
 
-// exact direct-difference squared distance of the wave's query to `row`.  D = 256 * DSUB; lane l
-// holds dimensions 256*sub + 4l .. +3 of the query for sub = 0 .. DSUB-1.
+// exact direct-difference squared distance of the wave's query to `row`.  D = 256 * DSUB; lane l holds dimensions
+// 256*sub + 4l .. +3 of the query for sub = 0 .. DSUB-1.  The query is held UNNORMALISED, as at k = 4 (exact_d2_g16):
+// qd = the integer counts with Tq = their sum and invT2 = 1 / Tq^2 (float64 rows: qd = the row, Tq = invT2 = 1, and the
+// expression below is q_i - r_i exactly), |q - r|^2 = sum_i (c_i - Tq r_i)^2 / Tq^2 -- one rounding per difference, inside
+// the fma, and no per-element division: forming q = c / Tq first cost the decision kernel 5 multiply-adds per element
+// (round 4; every route of a query -- decision kernel, exact candidate distances, brute force -- uses this one form).
 template <int DSUB>
-__device__ __forceinline__ double exact_d2(const double (&qd)[4 * DSUB], const double *row, int lane) {
+__device__ __forceinline__ double exact_d2(const double (&qd)[4 * DSUB], double Tq, double invT2, const double *row, int lane) {
     double acc = 0.0;
 #pragma unroll
     for (int sub = 0; sub < DSUB; ++sub) {
         const double2 a = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane];
         const double2 b = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane + 1];
-        const double d0 = qd[4 * sub + 0] - a.x, d1 = qd[4 * sub + 1] - a.y;
-        const double d2 = qd[4 * sub + 2] - b.x, d3 = qd[4 * sub + 3] - b.y;
+        const double d0 = fma(-Tq, a.x, qd[4 * sub + 0]), d1 = fma(-Tq, a.y, qd[4 * sub + 1]);
+        const double d2 = fma(-Tq, b.x, qd[4 * sub + 2]), d3 = fma(-Tq, b.y, qd[4 * sub + 3]);
         acc = fma(d0, d0, fma(d1, d1, fma(d2, d2, fma(d3, d3, acc))));
     }
-    return wave_sum(acc);
+    return wave_sum(acc) * invT2;
 }
 
 // Bound on |computed v - true v| of the proposal pass for a column with |r'| <= R.  u = 2^-24;
@@ -596,7 +600,7 @@ struct ErrBound {
 // error bound only has to hold for columns with |r'| <= R0 = |q'| + (upper bound of d_need).
 template <int DSUB>
 __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint32_t ncols, int need,
-                                const double (&qd)[4 * DSUB], double nqp2, const ErrBound &eb, const double vs,
+                                const double (&qd)[4 * DSUB], double Tq, double invT2, double nqp2, const ErrBound &eb, const double vs,
                                 const double *rows, const double *colnorm, bool want_d2, int lane,
                                 uint32_t (&out_idx)[3], double &out_d2, float pre_v, uint32_t pre_i, float pre_u,
                                 bool allow_margin = true, double u_extra = 0.0) {
@@ -639,7 +643,7 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
         if (((double)rv[need - 1] - (double)rv[need]) * vs > 2.0 * eps_m) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) out_idx[r] = ri[r];
-            if (want_d2) out_d2 = exact_d2<DSUB>(qd, rows + (uint64_t)ri[0] * (256 * DSUB), lane);
+            if (want_d2) out_d2 = exact_d2<DSUB>(qd, Tq, invT2, rows + (uint64_t)ri[0] * (256 * DSUB), lane);
             return true;
         }
     }
@@ -650,7 +654,7 @@ __device__ bool resolve_segment(const RerankParams &p, uint64_t q, int seg, uint
     for (int m = 0; m < 8; ++m) {
         const uint32_t c = __shfl(ix, m);
         if (c >= ncols) continue;
-        const double d2 = exact_d2<DSUB>(qd, rows + (uint64_t)c * (256 * DSUB), lane);
+        const double d2 = exact_d2<DSUB>(qd, Tq, invT2, rows + (uint64_t)c * (256 * DSUB), lane);
         // insert (d2, c) ascending; ties to the lower column index
         if (d2 < best[2] || (d2 == best[2] && c < bidx[2])) {
             best[2] = d2; bidx[2] = c;
@@ -739,8 +743,10 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
                                                  int lane) {
     constexpr int D = 256 * DSUB;
     typedef __attribute__((address_space(3))) const double lds_cdouble;
-    // exact float64 query elements of this lane (kmer.normalize_counts arithmetic): dims 256*sub + 4*lane .. +3
+    // this lane's query elements, dims 256*sub + 4*lane .. +3: the integer counts with their sum Tq (count rows) or the
+    // float64 row with Tq = 1 -- see exact_d2
     double qd[4 * DSUB];
+    double Tq = 1.0, invT2 = 1.0;
     double vs = p.vscale;
     bool nan_row = false;
     double ssq = 0.0, rtq = 1.0;   // count rows: sum of squares, reciprocal of the row sum
@@ -774,6 +780,8 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         double sq = 0.0, qc2 = 0.0;
         const double rcen = (double)phk_row_center(s, D);
         rtq = ry;
+        Tq = ds;
+        invT2 = 1.0 / (ds * ds);
         if (I8H) {
             const uint32_t cen = phk_row_center(s, D);
 #pragma unroll
@@ -784,14 +792,13 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
 #pragma unroll
         for (int sub = 0; sub < DSUB; ++sub) {
             const double x0 = (double)c[sub].x, x1 = (double)c[sub].y, x2 = (double)c[sub].z, x3 = (double)c[sub].w;
-            qd[4 * sub + 0] = phk_div_row(x0, ds, ry);   // = x / ds, bit for bit
-            qd[4 * sub + 1] = phk_div_row(x1, ds, ry);
-            qd[4 * sub + 2] = phk_div_row(x2, ds, ry);
-            qd[4 * sub + 3] = phk_div_row(x3, ds, ry);
+            qd[4 * sub + 0] = x0; qd[4 * sub + 1] = x1; qd[4 * sub + 2] = x2; qd[4 * sub + 3] = x3;
             sq = fma(x0, x0, fma(x1, x1, fma(x2, x2, fma(x3, x3, sq))));
-            cmx = max(max(cmx, max(c[sub].x, c[sub].y)), max(c[sub].z, c[sub].w));
-            cmn = min(min(cmn, min(c[sub].x, c[sub].y)), min(c[sub].z, c[sub].w));
-            if (DSUB > 1 && p.per_row_scale && p.eb_cAmax > 0.0) {   // norm of this 256-dimension chunk of c - c0 (f16 chains)
+            if (!I8H) {   // (the largest / smallest count: for the maximum-norm term of the f16 chains' bound only)
+                cmx = max(max(cmx, max(c[sub].x, c[sub].y)), max(c[sub].z, c[sub].w));
+                cmn = min(min(cmn, min(c[sub].x, c[sub].y)), min(c[sub].z, c[sub].w));
+            }
+            if (!I8H && DSUB > 1 && p.per_row_scale && p.eb_cAmax > 0.0) {   // norm of this 256-dimension chunk of c - c0 (f16 chains)
                 const double y0 = x0 - rcen, y1 = x1 - rcen, y2 = x2 - rcen, y3 = x3 - rcen;
                 qc2 = fmax(qc2, wave_sum(fma(y0, y0, fma(y1, y1, fma(y2, y2, y3 * y3)))));
             }
@@ -799,9 +806,9 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
         ssq = wave_sum(sq);   // sum of squared counts, exact: |q|^2 = ssq / T^2
         if (p.per_row_scale && !nan_row) {  // the operand of the count-exact chain: the counts minus their centre
             // (largest / smallest count: only where the bound has a maximum-norm term -- the f16 chains)
-            const double cmax = p.eb_cI > 0.0 ? wave_max((double)cmx) : rcen, cmin = p.eb_cI > 0.0 ? -wave_max(-(double)cmn) : rcen;
+            const double cmax = (!I8H && p.eb_cI > 0.0) ? wave_max((double)cmx) : rcen, cmin = (!I8H && p.eb_cI > 0.0) ? -wave_max(-(double)cmn) : rcen;
             cop = phk_centered_operand_fast(ssq, ds, ry, cmax, cmin, (double)D, p.eb_hsum);
-            if (DSUB > 1 && p.eb_cAmax > 0.0) cop.Q = phk_sqrt_up(qc2) * ry * (1.0 + 1e-9);   // (with the observed running sums)
+            if (!I8H && DSUB > 1 && p.eb_cAmax > 0.0) cop.Q = phk_sqrt_up(qc2) * ry * (1.0 + 1e-9);   // (with the observed running sums)
         }
     } else {
         const double *row = static_cast<const double *>(src) + q * D;
@@ -833,8 +840,9 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
             m0 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane];
             m1 = reinterpret_cast<const double2 *>(p.mu64 + 256 * sub)[2 * lane + 1];
         }
-        const double c0 = qd[4 * sub + 0] - m0.x, c1 = qd[4 * sub + 1] - m0.y;
-        const double c2 = qd[4 * sub + 2] - m1.x, c3 = qd[4 * sub + 3] - m1.y;
+        // q' in units of 1 / Tq (count rows: c_i - Tq mu_i; float64 rows: Tq = 1, q_i - mu_i exactly)
+        const double c0 = fma(-Tq, m0.x, qd[4 * sub + 0]), c1 = fma(-Tq, m0.y, qd[4 * sub + 1]);
+        const double c2 = fma(-Tq, m1.x, qd[4 * sub + 2]), c3 = fma(-Tq, m1.y, qd[4 * sub + 3]);
         if (SRC != 0)
             aq = fma(qd[4 * sub + 0], qd[4 * sub + 0], fma(qd[4 * sub + 1], qd[4 * sub + 1],
                      fma(qd[4 * sub + 2], qd[4 * sub + 2], fma(qd[4 * sub + 3], qd[4 * sub + 3], aq))));
@@ -847,7 +855,11 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     }
     // |q|^2 enters the error bound only: for count rows from the exact sum of squares (+ slack for the two roundings)
     const double nq2 = SRC == 0 ? ssq * (rtq * rtq) * (1.0 + 1e-12) : wave_sum(aq);
-    const double nqp2 = wave_sum(ap);
+    const double nqp2 = wave_sum(ap) * invT2;
+    if (SRC == 0) {   // (split-f16 lists of count rows: the maximum norm and the chunk norms in units of q)
+        am *= rtq;
+        pc2 *= invT2;
+    }
     ErrBound eb;   // (its norms: upper bounds, phk_sqrt_up)
     eb.A = phk_sqrt_up(nq2) + p.mu_norm;
     const double nqp_up = phk_sqrt_up(nqp2);
@@ -945,7 +957,7 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
 #pragma unroll
             for (int r = 0; r < 3; ++r) idx[r] = __shfl(cri[r], 0);
         } else {
-            ok = resolve_segment<DSUB>(p, q, 0, (uint32_t)p.M, p.kn, qd, nqp2, eb, vs, p.R64, p.colnorm, false, lane, idx, d2, pre_v, pre_i, pre_u, !I8H, uex0);
+            ok = resolve_segment<DSUB>(p, q, 0, (uint32_t)p.M, p.kn, qd, Tq, invT2, nqp2, eb, vs, p.R64, p.colnorm, false, lane, idx, d2, pre_v, pre_i, pre_u, !I8H, uex0);
         }
         if (ok) {
             int votes = 0;
@@ -956,13 +968,13 @@ __device__ __forceinline__ void rerank_one_query(const void *__restrict__ src, c
     if (ok && (p.method & PHK_METHOD_KMEANS)) {
         double dp2 = 0.0, dn2 = 0.0;
         if (certified & (1ull << 8))
-            dp2 = exact_d2<DSUB>(qd, p.C64 + (uint64_t)__shfl(cri[0], 8) * D, lane);
+            dp2 = exact_d2<DSUB>(qd, Tq, invT2, p.C64 + (uint64_t)__shfl(cri[0], 8) * D, lane);
         else
-            ok = resolve_segment<DSUB>(p, q, 1, (uint32_t)p.n_cpos, 1, qd, nqp2, eb, vs, p.C64, p.colnorm + p.M, true, lane, idx, dp2, pre_v, pre_i, pre_u, !I8H, uex1);
+            ok = resolve_segment<DSUB>(p, q, 1, (uint32_t)p.n_cpos, 1, qd, Tq, invT2, nqp2, eb, vs, p.C64, p.colnorm + p.M, true, lane, idx, dp2, pre_v, pre_i, pre_u, !I8H, uex1);
         if (ok && (certified & (1ull << 16)))
-            dn2 = exact_d2<DSUB>(qd, p.C64 + (p.n_cpos + (uint64_t)__shfl(cri[0], 16)) * D, lane);
+            dn2 = exact_d2<DSUB>(qd, Tq, invT2, p.C64 + (p.n_cpos + (uint64_t)__shfl(cri[0], 16)) * D, lane);
         else if (ok)
-            ok = resolve_segment<DSUB>(p, q, 2, (uint32_t)p.n_cneg, 1, qd, nqp2, eb, vs, p.C64 + p.n_cpos * D,
+            ok = resolve_segment<DSUB>(p, q, 2, (uint32_t)p.n_cneg, 1, qd, Tq, invT2, nqp2, eb, vs, p.C64 + p.n_cpos * D,
                                  p.colnorm + p.M + p.n_cpos, true, lane, idx, dn2, pre_v, pre_i, pre_u, !I8H, uex2);
         if (ok) {
             if (p.pend) {   // two square roots, a division and a tanh in float64 are ~180 instructions of this wave, for one
@@ -2203,7 +2215,15 @@ __global__ __launch_bounds__(256) void phk_rerank_h_kernel(const uint32_t *__res
                 const double cn = p.colnorm[p.M + (k2 ? p.n_cpos : 0) + ri[0]];
                 const double eh = cn <= R0 ? e_hi(1 + k2, R0) : eg;
                 good = ((double)rv[0] - (double)rv[1]) * vs > 2.0 * eh;
-                if (good) d2[k2] = exact_d2<DSUB>(qd, p.C64 + ((k2 ? p.n_cpos : 0) + (uint64_t)ri[0]) * D, lane);
+                if (good) {   // (the canonical form of exact_d2: raw counts and their sum)
+                    double qraw[4 * DSUB];
+#pragma unroll
+                    for (int sub = 0; sub < DSUB; ++sub) {
+                        qraw[4 * sub + 0] = (double)c[sub].x; qraw[4 * sub + 1] = (double)c[sub].y;
+                        qraw[4 * sub + 2] = (double)c[sub].z; qraw[4 * sub + 3] = (double)c[sub].w;
+                    }
+                    d2[k2] = exact_d2<DSUB>(qraw, Tq, 1.0 / (Tq * Tq), p.C64 + ((k2 ? p.n_cpos : 0) + (uint64_t)ri[0]) * D, lane);
+                }
             }
             ok = good;
         }
@@ -2404,6 +2424,7 @@ __global__ __launch_bounds__(512) void phk_fallback_group_kernel(const void *__r
         }
         stage(c0, 0);
         double qd[4 * DSUB];
+        double Tq = 1.0, invT2 = 1.0;
         if (SRC == 0) {
             const uint32_t *row = static_cast<const uint32_t *>(src) + q * D;
             uint4 c[DSUB];
@@ -2413,13 +2434,13 @@ __global__ __launch_bounds__(512) void phk_fallback_group_kernel(const void *__r
                 c[sub] = reinterpret_cast<const uint4 *>(row + 256 * sub)[lane];
                 sm += c[sub].x + c[sub].y + c[sub].z + c[sub].w;
             }
-            const double ds = (double)wave_sum(sm), ry = 1.0 / ds;
+            const double ds = (double)wave_sum(sm);
+            Tq = ds;
+            invT2 = 1.0 / (ds * ds);
 #pragma unroll
-            for (int sub = 0; sub < DSUB; ++sub) {
-                qd[4 * sub + 0] = phk_div_row((double)c[sub].x, ds, ry);
-                qd[4 * sub + 1] = phk_div_row((double)c[sub].y, ds, ry);
-                qd[4 * sub + 2] = phk_div_row((double)c[sub].z, ds, ry);
-                qd[4 * sub + 3] = phk_div_row((double)c[sub].w, ds, ry);
+            for (int sub = 0; sub < DSUB; ++sub) {   // the counts themselves: see exact_d2
+                qd[4 * sub + 0] = (double)c[sub].x; qd[4 * sub + 1] = (double)c[sub].y;
+                qd[4 * sub + 2] = (double)c[sub].z; qd[4 * sub + 3] = (double)c[sub].w;
             }
         } else {
             const double *row = static_cast<const double *>(src) + q * D;
@@ -2447,11 +2468,11 @@ __global__ __launch_bounds__(512) void phk_fallback_group_kernel(const void *__r
             for (int sub = 0; sub < DSUB; ++sub) {
                 const double2 a = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane];
                 const double2 b = reinterpret_cast<const double2 *>(row + 256 * sub)[2 * lane + 1];
-                const double d0 = qd[4 * sub + 0] - a.x, d1 = qd[4 * sub + 1] - a.y;
-                const double d2 = qd[4 * sub + 2] - b.x, d3 = qd[4 * sub + 3] - b.y;
+                const double d0 = fma(-Tq, a.x, qd[4 * sub + 0]), d1 = fma(-Tq, a.y, qd[4 * sub + 1]);
+                const double d2 = fma(-Tq, b.x, qd[4 * sub + 2]), d3 = fma(-Tq, b.y, qd[4 * sub + 3]);
                 acc = fma(d0, d0, fma(d1, d1, fma(d2, d2, fma(d3, d3, acc))));
             }
-            double dist = wave_sum(acc);   // the same value on every lane
+            double dist = wave_sum(acc) * invT2;   // the same value on every lane
             if (c < p.M) {
                 if (p.col_mask && p.col_mask[c]) dist = INFINITY;
                 double d = dist;
