@@ -246,6 +246,16 @@ int phk_model_set_column_mask(phk_ctx *ctx, phk_model *model, const uint8_t *mas
  * mean of the points labelled c, as learning.get_centroids computes it (scripts/learning.py:69-81). */
 int phk_kmeans(phk_ctx *ctx, const double *X, uint64_t n, uint64_t D, uint32_t k, uint64_t seed, int max_iter,
                double *centroids, uint32_t *labels, int *n_iter);
+/* The Lloyd iteration of scikit-learn's KMeans.fit (scripts/learning.py:138; _kmeans_single_lloyd) on the device, from
+ * GIVEN initial centres: E-step (float64 direct differences, ties to the lower centre), M-step, stop when no label changed
+ * or when the summed squared centre shift is <= tol (scikit-learn: 1e-4 x the mean per-feature variance), in which case
+ * one more E-step makes the labels match the final centres.  With the host-side k-means++ seeding of scikit-learn
+ * (kmeans_plusplus on the mean-centred rows, RandomState(10): phamers_amd/learning.py) the labels -- and so the reference's
+ * per-label means, learning.get_centroids -- equal those of KMeans(n_clusters=k, random_state=10).fit(X).
+ * X[n][D], init[k][D] host float64 -> labels[n]; centres (may be NULL); sweeps; number of empty clusters met (scikit-learn
+ * relocates an empty cluster, this entry does not: a caller that sees n_empty != 0 must use the host fit). */
+int phk_kmeans_lloyd(phk_ctx *ctx, const double *X, uint64_t n, uint64_t D, uint32_t k, const double *init, double tol,
+                     int max_iter, double *centres, uint32_t *labels, int *n_iter, int *n_empty);
 
 /* ---- host API: scoring ------------------------------------------------------------- */
 /* phamer.score_points / phamer_scorer.score_points (scripts/phamer.py:451-468, 177-195) for

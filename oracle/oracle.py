@@ -389,3 +389,39 @@ def kmeans_lloyd(X, k, seed=10, max_iter=300):
         if changed == 0:
             break
     return labels, centres, sweeps
+
+
+def kmeans_lloyd_seeded(X, init, tol_abs, max_iter=300):
+    """scikit-learn's Lloyd iteration (sklearn/cluster/_kmeans.py, _kmeans_single_lloyd -- what KMeans.fit, and so
+    scripts/learning.py:138, runs after its seeding) restated with float64 direct differences: E-step against the current
+    centres (ties to the lower centre), M-step (member means), stop when no label changed or when the summed squared
+    centre shift is <= tol_abs; in the second case one more E-step.  Returns (labels, sweeps, n_empty): the statement
+    phk_kmeans_lloyd is tested against (an empty cluster keeps its centre and is counted; scikit-learn relocates it)."""
+    X = np.asarray(X, dtype=float)
+    centres = np.array(init, dtype=float)
+    k = centres.shape[0]
+    labels_old = np.full(X.shape[0], -1, dtype=np.int64)
+    strict, sweeps, empties = False, 0, 0
+    for it in range(max_iter):
+        d2 = np.stack([((X - centres[c]) ** 2).sum(axis=1) for c in range(k)], axis=1)
+        labels = np.argmin(d2, axis=1)
+        new = centres.copy()
+        for c in range(k):
+            members = labels == c
+            if members.any():
+                new[c] = X[members].sum(axis=0) / members.sum()
+            else:
+                empties += 1
+        shift = float(((new - centres) ** 2).sum())
+        centres = new
+        sweeps = it + 1
+        if np.array_equal(labels, labels_old):
+            strict = True
+            break
+        if shift <= tol_abs:
+            break
+        labels_old = labels
+    if not strict:
+        d2 = np.stack([((X - centres[c]) ** 2).sum(axis=1) for c in range(k)], axis=1)
+        labels = np.argmin(d2, axis=1)
+    return labels, sweeps, empties

@@ -200,3 +200,82 @@ extern "C" int phk_kmeans(phk_ctx *ctx, const double *X, uint64_t n, uint64_t D,
     if (n_iter) *n_iter = it;
     return PHK_OK;
 }
+
+// ---- Lloyd sweeps from GIVEN initial centres, with scikit-learn's stopping rule (reference-equal centroids
+// without the host fit) ----
+// sum over the centres of |new - old|^2, and the number of empty clusters: one block
+__global__ __launch_bounds__(256) void km_shift_kernel(const double *__restrict__ a, const double *__restrict__ b, uint64_t count,
+                                                       const uint32_t *__restrict__ sizes, uint32_t k, double *__restrict__ out_shift,
+                                                       uint32_t *__restrict__ out_empty) {
+    __shared__ double part[256];
+    double s = 0.0;
+    for (uint64_t i = threadIdx.x; i < count; i += 256) {
+        const double d = a[i] - b[i];
+        s = fma(d, d, s);
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 256; ++i) t += part[i];
+        *out_shift = t;
+        uint32_t e = 0;
+        for (uint32_t c = 0; c < k; ++c) e += sizes[c] == 0 ? 1u : 0u;
+        *out_empty = e;
+    }
+}
+
+extern "C" int phk_kmeans_lloyd(phk_ctx *ctx, const double *X, uint64_t n, uint64_t D, uint32_t k, const double *init, double tol,
+                                int max_iter, double *centres_out, uint32_t *labels, int *n_iter, int *n_empty) {
+    PHK_REQUIRE(ctx && X && init && labels, "phk_kmeans_lloyd: NULL pointer");
+    PHK_REQUIRE(k >= 1 && k <= n, "phk_kmeans_lloyd: need 1 <= k <= n (k=%u, n=%llu)", k, (unsigned long long)n);
+    PHK_REQUIRE(D >= 1 && max_iter >= 1 && tol >= 0.0, "phk_kmeans_lloyd: bad D / max_iter / tol");
+    PHK_HIP(hipSetDevice(ctx->device));
+    void *dX, *dC, *dm, *dl, *dsz, *dflag;
+    PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &dX));
+    PHK_TRY(phk_ws(ctx, WS_Q64, 2 * (uint64_t)k * D * 8, &dC));      // the centres and the previous sweep's
+    PHK_TRY(phk_ws(ctx, WS_SCORES, n * 8, &dm));
+    PHK_TRY(phk_ws(ctx, WS_COUNTS, 2 * n * 4 + (uint64_t)k * 4, &dl));
+    PHK_TRY(phk_ws(ctx, WS_FLAGS, 64, &dflag));
+    dsz = (uint32_t *)dl + 2 * n;
+    double *cen = (double *)dC, *old = cen + (uint64_t)k * D;
+    PHK_HIP(hipMemcpyAsync(dX, X, n * D * 8, hipMemcpyHostToDevice, ctx->stream));
+    PHK_HIP(hipMemcpyAsync(cen, init, (uint64_t)k * D * 8, hipMemcpyHostToDevice, ctx->stream));
+    PHK_HIP(hipMemsetAsync(dl, 0xFF, n * 4, ctx->stream));
+    const unsigned wblocks = (unsigned)phk_div_up(n, 4);
+    struct { uint32_t changed, empty; double shift; } flag;
+    int it = 0, empties = 0;
+    bool strict = false;
+    // scikit-learn's _kmeans_single_lloyd: E-step against the current centres, M-step, then "labels unchanged" (strict
+    // convergence) or "total squared centre shift <= tol"; in the second case one more E-step so that the labels match the
+    // final centres.  An empty cluster keeps its centre here (scikit-learn relocates it): reported, and the caller falls back.
+    for (; it < max_iter; ++it) {
+        PHK_HIP(hipMemsetAsync(dflag, 0, 16, ctx->stream));
+        PHK_HIP(hipMemcpyAsync(old, cen, (uint64_t)k * D * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        PHK_LAUNCH(ctx, "km_assign_kernel",
+                   km_assign_kernel<<<dim3(wblocks), dim3(256), 0, ctx->stream>>>((const double *)dX, n, D, cen, k, (uint32_t *)dl,
+                                                                                (double *)dm, (uint32_t *)dflag));
+        PHK_LAUNCH(ctx, "km_update_kernel",
+                   km_update_kernel<<<dim3(k), dim3(256), 0, ctx->stream>>>((const double *)dX, n, D, (const uint32_t *)dl, cen,
+                                                                          (uint32_t *)dsz));
+        PHK_LAUNCH(ctx, "km_shift_kernel",
+                   km_shift_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(cen, old, (uint64_t)k * D, (const uint32_t *)dsz, k,
+                                                                         (double *)((uint32_t *)dflag + 2), (uint32_t *)dflag + 1));
+        PHK_HIP(hipMemcpyAsync(&flag, dflag, 16, hipMemcpyDeviceToHost, ctx->stream));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+        empties += (int)flag.empty;
+        if (flag.changed == 0) { strict = true; ++it; break; }
+        if (flag.shift <= tol) { ++it; break; }
+    }
+    if (!strict) {
+        PHK_LAUNCH(ctx, "km_assign_kernel",
+                   km_assign_kernel<<<dim3(wblocks), dim3(256), 0, ctx->stream>>>((const double *)dX, n, D, cen, k, (uint32_t *)dl,
+                                                                                (double *)dm, (uint32_t *)dflag));
+    }
+    if (centres_out) PHK_HIP(hipMemcpyAsync(centres_out, cen, (uint64_t)k * D * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipMemcpyAsync(labels, dl, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PHK_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_iter) *n_iter = it;
+    if (n_empty) *n_empty = empties;
+    return PHK_OK;
+}

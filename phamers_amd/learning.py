@@ -4,13 +4,14 @@ learning.py -- drop-in for the hot-path helpers of PhaMers' scripts/learning.py.
     knn(queries, ref_data, ref_labels, k=3)       scripts/learning.py:118-128   -> GPU
     distances(vector, data)                       scripts/learning.py:47-56     -> GPU (float64, direct differences)
     closest_to(point, picks)                      scripts/learning.py:59-66     -> GPU distances + first-index argmin
-    kmeans(data, k, ...)                          scripts/learning.py:131-146   -> scikit-learn (default) / GPU
+    kmeans(data, k, ...)                          scripts/learning.py:131-146   -> scikit-learn's seeding on the host + its Lloyd sweeps on the GPU
     get_centroids(data, assignment)               scripts/learning.py:69-81     -> NumPy (86 means)
 
-k-means uses scikit-learn by default, exactly as in the reference (a per-run fit that does not
-depend on the number of query contigs; the golden scores are pinned to
-its centroids); the centroids are an explicit input of the GPU scorer.  PHAMERS_KMEANS=gpu selects
-kmeans_gpu, a deterministic device Lloyd k-means (phk_kmeans).
+k-means reproduces the reference's scikit-learn fit (a per-run fit that does not depend on the number of
+query contigs; the golden scores are pinned to its centroids): the k-means++
+seeding is scikit-learn's own, on the host, the Lloyd iteration runs on the device (phk_kmeans_lloyd) and
+gives the same labels; PHAMERS_KMEANS=sklearn keeps the whole fit on the host, PHAMERS_KMEANS=gpu selects
+kmeans_gpu, a deterministic, version-independent device k-means (phk_kmeans).
 """
 import logging
 
@@ -86,12 +87,45 @@ def kmeans_gpu(data, k, seed=kmeans_seed, max_iter=300):
     return labels.astype(np.int64), centroids, n_iter.value
 
 
-def kmeans(data, k, verbose=False, sort_by_size=False):
-    """K-means labels (scripts/learning.py:131-146): scikit-learn with the reference's seed by default;
-    PHAMERS_KMEANS=gpu selects the deterministic device implementation."""
+def kmeans_reference_on_device(data, k, seed=kmeans_seed, max_iter=300, tol=1e-4, ctx=None):
+    """The labels of ``KMeans(n_clusters=k, random_state=seed).fit(data)`` (scripts/learning.py:138) with only the seeding
+    on the host: scikit-learn's own k-means++ (``kmeans_plusplus`` on the mean-centred rows with a fresh
+    ``RandomState(seed)`` -- what ``KMeans.fit`` does before its first sweep, n_init = 1) and its Lloyd iteration,
+    stopping rule included, on the device (phk_kmeans_lloyd).  Returns (labels, sweeps), or None when a cluster ran
+    empty (scikit-learn relocates it; the caller then takes the host fit)."""
+    import ctypes
+    from sklearn.cluster import kmeans_plusplus
+    X = np.array(data, dtype=np.float64, order="C")          # (a copy: centred in place, as KMeans.fit does)
+    n, D = X.shape
+    X -= X.mean(axis=0)
+    init, _ = kmeans_plusplus(X, int(k), random_state=np.random.RandomState(seed))
+    init = np.ascontiguousarray(init, dtype=np.float64)
+    tol_abs = float(np.mean(np.var(X, axis=0)) * tol)
+    labels = np.empty(n, dtype=np.uint32)
+    n_iter, n_empty = ctypes.c_int(), ctypes.c_int()
+    ctx = ctx or _lib.get_context()
+    _lib.check(ctx.lib.phk_kmeans_lloyd(ctx.handle, _lib.ptr(X), n, D, int(k), _lib.ptr(init), tol_abs, int(max_iter), None,
+                                        _lib.ptr(labels), ctypes.byref(n_iter), ctypes.byref(n_empty)))
+    if n_empty.value:
+        return None
+    return labels.astype(np.int32), n_iter.value
+
+
+def kmeans(data, k, verbose=False, sort_by_size=False, _ctx=None):
+    """K-means labels (scripts/learning.py:131-146), equal to the reference's ``KMeans(n_clusters=k,
+    random_state=10).fit(data).labels_``: scikit-learn's seeding on the host, its Lloyd iteration on the device
+    (kmeans_reference_on_device).  PHAMERS_KMEANS=sklearn keeps the whole fit on the host, PHAMERS_KMEANS=gpu selects
+    the version-independent device k-means (kmeans_gpu: other seeds, other centroids)."""
     import os
-    if os.environ.get("PHAMERS_KMEANS", "sklearn") == "gpu":
+    mode = os.environ.get("PHAMERS_KMEANS", "device")
+    if sort_by_size:
+        raise NotImplementedError("sort_by_size is outside the accelerated path")
+    if mode == "gpu":
         return kmeans_gpu(data, k)[0]
+    if mode != "sklearn":
+        got = kmeans_reference_on_device(data, k, ctx=_ctx)   # (_ctx: a context of the caller's own -- a helper thread's)
+        if got is not None:
+            return got[0]
     from sklearn.cluster import KMeans
     assignment = KMeans(n_clusters=k, random_state=kmeans_seed).fit(data).labels_
     if type(assignment) != np.ndarray:

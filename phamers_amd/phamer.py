@@ -151,10 +151,13 @@ class phamer_scorer(object):
             self._drop_batch()
             self._rows = None
             self._batch = _lib.Batch.from_fasta(ctx, fasta, self.kmer_length)
+            counts = self._batch.counts_u32()
         finally:
-            fasta.close()
+            # (on a helper thread, and only now: unmapping the file's 5 GB beside the page faults of the count matrix's
+            # first touch made that download six times slower)
+            fasta.close(wait=False)
         self.features_file = "{base}_features.csv".format(base=os.path.splitext(self.fasta_file)[0])
-        counts, ids, path = self._batch.counts_u32(), self.data_ids, self.features_file
+        ids, path = self.data_ids, self.features_file
         if self._defer_io:
             self._write_cache_async(counts, ids, path)
         else:
@@ -204,8 +207,18 @@ class phamer_scorer(object):
             fasta_ids, _lengths = kmer.fasta_lengths(self.fasta_file)
         else:
             fasta_ids = self.data_ids
-        long_ids = np.asarray(fasta_ids)[np.asarray(_lengths) >= self.length_requirement]
-        keep = np.isin(self.data_ids, long_ids)
+        is_long = np.asarray(_lengths) >= self.length_requirement
+        long_ids = np.asarray(fasta_ids)[is_long]
+        if fasta_ids is self.data_ids:
+            # the reference keeps a row when its id is that of SOME contig long enough (np.in1d): true for every long contig's
+            # own row, so only the short contigs' ids have to be looked up (none on a batch of long contigs; a sort of 10^6
+            # strings otherwise, 0.2 s)
+            keep = is_long.copy()
+            short = ~is_long
+            if short.any() and is_long.any():
+                keep[short] = np.isin(np.asarray(self.data_ids)[short], long_ids)
+        else:
+            keep = np.isin(self.data_ids, long_ids)
         if self._batch is not None:
             old, self._batch = self._batch, self._batch.select(np.flatnonzero(keep))
             old.close()
@@ -246,19 +259,27 @@ class phamer_scorer(object):
         raise NotImplementedError("scoring method %r is outside the accelerated path; knn / kmeans / combo are "
                                   "available" % (self.scoring_method,))
 
-    def _centroids_of(self, pos, neg, k_clusters):
-        return tuple(learning.get_centroids(d, learning.kmeans(d, k_clusters)) for d in (pos, neg))
+    def _centroids_of(self, pos, neg, k_clusters, own_context=False):
+        """k-means labels -> the reference's per-label means, for both classes.  own_context: called from a helper thread,
+        which gets a device context of its own (a context is not shared between threads)."""
+        ctx = _lib.Context(_lib.default_device()) if own_context else None
+        try:
+            return tuple(learning.get_centroids(d, learning.kmeans(d, k_clusters, _ctx=ctx)) for d in (pos, neg))
+        finally:
+            if ctx is not None:
+                ctx.close()
 
     def prefetch_centroids(self):
-        """Starts the k-means fit of the reference matrices as they are NOW on a host thread (scikit-learn releases the
-        GIL), so that it runs beside the FASTA ingest and the counting; _fit_centroids takes the result if the matrices
-        have not been replaced since, and fits afresh otherwise.  Host (scikit-learn) k-means only."""
-        if os.environ.get("PHAMERS_KMEANS", "sklearn") != "sklearn":
+        """Starts the k-means fit of the reference matrices as they are NOW on a helper thread, so that it runs beside the
+        FASTA ingest and the counting (the seeding is scikit-learn's and releases the GIL; the Lloyd sweeps run on the
+        device through a context of the thread's own); _fit_centroids takes the result if the matrices have not been
+        replaced since, and fits afresh otherwise."""
+        if os.environ.get("PHAMERS_KMEANS", "device") == "gpu":
             return
         from concurrent.futures import ThreadPoolExecutor
         pos, neg, k = self.positive_data, self.negative_data, self.k_clusters
         ex = ThreadPoolExecutor(max_workers=1, thread_name_prefix="phamers-kmeans")
-        self._centroid_future = (pos, neg, k, ex.submit(self._centroids_of, pos, neg, k))
+        self._centroid_future = (pos, neg, k, ex.submit(self._centroids_of, pos, neg, k, True))
         ex.shutdown(wait=False)
 
     def _fit_centroids(self):

@@ -1214,6 +1214,40 @@ def test_count_score_k5_with_the_operand_prepared_by_the_count_kernel():
 
 
 @pytest.mark.gpu
+def test_reference_kmeans_labels_from_the_device_lloyd():
+    """learning.kmeans (scripts/learning.py:131-146) without the host fit: scikit-learn's seeding on the host, its Lloyd
+    iteration on the device (phk_kmeans_lloyd) -- labels equal to oracle.kmeans_lloyd_seeded from the same seeds and to
+    KMeans(n_clusters=86, random_state=10).fit(X).labels_; the reference's per-label means (get_centroids) then equal the
+    golden centroids the reference's scores were generated with, and the golden kmeans / combo scores come out through
+    phamer.score_points on this route."""
+    from sklearn.cluster import KMeans, kmeans_plusplus
+    from oracle import oracle
+    from phamers_amd import learning, phamer
+    ref = helpers.load_npz("ref_features.npz")
+    g = helpers.load_npz("scoring_k4.npz")
+    pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))
+    neg = oracle.normalize_counts(ref["neg_counts"].astype(np.int64))
+    n = int(np.asarray(g["n_equalized"]).ravel()[0])
+    for X, want in ((pos[:n], g["cpos_eq"]), (neg[:n], g["cneg_eq"]), (pos, g["cpos_full"]), (neg, g["cneg_full"])):
+        got = learning.kmeans_reference_on_device(X, 86)
+        assert got is not None
+        labels, sweeps = got
+        Xc = X - X.mean(axis=0)
+        init, _ = kmeans_plusplus(Xc, 86, random_state=np.random.RandomState(10))
+        o_labels, o_sweeps, o_empty = oracle.kmeans_lloyd_seeded(Xc, init, float(np.mean(np.var(Xc, axis=0)) * 1e-4))
+        assert o_empty == 0 and sweeps == o_sweeps
+        assert np.array_equal(labels, o_labels)
+        assert np.array_equal(labels, KMeans(n_clusters=86, random_state=10).fit(X).labels_)
+        assert np.array_equal(learning.kmeans(X, 86), labels)          # the default route of the facade
+        assert np.allclose(learning.get_centroids(X, labels), want, rtol=0, atol=1e-10)
+    # the reference's scores through this route (centroids fitted here, not taken from the fixture)
+    q = g["q"]
+    for method, key in (("kmeans", "kmeans_eq"), ("combo", "combo_eq")):
+        got = phamer.score_points(q, pos[:n], neg[:n], method=method)
+        assert helpers.rel_err(got, g[key]) < 1e-6, method
+
+
+@pytest.mark.gpu
 def test_transforms_and_column_sums_on_resident_batches(tmp_path):
     """SURVEY 8(f)-4 on the device: transform_kmers as a device-to-device column gather of a resident batch
     (phk_batch_gather_columns) against the reference's own outputs (tests/golden/transform.npz) and against counting the

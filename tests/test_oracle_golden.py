@@ -187,3 +187,27 @@ def test_oracle_lloyd_kmeans_agrees_with_scikit_learn_from_the_same_seeds():
         assert np.array_equal(sk.labels_, labels), (rows, k)
         assert np.allclose(sk.cluster_centers_, cents, rtol=1e-10, atol=1e-14)
         assert 1 < sweeps < 300
+
+
+def test_seeded_lloyd_restatement_reproduces_the_reference_kmeans_fit():
+    """The route the product takes for learning.kmeans: scikit-learn's own k-means++ seeding (kmeans_plusplus on the
+    mean-centred rows, RandomState(10) -- what KMeans.fit does first) followed by oracle.kmeans_lloyd_seeded, the statement
+    of scikit-learn's Lloyd iteration and stopping rule that phk_kmeans_lloyd is tested against.  On the reference
+    matrices it must give the labels of KMeans(n_clusters=86, random_state=10).fit(X) (scripts/learning.py:138) and so,
+    through get_centroids (scripts/learning.py:69-81), the centroids the golden scores were generated with."""
+    from sklearn.cluster import KMeans, kmeans_plusplus
+    from oracle import oracle
+    ref = helpers.load_npz("ref_features.npz")
+    g = helpers.load_npz("scoring_k4.npz")
+    pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))
+    neg = oracle.normalize_counts(ref["neg_counts"].astype(np.int64))
+    n = int(np.asarray(g["n_equalized"]).ravel()[0])
+    for X, want in ((pos[:n], g["cpos_eq"]), (neg[:n], g["cneg_eq"]), (neg, g["cneg_full"])):
+        Xc = X - X.mean(axis=0)
+        init, _ = kmeans_plusplus(Xc, 86, random_state=np.random.RandomState(10))
+        labels, sweeps, empties = oracle.kmeans_lloyd_seeded(Xc, init, float(np.mean(np.var(Xc, axis=0)) * 1e-4))
+        sk = KMeans(n_clusters=86, random_state=10).fit(X)
+        assert empties == 0 and sweeps == sk.n_iter_
+        assert np.array_equal(labels, sk.labels_)
+        cents = np.array([np.mean(X[labels == c], axis=0) for c in sorted(set(labels))])
+        assert np.allclose(cents, want, rtol=0, atol=1e-10)

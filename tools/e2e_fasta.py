@@ -118,9 +118,18 @@ def main():
     # ---- (b) the command line as a user runs it ----
     if not a.skip_cli:
         argv = ["-in", indir, "-data", os.path.join(root, "data"), "--equalize_reference"] + (["--debug"] if os.environ.get("PHK_E2E_DEBUG") else [])
+        prof = None
+        if os.environ.get("PHK_E2E_PROFILE"):      # where the command line's time goes: cProfile, top of the cumulative list on stderr
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t = time.perf_counter()
         s1 = phamer.main(argv)
         out["cli_cold_s"] = time.perf_counter() - t
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
         out["cli_cold_gbases_per_s"] = bases / out["cli_cold_s"] / 1e9
         assert np.array_equal(s1.scores, scores)
         # the warm run reads <fasta>_features.csv (native reader; np.loadtxt needed minutes at 1 M contigs) and still
