@@ -46,6 +46,8 @@
 #define FB_CHUNKS 16   // column chunks per queued query in the exact brute-force fallback
 #define FB_LDS_MAX (160u * 1024u - 1024u)   // its dynamic LDS: one chunk of distances + the query, float64
 
+__global__ void phk_rowsum_kernel(const uint32_t *__restrict__ counts, uint64_t N, uint64_t D, uint32_t *__restrict__ out);   // score_f16.hip
+
 bool phk_fast_supports_dim(uint64_t D);
 
 // ------------------------------------------------------------------------------------
@@ -399,6 +401,7 @@ struct RerankParams {
     // lists) to q2_big, counted by q2_count[1] -- the f16 count-exact sweep takes it -- any other to q2_wide, counted by
     // q2_count[0] -- re-swept with all three digits (null: straight to the brute-force queue).
     const uint32_t *out_map = nullptr;
+    const uint32_t *rowsum = nullptr;       // row sums of the count rows (phk_decide_gen_kernel), or null
     uint32_t *q2_count = nullptr;
     uint32_t *q2_wide = nullptr;
     uint32_t *q2_big = nullptr;
@@ -1627,6 +1630,228 @@ __global__ __launch_bounds__(256) void phk_decide_kernel(const void *__restrict_
 }
 
 // ------------------------------------------------------------------------------------
+// 2c'. The same idea at general D for the lists of the two-part int8 sweep (round 4).  phk_rerank_kernel spends one wave per
+//     query, and most of that wave's ~650 instructions are per-query scalar work that all 64 lanes repeat (ranking, the
+//     error bound, the window and margin tests); a third of the step at configs[2].  Here a 64-thread block takes 64
+//     queries through the k = 4 kernel's three phases:
+//       A  lane = query : its six half-lists, the 4 best of each segment's 8 candidates, labels of the leaders
+//       B  16 lanes = query, 4 queries per pass: the count row in 1024-dimension chunks (G16 ownership: every load
+//          covers one contiguous 256 B piece) -- sum of squares, |q'|^2 against the training mean in LDS, and the exact
+//          distances to the leading positive / negative centroid in the canonical form of exact_d2
+//       C  lane = query : e_l, eps, the two-part window; a query is decided HERE when, in every segment the method uses,
+//          the window holds exactly `need` columns and ends above everything the half-lists dropped -- the case
+//          rerank_one_query decides "as it stands" (96 % of configs[2]); the margin test is implied:
+//          gap_lo vs < thr = gap_hi vs - 2 (e_l + eps_g)  =>  (gap_hi - gap_lo) vs > 2 eps.
+//     Everything else -- wider windows (they need the L product), windows past the lists, rows beyond the int8 operand,
+//     NaN rows excepted -- goes to slow_list, and phk_rerank_kernel (listed) treats those queries exactly as before.
+//     The row sum comes from p.rowsum (the count kernel's / the launcher's), so a chunk's c - T mu needs no second pass.
+// ------------------------------------------------------------------------------------
+template <int DSUB>
+__global__ __launch_bounds__(64, 3) void phk_decide_gen_kernel(const uint32_t *__restrict__ counts, RerankParams p) {
+    constexpr int D = 256 * DSUB;
+    constexpr int CHUNK = D < 1024 ? D : 1024;     // dimensions per chunk of phase B
+    constexpr int NCH = D / CHUNK;
+    constexpr int LPC = CHUNK / 64;                // uint4 loads per lane and chunk (4 dimensions each)
+    static_assert(LPC % 4 == 0, "loads in groups of four");
+    __shared__ double s_mu[D];
+    __shared__ uint32_t s_ix[2][64];
+    __shared__ double s_ssq[64], s_nqp2[64], s_dp2[64], s_dn2[64];
+    __shared__ float s_gap[NSEG][3][64];   // phase A -> C: need-th / (need+1)-th list value, best dropped value (not kept in registers across phase B)
+    __shared__ uint32_t s_flag[64];        // ... bits 0-2: segment filled, bits 4-6: labels of the three leading train columns
+    const int tid = threadIdx.x, t = tid & 15, grp = tid >> 4;
+    const uint64_t qb = (uint64_t)blockIdx.x * 64;
+    const bool want_knn = (p.method & PHK_METHOD_KNN) != 0, want_cen = (p.method & PHK_METHOD_KMEANS) != 0;
+    for (int i = tid; i < D / 2; i += 64) reinterpret_cast<double2 *>(s_mu)[i] = reinterpret_cast<const double2 *>(p.mu64)[i];
+
+    // ---- phase A: one lane per query ----
+    const uint64_t qa = qb + tid;
+    const bool in_a = qa < p.N;
+    const uint64_t qc = in_a ? qa : p.N - 1;
+    float gap_hi[NSEG], gap_lo[NSEG], Useg[NSEG];   // need-th and (need+1)-th list value, best dropped value
+    uint32_t lead[NSEG][3];
+    bool filled[NSEG];
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+        const uint32_t ncols = sg == 0 ? (uint32_t)p.M : sg == 1 ? (uint32_t)p.n_cpos : (uint32_t)p.n_cneg;
+        const int need = sg == 0 ? p.kn : 1;
+        Useg[sg] = fmaxf(p.cand_u[candu_at(sg, 0, qc, p.N)], p.cand_u[candu_at(sg, 1, qc, p.N)]);
+        float v[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        uint32_t ix[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        float w[8];
+        uint32_t wx[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {   // consecutive lanes = consecutive queries: coalesced
+            w[c] = p.cand_v[cand_at(sg, c >> 2, c & 3, qc, p.N)];
+            wx[c] = p.cand_i[cand_at(sg, c >> 2, c & 3, qc, p.N)];
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {   // the 4 best by insertion (descending; an equal value stays behind)
+            float x = wx[c] >= ncols ? -3.0e38f : w[c];
+            uint32_t xi = wx[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool up = x > v[k];
+                const float tv = v[k];
+                const uint32_t ti = ix[k];
+                v[k] = up ? x : tv;
+                ix[k] = up ? xi : ti;
+                x = up ? tv : x;
+                xi = up ? ti : xi;
+            }
+        }
+        gap_hi[sg] = need == 1 ? v[0] : need == 2 ? v[1] : v[2];
+        gap_lo[sg] = need == 1 ? v[1] : need == 2 ? v[2] : v[3];
+        filled[sg] = (need == 1 ? ix[0] : need == 2 ? ix[1] : ix[2]) < ncols;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) lead[sg][r] = ix[r];
+    }
+    s_ix[0][tid] = lead[1][0] < (uint32_t)p.n_cpos ? lead[1][0] : 0u;
+    s_ix[1][tid] = lead[2][0] < (uint32_t)p.n_cneg ? lead[2][0] : 0u;
+    {
+        uint32_t fl = 0;
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            s_gap[sg][0][tid] = gap_hi[sg];
+            s_gap[sg][1][tid] = gap_lo[sg];
+            s_gap[sg][2][tid] = Useg[sg];
+            fl |= filled[sg] ? 1u << sg : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) fl |= p.labels[lead[0][r] < (uint32_t)p.M ? lead[0][r] : 0u] ? 16u << r : 0u;
+        s_flag[tid] = fl;
+    }
+    __syncthreads();
+
+    // ---- phase B: 16 lanes per query, 4 queries per pass ----
+#pragma unroll 1
+    for (int pass = 0; pass < 16; ++pass) {
+        const int ql = pass * 4 + grp;
+        const uint64_t q = qb + ql < p.N ? qb + ql : p.N - 1;
+        const double Tq = (double)p.rowsum[q];
+        const uint4 *row = reinterpret_cast<const uint4 *>(counts + q * D) + t;
+        const double *cp = p.C64 + (uint64_t)s_ix[0][ql] * D, *cn = p.C64 + (p.n_cpos + (uint64_t)s_ix[1][ql]) * D;
+        // The exact distances are formed EXACTLY as exact_d2 forms them in a 64-lane wave, so that a score does not depend on
+        // which kernel decided it: that wave's lane 16 g + t owns dimensions 256 sub + 64 g + 4 t .. + 3 -- here load i of a
+        // chunk, g = i & 3, sub = 4 ch + (i >> 2) -- and accumulates them over sub with the same nesting; its reduction is
+        // the row sums of the four lane groups (the same DPP rotations over the same 16 positions), then (G0 + G1) + (G2 + G3).
+        double ssq = 0.0, ap = 0.0, dp[4] = {0.0, 0.0, 0.0, 0.0}, dn[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+        for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll 1
+            for (int io = 0; io < LPC / 4; ++io) {   // four loads at a time (one per lane group of the canonical form): ~80 registers in flight
+            uint4 c[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c[i] = row[ch * (CHUNK / 4) + 16 * (4 * io + i)];   // dimensions CHUNK ch + 64 (4 io + i) + 4 t .. + 3
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d0 = ch * CHUNK + 64 * (4 * io + i) + 4 * t;
+                const double x[4] = {(double)c[i].x, (double)c[i].y, (double)c[i].z, (double)c[i].w};
+                const double2 m0 = *reinterpret_cast<const double2 *>(s_mu + d0), m1 = *reinterpret_cast<const double2 *>(s_mu + d0 + 2);
+                const double mu4[4] = {m0.x, m0.y, m1.x, m1.y};
+                double2 a0 = {0.0, 0.0}, a1 = {0.0, 0.0}, b0 = {0.0, 0.0}, b1 = {0.0, 0.0};
+                if (want_cen) {
+                    a0 = *reinterpret_cast<const double2 *>(cp + d0); a1 = *reinterpret_cast<const double2 *>(cp + d0 + 2);
+                    b0 = *reinterpret_cast<const double2 *>(cn + d0); b1 = *reinterpret_cast<const double2 *>(cn + d0 + 2);
+                }
+                const double ca[4] = {a0.x, a0.y, a1.x, a1.y}, cb[4] = {b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ssq = fma(x[e], x[e], ssq);
+                    const double qm = fma(-Tq, mu4[e], x[e]);
+                    ap = fma(qm, qm, ap);
+                }
+                if (want_cen) {
+                    const double e0 = fma(-Tq, ca[0], x[0]), e1 = fma(-Tq, ca[1], x[1]), e2 = fma(-Tq, ca[2], x[2]), e3 = fma(-Tq, ca[3], x[3]);
+                    dp[i & 3] = fma(e0, e0, fma(e1, e1, fma(e2, e2, fma(e3, e3, dp[i & 3]))));
+                    const double f0 = fma(-Tq, cb[0], x[0]), f1 = fma(-Tq, cb[1], x[1]), f2 = fma(-Tq, cb[2], x[2]), f3 = fma(-Tq, cb[3], x[3]);
+                    dn[i & 3] = fma(f0, f0, fma(f1, f1, fma(f2, f2, fma(f3, f3, dn[i & 3]))));
+                }
+            }
+            }
+        }
+        ssq = group16_sum(ssq);
+        ap = group16_sum(ap);
+        double dps = 0.0, dns = 0.0;
+        if (want_cen) {
+            dps = (group16_sum(dp[0]) + group16_sum(dp[1])) + (group16_sum(dp[2]) + group16_sum(dp[3]));
+            dns = (group16_sum(dn[0]) + group16_sum(dn[1])) + (group16_sum(dn[2]) + group16_sum(dn[3]));
+        }
+        if (t == 0) {
+            s_ssq[ql] = ssq;
+            s_nqp2[ql] = ap;      // (x T^2)
+            s_dp2[ql] = dps;      // (x T^2)
+            s_dn2[ql] = dns;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase C: one lane per query ----
+    bool slow = false;
+    if (in_a) {
+        const uint32_t Tu = p.rowsum[qa];
+        const uint32_t fl = s_flag[tid];
+        if (Tu == 0u) {  // zero-count contig: the reference's normalised row is NaN
+            p.scores[p.q_base + qa] = __builtin_nan("");
+            if (p.status) atomicAdd(p.status, 1u);
+        } else {
+            const double Tq = (double)Tu, ry = 1.0 / Tq, invT2 = 1.0 / (Tq * Tq);
+            const double ssq = s_ssq[tid], nqp2 = s_nqp2[tid] * invT2;
+            const double vs = p.vscale * ry;
+            const double rcen = (double)phk_row_center(Tu, D);
+            const CenteredOperand cop = phk_centered_operand_fast(ssq, Tq, ry, rcen, rcen, (double)D, p.eb_hsum);
+            ErrBound eb;
+            eb.A = phk_sqrt_up(ssq * (ry * ry) * (1.0 + 1e-12)) + p.mu_norm;
+            eb.P = phk_sqrt_up(nqp2 + cop.shift2);
+            eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs;
+            eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI; eb.cIf = p.eb_cIf;
+            const double eps_g = eb(p.rmax);
+            // a segment is decided as it stands: the window [h_need - 2 (e_l + eps), ..] holds exactly `need` list values
+            // and ends above everything the half-lists dropped
+            auto as_it_stands = [&](int sg) {
+                if (!((fl >> sg) & 1u)) return false;
+                const double el = cop.Q * p.lam8[sg] * (1.0 + 1.0e-6);
+                const double thr = (double)s_gap[sg][0][tid] * vs - 2.0 * (el + eps_g);
+                return (double)s_gap[sg][2][tid] * vs < thr && (double)s_gap[sg][1][tid] * vs < thr;
+            };
+            bool ok = true;
+            double knn = 0.0;
+            if (want_knn) {
+                ok = as_it_stands(0);
+                int votes = 0;
+                for (int r = 0; r < p.kn; ++r) votes += (fl >> (4 + r)) & 1u;
+                knn = (2 * votes > p.kn) ? 1.0 : -1.0;
+            }
+            if (want_cen) ok = ok && as_it_stands(1) && as_it_stands(2);
+            if (ok) {
+                if (want_cen) {
+                    const uint64_t oq = p.out_map ? (uint64_t)p.out_map[qa] : qa;
+                    if (p.pend) {   // (phk_finish_cen_kernel turns them into the proximity metric)
+                        p.pend[2 * oq] = s_dp2[tid] * invT2;
+                        p.pend[2 * oq + 1] = s_dn2[tid] * invT2;
+                        p.scores[p.q_base + oq] = knn;
+                    } else {
+                        const double ep = sqrt(s_dp2[tid] * invT2), en = sqrt(s_dn2[tid] * invT2);
+                        p.scores[p.q_base + oq] = knn + tanh((en - ep) / (ep + en));  // scripts/phamer.py:206-209, 313
+                    }
+                } else {
+                    p.scores[p.q_base + (p.out_map ? (uint64_t)p.out_map[qa] : qa)] = knn;
+                }
+            } else {
+                slow = true;
+            }
+        }
+    }
+    // hand-over: one atomic per wave, not per query (same-line atomics retire one after the other)
+    const unsigned long long sm = __ballot(slow);
+    if (sm) {
+        uint32_t base = 0;
+        if (tid == 0) base = atomicAdd(p.fb_count + 2, (uint32_t)__popcll(sm));
+        base = __shfl(base, 0);
+        if (slow) p.slow_list[base + (uint32_t)__popcll(sm & ((1ull << tid) - 1ull))] = (uint32_t)qa;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // 2d. decision stage of the high-parts-only proposal (phk_knn_f16h_kernel; D = 256, uint32 counts).
 //     The lists hold HIGH-PART values  w^h_j  whose distance from the count-exact value  w_j  is the low product
 //         w_j - w^h_j = sum_i (c_i - T mu_i) lo_ji,      |.| <= T S |q'| lam_j,   lam_j = |lo_j| / S   (Cauchy-Schwarz).
@@ -2618,19 +2843,35 @@ static int launch_rerank(phk_ctx *ctx, unsigned blocks, const void *src, const R
             }
             break;
         }
+#define PHK_DECIDE_GEN(DS)                                                                                                       \
+    do {                                                                                                                         \
+        if (SRC == 0 && p.L8 && p.rowsum && ctx->knobs.rerank != 'w') {                                                          \
+            /* the lane-per-query decision kernel first; what it hands on, listed, to the wave-per-query kernel */              \
+            PHK_LAUNCH(ctx, "phk_decide_gen_kernel", (phk_decide_gen_kernel<DS><<<dim3((unsigned)phk_div_up(p.N, 64)), dim3(64), 0, ctx->stream>>>( \
+                                                         static_cast<const uint32_t *>(src), p)));                               \
+            RerankParams pl = p;                                                                                                 \
+            pl.slow_back = 2;                                                                                                    \
+            PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<0, DS, true><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, pl))); \
+            return PHK_OK;                                                                                                       \
+        }                                                                                                                        \
+    } while (0)
         case 512:
+            PHK_DECIDE_GEN(2);
             if (SRC == 0 && p.L8) { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<0, 2, true><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             else { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<SRC, 2><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             break;
         case 1024:
+            PHK_DECIDE_GEN(4);
             if (SRC == 0 && p.L8) { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<0, 4, true><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             else { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<SRC, 4><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             break;
         case 2048:
+            PHK_DECIDE_GEN(8);
             if (SRC == 0 && p.L8) { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<0, 8, true><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             else { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<SRC, 8><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             break;
         case 4096:
+            PHK_DECIDE_GEN(16);
             if (SRC == 0 && p.L8) { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<0, 16, true><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             else { PHK_LAUNCH(ctx, "phk_rerank_kernel", (phk_rerank_kernel<SRC, 16><<<dim3(wblocks), dim3(256), 0, ctx->stream>>>(src, p))); }
             break;
@@ -2638,6 +2879,7 @@ static int launch_rerank(phk_ctx *ctx, unsigned blocks, const void *src, const R
             phk_set_error("phk_score: no decision kernel for D = %llu", (unsigned long long)p.D);
             return PHK_ERR_UNSUPPORTED;
     }
+#undef PHK_DECIDE_GEN
     return PHK_OK;
 }
 
@@ -2736,6 +2978,13 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
         const void *src = d_counts ? (const void *)(d_counts + s * D) : (const void *)(d_Q + s * D);
         const uint32_t *rsum = d_rowsum ? d_rowsum + s : nullptr;
+        if (use_i8 && !rsum) {   // the int8 path's kernels (fragments, sweep, lane-per-query decision) take the row sums as input
+            void *rs;
+            PHK_TRY(phk_ws(ctx, WS_NWIN, nb * sizeof(uint32_t), &rs));
+            PHK_LAUNCH(ctx, "phk_rowsum_kernel",
+                       phk_rowsum_kernel<<<dim3((unsigned)phk_div_up(nb, 4)), dim3(256), 0, ctx->stream>>>((const uint32_t *)src, nb, D, (uint32_t *)rs));
+            rsum = (const uint32_t *)rs;
+        }
         // segments the method does not need are skipped by giving them zero blocks
         const uint32_t nref = (method & PHK_METHOD_KNN) ? m->n_rblk_ref : 0;
         const uint32_t npos = (method & PHK_METHOD_KMEANS) ? m->n_rblk_pos : 0;
@@ -2817,6 +3066,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
                                                    i8_groups, set_bytes, i8_two));
             i8_bound(p, i8_two);
             p.q2_count = q2c; p.q2_big = q2_big; p.q2_wide = i8_two ? q2_wide : nullptr;
+            p.rowsum = rsum;
         } else if (use_cx) {
             cx_bound(p);
         } else if (use_f16) {
@@ -2938,7 +3188,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
                                    (const uint32_t *)src, rsum, list, nq, D, sub_counts, sub_sum));
                     const uint32_t *sub_rs = rsum ? sub_sum : nullptr;
                     RerankParams p2 = pr;
-                    p2.N = nq; p2.out_map = list; p2.status = nullptr;
+                    p2.N = nq; p2.out_map = list; p2.status = nullptr; p2.rowsum = sub_rs;
                     p2.q2_count = nullptr; p2.q2_wide = p2.q2_big = nullptr;
                     if (pass == 0) {
                         PHK_TRY(phk_launch_proposal_i8_general(ctx, m, sub_counts, sub_rs, nq, nref, npos, nneg, (float *)cv, ci, cu,
