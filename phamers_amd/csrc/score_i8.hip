@@ -290,8 +290,16 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
     uint64_t wg = blockIdx.x;
     uint32_t col0 = 0;
     if (ngroups > 1) {   // 2-D launch: see phk_knn_f16_general_kernel
-        const uint32_t li = blockIdx.x >> 3, g = li % ngroups;
-        wg = (uint64_t)(li / ngroups) * 8 + (blockIdx.x & 7u);
+        uint32_t g;
+        if (ngroups >> 31) {   // one launch per column group (bits 16 .. 30: which): the groups follow one another in time, so
+                               // that a group's column records stay in the XCDs' L2 caches while every workgroup streams them
+            g = (ngroups >> 16) & 0x7FFFu;
+            ngroups &= 0xFFFFu;
+        } else {
+            const uint32_t li = blockIdx.x >> 3;
+            g = li % ngroups;
+            wg = (uint64_t)(li / ngroups) * 8 + (blockIdx.x & 7u);
+        }
         const uint32_t b0 = (uint32_t)((uint64_t)nblk_ref * g / ngroups), b1 = (uint32_t)((uint64_t)nblk_ref * (g + 1) / ngroups);
         blk0 += b0;
         col0 = 32u * b0;
@@ -692,10 +700,17 @@ int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint3
     // skewed contigs) are flagged in `big`: the sweep stores sentinel lists for them and the decision kernel hands them to
     // the f16 count-exact sweep, row by row (phk_score_fast).
     const uint32_t blk0 = nref ? 0 : m->n_rblk_ref;
+    const bool seq = ctx->knobs.gen_seq && groups > 1;   // one launch per column group instead of a 2-D launch
     const uint32_t ng = (groups > 1 && nref >= 8u * groups && nqb >= 64) ? groups : 1u;
     const uint64_t nqg = phk_div_up(nqb, I8_NW);
-    const unsigned gblocks = ng > 1 ? (unsigned)(phk_div_up(nqg, 8) * 8 * ng) : (unsigned)nqg;
-    if (two_parts) {
+    const unsigned gblocks = ng > 1 && !seq ? (unsigned)(phk_div_up(nqg, 8) * 8 * ng) : (unsigned)nqg;
+    if (two_parts && seq && ng > 1) {
+        for (uint32_t g = 0; g < ng; ++g)
+            PHK_LAUNCH(ctx, "phk_knn_i8_general_kernel",
+                       (phk_knn_i8_general_kernel<2, 6><<<dim3(gblocks), dim3(64 * I8_NW), I8Shape<2, 6>::LDS_BYTES, ctx->stream>>>(
+                           (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_A8h, m->rec8h_bytes / 16, (const uint4 *)m->d_T8, d_rowsum,
+                           (const uint32_t *)bg, blk0, nref, npos, nneg, cv, ci, cu, 0x80000000u | (g << 16) | ng, set_bytes)));
+    } else if (two_parts) {
         PHK_LAUNCH(ctx, "phk_knn_i8_general_kernel",
                    (phk_knn_i8_general_kernel<2, 6><<<dim3(gblocks), dim3(64 * I8_NW), I8Shape<2, 6>::LDS_BYTES, ctx->stream>>>(
                        (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_A8h, m->rec8h_bytes / 16, (const uint4 *)m->d_T8, d_rowsum,

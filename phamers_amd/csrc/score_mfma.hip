@@ -3287,6 +3287,7 @@ extern "C" int phk_model_set_centroids(phk_ctx *ctx, phk_model *m, const double 
     }
     PHK_HIP(hipMemcpy(m->d_colnorm + m->M, cnorm.data(), cnorm.size() * sizeof(double), hipMemcpyHostToDevice));
     m->max_colnorm = mx;
+    m->cen_replaced = true;
     m->bf_stale = true;
     return phk_model_update_centroids_f16(m, cpos, cneg, cnorm.data());
 }
@@ -3306,7 +3307,9 @@ extern "C" int phk_model_set_column_mask(phk_ctx *ctx, phk_model *m, const uint8
     }
     m->has_mask = mask != nullptr;
     if (m->fast) {
-        m->bf_stale = true;
+        // (the fp32 / int8 operands are never masked -- those sweeps stand down while a mask is set -- so clearing the mask
+        // makes them valid again unless the centroids were replaced meanwhile)
+        m->bf_stale = m->has_mask || m->cen_replaced;
         PHK_TRY(phk_model_apply_mask_f16(ctx, m));
         PHK_HIP(hipStreamSynchronize(ctx->stream));
     }

@@ -45,7 +45,8 @@ struct phk_model {
     float *d_term_orig = nullptr;     // [3][n_rblk_ref * 32]: norm terms, bias terms, high-part bias terms
     uint8_t *d_col_mask = nullptr;    // [M], 1 = excluded; null until a mask is set
     bool has_mask = false;
-    bool bf_stale = false;            // the fp32 MFMA operand no longer matches (centroids replaced / mask set)
+    bool bf_stale = false;            // the fp32 / int8 MFMA operands no longer match: centroids replaced, or a column mask set
+    bool cen_replaced = false;        // phk_model_set_centroids was called (stays: those operands are not rebuilt); a mask can be cleared
     std::vector<double> h_mu;
     double max_colnorm_train = 0.0;
     uint32_t n_rblk_ref = 0, n_rblk_pos = 0, n_rblk_neg = 0;  // 32-column blocks per segment
