@@ -1248,6 +1248,57 @@ def test_reference_kmeans_labels_from_the_device_lloyd():
 
 
 @pytest.mark.gpu
+def test_clearing_the_column_mask_brings_the_int8_sweep_back():
+    """The cross-validation service masks train columns on a resident model (phk_model_set_column_mask); the int8 operand is
+    never masked, so the int8 sweep stands down while a mask is set (the f16 kernel follows the mask) -- and must come back
+    when the mask is cleared, with the scores of the unmasked model."""
+    from phamers_amd import _lib, device
+    ctx = _lib.get_context()
+    k, D, n_ref, n_q = 5, 1024, 600, 700
+
+    def device_counts(seed, n, L):
+        T = n * L
+        d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+        d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+        device.synth_packed(ctx, seed, 0, n, L, d_packed, d_off)
+        d_counts = device.DeviceArray(ctx, (n, D), np.uint32)
+        device.count(ctx, d_packed, None, T, d_off, n, k, d_counts)
+        return d_counts
+
+    ref = device_counts(71, n_ref, 30000).to_host().astype(np.float64)
+    ref[: n_ref // 2] *= 1.0 + 0.3 * np.sin(np.arange(D) * 0.37)
+    ref /= ref.sum(axis=1, keepdims=True)
+    pos, neg = ref[: n_ref // 2], ref[n_ref // 2:]
+    cpos = np.stack([pos[i::8].mean(axis=0) for i in range(8)])
+    cneg = np.stack([neg[i::8].mean(axis=0) for i in range(8)])
+    model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
+    d_q = device_counts(72, n_q, 10000)
+
+    def run():
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        d_scores = device.DeviceArray(ctx, n_q, np.float64)
+        device.score_counts(ctx, model, d_q, n_q, "combo", d_scores, None)
+        out = d_scores.to_host()
+        ctx.profile_enable(False)
+        return out, ctx.profile()
+
+    base, prof = run()
+    assert "phk_knn_i8_general_kernel" in prof
+    mask = np.zeros(n_ref, dtype=np.uint8)
+    mask[n_ref // 2:] = 1            # the whole negative class: the votes of these (unskewed) queries flip
+    model.set_column_mask(mask)
+    masked, prof = run()
+    assert "phk_knn_i8_general_kernel" not in prof and "phk_knn_f16_general_kernel" in prof
+    assert not np.array_equal(masked, base)
+    model.set_column_mask(None)
+    again, prof = run()
+    assert "phk_knn_i8_general_kernel" in prof
+    assert np.array_equal(again, base)
+    model.close()
+
+
+@pytest.mark.gpu
 def test_transforms_and_column_sums_on_resident_batches(tmp_path):
     """SURVEY 8(f)-4 on the device: transform_kmers as a device-to-device column gather of a resident batch
     (phk_batch_gather_columns) against the reference's own outputs (tests/golden/transform.npz) and against counting the
