@@ -1051,27 +1051,42 @@ __global__ __launch_bounds__(NTH) void phk_count_pairs_kernel(const uint32_t *__
 // words straight from memory and no wave waits for another before the flush.  Same bins as phk_count_slots_kernel
 // (bins[code][slot], 16 contigs per workgroup at k = 5), one add per window, 64 windows per lane and round.
 // ------------------------------------------------------------------------------------
-template <int K, int SLOTS, int NTH>
-__global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *__restrict__ packed, const uint64_t *__restrict__ offsets,
+template <int K, int SLOTS, int NTH, bool MASK>
+__global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask,
+                                                              const uint64_t *__restrict__ offsets,
                                                               uint64_t n, uint64_t max_word, uint32_t long_thr,
                                                               uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin,
                                                               uint2 *__restrict__ long_list, uint32_t *__restrict__ long_count,
+                                                              const uint2 *__restrict__ order,   // sorted (contig, piece) items of a ragged batch, or NULL
                                                               uint32_t piece_w,
+                                                              uint32_t skip_plain,             // 1: a batch that is not ragged is another kernel's (pairs)
                                                               uint4 *__restrict__ frag8,      // the scorer's int8 operand (PhkPrep8), or NULL
                                                               uint32_t *__restrict__ big8) {
     constexpr uint32_t D = 1u << (2 * K);
     constexpr int PARTS = NTH / SLOTS;      // lanes per contig
     constexpr int XPT = (int)D / PARTS;     // codes a thread flushes
     constexpr int SHB = SLOTS == 32 ? 7 : 6;  // log2 of a bin row in bytes
-    static_assert(XPT % 16 == 0 && K <= 5, "flush geometry / window fits the funnel");
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][SLOTS]
-    if (!phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) {   // ragged: the sorted slot kernel's
+    static_assert(XPT % 4 == 0 && K <= 5, "flush geometry / window fits the funnel");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][SLOTS] | counted windows [SLOTS] | piece owner [SLOTS]
+    uint32_t *nwin_s = lds + D * SLOTS;
+    uint32_t *split_s = nwin_s + SLOTS;
+    // plain walk when the statistics allow it, else the sorted work list (as phk_count_slots_kernel)
+    if (phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) {
+        if (skip_plain) return;
+        order = nullptr;
+    } else {
         if (big8 && blockIdx.x == 0 && threadIdx.x == 0) big8[n] = 2u;   // (nothing prepared for the scorer)
-        return;
+        if (!order) return;
+    }
+    if (order) {
+        n = long_count[1];   // items, counted by the sort kernels
+        frag8 = nullptr;
+        big8 = nullptr;
     }
     const int t = threadIdx.x;
     const int slot = t & (SLOTS - 1), part = t / SLOTS;
     for (uint32_t b = t * 4; b < D * SLOTS; b += 4 * NTH) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
+    if (t < SLOTS) nwin_s[t] = 0;
     __syncthreads();
     const uint32_t colb = (uint32_t)slot * 4u;
     typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -1082,15 +1097,27 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
     };
     auto add1 = [&](lds_u32 *p, uint32_t val) { __hip_atomic_fetch_add(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     const uint64_t wlast = max_word + 1;   // the pad word: the last one that exists
+    const uint64_t mlast = (max_word >> 1) + 1;   // last mask word that exists (ceil(T / 32) + 1 words)
 
     for (uint64_t batch = blockIdx.x; batch * SLOTS < n; batch += gridDim.x) {
-        const uint64_t c = batch * SLOTS + slot;
-        const bool have = c < n;
-        const uint64_t st = have ? offsets[c] : 0;
+        const uint64_t ci = batch * SLOTS + slot;
+        const bool have = ci < n;
+        const uint2 item = (have && order) ? order[ci] : make_uint2(0, 0);
+        const uint64_t c = have ? (order ? (uint64_t)item.x : ci) : 0;
+        uint64_t st = have ? offsets[c] : 0;
         const uint64_t en = have ? offsets[c + 1] : 0;
         const uint64_t len = en - st;
         uint32_t W = len >= (uint64_t)K ? (uint32_t)((len - K + 1) < 0xFFFFFFFFull ? (len - K + 1) : 0xFFFFFFFFull) : 0;
-        const bool handed_over = W > long_thr;
+        // an item of the sorted work list is a whole contig or one piece of a long one: the piece's windows start at
+        // st + piece * piece_w, and its histogram is added onto the contig's row (zeroed by the sort) at the flush
+        const bool split = order && piece_w && W > long_thr;
+        if (split) {
+            const uint64_t first = (uint64_t)item.y * piece_w;
+            st += first;
+            W = (uint32_t)((uint64_t)W - first < piece_w ? (uint64_t)W - first : piece_w);
+        }
+        const bool handed_over = !order && W > long_thr;
+        if (order && part == 0) split_s[slot] = split ? (uint32_t)c + 1u : 0u;
         if (handed_over) {
             if (part == 0) {
                 const uint32_t np = piece_w ? (W + piece_w - 1) / piece_w : 1u;
@@ -1103,11 +1130,13 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
         const uint64_t U0 = st >> 6;
         const uint32_t rst = (uint32_t)(st - (U0 << 6));
         const uint64_t rlast64 = (uint64_t)rst + W - 1;                  // the last window (W > 0)
-        const uint32_t rlast = rlast64 < 0xFFFFFFC0ull ? (uint32_t)rlast64 : 0xFFFFFFC0u;   // (long_thr keeps W far below this)
+        const uint32_t rlast = rlast64 < 0xFFFFFFC0ull ? (uint32_t)rlast64 : 0xFFFFFFC0u;   // (long_thr / piece_w keep W far below this)
         const uint32_t nunit = W ? (rlast >> 6) + 1u : 0u;
         const uint32_t *pc = packed + 4 * U0;
         const uint32_t wlim = (uint32_t)((wlast - 4 * U0) < 0x7FFFFFFFull ? (wlast - 4 * U0) : 0x7FFFFFFFull);
-        auto load5 = [&](uint32_t j, uint32_t (&w)[5]) {
+        const uint32_t *pm = MASK ? mask + 2 * U0 : nullptr;            // validity words of the first unit (2 per unit + the next)
+        const uint32_t mlim = MASK ? (uint32_t)((mlast - 2 * U0) < 0x7FFFFFFFull ? (mlast - 2 * U0) : 0x7FFFFFFFull) : 0u;
+        auto load5 = [&](uint32_t j, uint32_t (&w)[5], uint32_t (&mk)[3]) {
             const uint32_t w0 = 4u * j;
             if (w0 + 3 <= wlim) {
                 const uint4 a = *reinterpret_cast<const uint4 *>(pc + w0);
@@ -1116,16 +1145,36 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
                 w[0] = pc[w0]; w[1] = pc[w0 + 1 < wlim ? w0 + 1 : wlim]; w[2] = pc[w0 + 2 < wlim ? w0 + 2 : wlim]; w[3] = pc[wlim];
             }
             w[4] = pc[w0 + 4 < wlim ? w0 + 4 : wlim];
+            if (MASK) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) mk[i] = pm[2 * j + i < mlim ? 2 * j + i : mlim];
+            }
         };
-        uint32_t cur[5] = {0, 0, 0, 0, 0}, nxt[5] = {0, 0, 0, 0, 0};
+        uint32_t cur[5] = {0, 0, 0, 0, 0}, nxt[5] = {0, 0, 0, 0, 0}, mcur[3] = {0, 0, 0}, mnxt[3] = {0, 0, 0};
+        uint32_t cnt_ok = 0;
         uint32_t j = (uint32_t)part;
-        if (j < nunit) load5(j, cur);
+        if (j < nunit) load5(j, cur, mcur);
         while (__any(j < nunit)) {
             const bool live = j < nunit;
-            if (j + PARTS < nunit) load5(j + PARTS, nxt);
+            if (j + PARTS < nunit) load5(j + PARTS, nxt, mnxt);
             const uint32_t fb = 64u * j;                                  // window i of the unit starts at fb + i
-            const bool all = live && fb >= rst && fb + 63u <= rlast;
-            if (!__any(live && !all)) {   // wave-uniform: every live lane's unit is interior to its contig
+            bool all = live && fb >= rst && fb + 63u <= rlast;
+            uint64_t wv = 0;                                              // bit 63 - i: window i is counted
+            if (live) {
+                const uint32_t lo = rst > fb ? rst - fb : 0u;
+                const uint32_t hi = rlast - fb < 63u ? rlast - fb : 63u;
+                wv = (hi - lo == 63u) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << (63 - hi));
+                if (MASK) {
+                    const uint64_t vb = ((uint64_t)mcur[0] << 32) | mcur[1];   // bit 63 - i: base i of the unit valid
+                    uint64_t w = vb;
+#pragma unroll
+                    for (int jj = 1; jj < K; ++jj) w &= (vb << jj) | ((uint64_t)mcur[2] >> (32 - jj));
+                    wv &= w;
+                    all = all && w == ~0ull;
+                    cnt_ok += (uint32_t)__popcll(wv);
+                }
+            }
+            if (!__any(live && !all)) {   // wave-uniform: every live lane's unit is interior to its contig (and all valid)
                 if (all) {
 #pragma unroll
                     for (int wd = 0; wd < 4; ++wd) {
@@ -1134,10 +1183,7 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
                         for (int jw = 0; jw < 16; ++jw) add1(bin(jw < 8 ? y : u, jw & 7), 1u);
                     }
                 }
-            } else if (live) {            // a lane at an edge of its contig: the window's bit instead of 1
-                const uint32_t lo = rst > fb ? rst - fb : 0u;
-                const uint32_t hi = rlast - fb < 63u ? rlast - fb : 63u;
-                const uint64_t wv = (hi - lo == 63u) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << (63 - hi));   // bit 63 - i: window i is counted
+            } else if (live) {            // a lane at an edge of its contig / with an invalid base: the window's bit instead of 1
                 const uint32_t vhi = (uint32_t)(wv >> 32), vlo = (uint32_t)wv;
 #pragma unroll
                 for (int wd = 0; wd < 4; ++wd) {
@@ -1151,40 +1197,64 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
             }
 #pragma unroll
             for (int i = 0; i < 5; ++i) cur[i] = nxt[i];
+            if (MASK) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) mcur[i] = mnxt[i];
+            }
             j += PARTS;
         }
+        if (MASK && cnt_ok) atomicAdd(nwin_s + slot, cnt_ok);
         phk_lds_barrier();  // every wave's adds have landed
+        // ---- pieces first: wave w adds the columns of slots w, w + NTH / 64, .. onto their contigs' rows, 64 consecutive codes per
+        // instruction (coalesced global atomics; see phk_count_slots_kernel)
+        if (order) {
+            for (int sl = t >> 6; sl < SLOTS; sl += NTH / 64) {
+                const uint32_t cs = split_s[sl];
+                if (!cs) continue;
+                uint32_t *rowp = counts + (uint64_t)(cs - 1u) * D;
+                for (uint32_t code = (uint32_t)(t & 63); code < D; code += 64) {
+                    const uint32_t v = lds[code * SLOTS + sl];
+                    if (v) atomicAdd(rowp + code, v);
+                }
+            }
+            phk_lds_barrier();
+        }
         {   // flush: thread (slot, g) writes codes [g XPT, (g + 1) XPT) of contig `slot` and clears them
             uint32_t *cellb = lds + ((uint32_t)part * XPT) * SLOTS + slot;
             uint32_t *rowo = counts + c * D + (uint32_t)part * XPT;
-            // ... and, for the scorer's int8 sweep (score_i8.hip), the same 16 codes per piece as int8 around the row's centre in
-            // fragment order: piece (k-step s = dims / 32, half h) of query c at [(c / 32) (D / 32) + s][32 h + c % 32]
-            const int cen = (int)phk_row_center(W, D);
+            const uint32_t Wc = MASK ? nwin_s[slot] : W;   // counted windows = the row sum
+            // ... and, for the scorer's int8 sweep (score_i8.hip), the same codes as int8 around the row's centre in fragment
+            // order: piece (k-step s = dims / 32, half h) of query c at [(c / 32) (D / 32) + s][32 h + c % 32]
+            const int cen = (int)phk_row_center(Wc, D);
             uint32_t mx = 0, l1 = 0;
+            constexpr int PZ = XPT >= 16 ? XPT / 16 : 1, CPZ = XPT >= 16 ? 4 : XPT / 4;   // 16-code pieces per thread, uint4 loads per piece
 #pragma unroll
-            for (uint32_t pz = 0; pz < XPT / 16; ++pz) {
-                uint32_t pk[4];
+            for (uint32_t pz = 0; pz < (uint32_t)PZ; ++pz) {
+                uint32_t pk[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (uint32_t i = 0; i < 4; ++i) {
+                for (uint32_t i = 0; i < (uint32_t)CPZ; ++i) {
                     uint32_t *cell = cellb + (16 * pz + 4 * i) * SLOTS;
                     const uint4 o = make_uint4(cell[0], cell[SLOTS], cell[2 * SLOTS], cell[3 * SLOTS]);
                     cell[0] = 0; cell[SLOTS] = 0; cell[2 * SLOTS] = 0; cell[3 * SLOTS] = 0;
-                    if (have && (!handed_over || piece_w)) *reinterpret_cast<uint4 *>(rowo + 16 * pz + 4 * i) = o;
-                    const uint32_t cc[4] = {o.x, o.y, o.z, o.w};
-                    uint32_t word = 0;
+                    // (a contig handed over in pieces gets its zero row here: the pieces are added onto it atomically)
+                    if (!split && have && (!handed_over || piece_w)) *reinterpret_cast<uint4 *>(rowo + 16 * pz + 4 * i) = o;
+                    if (XPT >= 16) {
+                        const uint32_t cc[4] = {o.x, o.y, o.z, o.w};
+                        uint32_t word = 0;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const int d = (int)cc[b] - cen;
-                        const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
-                        mx = max(mx, ad);
-                        l1 += min(ad, 127u);
-                        const int q = d < -127 ? -127 : (d > 127 ? 127 : d);
-                        word |= ((uint32_t)q & 0xFFu) << (8 * b);
+                        for (int b = 0; b < 4; ++b) {
+                            const int d = (int)cc[b] - cen;
+                            const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
+                            mx = max(mx, ad);
+                            l1 += min(ad, 127u);
+                            const int q = d < -127 ? -127 : (d > 127 ? 127 : d);
+                            word |= ((uint32_t)q & 0xFFu) << (8 * b);
+                        }
+                        pk[i] = word;
                     }
-                    pk[i] = word;
                 }
-                if (frag8 && have && !handed_over) {
-                    const uint32_t dim16 = (uint32_t)part * (XPT / 16) + pz;   // which 16 dimensions of the row
+                if (XPT >= 16 && frag8 && have && !handed_over) {
+                    const uint32_t dim16 = (uint32_t)part * PZ + pz;   // which 16 dimensions of the row
                     frag8[((c >> 5) * (D / 32) + (dim16 >> 1)) * 64 + 32u * (dim16 & 1u) + (uint32_t)(c & 31)] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
                 }
             }
@@ -1196,11 +1266,16 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
                     }
                 } else {
                     if (mx > 127u) atomicOr(big8 + c, 0x80000000u);
-                    if (2ull * W + D > PHK_I8_L1_MAX) atomicAdd(big8 + c, l1);
+                    if (2ull * Wc + D > PHK_I8_L1_MAX) atomicAdd(big8 + c, l1);
                 }
             }
-            if (nwin && have && part == 0 && (!handed_over || piece_w)) nwin[c] = W;
+            if (nwin && have && part == 0) {
+                if (split) atomicAdd(nwin + c, Wc);
+                else if (!handed_over || piece_w) nwin[c] = Wc;
+            }
         }
+        phk_lds_barrier();
+        if (t < SLOTS) nwin_s[t] = 0;
         phk_lds_barrier();
     }
 }
@@ -1279,10 +1354,17 @@ int phk_count_init_device(phk_ctx *ctx) {
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     bool ok = true;
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_direct_kernel<5, 16, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_direct_kernel<5, 16, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    PHK_TRY(slots_instance_ok(phk_count_direct_kernel<5, 16, 512>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_direct_kernel<5, 16, 1024>, &ok));
+#define PHK_DIRECT_INIT(K_, S_, T_)                                                                                                  \
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_direct_kernel<K_, S_, T_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_direct_kernel<K_, S_, T_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));  \
+    PHK_TRY(slots_instance_ok(phk_count_direct_kernel<K_, S_, T_, false>, &ok));                                                     \
+    PHK_TRY(slots_instance_ok(phk_count_direct_kernel<K_, S_, T_, true>, &ok))
+    PHK_DIRECT_INIT(3, 32, 512);
+    PHK_DIRECT_INIT(4, 32, 512);
+    PHK_DIRECT_INIT(4, 32, 1024);
+    PHK_DIRECT_INIT(5, 16, 512);
+    PHK_DIRECT_INIT(5, 16, 1024);
+#undef PHK_DIRECT_INIT
     PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<512>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<1024>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 256, false>, &ok));
@@ -1326,7 +1408,7 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         const uint32_t slots = k == 5 ? 16u : 32u;
         // count_lanes: '2' = slot kernel whatever the batch looks like (tests), 'q' / 'Q' = the same with the two-windows-per-add
         // kernel (512 / 1024 threads) for k = 4 without a mask; 'p' / 'P' = that kernel where the statistics allow
-        const bool forced = lanes_knob == '2' || lanes_knob == 'q' || lanes_knob == 'Q';
+        const bool forced = lanes_knob == '2' || lanes_knob == 'q' || lanes_knob == 'Q' || lanes_knob == 'f';   // ('f': the unstaged slot kernel, forced)
         const bool sorted = ctx->knobs.count_sort && !forced;
         // contigs much longer than the batch mean leave the slot kernel (a workgroup runs as many stages as its longest
         // contig): with count_sort they go to the wave-per-contig kernel as PIECES of 32768 windows, each its own work
@@ -1388,31 +1470,44 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
             }
             skip_plain = 1;
         }
-        // k = 5 without a validity mask: the slot kernel's bins without its staging and stage barriers (phk_count_direct_kernel)
-        if (k == 5 && !d_mask && (lanes_knob == 0 || lanes_knob == 'd' || lanes_knob == 'D')) {
-            const size_t dlds = (size_t)1024 * 16 * 4;
-            uint64_t dblocks = phk_div_up(n, 16);
-            const uint64_t dcap = (uint64_t)ctx->num_cus * 2;
-            if (dblocks > dcap) dblocks = dcap;
-            // the scorer's int8 operand beside the counts, when phk_count_score_dev armed it for exactly this matrix
+        // The unstaged slot kernel (phk_count_direct_kernel) for everything else the slot kernel used to count: masked batches,
+        // the sorted walk of ragged batches, k = 3 and k = 5 (count_lanes '1' / '2' keep phk_count_slots_kernel, for comparison).
+        // At k = 5 without a mask it also writes the scorer's int8 operand when phk_count_score_dev armed it for this matrix.
+        if (lanes_knob != '1' && lanes_knob != '2') {
             PhkPrep8 &pp = ctx->prep8;
-            const bool prep = pp.armed && pp.counts == d_counts && pp.n == n && pp.D == 1024;
+            const bool prep = k == 5 && !d_mask && pp.armed && pp.counts == d_counts && pp.n == n && pp.D == 1024;
             uint4 *frag8 = prep ? (uint4 *)pp.frag : nullptr;
             uint32_t *big8 = prep ? pp.big : nullptr;
-            if (lanes_knob == 'd') {
-                PHK_LAUNCH(ctx, "phk_count_direct_kernel",
-                           (phk_count_direct_kernel<5, 16, 512><<<dim3((unsigned)dblocks), dim3(512), dlds, ctx->stream>>>(
-                               d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w, frag8, big8)));
-            } else {
-                PHK_LAUNCH(ctx, "phk_count_direct_kernel",
-                           (phk_count_direct_kernel<5, 16, 1024><<<dim3((unsigned)dblocks), dim3(1024), dlds, ctx->stream>>>(
-                               d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w, frag8, big8)));
-            }
-            pp.armed = prep;   // (stays armed only if the kernel that prepares it was launched)
-            skip_plain = 1;
-        } else {
-            ctx->prep8.armed = false;
+            pp.armed = prep;   // (stays armed only if the kernel that prepares it is launched)
+            const size_t dlds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * 4;
+            const unsigned dfit = (unsigned)((160u * 1024u - 1024u) / dlds);
+            // shapes, measured (1M contigs, ms): k = 3 unmasked 0.70 (slot kernel 0.79); k = 4 masked 1.00 with 512 threads, 1.22 with 1024
+            // (slot kernel 1.13-1.15); k = 5 masked 2.68 with 1024 (slot kernel 3.87); ragged k = 4 / k = 5: 0.94 / 1.12 (0.92 / 1.58)
+            const bool small = lanes_knob == 'd' || lanes_knob == 'p' || lanes_knob == 'q' || (k == 4 && lanes_knob != 'D');
+            const unsigned dth = (k == 3 || small) ? 512u : 1024u;
+            const unsigned dper = dfit > (2048u / dth) ? 2048u / dth : dfit;                 // (at most 32 waves per CU)
+            uint64_t dblocks = phk_div_up(sorted ? max_items : n, slots);
+            const uint64_t dcap = (uint64_t)ctx->num_cus * (dper < 1 ? 1 : dper);
+            if (dblocks > dcap) dblocks = dcap;
+#define PHK_DIRECT(K_, S_, T_)                                                                                                   \
+            if (d_mask) {                                                                                                        \
+                PHK_LAUNCH(ctx, "phk_count_direct_kernel",                                                                       \
+                           (phk_count_direct_kernel<K_, S_, T_, true><<<dim3((unsigned)dblocks), dim3(T_), dlds, ctx->stream>>>(  \
+                               d_packed, d_mask, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w, skip_plain, frag8, big8))); \
+            } else {                                                                                                             \
+                PHK_LAUNCH(ctx, "phk_count_direct_kernel",                                                                       \
+                           (phk_count_direct_kernel<K_, S_, T_, false><<<dim3((unsigned)dblocks), dim3(T_), dlds, ctx->stream>>>( \
+                               d_packed, nullptr, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w, skip_plain, frag8, big8))); \
+            }                                                                                                                    \
+            return launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                                       \
+                ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count, piece_w)
+            if (k == 3) { PHK_DIRECT(3, 32, 512); }
+            if (k == 4) { if (small) { PHK_DIRECT(4, 32, 512); } PHK_DIRECT(4, 32, 1024); }
+            if (small) { PHK_DIRECT(5, 16, 512); }
+            PHK_DIRECT(5, 16, 1024);
+#undef PHK_DIRECT
         }
+        ctx->prep8.armed = false;
         const size_t lds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * SLOT_ROW * 4 + 16 + 2 * slots * 4;
         // resident blocks per CU: the LDS allocation granule keeps a block that would exactly fill the 160 KiB out
         const unsigned fit = (unsigned)((160u * 1024u - 1024u) / lds);
