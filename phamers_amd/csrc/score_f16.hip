@@ -463,6 +463,11 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
                 x[2 * t + 0] = (float)((c.x - mm.x) * (double)F16_SCALE);
                 x[2 * t + 1] = (float)((c.y - mm.y) * (double)F16_SCALE);
             }
+            // (the float values are made opaque: hipcc otherwise folds double -> float -> half into ONE double -> half
+            // conversion -- legal, 24 >= 2 * 11 + 2 bits -- for which gfx950 has no instruction: ~45 instructions of integer
+            // arithmetic per element, a 6 000-line prologue and 276 spilled registers; v_cvt_f32_f64 + v_cvt_f16_f32 are two)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm("" : "+v"(x[e]));
             f16_split8(x, bh[s], bl[s]);
         }
     }
@@ -1299,7 +1304,10 @@ __global__ __launch_bounds__(256) void phk_split_queries_kernel(const void *__re
             const double *row = static_cast<const double *>(src) + qrow * D + d0 + 8 * s;
             const double *mp = mu64 + d0 + 8 * s;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) x[t] = (float)((row[t] - mp[t]) * (double)F16_SCALE);
+            for (int t = 0; t < 8; ++t) {
+                x[t] = (float)((row[t] - mp[t]) * (double)F16_SCALE);
+                asm("" : "+v"(x[t]));   // (opaque: no fold into a software double -> half conversion; see phk_knn_f16_kernel)
+            }
         }
         half8 hi, lo;
         f16_split8(x, hi, lo);

@@ -1207,7 +1207,7 @@ __device__ bool resolve_segment_g16(const RerankParams &p, uint64_t q, int seg, 
 // MODE 0: every query of the batch; 1: the queries phk_decide_kernel handed over (slow_list); 2: second chance -- rows
 // map[0 .. *map_count) with their lists at dense positions (see RerankParams)
 template <int SRC, int MODE>
-__global__ __launch_bounds__(256, 4) void phk_rerank16_kernel(const void *__restrict__ src, RerankParams p) {
+__global__ __launch_bounds__(256, 3) void phk_rerank16_kernel(const void *__restrict__ src, RerankParams p) {
     const int lane = threadIdx.x & 63, t = lane & 15;
     uint64_t qraw = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 4 + (lane >> 4);
     bool inrange;
