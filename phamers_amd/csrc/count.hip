@@ -1051,7 +1051,7 @@ __global__ __launch_bounds__(NTH) void phk_count_pairs_kernel(const uint32_t *__
 // words straight from memory and no wave waits for another before the flush.  Same bins as phk_count_slots_kernel
 // (bins[code][slot], 16 contigs per workgroup at k = 5), one add per window, 64 windows per lane and round.
 // ------------------------------------------------------------------------------------
-template <int K, int SLOTS, int NTH, bool MASK>
+template <int K, int SLOTS, int NTH, bool MASK, bool ORDERED>
 __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask,
                                                               const uint64_t *__restrict__ offsets,
                                                               uint64_t n, uint64_t max_word, uint32_t long_thr,
@@ -1070,18 +1070,22 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][SLOTS] | counted windows [SLOTS] | piece owner [SLOTS]
     uint32_t *nwin_s = lds + D * SLOTS;
     uint32_t *split_s = nwin_s + SLOTS;
-    // plain walk when the statistics allow it, else the sorted work list (as phk_count_slots_kernel)
-    if (phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) {
-        if (skip_plain) return;
-        order = nullptr;
-    } else {
-        if (big8 && blockIdx.x == 0 && threadIdx.x == 0) big8[n] = 2u;   // (nothing prepared for the scorer)
-        if (!order) return;
-    }
-    if (order) {
+    // Two instances are launched back to back and decide on the device which of them counts the batch: the plain walk
+    // (ORDERED = false) when the statistics allow it, else the sorted work list (ORDERED = true; as phk_count_slots_kernel).
+    // The plain instance carries none of the sorted walk's code: with it the k = 5 kernel ran 15 % slower.
+    const bool plain = phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2));
+    if (ORDERED) {
+        if (plain || !order) return;
         n = long_count[1];   // items, counted by the sort kernels
         frag8 = nullptr;
         big8 = nullptr;
+    } else {
+        if (!plain) {
+            if (big8 && blockIdx.x == 0 && threadIdx.x == 0) big8[n] = 2u;   // (nothing prepared for the scorer)
+            return;
+        }
+        if (skip_plain) return;
+        order = nullptr;
     }
     const int t = threadIdx.x;
     const int slot = t & (SLOTS - 1), part = t / SLOTS;
@@ -1102,22 +1106,22 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
     for (uint64_t batch = blockIdx.x; batch * SLOTS < n; batch += gridDim.x) {
         const uint64_t ci = batch * SLOTS + slot;
         const bool have = ci < n;
-        const uint2 item = (have && order) ? order[ci] : make_uint2(0, 0);
-        const uint64_t c = have ? (order ? (uint64_t)item.x : ci) : 0;
+        const uint2 item = (ORDERED && have) ? order[ci] : make_uint2(0, 0);
+        const uint64_t c = have ? (ORDERED ? (uint64_t)item.x : ci) : 0;
         uint64_t st = have ? offsets[c] : 0;
         const uint64_t en = have ? offsets[c + 1] : 0;
         const uint64_t len = en - st;
         uint32_t W = len >= (uint64_t)K ? (uint32_t)((len - K + 1) < 0xFFFFFFFFull ? (len - K + 1) : 0xFFFFFFFFull) : 0;
         // an item of the sorted work list is a whole contig or one piece of a long one: the piece's windows start at
         // st + piece * piece_w, and its histogram is added onto the contig's row (zeroed by the sort) at the flush
-        const bool split = order && piece_w && W > long_thr;
+        const bool split = ORDERED && piece_w && W > long_thr;
         if (split) {
             const uint64_t first = (uint64_t)item.y * piece_w;
             st += first;
             W = (uint32_t)((uint64_t)W - first < piece_w ? (uint64_t)W - first : piece_w);
         }
-        const bool handed_over = !order && W > long_thr;
-        if (order && part == 0) split_s[slot] = split ? (uint32_t)c + 1u : 0u;
+        const bool handed_over = !ORDERED && W > long_thr;
+        if (ORDERED && part == 0) split_s[slot] = split ? (uint32_t)c + 1u : 0u;
         if (handed_over) {
             if (part == 0) {
                 const uint32_t np = piece_w ? (W + piece_w - 1) / piece_w : 1u;
@@ -1160,7 +1164,7 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
             const uint32_t fb = 64u * j;                                  // window i of the unit starts at fb + i
             bool all = live && fb >= rst && fb + 63u <= rlast;
             uint64_t wv = 0;                                              // bit 63 - i: window i is counted
-            if (live) {
+            if (MASK ? live : (live && !all)) {   // (without a mask only the units at a contig's edges need their window bits)
                 const uint32_t lo = rst > fb ? rst - fb : 0u;
                 const uint32_t hi = rlast - fb < 63u ? rlast - fb : 63u;
                 wv = (hi - lo == 63u) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << (63 - hi));
@@ -1184,6 +1188,7 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
                     }
                 }
             } else if (live) {            // a lane at an edge of its contig / with an invalid base: the window's bit instead of 1
+                if (!MASK && all) wv = ~0ull;   // (an interior unit in a wave that has an edge unit elsewhere)
                 const uint32_t vhi = (uint32_t)(wv >> 32), vlo = (uint32_t)wv;
 #pragma unroll
                 for (int wd = 0; wd < 4; ++wd) {
@@ -1207,7 +1212,7 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
         phk_lds_barrier();  // every wave's adds have landed
         // ---- pieces first: wave w adds the columns of slots w, w + NTH / 64, .. onto their contigs' rows, 64 consecutive codes per
         // instruction (coalesced global atomics; see phk_count_slots_kernel)
-        if (order) {
+        if (ORDERED) {
             for (int sl = t >> 6; sl < SLOTS; sl += NTH / 64) {
                 const uint32_t cs = split_s[sl];
                 if (!cs) continue;
@@ -1275,8 +1280,10 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
             }
         }
         phk_lds_barrier();
-        if (t < SLOTS) nwin_s[t] = 0;
-        phk_lds_barrier();
+        if (MASK) {
+            if (t < SLOTS) nwin_s[t] = 0;
+            phk_lds_barrier();
+        }
     }
 }
 
@@ -1354,17 +1361,19 @@ int phk_count_init_device(phk_ctx *ctx) {
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     bool ok = true;
+#define PHK_DIRECT_INIT1(K_, S_, T_, M_, O_)                                                                                         \
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_direct_kernel<K_, S_, T_, M_, O_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
+    PHK_TRY(slots_instance_ok(phk_count_direct_kernel<K_, S_, T_, M_, O_>, &ok))
 #define PHK_DIRECT_INIT(K_, S_, T_)                                                                                                  \
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_direct_kernel<K_, S_, T_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_direct_kernel<K_, S_, T_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));  \
-    PHK_TRY(slots_instance_ok(phk_count_direct_kernel<K_, S_, T_, false>, &ok));                                                     \
-    PHK_TRY(slots_instance_ok(phk_count_direct_kernel<K_, S_, T_, true>, &ok))
+    PHK_DIRECT_INIT1(K_, S_, T_, false, false); PHK_DIRECT_INIT1(K_, S_, T_, false, true);                                         \
+    PHK_DIRECT_INIT1(K_, S_, T_, true, false); PHK_DIRECT_INIT1(K_, S_, T_, true, true)
     PHK_DIRECT_INIT(3, 32, 512);
     PHK_DIRECT_INIT(4, 32, 512);
     PHK_DIRECT_INIT(4, 32, 1024);
     PHK_DIRECT_INIT(5, 16, 512);
     PHK_DIRECT_INIT(5, 16, 1024);
 #undef PHK_DIRECT_INIT
+#undef PHK_DIRECT_INIT1
     PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<512>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<1024>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 256, false>, &ok));
@@ -1489,15 +1498,17 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
             uint64_t dblocks = phk_div_up(sorted ? max_items : n, slots);
             const uint64_t dcap = (uint64_t)ctx->num_cus * (dper < 1 ? 1 : dper);
             if (dblocks > dcap) dblocks = dcap;
+#define PHK_DIRECT1(K_, S_, T_, M_, O_)                                                                                            \
+            PHK_LAUNCH(ctx, "phk_count_direct_kernel",                                                                           \
+                       (phk_count_direct_kernel<K_, S_, T_, M_, O_><<<dim3((unsigned)dblocks), dim3(T_), dlds, ctx->stream>>>(    \
+                           d_packed, M_ ? d_mask : nullptr, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w, skip_plain, frag8, big8)))
 #define PHK_DIRECT(K_, S_, T_)                                                                                                   \
             if (d_mask) {                                                                                                        \
-                PHK_LAUNCH(ctx, "phk_count_direct_kernel",                                                                       \
-                           (phk_count_direct_kernel<K_, S_, T_, true><<<dim3((unsigned)dblocks), dim3(T_), dlds, ctx->stream>>>(  \
-                               d_packed, d_mask, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w, skip_plain, frag8, big8))); \
+                PHK_DIRECT1(K_, S_, T_, true, false);                                                                            \
+                if (d_ord) { PHK_DIRECT1(K_, S_, T_, true, true); }                                                              \
             } else {                                                                                                             \
-                PHK_LAUNCH(ctx, "phk_count_direct_kernel",                                                                       \
-                           (phk_count_direct_kernel<K_, S_, T_, false><<<dim3((unsigned)dblocks), dim3(T_), dlds, ctx->stream>>>( \
-                               d_packed, nullptr, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w, skip_plain, frag8, big8))); \
+                PHK_DIRECT1(K_, S_, T_, false, false);                                                                           \
+                if (d_ord) { PHK_DIRECT1(K_, S_, T_, false, true); }                                                             \
             }                                                                                                                    \
             return launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                                       \
                 ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count, piece_w)
@@ -1506,6 +1517,7 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
             if (small) { PHK_DIRECT(5, 16, 512); }
             PHK_DIRECT(5, 16, 1024);
 #undef PHK_DIRECT
+#undef PHK_DIRECT1
         }
         ctx->prep8.armed = false;
         const size_t lds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * SLOT_ROW * 4 + 16 + 2 * slots * 4;
