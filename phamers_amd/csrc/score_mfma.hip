@@ -2889,10 +2889,6 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
                    const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status) {
     const uint64_t D = m->D;
     // batch: bounds the candidate (200 B/query), fallback (1 KiB/query) and split-query (4 D B/query) workspaces
-    uint64_t BATCH = 1ull << 20;
-    while (BATCH > 4096 && BATCH * D * 4 > (2ull << 30)) BATCH >>= 1;
-    if (ctx->knobs.score_batch) BATCH = ctx->knobs.score_batch < 64 ? 64 : ctx->knobs.score_batch;
-    const uint64_t nb_max = N < BATCH ? N : BATCH;
     // proposal pass: split-f16 MFMA by default; proposal=f32 selects the fp32-input MFMA kernel (k = 4 only)
     const char *prop = ctx->knobs.proposal;
     const bool use_f16 = D != FAST_D || !(prop[0] == 'f' && prop[1] == '3');
@@ -2924,6 +2920,12 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // its two-part form (H and M digits in the sweep, the L product added by the decision kernel to the window's members) is
     // the default; proposal=i83 keeps all three parts in the sweep
     const bool i8_two = use_i8 && m->d_A8h && m->d_L8 && !(prop[0] == 'i' && prop[1] == '8' && prop[2] == '3');
+    // (the split-query workspace is what bounds a batch: 4 D bytes per query for the f16 sweeps, D for the int8 sweep -- whose
+    // batches are therefore four times larger: half as many per-batch launches and read-backs at configs[2])
+    uint64_t BATCH = 1ull << 20;
+    while (BATCH > 4096 && BATCH * D * (use_i8 ? 1 : 4) > (2ull << 30)) BATCH >>= 1;
+    if (ctx->knobs.score_batch) BATCH = ctx->knobs.score_batch < 64 ? 64 : ctx->knobs.score_batch;
+    const uint64_t nb_max = N < BATCH ? N : BATCH;
     const uint64_t cap2 = second ? (nb_max / 8 > 4096 ? nb_max / 8 : (nb_max < 4096 ? nb_max : 4096)) : 0;
     const uint64_t per_list = nb_max * NSEG * 2, per_list2 = cap2 * NSEG * 2;
     const uint64_t list_bytes = sizeof(float4) + sizeof(uint4) + sizeof(float);
