@@ -1025,13 +1025,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     // insertion of one value: w = acc - T * bias, index bits embedded, 5 x v_med3
     auto insert = [&](int t, float a, float bias, int r) {
         const float w = fmaf(negT[t], bias, a);
+        // A value no lane of the wave can place (w <= the best value its list has dropped, in every lane) changes nothing:
+        // wave-uniform skip of the index bits and the five v_med3.  A lane's list holds the 5 best of the n values it has
+        // seen, so a value enters with probability 5 / n and some lane of the wave takes one with 1 - (1 - 5/n)^64: 63 % of
+        // the insertions of a 4000-column sweep are skipped (2.39 -> 2.23 ms on configs[1]).  The branch is uniform; the
+        // MFMAs stay one per basic block.  (The test is on the value before its index bits: both are "the computed value"
+        // within the 31 ulp the error model charges.)
+        if (__builtin_amdgcn_ballot_w64(w > lv[t][4]) == 0) return;
         const float x = __uint_as_float((__float_as_uint(w) & ~31u) | (uint32_t)(2 * r + 1));
-        // A value no lane of the wave can place (x <= the best value its list has dropped, in every lane) changes nothing:
-        // wave-uniform skip of the five v_med3.  A lane's list holds the 5 best of the n values it has seen, so a value
-        // enters with probability 5 / n and some lane of the wave takes one with 1 - (1 - 5/n)^64: 63 % of the insertions
-        // of a 4000-column sweep are skipped (2.39 -> 2.23 ms on configs[1]).  The branch is uniform; the MFMAs stay one
-        // per basic block.
-        if (__builtin_amdgcn_ballot_w64(x > lv[t][4]) == 0) return;
         // in place, last slot first (slot c takes med3(slot c-1, slot c, x), both still the old values): as builtins the
         // five results are temporaries that the join after the skip has to move into the list's registers -- 129 v_mov
         // per block iteration, a quarter of its vector instructions
