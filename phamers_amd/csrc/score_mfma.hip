@@ -2496,8 +2496,8 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
         // The distances are evaluated in the SAME float64 form, element ownership and summation order as every other
         // exact evaluation of this model shape, so that a query's score does not depend on the route that decided it
         // (which depends on how many rows its batch queued): D = 256 -- exact_d2_g16 (raw counts c and the row sum T,
-        // sum (c_i - T r_i)^2 / T^2, 16 lanes per column in G16 ownership); other D -- exact_d2<DSUB> (the normalised
-        // row c / T of kmer.normalize_counts, one wave per column, lane l on dimensions 256 sub + 4 l .. + 3).
+        // sum (c_i - T r_i)^2 / T^2, 16 lanes per column in G16 ownership).  (Other D: phk_fallback_group_kernel; the branch
+        // below for them is not reached by phk_score_fast.)
         const bool g16 = D == FAST_D;
         double Tq = 1.0, invT2 = 1.0;
         if (SRC == 0) {
@@ -3229,10 +3229,10 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         if (D == FAST_D) {
             if (d_counts) {
                 PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
-                           phk_fallback_partial_kernel<0><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, pf));
+                           phk_fallback_partial_kernel<0><<<dim3((unsigned)ctx->num_cus * 2), dim3(256), fb_lds, ctx->stream>>>(src, pf));
             } else {
                 PHK_LAUNCH(ctx, "phk_fallback_partial_kernel",
-                           phk_fallback_partial_kernel<1><<<dim3(2048), dim3(256), fb_lds, ctx->stream>>>(src, pf));
+                           phk_fallback_partial_kernel<1><<<dim3((unsigned)ctx->num_cus * 2), dim3(256), fb_lds, ctx->stream>>>(src, pf));
             }
         } else {
             // general D: the queued queries eight at a time against a chunk of the reference (see the kernel)

@@ -87,18 +87,60 @@ def kmeans_gpu(data, k, seed=kmeans_seed, max_iter=300):
     return labels.astype(np.int64), centroids, n_iter.value
 
 
+def kmeans_plusplus_seeds(X, n_clusters, random_state):
+    """scikit-learn's k-means++ seeding (sklearn/cluster/_kmeans.py, ``_kmeans_plusplus`` with its default
+    ``n_local_trials = 2 + int(log k)`` and unit sample weights -- what ``KMeans.fit``, and so scripts/learning.py:138, runs
+    on the mean-centred rows before its first sweep), restated with NumPy so that the product path does not import
+    scikit-learn (0.5 s): the same draws from the same ``RandomState`` (one ``choice``, then ``uniform(size=trials)`` per
+    centre), the same expressions in the same order (``-2 X Y^T + |x|^2 + |y|^2`` clipped at 0, ``cumsum`` +
+    ``searchsorted``, the greedy choice among the trials).  Pinned to ``sklearn.cluster.kmeans_plusplus`` -- same indices
+    -- on the reference matrices and on random ones by tests/test_host_rules.py."""
+    X = np.asarray(X, dtype=np.float64)
+    n_samples, n_features = X.shape
+    x_sq = np.einsum("ij,ij->i", X, X)                       # row_norms(X, squared=True)
+    weight = np.ones(n_samples, dtype=np.float64)            # _check_sample_weight(None, X)
+    centers = np.empty((n_clusters, n_features), dtype=X.dtype)
+    indices = np.full(n_clusters, -1, dtype=int)
+    n_local_trials = 2 + int(np.log(n_clusters))
+
+    def sq_dists(A):                                         # _euclidean_distances(A, X, Y_norm_squared=x_sq, squared=True)
+        d = -2 * (A @ X.T)
+        d += np.einsum("ij,ij->i", A, A)[:, None]
+        d += x_sq.reshape(1, -1)
+        np.maximum(d, 0, out=d)
+        return d
+
+    center_id = random_state.choice(n_samples, p=weight / weight.sum())
+    centers[0] = X[center_id]
+    indices[0] = center_id
+    closest = sq_dists(centers[0, np.newaxis])
+    pot = closest @ weight
+    for c in range(1, n_clusters):
+        rand_vals = random_state.uniform(size=n_local_trials) * pot
+        cand = np.searchsorted(np.cumsum(weight * closest, dtype=np.float64), rand_vals)
+        np.clip(cand, None, closest.size - 1, out=cand)
+        d = sq_dists(X[cand])
+        np.minimum(closest, d, out=d)
+        cand_pot = d @ weight.reshape(-1, 1)
+        best = np.argmin(cand_pot)
+        pot = cand_pot[best]
+        closest = d[best]
+        centers[c] = X[cand[best]]
+        indices[c] = cand[best]
+    return centers, indices
+
+
 def kmeans_reference_on_device(data, k, seed=kmeans_seed, max_iter=300, tol=1e-4, ctx=None):
     """The labels of ``KMeans(n_clusters=k, random_state=seed).fit(data)`` (scripts/learning.py:138) with only the seeding
-    on the host: scikit-learn's own k-means++ (``kmeans_plusplus`` on the mean-centred rows with a fresh
+    on the host: scikit-learn's k-means++ (kmeans_plusplus_seeds, on the mean-centred rows with a fresh
     ``RandomState(seed)`` -- what ``KMeans.fit`` does before its first sweep, n_init = 1) and its Lloyd iteration,
     stopping rule included, on the device (phk_kmeans_lloyd).  Returns (labels, sweeps), or None when a cluster ran
     empty (scikit-learn relocates it; the caller then takes the host fit)."""
     import ctypes
-    from sklearn.cluster import kmeans_plusplus
     X = np.array(data, dtype=np.float64, order="C")          # (a copy: centred in place, as KMeans.fit does)
     n, D = X.shape
     X -= X.mean(axis=0)
-    init, _ = kmeans_plusplus(X, int(k), random_state=np.random.RandomState(seed))
+    init, _ = kmeans_plusplus_seeds(X, int(k), np.random.RandomState(seed))
     init = np.ascontiguousarray(init, dtype=np.float64)
     tol_abs = float(np.mean(np.var(X, axis=0)) * tol)
     labels = np.empty(n, dtype=np.uint32)

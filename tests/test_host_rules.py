@@ -156,3 +156,27 @@ def test_row_division_by_a_shared_reciprocal_is_the_ieee_quotient():
     for x, T in cases:
         xf, Tf = float(x), float(T)
         assert div_row(xf, Tf, 1.0 / Tf) == xf / Tf, (x, T)
+
+
+def test_kmeans_plusplus_seeds_equal_scikit_learn():
+    """learning.kmeans_plusplus_seeds, the NumPy statement of scikit-learn's k-means++ seeding that the product's k-means route
+    runs on the host (scripts/learning.py:138 -> KMeans.fit -> _kmeans_plusplus): the same indices and centres as
+    sklearn.cluster.kmeans_plusplus from the same RandomState, on the mean-centred reference matrices (the data the golden
+    centroids were fitted on), on a fold-sized subset and on random matrices of other shapes and seeds."""
+    from sklearn.cluster import kmeans_plusplus
+    from oracle import oracle
+    from phamers_amd import learning
+    from tests import helpers
+    ref = helpers.load_npz("ref_features.npz")
+    pos = oracle.normalize_counts(ref["pos_counts"].astype(np.int64))
+    neg = oracle.normalize_counts(ref["neg_counts"].astype(np.int64))
+    rng = np.random.default_rng(3)
+    cases = [(pos[:2255], 86, 10), (neg[:2255], 86, 10), (pos, 86, 10), (neg, 86, 10), (rng.random((700, 64)), 12, 3),
+             (rng.standard_normal((3000, 40)), 50, 7), (pos[rng.permutation(len(pos))[:1800]], 86, 10), (rng.random((9, 5)), 9, 1)]
+    for X, k, seed in cases:
+        Xc = np.array(X, dtype=np.float64, order="C")
+        Xc -= Xc.mean(axis=0)
+        got_c, got_i = learning.kmeans_plusplus_seeds(Xc, k, np.random.RandomState(seed))
+        want_c, want_i = kmeans_plusplus(Xc, k, random_state=np.random.RandomState(seed))
+        assert np.array_equal(got_i, want_i), (X.shape, k, seed)
+        assert np.array_equal(got_c, want_c), (X.shape, k, seed)
