@@ -122,6 +122,10 @@ int phk_permute_columns_i64(phk_ctx *ctx, const int64_t *rows, uint64_t n, uint6
  * Returns PHK_ERR_IO when the file cannot be read (count_file then returns (None, None),
  * scripts/kmer.py:126-128). */
 int phk_fasta_read(const char *path, int threads, phk_fasta **out);
+/* Titles, ids and sequence LENGTHS only (offsets as phk_fasta_read gives them; phk_fasta_data returns NULL for the bases
+ * and the handle cannot be counted): what phamer_scorer.screen_by_length needs when the features came from the cache
+ * (scripts/phamer.py:144-157 parses the whole file again for the lengths).  One pass over the file, no sequence buffer. */
+int phk_fasta_index(const char *path, int threads, phk_fasta **out);
 /* The same pass over ONE rank's share of the file (the multi-GPU form of kmer.count_file's loop, scripts/kmer.py:
  * 124-140 with fileIO.get_fasta_ids scripts/fileIO.py:62-77: records are independent, so the file is cut by bytes):
  * the records whose '>' line begins in bytes [byte_lo, byte_hi) of the file (of the decompressed stream for ".gz").

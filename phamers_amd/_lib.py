@@ -42,6 +42,7 @@ SIGNATURES = {
     "phk_normalize_f64": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p]),
     "phk_permute_columns_i64": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_void_p, c_void_p]),
     "phk_fasta_read": (c_int, [c_char_p, c_int, P(c_void_p)]),
+    "phk_fasta_index": (c_int, [c_char_p, c_int, P(c_void_p)]),
     "phk_fasta_read_range": (c_int, [c_char_p, c_u64, c_u64, c_int, P(c_void_p)]),
     "phk_fasta_read_part": (c_int, [c_char_p, c_u32, c_u32, c_int, P(c_void_p)]),
     "phk_fasta_shape": (c_int, [c_void_p, P(c_u64), P(c_u64), P(c_u64)]),
@@ -390,12 +391,15 @@ class Batch(object):
 class Fasta(object):
     """A FASTA file parsed by the native multi-threaded reader (phk_fasta_read)."""
 
-    def __init__(self, path, threads=0, part=None, byte_range=None):
+    def __init__(self, path, threads=0, part=None, byte_range=None, index_only=False):
         """``part`` = (i, n): only the records that begin in the i-th of n equal byte ranges of the file (one rank's
-        share, phk_fasta_read_part); ``byte_range`` = (lo, hi): those that begin in [lo, hi) (phk_fasta_read_range)."""
+        share, phk_fasta_read_part); ``byte_range`` = (lo, hi): those that begin in [lo, hi) (phk_fasta_read_range);
+        ``index_only``: ids, titles and lengths without the sequences (phk_fasta_index)."""
         self.lib = load()
         h = ctypes.c_void_p()
-        if part is not None:
+        if index_only:
+            rc = self.lib.phk_fasta_index(os.fsencode(path), int(threads), ctypes.byref(h))
+        elif part is not None:
             rc = self.lib.phk_fasta_read_part(os.fsencode(path), int(part[0]), int(part[1]), int(threads), ctypes.byref(h))
         elif byte_range is not None:
             hi = 0xFFFFFFFFFFFFFFFF if byte_range[1] is None else int(byte_range[1])
@@ -461,6 +465,8 @@ class Fasta(object):
 
     def sequences(self):
         off = self.offsets()
+        if self.total_bases and not self._bases:
+            raise ValueError("this Fasta was opened with index_only=True: it holds no sequences")
         raw = ctypes.string_at(self._bases, self.total_bases) if self.total_bases else b""
         return [raw[int(off[i]):int(off[i + 1])].decode("latin-1") for i in range(self.n_records)]
 

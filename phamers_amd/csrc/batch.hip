@@ -23,7 +23,7 @@ struct phk_batch {
     std::vector<uint64_t> len;      // [n] bases per contig (host): what a selection's total_bases is summed from
 };
 
-#define BATCH_CHUNK (256ull << 20)   // bases per upload chunk (a multiple of 32: chunks pack independently)
+#define BATCH_CHUNK (64ull << 20)    // bases per upload chunk (a multiple of 32: chunks pack independently)
 
 static void batch_release(phk_batch *b) {
     if (!b) return;
@@ -65,7 +65,6 @@ extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint6
     int rc = PHK_OK;
     hipStream_t copy_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, packed_ev[2] = {nullptr, nullptr};
-    bool registered = false;
     void *d_chunk[2] = {nullptr, nullptr};
     auto body = [&]() -> int {
         if (hipMalloc(&b->d_counts, n * b->D * sizeof(uint32_t)) != hipSuccess ||
@@ -85,10 +84,20 @@ extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint6
             const uint64_t chunk_bytes = T < BATCH_CHUNK ? ((T + 63) & ~63ull) : BATCH_CHUNK;
             for (int i = 0; i < (nchunks > 1 ? 2 : 1); ++i)
                 if (hipMalloc(&d_chunk[i], chunk_bytes) != hipSuccess) return PHK_ERR_NOMEM;
-            // pin the caller's buffer in place so that the uploads are true asynchronous DMA (pageable copies are staged
-            // by the runtime and serialise with everything); if that is refused the copies below still work, just slower
-            if (nchunks > 1) registered = hipHostRegister((void *)bases, T, hipHostRegisterDefault) == hipSuccess;
-            if (!registered) (void)hipGetLastError();
+            // A multi-chunk upload goes through two pinned staging buffers of the context, filled by host threads while
+            // the previous chunk is on the bus.  Not hipHostRegister on the caller's buffer, and not a copy straight from
+            // it either (the runtime then pins the pages itself): a 5 GB buffer the device has once been given costs
+            // 0.26-0.6 s to free afterwards instead of 0.05 (measured, tools/diag/fasta_free_time.py), with every HIP call
+            // of the process waiting meanwhile.
+            const bool staged = nchunks > 1;
+            if (staged && !ctx->stage[0]) {
+                for (int i = 0; i < 2; ++i)
+                    if (hipHostMalloc(&ctx->stage[i], BATCH_CHUNK, hipHostMallocDefault) != hipSuccess) {
+                        phk_set_error("phk_batch: cannot allocate the pinned staging buffers");
+                        return PHK_ERR_NOMEM;
+                    }
+                ctx->stage_bytes = BATCH_CHUNK;
+            }
             PHK_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
             for (int i = 0; i < 2; ++i) {
                 PHK_HIP(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
@@ -98,7 +107,18 @@ extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint6
                 const int s = (int)(c & 1);
                 const uint64_t o = c * BATCH_CHUNK, len = T - o < BATCH_CHUNK ? T - o : BATCH_CHUNK;
                 if (c >= 2) PHK_HIP(hipStreamWaitEvent(copy_stream, packed_ev[s], 0));   // the packer is done with this buffer
-                PHK_HIP(hipMemcpyAsync(d_chunk[s], bases + o, len, hipMemcpyHostToDevice, copy_stream));
+                const char *src = bases + o;
+                if (staged) {
+                    if (c >= 2) PHK_HIP(hipEventSynchronize(copied[s]));   // the bus is done with this staging buffer
+                    char *dst = (char *)ctx->stage[s];
+                    const uint64_t piece = 1ull << 20;
+                    phk_parallel_for(phk_div_up(len, piece), [&](uint64_t i) {
+                        const uint64_t a = i * piece, m = len - a < piece ? len - a : piece;
+                        memcpy(dst + a, src + a, m);
+                    });
+                    src = dst;
+                }
+                PHK_HIP(hipMemcpyAsync(d_chunk[s], src, len, hipMemcpyHostToDevice, copy_stream));
                 PHK_HIP(hipEventRecord(copied[s], copy_stream));
                 PHK_HIP(hipStreamWaitEvent(ctx->stream, copied[s], 0));
                 PHK_TRY(phk_launch_pack(ctx, (const char *)d_chunk[s], len, sym, (uint32_t *)d_packed + o / 16,
@@ -125,7 +145,6 @@ extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint6
         if (packed_ev[i]) (void)hipEventDestroy(packed_ev[i]);
         if (d_chunk[i]) (void)hipFree(d_chunk[i]);
     }
-    if (registered) (void)hipHostUnregister((void *)bases);
     if (rc != PHK_OK) {
         batch_release(b);
         return rc;

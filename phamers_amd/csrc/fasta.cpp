@@ -43,8 +43,25 @@ struct RawBytes {
     ~RawBytes() { release(); }
     void release() {
         if (!p) return;
-        if (mapped) munmap(p, mapped);
-        else delete[] p;
+        if (mapped) {
+            // The kernel clears pages as it frees them (0.23 s for 5 GB from one thread, and munmap holds the address
+            // space's lock meanwhile: every other thread's page faults and allocations wait).  MADV_DONTNEED gives the
+            // pages back under the shared lock, so slices are released from several threads; the munmap that follows
+            // finds nothing left to free.
+            const size_t huge = (size_t)2u << 20;
+            if (mapped >= ((size_t)256u << 20)) {
+                unsigned nt = std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+                if (const char *e = getenv("PHK_FREE_THREADS")) nt = (unsigned)std::max(0, atoi(e));
+                const size_t pages = mapped / huge;
+                std::vector<std::thread> pool;
+                for (unsigned t = 0; t < nt; ++t) {
+                    const size_t lo = pages * t / nt * huge, hi = (t + 1 == nt) ? mapped : pages * (t + 1) / nt * huge;
+                    if (hi > lo) pool.emplace_back([this, lo, hi]() { (void)madvise(p + lo, hi - lo, MADV_DONTNEED); });
+                }
+                for (auto &th : pool) th.join();
+            }
+            munmap(p, mapped);
+        } else delete[] p;
         p = nullptr;
         n = mapped = 0;
     }
@@ -339,13 +356,23 @@ static size_t next_record_start(const char *b, size_t n, size_t from) {
     return n;
 }
 
-static int parse_fasta_bytes(const char *b, size_t n, int threads, phk_fasta **out);
+static int parse_fasta_bytes(const char *b, size_t n, int threads, phk_fasta **out, bool with_bases = true);
 
 extern "C" int phk_fasta_read(const char *path, int threads, phk_fasta **out) {
     PHK_REQUIRE(path && out, "phk_fasta_read: NULL argument");
     FileBytes fb;
     PHK_TRY(open_fasta_bytes(path, fb));
     return parse_fasta_bytes(fb.data, fb.size, threads, out);
+}
+
+// Ids, titles and sequence LENGTHS only (offsets as in phk_fasta_read; the sequence bytes are not gathered, phk_fasta_data
+// returns a NULL bases pointer): what the length screen of a run that took its features from the cache needs
+// (scripts/phamer.py:144-157 parses the whole file again for it).  One pass over the file instead of two and no 5 GB buffer.
+extern "C" int phk_fasta_index(const char *path, int threads, phk_fasta **out) {
+    PHK_REQUIRE(path && out, "phk_fasta_index: NULL argument");
+    FileBytes fb;
+    PHK_TRY(open_fasta_bytes(path, fb));
+    return parse_fasta_bytes(fb.data, fb.size, threads, out, false);
 }
 
 // The records whose '>' line begins in bytes [byte_lo, byte_hi) of the file (of the decompressed stream for ".gz"):
@@ -376,7 +403,7 @@ extern "C" int phk_fasta_read_part(const char *path, uint32_t part, uint32_t n_p
     return parse_fasta_bytes(fb.data + lo, hi > lo ? hi - lo : 0, threads, out);
 }
 
-static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fasta **out) {
+static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fasta **out, const bool with_bases) {
     if (threads < 1) threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
     // One pass finds the records and measures them: the file is cut into one slice per thread (a slice begins at the
     // first line start at or after its cut); each thread lists the '>' line starts inside its slice with the title length
@@ -445,7 +472,10 @@ static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fas
                 const size_t lo = nrec * (size_t)t / (size_t)threads, hi = nrec * (size_t)(t + 1) / (size_t)threads;
                 for (size_t r = lo; r < hi; ++r) {
                     const RecSpan s = span(r);
-                    write_record(b, s.begin, s.end, f->bases.data() + f->offsets[r], f->titles.data() + f->title_off[r]);
+                    if (with_bases)
+                        write_record(b, s.begin, s.end, f->bases.data() + f->offsets[r], f->titles.data() + f->title_off[r]);
+                    else   // the title as the scan pass measured it: '>' excluded, trailing white space already cut
+                        memcpy(f->titles.data() + f->title_off[r], b + s.begin + 1, f->title_off[r + 1] - f->title_off[r]);
                 }
             });
         for (auto &th : pool) th.join();
@@ -454,8 +484,10 @@ static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fas
         f->offsets[r + 1] += f->offsets[r];
         f->title_off[r + 1] += f->title_off[r];
     }
-    f->bases.resize(f->offsets[nrec] + 64);  // slack: the device packer reads whole 16-byte groups
-    memset(f->bases.data() + f->offsets[nrec], 0, 64);
+    if (with_bases) {
+        f->bases.resize(f->offsets[nrec] + 64);  // slack: the device packer reads whole 16-byte groups
+        memset(f->bases.data() + f->offsets[nrec], 0, 64);
+    }
     f->titles.resize(f->title_off[nrec] + 1);
     write_all_records();
     // ids: the PhaMers id of every record.id (first white-space delimited word of the title), in parallel
@@ -548,10 +580,12 @@ extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint6
 
 extern "C" int phk_batch_from_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *symbols4, phk_batch **out) {
     PHK_REQUIRE(ctx && f, "phk_batch_from_fasta: NULL");
+    PHK_REQUIRE(f->bases.data() || f->offsets.back() == 0, "phk_batch_from_fasta: the file was only indexed (phk_fasta_index)");
     return phk_batch_from_ascii(ctx, f->bases.data(), f->offsets.data(), f->offsets.size() - 1, k, symbols4, out);
 }
 
 extern "C" int phk_count_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *symbols4, int64_t *counts) {
     PHK_REQUIRE(ctx && f, "phk_count_fasta: NULL");
+    PHK_REQUIRE(f->bases.data() || f->offsets.back() == 0, "phk_count_fasta: the file was only indexed (phk_fasta_index)");
     return phk_count_ascii(ctx, f->bases.data(), f->offsets.data(), f->offsets.size() - 1, k, symbols4, counts);
 }

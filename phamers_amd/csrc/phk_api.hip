@@ -125,6 +125,8 @@ extern "C" int phk_destroy(phk_ctx *ctx) {
     for (auto &t : ctx->timed)
         for (auto e : t.ev) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (void *p : ctx->stage)
+        if (p) (void)hipHostFree(p);
     if (ctx->aux) {
         (void)hipStreamSynchronize(ctx->aux);
         (void)hipStreamDestroy(ctx->aux);

@@ -142,6 +142,9 @@ struct phk_ctx {
     bool last_score_fast = false;  // WS_DIST holds the MFMA path's counters
     std::vector<PhkTimed> timed;
     std::vector<hipEvent_t> ev_pool;
+    // pinned staging buffers of the sequence upload (phk_batch_from_ascii), allocated at the first multi-chunk upload
+    void *stage[2] = {nullptr, nullptr};
+    uint64_t stage_bytes = 0;
 };
 
 int phk_ws(phk_ctx *ctx, int slot, uint64_t bytes, void **out);

@@ -190,7 +190,7 @@ def read_fasta(fasta_file):
 def fasta_lengths(fasta_file):
     """(ids, sequence lengths): what phamer_scorer.screen_by_length needs (scripts/phamer.py:144-157)
     without materialising the sequences as Python strings."""
-    fasta = _lib.Fasta(fasta_file)
+    fasta = _lib.Fasta(fasta_file, index_only=True)
     try:
         return fasta.phamers_ids(), fasta.lengths()
     finally:

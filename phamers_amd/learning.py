@@ -130,6 +130,17 @@ def kmeans_plusplus_seeds(X, n_clusters, random_state):
     return centers, indices
 
 
+def _one_blas_thread():
+    """The seeding's matrix products are (a few trials) x D by D x n: one thread does them in microseconds, while a BLAS
+    pool sized for the whole machine spins on cores the FASTA ingest and the upload are using beside this thread."""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(1, user_api="blas")
+    except ImportError:      # (threadpoolctl comes with scikit-learn; without it the products just run on BLAS's pool)
+        import contextlib
+        return contextlib.nullcontext()
+
+
 def kmeans_reference_on_device(data, k, seed=kmeans_seed, max_iter=300, tol=1e-4, ctx=None):
     """The labels of ``KMeans(n_clusters=k, random_state=seed).fit(data)`` (scripts/learning.py:138) with only the seeding
     on the host: scikit-learn's k-means++ (kmeans_plusplus_seeds, on the mean-centred rows with a fresh
@@ -140,7 +151,8 @@ def kmeans_reference_on_device(data, k, seed=kmeans_seed, max_iter=300, tol=1e-4
     X = np.array(data, dtype=np.float64, order="C")          # (a copy: centred in place, as KMeans.fit does)
     n, D = X.shape
     X -= X.mean(axis=0)
-    init, _ = kmeans_plusplus_seeds(X, int(k), np.random.RandomState(seed))
+    with _one_blas_thread():
+        init, _ = kmeans_plusplus_seeds(X, int(k), np.random.RandomState(seed))
     init = np.ascontiguousarray(init, dtype=np.float64)
     tol_abs = float(np.mean(np.var(X, axis=0)) * tol)
     labels = np.empty(n, dtype=np.uint32)

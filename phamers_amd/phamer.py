@@ -83,6 +83,7 @@ class phamer_scorer(object):
         self._defer_io = False
         self._pending_io = []
         self._centroid_future = None
+        self._centroid_start = None
 
     # ---- data_points: the reference's attribute, lazily backed by the device batch --------------------
     @property
@@ -133,7 +134,10 @@ class phamer_scorer(object):
             logger.info("Reading features from: %s..." % os.path.basename(self.features_file))
             from . import kmer
             self.data_ids, counts = fileIO.read_feature_file(self.features_file)
+            _lap("features file read")
             self.data_points = kmer.normalize_counts(counts)
+            _lap("features normalised")
+            self._start_pending_centroids()      # (beside the scan of the FASTA file for the length screen)
         elif self.fasta_file and os.path.exists(self.fasta_file):
             logger.info("Calculating features of: %s" % os.path.basename(self.fasta_file))
             lengths = self._count_fasta_on_device()
@@ -145,13 +149,17 @@ class phamer_scorer(object):
     def _count_fasta_on_device(self):
         ctx = _lib.get_context()
         fasta = _lib.Fasta(self.fasta_file)
+        _lap("FASTA parsed")
+        self._start_pending_centroids()
         try:
             self.data_ids = fasta.phamers_ids()
             lengths = fasta.lengths()
             self._drop_batch()
             self._rows = None
             self._batch = _lib.Batch.from_fasta(ctx, fasta, self.kmer_length)
+            _lap("uploaded + counted")
             counts = self._batch.counts_u32()
+            _lap("counts on the host")
         finally:
             # (on a helper thread, and only now: unmapping the file's 5 GB beside the page faults of the count matrix's
             # first touch made that download six times slower)
@@ -208,8 +216,15 @@ class phamer_scorer(object):
         else:
             fasta_ids = self.data_ids
         is_long = np.asarray(_lengths) >= self.length_requirement
+        # the rows are the file's records in the file's order: always so when they were just counted from it, and the
+        # usual case when they came from the features cache written beside it (one vectorised comparison to know)
+        own_rows = fasta_ids is self.data_ids or (
+            len(fasta_ids) == len(self.data_ids) and bool(np.array_equal(np.asarray(fasta_ids), np.asarray(self.data_ids))))
+        if own_rows and is_long.all():
+            self.data_ids = np.asarray(self.data_ids)
+            return      # every row is a long contig's own: nothing to drop (and 10^6 ids not sorted and copied, 0.4 s)
         long_ids = np.asarray(fasta_ids)[is_long]
-        if fasta_ids is self.data_ids:
+        if own_rows:
             # the reference keeps a row when its id is that of SOME contig long enough (np.in1d): true for every long contig's
             # own row, so only the short contigs' ids have to be looked up (none on a batch of long contigs; a sort of 10^6
             # strings otherwise, 0.2 s)
@@ -225,7 +240,7 @@ class phamer_scorer(object):
             self._rows = None if self._rows is None else self._rows[keep]
         elif self._rows is not None:
             self._rows = self._rows[keep]
-        self.data_ids = np.array(long_ids)
+        self.data_ids = long_ids      # (already a copy: boolean indexing)
 
     def get_phamer_output_filename(self):
         return os.path.join(self.output_directory, "phamer_scores.csv")
@@ -259,31 +274,62 @@ class phamer_scorer(object):
         raise NotImplementedError("scoring method %r is outside the accelerated path; knn / kmeans / combo are "
                                   "available" % (self.scoring_method,))
 
-    def _centroids_of(self, pos, neg, k_clusters, own_context=False):
-        """k-means labels -> the reference's per-label means, for both classes.  own_context: called from a helper thread,
-        which gets a device context of its own (a context is not shared between threads)."""
-        ctx = _lib.Context(_lib.default_device()) if own_context else None
+    def _centroids_of(self, pos, neg, k_clusters, deliver=None):
+        """k-means labels -> the reference's per-label means, for both classes.  deliver: called from a helper thread,
+        which gets a device context of its own (a context is not shared between threads) and hands the result (or the
+        exception) to this Future BEFORE it closes that context -- freeing the context's buffers waits for the device,
+        0.2 s beside the main thread's upload."""
+        _lap("k-means: begin")
+        ctx = _lib.Context(_lib.default_device()) if deliver is not None else None
         try:
-            return tuple(learning.get_centroids(d, learning.kmeans(d, k_clusters, _ctx=ctx)) for d in (pos, neg))
+            try:
+                out = []
+                for d in (pos, neg):
+                    out.append(learning.get_centroids(d, learning.kmeans(d, k_clusters, _ctx=ctx)))
+                    _lap("k-means: one class done")
+                out = tuple(out)
+            except BaseException as e:   # noqa: BLE001 -- raised again by Future.result() in the main thread
+                if deliver is None:
+                    raise
+                deliver.set_exception(e)
+                return None
+            if deliver is not None:
+                deliver.set_result(out)
+            return out
         finally:
             if ctx is not None:
                 ctx.close()
 
-    def prefetch_centroids(self):
+    def prefetch_centroids(self, after_fasta_read=False):
         """Starts the k-means fit of the reference matrices as they are NOW on a helper thread, so that it runs beside the
-        FASTA ingest and the counting (the seeding is scikit-learn's and releases the GIL; the Lloyd sweeps run on the
-        device through a context of the thread's own); _fit_centroids takes the result if the matrices have not been
-        replaced since, and fits afresh otherwise."""
+        upload, the counting and the cache write (the seeding's matrix products release the GIL; the Lloyd sweeps run on
+        the device through a context of the thread's own); _fit_centroids takes the result if the matrices have not been
+        replaced since, and fits afresh otherwise.  after_fasta_read: the thread starts when the FASTA file has been
+        parsed -- beside the native reader's threads it took the parse from 0.32 to 0.48 s (1M contigs) and gained
+        nothing, since the fit (0.11 s) fits beside what follows."""
         if os.environ.get("PHAMERS_KMEANS", "device") == "gpu":
             return
-        from concurrent.futures import ThreadPoolExecutor
         pos, neg, k = self.positive_data, self.negative_data, self.k_clusters
-        ex = ThreadPoolExecutor(max_workers=1, thread_name_prefix="phamers-kmeans")
-        self._centroid_future = (pos, neg, k, ex.submit(self._centroids_of, pos, neg, k, True))
-        ex.shutdown(wait=False)
+
+        def start():
+            import threading
+            from concurrent.futures import Future
+            fut = Future()
+            self._centroid_future = (pos, neg, k, fut)
+            threading.Thread(target=self._centroids_of, args=(pos, neg, k, fut), name="phamers-kmeans").start()
+        if after_fasta_read and os.environ.get("PHAMERS_KMEANS_START", "after_read") != "early":
+            self._centroid_start = start      # _count_fasta_on_device() calls it once the file is parsed
+        else:
+            start()
+
+    def _start_pending_centroids(self):
+        start, self._centroid_start = self._centroid_start, None
+        if start is not None:
+            start()
 
     def _fit_centroids(self):
         """k-means with k_clusters on each class, then the cluster means (scripts/phamer.py:245-248)."""
+        self._centroid_start = None       # (never started: no FASTA was read -- fit here, in the main thread's context)
         fut, self._centroid_future = self._centroid_future, None
         if fut is not None and fut[0] is self.positive_data and fut[1] is self.negative_data and fut[2] == self.k_clusters:
             self.positive_centroids, self.negative_centroids = fut[3].result()
@@ -343,6 +389,16 @@ def score_contigs(sequences, positive_training_data, negative_training_data, kme
         return scorer.score_points()
     finally:
         scorer._drop_batch()
+
+
+_clock0 = [None]
+
+
+def _lap(what):
+    """--debug: seconds since main() began, from whichever thread."""
+    import time
+    if _clock0[0] is not None:
+        logger.debug("%-34s %.3f s" % (what, time.perf_counter() - _clock0[0]))
 
 
 def main(argv=None):
@@ -410,17 +466,15 @@ def _run(ap, args):
     # read (and equalised) first, their k-means fit runs beside the FASTA ingest and the counting, and the features
     # cache is written beside the scoring.  Same files, same numbers as the sequential order of the reference.
     import time
-    t0 = time.perf_counter()
-
-    def lap(what):
-        logger.debug("%-28s %.3f s" % (what, time.perf_counter() - t0))
+    _clock0[0] = time.perf_counter()
+    lap = _lap
     scorer._defer_io = True
     try:
         scorer._load_reference()
         if args.equalize_reference:
             scorer.equalize_reference_data()
         lap("reference matrices")
-        scorer.prefetch_centroids()
+        scorer.prefetch_centroids(after_fasta_read=True)
         scorer._load_queries(args.length_requirement)
         lap("contigs counted")
         os.makedirs(scorer.output_directory, exist_ok=True)

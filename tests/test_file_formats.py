@@ -123,7 +123,15 @@ def test_native_fasta_reader_matches_seqio_rules(tmp_path, threads):
         assert f.sequences() == want_seqs
         assert f.ids() == [(t.split(None, 1) or [""])[0] for t in want_titles]
         assert f.lengths().tolist() == [len(s) for s in want_seqs]
+        # the index-only pass (phk_fasta_index: the length screen of a run that read its features from the cache):
+        # same titles, ids and lengths, no sequences
+        g = _lib.Fasta(path, threads=threads, index_only=True)
+        assert g.titles() == want_titles and g.lengths().tolist() == f.lengths().tolist()
+        assert g.ids() == f.ids()
+        with pytest.raises(ValueError):
+            g.sequences()
         f.close()
+        g.close()
     with pytest.raises(IOError):
         _lib.Fasta(str(tmp_path / "missing.fa"))
     empty = tmp_path / "empty.fa"
@@ -158,6 +166,9 @@ def test_native_fasta_reader_slices_of_a_large_file(tmp_path):
         f = _lib.Fasta(str(path), threads=threads)
         got = (f.titles(), f.sequences(), f.lengths().tolist(), f.ids())
         f.close()
+        g = _lib.Fasta(str(path), threads=threads, index_only=True)
+        assert (g.titles(), g.lengths().tolist(), g.ids()) == (got[0], got[2], got[3]), threads
+        g.close()
         if ref is None:
             ref = got
             assert got[0] == want_titles and got[1] == want_seqs
