@@ -45,6 +45,7 @@ static int set_knob(PhkKnobs &k, const char *key, const char *value) {
     else if (!strcmp(key, "pipeline")) k.pipeline = v[0] ? atoi(v) : 1;
     else if (!strcmp(key, "gen_groups")) k.gen_groups = v[0] ? atoi(v) : 0;
     else if (!strcmp(key, "gen_seq")) k.gen_seq = v[0] == '1';
+    else if (!strcmp(key, "i8_insert")) k.i8_insert = (v[0] >= '0' && v[0] <= '2') ? v[0] : 0;
     else return PHK_ERR_ARG;
     return PHK_OK;
 }
@@ -55,7 +56,7 @@ static void knobs_from_env(PhkKnobs &k) {
                                            {"proposal", "PHK_PROPOSAL"}, {"cx_cfg", "PHK_CX_CFG"},
                                            {"rerank", "PHK_RERANK"}, {"count_sort", "PHK_COUNT_SORT"},
                                            {"score_batch", "PHK_SCORE_BATCH"}, {"pipeline", "PHK_PIPELINE"},
-                                           {"gen_groups", "PHK_GEN_GROUPS"}, {"gen_seq", "PHK_GEN_SEQ"}};
+                                           {"gen_groups", "PHK_GEN_GROUPS"}, {"gen_seq", "PHK_GEN_SEQ"}, {"i8_insert", "PHK_I8_INSERT"}};
     for (auto &n : names) {
         const char *e = getenv(n[1]);
         if (e) (void)set_knob(k, n[0], e);

@@ -102,6 +102,8 @@ struct PhkKnobs {
     char rerank = 0;           // 'w' wave per query, 'g' 16 lanes per query for all
     bool count_sort = true;    // length-bucketed contig order for the slot count kernel on ragged batches
     uint64_t score_batch = 0;  // queries per scoring batch of the MFMA path (0 = default 2^20; tests shrink it)
+    char i8_insert = 0;        // two-part int8 sweep, how a tile's values meet the lists: '0' test per eight and per value, '1' test per eight,
+                               // '2' no test (0 = by the number of columns, phk_launch_proposal_i8_general)
     bool gen_seq = false;      // int8 sweep: the column groups as successive launches (each group's records L2-resident) instead of a 2-D launch
     int gen_groups = 0;        // column groups of the general-D sweep's 2-D launch (0 = default: PHK_GEN_GROUPS at D >= 2048, else 1)
     int pipeline = 1;          // chunks of phk_count_score_dev's count / score pipeline at k = 4 (1 = off, the default:

@@ -30,12 +30,14 @@
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
 #define I8_NMAX 8300000.0      // |n| <= this: H = n / 65536 (balanced) stays within [-127, 127]
 #define I8_KS 2                // k-steps (32 dimensions each) per chunk of the sweep: chunks of 64 dimensions
 #define I8_L1_MAX PHK_I8_L1_MAX   // (phk_common.h)
 #define I8_SENT 0x03FFFFFFu    // id of an empty list slot (two-part sweep)
+#define I8_INS2_BLOCKS 320     // sweeps of at most this many column blocks (10 240 columns) insert without tests (measured: see the epilogue)
 #define I8_CT_MAX 6            // most column blocks a tile of any variant holds (padding of the record / term arrays)
 // Two variants of the sweep, <parts NP, column blocks per tile CT> -- both keep 192 int32 accumulator registers per wave and
 // 24 MFMAs + 40 LDS-DMA pieces per 64-dimension step:
@@ -161,6 +163,10 @@ int phk_model_build_i8(phk_model *m, const double *pos, const double *neg, const
     if (hipMemcpy(m->d_L8, low.data(), low.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     if (hipMalloc(&m->d_T8, term.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
     if (hipMemcpy(m->d_T8, term.data(), term.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+    for (uint64_t b = 0; b < term.size() / 64; ++b)
+        for (int i = 0; i < 32; ++i) term[b * 64 + i] *= 256.0f;   // (a power of two: exact)
+    if (hipMalloc(&m->d_T8h, term.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
+    if (hipMemcpy(m->d_T8h, term.data(), term.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     m->rec8_bytes = rec3_bytes;
     m->rec8h_bytes = rec2_bytes;
     return PHK_OK;
@@ -273,7 +279,7 @@ __device__ __forceinline__ const T *i8_uniform_ptr(const T *q) {
     return reinterpret_cast<const T *>((uintptr_t)(((uint64_t)hi << 32) | lo));
 }
 
-template <int NP, int CT>
+template <int NP, int CT, int INS = 0>
 __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kernel(
     const uint4 *__restrict__ Bq, uint64_t N, uint32_t nchunk, const uint4 *__restrict__ A8, uint64_t rec_u4,
     const uint4 *__restrict__ T8, const uint32_t *__restrict__ rowsum, const uint32_t *__restrict__ big, uint32_t blk0, uint32_t nblk_ref, uint32_t nblk_pos,
@@ -380,15 +386,14 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
     uint32_t lb[4] = {I8_SENT, I8_SENT, I8_SENT, I8_SENT};
     auto insert5 = [&](float w, int r) {
         const float x = __uint_as_float((__float_as_uint(w) & ~31u) | (uint32_t)(2 * r + 1));
-        const float n4 = __builtin_amdgcn_fmed3f(l5[3], l5[4], x);
-        const float n3 = __builtin_amdgcn_fmed3f(l5[2], l5[3], x);
-        const float n2 = __builtin_amdgcn_fmed3f(l5[1], l5[2], x);
-        const float n1 = __builtin_amdgcn_fmed3f(l5[0], l5[1], x);
-        l5[0] = __builtin_amdgcn_fmed3f(l5[0], x, fbig);
-        l5[1] = n1;
-        l5[2] = n2;
-        l5[3] = n3;
-        l5[4] = n4;
+        // in place, last slot first (slot c takes med3(slot c-1, slot c, x), both still the old values): written as builtins
+        // the five results are temporaries, and the join behind the wave-uniform skip moves them into the list's registers --
+        // 4 v_mov per insertion, 384 per tile epilogue (as in phk_knn_f16h_kernel, score_f16.hip)
+        asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(l5[4]) : "v"(l5[3]), "v"(x));
+        asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(l5[3]) : "v"(l5[2]), "v"(x));
+        asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(l5[2]) : "v"(l5[1]), "v"(x));
+        asm volatile("v_med3_f32 %0, %1, %0, %2" : "+v"(l5[1]) : "v"(l5[0]), "v"(x));
+        asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(l5[0]) : "v"(x), "v"(fbig));
     };
     auto settle = [&](uint32_t cur) {
         uint32_t m[4];
@@ -409,7 +414,8 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
     };
     const uint64_t qr = (qb < nqb && q0 + j < N) ? q0 + j : N - 1;
     const float negT = -(float)rowsum[qr];
-    const f32x2 negT2 = {negT, negT}, c256 = {256.0f, 256.0f};
+    const f32x2 negT2 = {negT, negT};
+    [[maybe_unused]] const f32x2 c256 = {256.0f, 256.0f};
     float pend_v = -3.0e38f;     // the lane's parked candidate (see the epilogue): value, position in the tile
     uint32_t pend_i = 0;
     const uint32_t bigw = big[qr];
@@ -555,23 +561,33 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
                                 const f32x2 fl = {(float)acc[cb][NP - 1][r], (float)acc[cb][NP - 1][r + 1]};
                                 sf = __builtin_elementwise_fma(c256, fhm, fl);
                             } else {
-                                sf = c256 * fhm;   // (exact)
+                                sf = fhm;   // (the factor 256 is in the quantum: this variant reads the terms of d_T8h)
                             }
                             val[2 * m + e2] = __builtin_elementwise_fma(sf, gg[e2], negT2 * bb[e2]);
                         }
+                    }
+                    if (NP == 2 && INS == 2) {
+                        // a short sweep (a few thousand columns): most values still enter some lane's list, and a wave-uniform
+                        // test costs a compare, a branch and the bubble behind it -- more than the six instructions it guards
+                        touched = true;
+#pragma unroll
+                        for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) insert5(val[pr][e], 8 * hb + 2 * pr + e);
+                        continue;
                     }
                     const float vmax = fmaxf(fmaxf(fmaxf(val[0][0], val[0][1]), fmaxf(val[1][0], val[1][1])),
                                              fmaxf(fmaxf(val[2][0], val[2][1]), fmaxf(val[3][0], val[3][1])));
                     if (NP == 2) {
                         // one test for the eight (late in a long sweep most hold no candidate in any lane), then per value: the
-                        // five v_med3 only when some lane can place it
+                        // five v_med3 only when some lane can place it (INS == 1: all eight without further tests)
                         if (__builtin_amdgcn_ballot_w64(vmax > l5[4]) != 0) {
                             touched = true;
 #pragma unroll
                             for (int pr = 0; pr < 4; ++pr)
 #pragma unroll
                                 for (int e = 0; e < 2; ++e)
-                                    if (__builtin_amdgcn_ballot_w64(val[pr][e] > l5[4]) != 0) insert5(val[pr][e], 8 * hb + 2 * pr + e);
+                                    if (INS == 1 || __builtin_amdgcn_ballot_w64(val[pr][e] > l5[4]) != 0) insert5(val[pr][e], 8 * hb + 2 * pr + e);
                         }
                     } else if (__builtin_amdgcn_ballot_w64(vmax > ldrop) != 0) {
 #pragma unroll
@@ -659,6 +675,17 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Measured and NOT kept (round 4; profiles/r04/README.md, "epilogue under the matrix pipe"): the tile epilogue of the two-part
+// sweep inside the step loop.  All eight waves of a workgroup reach a tile's epilogue together -- 29 % of the D = 1024 sweep
+// by the phase timers (tools/diag/i8_timers.sh) with no MFMA in flight -- and two sets of 192 accumulator registers do not
+// exist.  Two kernels that rotate the 192 registers through accumulate / epilogue phases instead (three streams of two blocks
+// in slots of 8 steps; six one-block streams three steps apart in a period of 18 steps, a block walking the chunks
+// cyclically from wherever the counter stands so that all streams share a step's query fragments), both parity-green,
+// ran 91 / 90 ms at configs[2] against 85: the step loop WITHOUT any epilogue instruction already took 76 ms (60 in the
+// kernel above) -- a step costs ~1 us whether it issues 24, 20 or 16 MFMAs per wave, the 40 KiB of LDS-DMA per step and the
+// barrier set its length -- and the interleaved epilogue added 13 ms where it costs 25 outside the loop.
+// ------------------------------------------------------------------------------------
 __global__ void phk_rowsum_kernel(const uint32_t *__restrict__ counts, uint64_t N, uint64_t D, uint32_t *__restrict__ out);
 __global__ void phk_merge_list_sets_kernel(float *__restrict__ cv, uint32_t *__restrict__ ci, float *__restrict__ cu, uint64_t Nlist,
                                            uint64_t set_bytes, int S, const uint32_t *__restrict__ qcount, float *__restrict__ ca,
@@ -708,13 +735,26 @@ int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint3
         for (uint32_t g = 0; g < ng; ++g)
             PHK_LAUNCH(ctx, "phk_knn_i8_general_kernel",
                        (phk_knn_i8_general_kernel<2, 6><<<dim3(gblocks), dim3(64 * I8_NW), I8Shape<2, 6>::LDS_BYTES, ctx->stream>>>(
-                           (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_A8h, m->rec8h_bytes / 16, (const uint4 *)m->d_T8, d_rowsum,
+                           (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_A8h, m->rec8h_bytes / 16, (const uint4 *)m->d_T8h, d_rowsum,
                            (const uint32_t *)bg, blk0, nref, npos, nneg, cv, ci, cu, 0x80000000u | (g << 16) | ng, set_bytes)));
     } else if (two_parts) {
-        PHK_LAUNCH(ctx, "phk_knn_i8_general_kernel",
-                   (phk_knn_i8_general_kernel<2, 6><<<dim3(gblocks), dim3(64 * I8_NW), I8Shape<2, 6>::LDS_BYTES, ctx->stream>>>(
-                       (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_A8h, m->rec8h_bytes / 16, (const uint4 *)m->d_T8, d_rowsum,
-                       (const uint32_t *)bg, blk0, nref, npos, nneg, cv, ci, cu, ng, set_bytes)));
+        // how a tile's values meet the lists, by the length of the sweep per lane (see the kernel's epilogue)
+        const uint32_t blocks_per_group = (nref + npos + nneg) / ng;
+        int ins = blocks_per_group <= I8_INS2_BLOCKS ? 2 : 0;
+        if (ctx->knobs.i8_insert) ins = ctx->knobs.i8_insert - '0';
+#define PHK_I8_LAUNCH2(INS_)                                                                                                     \
+        PHK_LAUNCH(ctx, "phk_knn_i8_general_kernel",                                                                             \
+                   (phk_knn_i8_general_kernel<2, 6, INS_><<<dim3(gblocks), dim3(64 * I8_NW), I8Shape<2, 6>::LDS_BYTES, ctx->stream>>>( \
+                       (const uint4 *)bq, nb, (uint32_t)nchunk, (const uint4 *)m->d_A8h, m->rec8h_bytes / 16, (const uint4 *)m->d_T8h, d_rowsum, \
+                       (const uint32_t *)bg, blk0, nref, npos, nneg, cv, ci, cu, ng, set_bytes)))
+        if (ins == 2) {
+            PHK_I8_LAUNCH2(2);
+        } else if (ins == 1) {
+            PHK_I8_LAUNCH2(1);
+        } else {
+            PHK_I8_LAUNCH2(0);
+        }
+#undef PHK_I8_LAUNCH2
     } else {
         PHK_LAUNCH(ctx, "phk_knn_i8_general_kernel",
                    (phk_knn_i8_general_kernel<3, 4><<<dim3(gblocks), dim3(64 * I8_NW), I8Shape<3, 4>::LDS_BYTES, ctx->stream>>>(
@@ -732,6 +772,8 @@ int phk_launch_proposal_i8_general(phk_ctx *ctx, const phk_model *m, const uint3
 int phk_score_i8_init_device(phk_ctx *ctx) {
     (void)ctx;
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_i8_general_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, I8Shape<3, 4>::LDS_BYTES));
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_i8_general_kernel<2, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, I8Shape<2, 6>::LDS_BYTES));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_i8_general_kernel<2, 6, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, I8Shape<2, 6>::LDS_BYTES));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_i8_general_kernel<2, 6, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, I8Shape<2, 6>::LDS_BYTES));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_i8_general_kernel<2, 6, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, I8Shape<2, 6>::LDS_BYTES));
     return PHK_OK;
 }

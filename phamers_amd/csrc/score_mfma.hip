@@ -173,6 +173,8 @@ void phk_model_free_fast(phk_model *m) {
     if (m->d_A8h) (void)hipFree(m->d_A8h);
     if (m->d_L8) (void)hipFree(m->d_L8);
     if (m->d_T8) (void)hipFree(m->d_T8);
+    if (m->d_T8h) (void)hipFree(m->d_T8h);
+    m->d_T8h = nullptr;
     m->d_A8 = m->d_A8h = nullptr;
     m->d_L8 = nullptr;
     m->d_T8 = nullptr;

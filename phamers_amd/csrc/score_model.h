@@ -29,6 +29,7 @@ struct phk_model {
     // parts + (quantum, bias) per column; kappa8 = max_j |r'_j - r~'_j| / |r'_j| of that quantisation, hsum8 as hsum_*
     void *d_A8 = nullptr;
     float *d_T8 = nullptr;        // [blocks + padding][64]: quanta and bias terms
+    float *d_T8h = nullptr;       // the same with the quanta times 256 (exact): what the two-part sweep multiplies 256 S_H + S_M by
     uint64_t rec8_bytes = 0;
     double kappa8 = 0.0, hsum8 = 0.0;
     // two-part sweep (the default): records of the H and M parts only; the L digits row-major for the decision stage,

@@ -12,6 +12,12 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-6   # north_star: "within 1e-6 relative for the float scores"
 
 
+def _i8_sweeps(prof):
+    """Launches of the int8 sweep in a profile."""
+    return prof.get("phk_knn_i8_general_kernel", (0.0, 0))[1]
+
+
+
 def _ref_matrices(oracle_norm=True):
     from oracle import oracle
     ref = helpers.load_npz("ref_features.npz")
@@ -309,7 +315,7 @@ def test_general_dim_mfma_path_agrees_with_exact_path(monkeypatch, k, n_ref, n_q
             st = ctx.score_stats_ex()
             n_big = 8 + len(range(8, n_q, 8))
             prof = ctx.profile()
-            assert prof["phk_knn_i8_general_kernel"][1] >= 1, prof
+            assert _i8_sweeps(prof) >= 1, prof
             if n_big >= 32:      # (a shorter queue goes straight to the brute force)
                 assert 4 <= st["brute_forced"] < 32, st
                 assert st["swept_f16_beyond_int8"] == n_big, st
@@ -663,7 +669,7 @@ def test_two_digit_sweep_safety_valve_on_near_duplicate_references():
         ctx.profile_enable(False)
         stats[path] = ctx.score_stats()
         stats_ex[path] = ctx.score_stats_ex()
-        sweeps[path] = ctx.profile().get("phk_knn_i8_general_kernel", (0.0, 0))[1]
+        sweeps[path] = _i8_sweeps(ctx.profile())
     ctx.set_option("proposal", "")
     ctx.set_option("force_exact", "0")
     # two sweeps per call on the default path (the batch with two digits, the queued rows alone with three), one with
@@ -1195,7 +1201,7 @@ def test_count_score_k5_with_the_operand_prepared_by_the_count_kernel():
         fused_counts, fused = d_counts.to_host(), d_scores.to_host()
         ctx.profile_enable(False)
         prof = ctx.profile()
-        assert "phk_count_direct_kernel" in prof and "phk_knn_i8_general_kernel" in prof, (name, sorted(prof))
+        assert "phk_count_direct_kernel" in prof and _i8_sweeps(prof), (name, sorted(prof))
         stats = ctx.score_stats_ex()
         d_counts2 = device.DeviceArray.from_host(ctx, np.full((n, D), 0x1234, np.uint32))
         d_scores2 = device.DeviceArray(ctx, n, np.float64)
@@ -1284,16 +1290,16 @@ def test_clearing_the_column_mask_brings_the_int8_sweep_back():
         return out, ctx.profile()
 
     base, prof = run()
-    assert "phk_knn_i8_general_kernel" in prof
+    assert _i8_sweeps(prof)
     mask = np.zeros(n_ref, dtype=np.uint8)
     mask[n_ref // 2:] = 1            # the whole negative class: the votes of these (unskewed) queries flip
     model.set_column_mask(mask)
     masked, prof = run()
-    assert "phk_knn_i8_general_kernel" not in prof and "phk_knn_f16_general_kernel" in prof
+    assert not _i8_sweeps(prof) and "phk_knn_f16_general_kernel" in prof
     assert not np.array_equal(masked, base)
     model.set_column_mask(None)
     again, prof = run()
-    assert "phk_knn_i8_general_kernel" in prof
+    assert _i8_sweeps(prof)
     assert np.array_equal(again, base)
     model.close()
 
