@@ -189,7 +189,7 @@ int phk_features_close(phk_features *f);
 /* ---- device-resident contig batches (the facade's data path) ------------------------- */
 /* What a PhaMers user calls on a FASTA input -- phamer_scorer.load_data + score_points (scripts/phamer.py:131, 139,
  * 579), kmer.count_file (scripts/kmer.py:114-140) -- with every intermediate kept on the device.  A batch is built
- * from host sequence bytes (uploaded once: pinned in place, chunked, copies overlapped with the packer) and owns
+ * from host sequence bytes (uploaded once, in chunks through pinned staging buffers, copies overlapped with the packer) and owns
  * counts[n][4^k] uint32 + row sums in HBM; counts come back only when asked for (the features cache,
  * scripts/phamer.py:132-134), scores are the only per-call download. */
 int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n, int k,

@@ -471,3 +471,48 @@ def test_kmer_command_line_end_to_end(tmp_path):
     assert sorted(str(x) for x in ids2) == sorted(want)
     for i, name in enumerate(ids2):
         assert np.array_equal(counts2[i], want[str(name)])
+
+
+@pytest.mark.gpu
+def test_multi_chunk_upload_through_the_staging_buffers(ctx):
+    """phk_batch_from_ascii on 150 MB of bases: three 64 MB upload chunks through the context's two pinned staging buffers
+    (filled by host threads while the previous chunk is on the bus), contigs that straddle the chunk cuts, a stretch of
+    non-symbols across one cut.  Counts = the single-copy device path (DeviceArray.from_host + pack + count) on the same
+    bytes, bit for bit, and = the oracle on a sample of contigs including those on the cuts."""
+    import ctypes
+    from oracle import oracle
+    from phamers_amd import _lib, device
+    rng = np.random.default_rng(2024)
+    T = 150 * (1 << 20) + 12345
+    bases = np.frombuffer(b"ATGC", dtype=np.uint8)[rng.integers(0, 4, size=T, dtype=np.uint8)]
+    chunk = 64 << 20
+    bases[chunk - 40:chunk + 40] = ord("N")               # non-symbols across the first cut
+    bases[rng.integers(0, T, size=2000)] = ord("n")        # and sprinkled (lower case is not a symbol)
+    lens = rng.integers(1000, 9000, size=40000)
+    cuts = np.cumsum(lens)
+    cuts = cuts[cuts < T]
+    offsets = np.concatenate(([0], cuts, [T])).astype(np.uint64)
+    n = len(offsets) - 1
+    k = 4
+    h = ctypes.c_void_p()
+    _lib.check(ctx.lib.phk_batch_from_ascii(ctx.handle, _lib.ptr(bases), _lib.ptr(offsets), n, k, b"ATGC", ctypes.byref(h)))
+    batch = _lib.Batch(ctx, h)
+    try:
+        assert batch.n == n and batch.total_bases == T and batch.any_invalid
+        got = batch.counts_u32()
+    finally:
+        batch.close()
+    d_raw = device.DeviceArray.from_host(ctx, bases)
+    d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    d_mask = device.DeviceArray(ctx, device.mask_words(T), np.uint32)
+    d_flag = device.DeviceArray(ctx, 1, np.uint32)
+    device.pack_ascii(ctx, d_raw, T, d_packed, d_mask, d_flag)
+    d_off = device.DeviceArray.from_host(ctx, offsets)
+    d_counts = device.DeviceArray(ctx, (n, 4 ** k), np.uint32)
+    d_nwin = device.DeviceArray(ctx, n, np.uint32)
+    device.count(ctx, d_packed, d_mask, T, d_off, n, k, d_counts, d_nwin)
+    assert np.array_equal(got, d_counts.to_host())
+    on_cuts = [int(np.searchsorted(offsets, c, side="right") - 1) for c in (chunk, 2 * chunk)]
+    sample = sorted(set(on_cuts + [0, n - 1] + rng.integers(0, n, size=60).tolist()))
+    seqs = [bases[int(offsets[c]):int(offsets[c + 1])].tobytes().decode() for c in sample]
+    assert np.array_equal(got[sample].astype(np.int64), oracle.count(seqs, k))
