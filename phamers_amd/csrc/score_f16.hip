@@ -438,8 +438,14 @@ __global__ __launch_bounds__(256, 2) void phk_knn_f16_kernel(const void *__restr
         const float4 *mp = reinterpret_cast<const float4 *>(mu32 + 128 * h);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const uint4 c0 = row[2 * s], c1 = row[2 * s + 1];
-            const float4 m0 = mp[2 * s], m1 = mp[2 * s + 1];
+            // (every second k-step the row and centre addresses are made to depend on the fragments of two k-steps before: hoisted
+            // to the top, all 64 loads beside the 128 fragment registers spilled 24 registers)
+            uint64_t ro = 0;   // (an offset of 0 that only exists once the fragments of two k-steps ago do)
+            if (s >= 2 && (s & 1) == 0) asm volatile("" : "+v"(ro) : "v"(bh[s - 2]), "v"(bl[s - 2]));
+            const uint4 *rw = row + ro;
+            const float4 *mw = mp + ro;
+            const uint4 c0 = rw[2 * s], c1 = rw[2 * s + 1];
+            const float4 m0 = mw[2 * s], m1 = mw[2 * s + 1];
             float x[8];
             x[0] = fmaf((float)c0.x, inv, -m0.x * F16_SCALE);
             x[1] = fmaf((float)c0.y, inv, -m0.y * F16_SCALE);
@@ -1060,7 +1066,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
         dma_block(g + 1, (g + 1) & 1);  // one past the end on the last block: the record array is padded
         const uint8_t *buf = smem + (g & 1) * F16H_BLOCK_BYTES;
         ++g;
-        const half8 *fr = reinterpret_cast<const half8 *>(buf) + lane;
+        const half8 *fr = reinterpret_cast<const half8 *>(buf + lane16);   // (lane16 is live for the DMAs: `lane` itself was spilled for this)
         half8 ahn = fr[0];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
