@@ -679,12 +679,15 @@ __global__ __launch_bounds__(64 * I8_NW, 8 / I8_NW) void phk_knn_i8_general_kern
 // Measured and NOT kept (round 4; profiles/r04/README.md, "epilogue under the matrix pipe"): the tile epilogue of the two-part
 // sweep inside the step loop.  All eight waves of a workgroup reach a tile's epilogue together -- 29 % of the D = 1024 sweep
 // by the phase timers (tools/diag/i8_timers.sh) with no MFMA in flight -- and two sets of 192 accumulator registers do not
-// exist.  Two kernels that rotate the 192 registers through accumulate / epilogue phases instead (three streams of two blocks
-// in slots of 8 steps; six one-block streams three steps apart in a period of 18 steps, a block walking the chunks
-// cyclically from wherever the counter stands so that all streams share a step's query fragments), both parity-green,
-// ran 91 / 90 ms at configs[2] against 85: the step loop WITHOUT any epilogue instruction already took 76 ms (60 in the
-// kernel above) -- a step costs ~1 us whether it issues 24, 20 or 16 MFMAs per wave, the 40 KiB of LDS-DMA per step and the
-// barrier set its length -- and the interleaved epilogue added 13 ms where it costs 25 outside the loop.
+// exist.  Three kernels that rotate the 192 registers through accumulate / epilogue phases instead, all parity-green: three
+// streams of two blocks in slots of 8 steps (91 ms at configs[2] against 85); six one-block streams three steps apart that
+// pause two steps for their values (90); six streams that never pause, a finished block's 16 values met with the lists
+// straight out of the accumulators behind the first 16 MFMAs of the step in which the stream starts its next block, its own
+// four MFMAs last (24 MFMAs in every step, the 40-piece sets of this kernel; 90).  In each the step loop WITHOUT a single
+// epilogue instruction already took 76 - 78 ms against this kernel's 60, and the interleaved values added 12 - 13 ms where
+// they cost 25 outside the loop.  A wave issues about one instruction of any kind per 5 cycles (tools/micro/mfma_valu_overlap:
+// six vector instructions per MFMA and wave hide under the pipe, each further one costs 1.25 ns per MFMA and SIMD), and the
+// bookkeeping of per-stream phases, block pointers and term slots put 160 - 180 instructions into a step that has 138 here.
 // ------------------------------------------------------------------------------------
 __global__ void phk_rowsum_kernel(const uint32_t *__restrict__ counts, uint64_t N, uint64_t D, uint32_t *__restrict__ out);
 __global__ void phk_merge_list_sets_kernel(float *__restrict__ cv, uint32_t *__restrict__ ci, float *__restrict__ cu, uint64_t Nlist,
