@@ -129,6 +129,7 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
 
 #define F16H_PIECES 17
 #define F16H_BLOCK_BYTES (F16H_PIECES * 1024)
+#define F16H_NBUF 3      // LDS ring of block records in phk_knn_f16h_kernel
 
 int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, const double *cpos,
                         const double *cneg, const double *mu, const double *colnorm) {
@@ -196,7 +197,7 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
     }
     if (hi_only && hi_records) {
         // 17-piece records: the 16 hi fragments of the full record + one piece of bias terms
-        std::vector<uint8_t> rech((nblk + 1) * F16H_BLOCK_BYTES, 0);
+        std::vector<uint8_t> rech((nblk + 2) * F16H_BLOCK_BYTES, 0);   // (two padding records: the sweep's prefetch runs two blocks ahead)
         for (uint64_t b = 0; b < nblk; ++b) {
             for (int st = 0; st < 16; ++st)
                 memcpy(rech.data() + b * F16H_BLOCK_BYTES + st * 1024, rec.data() + b * rec_bytes + (2 * st) * 1024, 1024);
@@ -938,7 +939,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rowsum, uint64_t N, const uint4 *__restrict__ Af,
     uint32_t nblk_ref, uint32_t nblk_pos, uint32_t nblk_neg, float *__restrict__ cand_v, uint32_t *__restrict__ cand_i,
     float *__restrict__ cand_u) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x F16H_BLOCK_BYTES
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // F16H_NBUF x F16H_BLOCK_BYTES
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -946,23 +947,36 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
     const uint32_t lane16 = (uint32_t)lane * 16u;
-    auto dma_block = [&](uint32_t blk, int buf) {
-        // scalar base + the lane's 16-byte offset: the address of a piece costs two scalar additions, not 64-bit vector
-        // arithmetic in the hot loop's issue stream
+    // One block record -> LDS buffer `buf`, as 16 / NW fragment pieces + the bias terms per wave (32 floats of the 17th piece;
+    // every wave fetches the same 256 bytes, so that each wave has issued exactly 16 / NW + 1 DMAs per block and can count
+    // them).  Scalar base + the lane's offset: the address of a piece costs two scalar additions.  piece(k): the k-th of
+    // this wave's requests for a block -- they are issued one at a time between the MFMAs of the k-step loop, not as a
+    // burst behind the barrier (in-kernel stamps of the burst version: 8 % of a block iteration spent issuing it).
+    constexpr int NPW = 16 / NW + 1;
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    auto dma_piece = [&](uint32_t blk, uint32_t buf, int k) {
         const char *g = reinterpret_cast<const char *>(Af) + (uint64_t)blk * F16H_BLOCK_BYTES;
-        const uint32_t l = lds_base + (uint32_t)buf * F16H_BLOCK_BYTES;
-        // 16 / NW + 1 pieces per wave, no loop (a loop here splits the hot loop into basic blocks and hipcc then sinks the
-        // insertions away from the MFMAs they are meant to hide behind); the bias piece is fetched by every wave
-#pragma unroll
-        for (int k = 0; k < 16 / NW + 1; ++k) {
-            if (k == 16 / NW && wave != (int)(blk % NW)) break;   // the bias piece: one wave's job, taken in turn
-            const int p = k < 16 / NW ? wave + NW * k : 16;
+        const uint32_t l = lds_base + buf * (uint32_t)F16H_BLOCK_BYTES;
+        if (k < 16 / NW) {
+            const int p = wave + NW * k;
             const char *gp = g + p * 1024;
             const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gp), "s"(lp) : "memory");
+        } else {
+            const char *gp = g + 16 * 1024;
+            const uint32_t lp = __builtin_amdgcn_readfirstlane(l + 16u * 1024u);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(lane4), "s"(gp), "s"(lp) : "memory");
         }
     };
-    if (total) dma_block(0, 0);
+    // the ring is F16H_NBUF = 3 buffers deep: block g + 2 is requested while block g computes, and a wave waits for ITS
+    // pieces of block g with s_waitcnt vmcnt(NPW) -- those of block g + 1 may still be in flight (with two buffers and
+    // vmcnt(0) a block had one iteration, ~1.2 us, to arrive: an L2 / fabric round trip under load)
+    if (total) {
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) dma_piece(0, 0, k);
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) dma_piece(1, 1, k);   // (one past the end on a one-block sweep: the record array is padded)
+    }
 
     // ---- prologue: centred counts -> fp16 (exact up to 2048 in magnitude), row sum (from the caller) ----
     half8 bq[NT][16];
@@ -1056,16 +1070,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     // flow of the hot loop is the wave-uniform skip inside insert().  The pipeline drains at the end of a segment (3 times per sweep); the DMA stream does not.
     float bias[16];
     f32x16 accA[NT], accB[NT];
-    uint32_t g = 0;  // global block number: LDS buffer parity and DMA source
+    uint32_t g = 0;  // global block number: DMA source
+    uint32_t cur = 0, nxt = 2;   // ring positions of the block being read / requested
 
-    auto block_iter = [&](uint32_t settle_id, f32x16 (&cur)[NT], const f32x16 (&prev)[NT]) {
-        // block g has landed (every wave waits for its own pieces, then the barrier), and every wave is done
-        // reading the other buffer, which the next DMA overwrites
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto block_iter = [&](uint32_t settle_id, f32x16 (&cur_acc)[NT], const f32x16 (&prev)[NT]) {
+        // block g has landed (every wave waits for its own pieces -- those of block g + 1 may be outstanding -- then the
+        // barrier), and every wave is done reading the buffer of block g - 1, which block g + 2's DMAs overwrite
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         __syncthreads();
-        dma_block(g + 1, (g + 1) & 1);  // one past the end on the last block: the record array is padded
-        const uint8_t *buf = smem + (g & 1) * F16H_BLOCK_BYTES;
-        ++g;
+        const uint8_t *buf = smem + cur * F16H_BLOCK_BYTES;
         const half8 *fr = reinterpret_cast<const half8 *>(buf + lane16);   // (lane16 is live for the DMAs: `lane` itself was spilled for this)
         half8 ahn = fr[0];
 #pragma unroll
@@ -1080,16 +1093,21 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.0f;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], z, 0, 0, 0);
+                for (int t = 0; t < NT; ++t) cur_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], z, 0, 0, 0);
             } else {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], cur[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) cur_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], cur_acc[t], 0, 0, 0);
             }
+            // block g + 2's pieces, one behind the MFMAs of every third k-step (one past the end on the last blocks: padded)
+            if (s % 3 == 1 && s / 3 < NPW) dma_piece(g + 2, nxt, s / 3);
             if (s == 0) settle(settle_id);
 #pragma unroll
             for (int t = 0; t < NT; ++t) insert(t, prev[t][s], bias[s], s);
 
         }
+        ++g;
+        cur = cur == F16H_NBUF - 1 ? 0 : cur + 1;
+        nxt = nxt == F16H_NBUF - 1 ? 0 : nxt + 1;
         // D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h'; its bias terms
         // (the buffer is recycled after the next barrier)
         const float4 *cn = reinterpret_cast<const float4 *>(buf + 16 * 1024) + h;
@@ -1112,7 +1130,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
         settle(nb - 1);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const uint64_t qi = q0 + 32 * t + j;
+            // (the query number is formed here, three times per sweep, from the DMA offset register by an opaque instruction:
+            // as the prologue's value it is kept -- spilled -- across the block loop)
+            uint32_t jj;
+            asm volatile("v_bfe_u32 %0, %1, 4, 5" : "=v"(jj) : "v"(lane16));
+            const uint64_t qi = q0 + 32 * t + jj;
             if (qi < N) {
                                 uint32_t ix[4];
 #pragma unroll
@@ -1131,7 +1153,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
         if (nb == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const uint64_t qi = q0 + 32 * t + j;
+                uint32_t jj;   // (as in finish(): not the prologue's value)
+                asm volatile("v_bfe_u32 %0, %1, 4, 5" : "=v"(jj) : "v"(lane16));
+                const uint64_t qi = q0 + 32 * t + jj;
                 if (qi < N) {
                                         cand_store_empty(cand_v, cand_i, cand_u, seg, h, qi, N);
                 }
@@ -1205,7 +1229,7 @@ int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d
 int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu) {
     PHK_TRY(ensure_rowsum(ctx, d_counts, nb, m->D, d_rowsum));
-    const size_t lds = 2 * F16H_BLOCK_BYTES;
+    const size_t lds = F16H_NBUF * F16H_BLOCK_BYTES;
     const uint4 *af = (const uint4 *)m->d_Af16h + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16H_BLOCK_BYTES / 16);
     // Two 4-wave workgroups per CU (default, "24") or one 8-wave workgroup ("28"): with two workgroups the two waves of a
     // SIMD share no barrier, and the one that lost the issue arbitration does not hold the other up at every block
@@ -1664,8 +1688,8 @@ int phk_score_f16_init_device(phk_ctx *ctx) {
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16h_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F16H_BLOCK_BYTES));
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16h_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F16H_BLOCK_BYTES));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16h_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, F16H_NBUF * F16H_BLOCK_BYTES));
+    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16h_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F16H_NBUF * F16H_BLOCK_BYTES));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<true, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
