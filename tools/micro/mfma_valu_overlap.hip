@@ -120,6 +120,46 @@ static void run_values(const uint4 *d_in, float *d_out, int cus) {
     printf("i8 32x32x32  %s: %.2f ns per MFMA and SIMD\n", MODE == 0 ? "one list value (10 instructions) behind every MFMA" : MODE == 1 ? "the same inside a wave-uniform branch" : "two values behind every MFMA", ms * 1e6 / ((double)iters * 8));
 }
 
+// How many independent accumulators does a wave need?  NACC accumulators per wave, MFMAs issued round-robin (each depends on
+// the one NACC back), no other instructions.  phk_knn_f16h_kernel has 2 per wave, the int8 sweep 12.
+template <int KIND, int NACC>
+__global__ __launch_bounds__(512, 1) void loop_chains(const uint4 *in, float *out, int iters) {
+    const int lane = threadIdx.x & 63;
+    uint4 a[4], b;
+    for (int i = 0; i < 4; ++i) a[i] = in[(lane * 5 + i * 131) & 1023];
+    b = in[(lane * 3 + 7) & 1023];
+    f32x16 accf[NACC]; i32x16 acci[NACC];
+    for (int t = 0; t < NACC; ++t) for (int r = 0; r < 16; ++r) { accf[t][r] = 0.f; acci[t][r] = 0; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (KIND == 0) accf[t % NACC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<half8 *>(&a[t & 3]), *reinterpret_cast<half8 *>(&b), accf[t % NACC], 0, 0, 0);
+            else acci[t % NACC] = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<i32x4 *>(&a[t & 3]), *reinterpret_cast<i32x4 *>(&b), acci[t % NACC], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+    for (int t = 0; t < NACC; ++t) for (int r = 0; r < 16; ++r) s += KIND == 0 ? accf[t][r] : (float)acci[t][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int KIND, int NACC>
+static void run_chains(const uint4 *d_in, float *d_out, int cus, int threads) {
+    const int iters = 10000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    loop_chains<KIND, NACC><<<cus, threads>>>(d_in, d_out, 200);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    loop_chains<KIND, NACC><<<cus, threads>>>(d_in, d_out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    const int waves_per_simd = threads / 256;
+    printf("%s %d accumulator(s) per wave, %d wave(s) per SIMD: %.2f ns per MFMA and SIMD\n", KIND ? "i8 32x32x32 " : "f16 32x32x16", NACC, waves_per_simd,
+           ms * 1e6 / ((double)iters * 8 * waves_per_simd));
+}
+
 int main() {
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
@@ -136,6 +176,9 @@ int main() {
     run<1, 8, 0>(d_in, d_out, cus); run<1, 10, 0>(d_in, d_out, cus); run<1, 12, 0>(d_in, d_out, cus); run<1, 16, 0>(d_in, d_out, cus);
     run<1, 4, 1>(d_in, d_out, cus); run<1, 8, 1>(d_in, d_out, cus); run<1, 12, 1>(d_in, d_out, cus);
     run<0, 0, 0>(d_in, d_out, cus); run<0, 4, 0>(d_in, d_out, cus); run<0, 8, 0>(d_in, d_out, cus); run<0, 12, 0>(d_in, d_out, cus);
+    run_chains<0, 1>(d_in, d_out, cus, 512); run_chains<0, 2>(d_in, d_out, cus, 512); run_chains<0, 4>(d_in, d_out, cus, 512); run_chains<0, 8>(d_in, d_out, cus, 512);
+    run_chains<0, 2>(d_in, d_out, cus, 256); run_chains<0, 4>(d_in, d_out, cus, 256);
+    run_chains<1, 2>(d_in, d_out, cus, 512); run_chains<1, 4>(d_in, d_out, cus, 512);
     run_values<0>(d_in, d_out, cus); run_values<1>(d_in, d_out, cus); run_values<2>(d_in, d_out, cus);
     return 0;
 }
