@@ -86,8 +86,9 @@ def main():
     import torch
     from phamers_amd import _lib
     ctx = _lib.get_context()
-    rng = np.random.default_rng(20261005)
-    n = 1 << 17                                   # 131 072 instructions per family
+    # (a one-off larger run for the record: PHK_FUZZ_LOG2N=20 PHK_FUZZ_SEED=... python -m tests.mfma_fuzz_worker)
+    rng = np.random.default_rng(int(os.environ.get("PHK_FUZZ_SEED", "20261005")))
+    n = 1 << int(os.environ.get("PHK_FUZZ_LOG2N", "17"))   # 131 072 instructions per family
     worst = {}
 
     def run_single(name, gen, chunk=16384):
