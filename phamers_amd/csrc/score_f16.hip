@@ -1081,6 +1081,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
         const uint8_t *buf = smem + cur * F16H_BLOCK_BYTES;
         const half8 *fr = reinterpret_cast<const half8 *>(buf + lane16);   // (lane16 is live for the DMAs: `lane` itself was spilled for this)
         half8 ahn = fr[0];
+        // block i - 2's ids are settled here, under the latency of the first fragment read (38 vector instructions that need
+        // nothing from LDS), not behind the first MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        settle(settle_id);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const half8 ah = ahn;
@@ -1100,25 +1105,22 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
             }
             // block g + 2's pieces, one behind the MFMAs of every third k-step (one past the end on the last blocks: padded)
             if (s % 3 == 1 && s / 3 < NPW) dma_piece(g + 2, nxt, s / 3);
-            if (s == 0) settle(settle_id);
 #pragma unroll
             for (int t = 0; t < NT; ++t) insert(t, prev[t][s], bias[s], s);
-
+            // the bias terms of the block being computed replace those of the previous one four at a time, as soon as the
+            // insertions that read them are done: their LDS latency falls inside the loop, not in front of the next barrier
+            // (D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h')
+            if (s % 4 == 3) {
+                const float4 c4 = (reinterpret_cast<const float4 *>(buf + 16 * 1024) + h)[2 * (s / 4)];
+                bias[s - 3] = c4.x;
+                bias[s - 2] = c4.y;
+                bias[s - 1] = c4.z;
+                bias[s] = c4.w;
+            }
         }
         ++g;
         cur = cur == F16H_NBUF - 1 ? 0 : cur + 1;
         nxt = nxt == F16H_NBUF - 1 ? 0 : nxt + 1;
-        // D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h'; its bias terms
-        // (the buffer is recycled after the next barrier)
-        const float4 *cn = reinterpret_cast<const float4 *>(buf + 16 * 1024) + h;
-#pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) {
-            const float4 c4 = cn[2 * m4];
-            bias[4 * m4 + 0] = c4.x;
-            bias[4 * m4 + 1] = c4.y;
-            bias[4 * m4 + 2] = c4.z;
-            bias[4 * m4 + 3] = c4.w;
-        }
     };
     // drain: the last block's values (in `last`, bias terms loaded), ids, then the segment's lists go out
     auto finish = [&](int seg, uint32_t nb, const f32x16 (&last)[NT]) {
