@@ -195,6 +195,12 @@ int phk_features_close(phk_features *f);
 int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n, int k,
                          const char *symbols4, phk_batch **out);
 int phk_batch_from_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *symbols4, phk_batch **out);
+/* A batch from a count matrix on the host -- the features cache read back by fileIO.read_feature_file
+ * (scripts/phamer.py:132-136, scripts/fileIO.py:134-166): counts[n][D] int64 row-major, D = 4^k.  The run then scores from
+ * the same resident integers as one that counted the FASTA file (the reference normalises the cached counts to float rows
+ * first: the scores are equal to rounding, and equal bit for bit to the cold run's here).  total_bases of such a batch is 0.
+ * PHK_ERR_UNSUPPORTED: D is not 4^k with k <= PHK_MAX_K, or an entry is negative or >= 2^32. */
+int phk_batch_from_counts(phk_ctx *ctx, const int64_t *counts, uint64_t n, uint64_t D, phk_batch **out);
 int phk_batch_shape(const phk_batch *b, uint64_t *n, uint64_t *D, uint64_t *total_bases, int *any_invalid);
 /* borrowed device pointers (valid until phk_batch_free): counts[n][D] uint32, row sums[n] uint32 */
 int phk_batch_device_ptrs(const phk_batch *b, const uint32_t **d_counts, const uint32_t **d_rowsums);

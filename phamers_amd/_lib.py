@@ -54,6 +54,7 @@ SIGNATURES = {
     "phk_count_fasta": (c_int, [c_void_p, c_void_p, c_int, c_char_p, c_void_p]),
     "phk_batch_from_ascii": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_char_p, P(c_void_p)]),
     "phk_batch_from_fasta": (c_int, [c_void_p, c_void_p, c_int, c_char_p, P(c_void_p)]),
+    "phk_batch_from_counts": (c_int, [c_void_p, c_void_p, c_u64, c_u64, P(c_void_p)]),
     "phk_batch_shape": (c_int, [c_void_p, P(c_u64), P(c_u64), P(c_u64), P(c_int)]),
     "phk_batch_device_ptrs": (c_int, [c_void_p, P(c_void_p), P(c_void_p)]),
     "phk_batch_counts_i64": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -328,6 +329,20 @@ class Batch(object):
         h = ctypes.c_void_p()
         check(ctx.lib.phk_batch_from_ascii(ctx.handle, ptr(np.ascontiguousarray(bases)), ptr(offsets), len(raw),
                                            int(kmer_length), symbols, ctypes.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_counts(cls, ctx, counts):
+        """A batch from an integer count matrix (n, 4^k) on the host -- the features cache of an earlier run (phk_batch_from_counts).
+        None when the matrix is not such a one (another width, negative or huge entries): the caller keeps the float rows."""
+        c = np.ascontiguousarray(counts, dtype=np.int64)
+        if c.ndim != 2:
+            return None
+        h = ctypes.c_void_p()
+        rc = ctx.lib.phk_batch_from_counts(ctx.handle, ptr(c), c.shape[0], c.shape[1], ctypes.byref(h))
+        if rc == PHK_ERR_UNSUPPORTED:
+            return None
+        check(rc)
         return cls(ctx, h)
 
     def counts(self):

@@ -153,6 +153,92 @@ extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint6
     return PHK_OK;
 }
 
+__global__ void phk_rowsum_kernel(const uint32_t *__restrict__ counts, uint64_t N, uint64_t D, uint32_t *__restrict__ out);
+
+// A batch from a count matrix the host already holds -- the features cache of an earlier run, read back by
+// fileIO.read_feature_file (scripts/phamer.py:132-136): int64 counts [n][4^k] go up once, narrowed to uint32 on the way into
+// the pinned staging buffers, row sums are formed on the device, and the run scores from the same resident integers as a
+// run that counted the FASTA.  PHK_ERR_UNSUPPORTED when D is not 4^k (k <= PHK_MAX_K) or an entry is negative / >= 2^32
+// (the facade then keeps the reference's float rows).
+extern "C" int phk_batch_from_counts(phk_ctx *ctx, const int64_t *counts, uint64_t n, uint64_t D, phk_batch **out) {
+    PHK_ENTER(ctx, "phk_batch_from_counts");
+    PHK_REQUIRE(out && (n == 0 || counts), "phk_batch_from_counts: NULL");
+    int k = 0;
+    while (k <= PHK_MAX_K && phk_pow4(k) != D) ++k;
+    if (k < 1 || k > PHK_MAX_K) {
+        phk_set_error("phk_batch_from_counts: %llu columns is not 4^k for 1 <= k <= %d", (unsigned long long)D, PHK_MAX_K);
+        return PHK_ERR_UNSUPPORTED;
+    }
+    phk_batch *b = new phk_batch();
+    b->n = n;
+    b->k = k;
+    b->D = D;
+    b->len.assign(n, 0);
+    if (n == 0) {
+        *out = b;
+        return PHK_OK;
+    }
+    int rc = PHK_OK;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    auto body = [&]() -> int {
+        if (hipMalloc(&b->d_counts, n * D * sizeof(uint32_t)) != hipSuccess || hipMalloc(&b->d_nwin, n * sizeof(uint32_t)) != hipSuccess) {
+            phk_set_error("phk_batch: cannot allocate %llu x %llu counts on the device", (unsigned long long)n, (unsigned long long)D);
+            return PHK_ERR_NOMEM;
+        }
+        if (!ctx->stage[0]) {
+            for (int i = 0; i < 2; ++i)
+                if (hipHostMalloc(&ctx->stage[i], BATCH_CHUNK, hipHostMallocDefault) != hipSuccess) {
+                    phk_set_error("phk_batch: cannot allocate the pinned staging buffers");
+                    return PHK_ERR_NOMEM;
+                }
+            ctx->stage_bytes = BATCH_CHUNK;
+        }
+        for (int i = 0; i < 2; ++i) PHK_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        const uint64_t total = n * D, per = BATCH_CHUNK / sizeof(uint32_t), nchunks = phk_div_up(total, per);
+        std::vector<uint8_t> bad(nchunks, 0);
+        for (uint64_t c = 0; c < nchunks; ++c) {
+            const int s = (int)(c & 1);
+            const uint64_t o = c * per, m = total - o < per ? total - o : per;
+            if (c >= 2) PHK_HIP(hipEventSynchronize(done[s]));   // the bus is done with this staging buffer
+            uint32_t *dst = (uint32_t *)ctx->stage[s];
+            const int64_t *src = counts + o;
+            const uint64_t piece = 1ull << 18;
+            std::vector<uint8_t> pbad(phk_div_up(m, piece), 0);
+            phk_parallel_for(phk_div_up(m, piece), [&](uint64_t i) {
+                const uint64_t a = i * piece, e = a + piece < m ? a + piece : m;
+                uint64_t any = 0;
+                for (uint64_t j = a; j < e; ++j) {
+                    const uint64_t v = (uint64_t)src[j];
+                    any |= v >> 32;            // (negative or >= 2^32)
+                    dst[j] = (uint32_t)v;
+                }
+                pbad[i] = any != 0;
+            });
+            for (uint8_t f : pbad) bad[c] |= f;
+            if (bad[c]) {
+                phk_set_error("phk_batch_from_counts: an entry is negative or does not fit 32 bits");
+                return PHK_ERR_UNSUPPORTED;
+            }
+            PHK_HIP(hipMemcpyAsync(b->d_counts + o, dst, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            PHK_HIP(hipEventRecord(done[s], ctx->stream));
+        }
+        PHK_LAUNCH(ctx, "phk_rowsum_kernel",
+                   phk_rowsum_kernel<<<dim3((unsigned)phk_div_up(n, 4)), dim3(256), 0, ctx->stream>>>(b->d_counts, n, D, b->d_nwin));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+        return PHK_OK;
+    };
+    rc = body();
+    if (rc != PHK_OK) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; ++i)
+        if (done[i]) (void)hipEventDestroy(done[i]);
+    if (rc != PHK_OK) {
+        batch_release(b);
+        return rc;
+    }
+    *out = b;
+    return PHK_OK;
+}
+
 extern "C" int phk_batch_shape(const phk_batch *b, uint64_t *n, uint64_t *D, uint64_t *total_bases, int *any_invalid) {
     PHK_REQUIRE(b, "phk_batch_shape: NULL");
     if (n) *n = b->n;

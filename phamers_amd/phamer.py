@@ -135,8 +135,21 @@ class phamer_scorer(object):
             from . import kmer
             self.data_ids, counts = fileIO.read_feature_file(self.features_file)
             _lap("features file read")
-            self.data_points = kmer.normalize_counts(counts)
-            _lap("features normalised")
+            # the cached counts go up once and the run scores from the same resident integers as a run that counted the
+            # FASTA file (data_points, the reference's normalised float rows, is formed on demand); a file that is not an
+            # integer k-mer count matrix keeps the reference's float rows
+            self._drop_batch()
+            self._rows = None
+            batch = None
+            if np.issubdtype(np.asarray(counts).dtype, np.integer) and np.asarray(counts).ndim == 2 and len(counts):
+                batch = _lib.Batch.from_counts(_lib.get_context(), counts)
+            if batch is not None:
+                self._batch = batch
+                self.kmer_length = int(round(np.log(batch.D) / np.log(4)))
+            else:
+                self.data_points = kmer.normalize_counts(counts)
+            del counts
+            _lap("features on the device")
             self._start_pending_centroids()      # (beside the scan of the FASTA file for the length screen)
         elif self.fasta_file and os.path.exists(self.fasta_file):
             logger.info("Calculating features of: %s" % os.path.basename(self.fasta_file))
@@ -213,6 +226,7 @@ class phamer_scorer(object):
                 return
             from . import kmer
             fasta_ids, _lengths = kmer.fasta_lengths(self.fasta_file)
+            _lap("FASTA indexed (ids, lengths)")
         else:
             fasta_ids = self.data_ids
         is_long = np.asarray(_lengths) >= self.length_requirement
@@ -220,6 +234,7 @@ class phamer_scorer(object):
         # usual case when they came from the features cache written beside it (one vectorised comparison to know)
         own_rows = fasta_ids is self.data_ids or (
             len(fasta_ids) == len(self.data_ids) and bool(np.array_equal(np.asarray(fasta_ids), np.asarray(self.data_ids))))
+        _lap("length screen: rows matched")
         if own_rows and is_long.all():
             self.data_ids = np.asarray(self.data_ids)
             return      # every row is a long contig's own: nothing to drop (and 10^6 ids not sorted and copied, 0.4 s)

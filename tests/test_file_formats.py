@@ -321,13 +321,24 @@ def test_config0_cli_end_to_end(tmp_path):
     assert np.array_equal(np.sign(scores), np.sign(g["combo_eq"]))
     # second run picks up the features cache (counting skipped) and gives the same file
     first = out.read_text()
-    phamer.main(["-in", str(indir), "-data", str(tmp_path / "data"), "--equalize_reference", "-l", "0"])
+    warm = phamer.main(["-in", str(indir), "-data", str(tmp_path / "data"), "--equalize_reference", "-l", "0"])
     assert fileIO.read_phamer_output(str(out)).keys() >= got.keys()
-    # (the first run scored the resident integer counts, this one the cached float64 rows: two float64 forms of the
-    # same distances, equal to rounding)
+    # the cached counts went up as integers (phk_batch_from_counts): the same resident matrix as the first run's, so the
+    # same scores bit for bit, and again no float matrix on the host
+    assert warm._batch is not None and warm._batch.n == 101 and warm._rows is None
+    assert np.array_equal(warm.scores[:100], scorer.scores)
     again = fileIO.read_phamer_output(str(out))
     assert helpers.rel_err(np.array([again[str(c)] for c in range(100)]), scores) < 1e-12
     assert first.count("\n") == out.read_text().count("\n") - 1    # the 12-base contig is scored without the screen
+    # a features file that is not a k-mer count matrix (a negative entry) keeps the reference's float rows
+    from phamers_amd import _lib
+    bad = np.array(ref["pos_counts"][:4], dtype=np.int64)
+    bad[1, 7] = -3
+    assert _lib.Batch.from_counts(_lib.get_context(), bad) is None
+    assert _lib.Batch.from_counts(_lib.get_context(), np.ones((3, 100), dtype=np.int64)) is None
+    b = _lib.Batch.from_counts(_lib.get_context(), ref["pos_counts"][:50])
+    assert np.array_equal(b.counts(), ref["pos_counts"][:50]) and b.total_bases == 0
+    b.close()
 
 
 def test_native_feature_file_reader_equals_loadtxt_and_steps_aside(tmp_path, monkeypatch):
