@@ -375,3 +375,57 @@ def test_native_feature_file_reader_equals_loadtxt_and_steps_aside(tmp_path, mon
         fileIO.read_feature_file(other)
     with pytest.raises((IOError, OSError)):
         fileIO.read_feature_file(str(tmp_path / "missing.csv"))
+
+
+def test_fasta_line_scanner_simd_and_plain_agree(tmp_path):
+    """The parser's line scanner has an AVX2 form (picked when the library is loaded) and a memchr form
+    (PHK_FASTA_NO_SIMD=1): a child process parses the same awkward file with the plain one -- lines of every length from 0 to
+    200 around the 32-byte step, blanks and CR inside and at the end of lines, no final newline -- and must see what this
+    process sees."""
+    import hashlib
+    import subprocess
+    import sys
+    from phamers_amd import _lib
+    rng = np.random.default_rng(5)
+    alphabet = np.frombuffer(b"ATGCN", dtype=np.uint8)
+    parts = ["; comment before the first record\n"]
+    for c in range(400):
+        w = c % 201
+        n = int(rng.integers(0, 3000))
+        seq = alphabet[rng.integers(0, 5, size=n)].tobytes().decode()
+        lines = [seq[i:i + max(w, 1)] for i in range(0, n, max(w, 1))] if w else [seq]
+        if c % 5 == 1:
+            lines = [ln[:len(ln) // 2] + " " + ln[len(ln) // 2:] for ln in lines]
+        if c % 5 == 2:
+            lines = [ln + "\r" for ln in lines]
+        if c % 5 == 3:
+            lines = [ln + "  \t" for ln in lines]
+        if c % 7 == 0:
+            lines.insert(len(lines) // 2, "")
+        parts.append(">rec_%d some words\t%d \n" % (c, n) + "\n".join(lines) + "\n")
+    text = "".join(parts).rstrip("\n")
+    path = tmp_path / "lines.fasta"
+    path.write_text(text)
+    want_titles, want_seqs = _seqio_like(text)
+
+    def digest(f):
+        h = hashlib.sha256()
+        for t, s in zip(f.titles(), f.sequences()):
+            h.update(t.encode() + b"\0" + s.encode() + b"\1")
+        h.update(str(f.lengths().tolist()).encode())
+        return h.hexdigest()
+    f = _lib.Fasta(str(path), threads=3)
+    assert f.titles() == want_titles and f.sequences() == want_seqs
+    mine = digest(f)
+    f.close()
+    code = ("import sys, hashlib; sys.path.insert(0, %r)\n"
+            "from phamers_amd import _lib\n"
+            "f = _lib.Fasta(%r, threads=3)\n"
+            "h = hashlib.sha256()\n"
+            "[h.update(t.encode() + b'\\0' + s.encode() + b'\\1') for t, s in zip(f.titles(), f.sequences())]\n"
+            "h.update(str(f.lengths().tolist()).encode()); print(h.hexdigest())\n") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(path))
+    env = dict(os.environ, PHK_FASTA_NO_SIMD="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == mine
