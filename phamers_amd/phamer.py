@@ -193,7 +193,9 @@ class phamer_scorer(object):
         def write():
             tmp = path + ".part"
             try:
+                _lap("features cache: write begins")
                 fileIO.save_counts(counts, ids, tmp)
+                _lap("features cache: written")
                 os.replace(tmp, path)
             except BaseException as e:   # noqa: BLE001 -- handed to finish_io(), which raises it where the
                 th.error = e             # reference's sequential save_counts would have
