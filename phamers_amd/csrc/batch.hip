@@ -255,58 +255,6 @@ extern "C" int phk_batch_device_ptrs(const phk_batch *b, const uint32_t **d_coun
     return PHK_OK;
 }
 
-// Device -> host for the matrices a caller asks back (counts for the features cache, normalised rows): through the
-// context's two pinned staging buffers, copied on into the caller's array by host threads while the next chunk is on the
-// bus.  A plain hipMemcpy into pageable memory pins the destination's pages inside the runtime, and such an array then
-// costs ~0.07 s per GB to free (tools/diag/fasta_free_time.py measured the same for uploads) -- in the command line that
-// was the last thing the features-cache thread did before the run could end.
-static int copy_to_host_staged(phk_ctx *ctx, void *dst, const void *d_src, uint64_t bytes) {
-    if (bytes < (2 * BATCH_CHUNK)) {
-        PHK_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        PHK_HIP(hipStreamSynchronize(ctx->stream));
-        return PHK_OK;
-    }
-    if (!ctx->stage[0]) {
-        for (int i = 0; i < 2; ++i)
-            if (hipHostMalloc(&ctx->stage[i], BATCH_CHUNK, hipHostMallocDefault) != hipSuccess) {
-                phk_set_error("phk_batch: cannot allocate the pinned staging buffers");
-                return PHK_ERR_NOMEM;
-            }
-        ctx->stage_bytes = BATCH_CHUNK;
-    }
-    hipEvent_t landed[2] = {nullptr, nullptr};
-    int rc = PHK_OK;
-    auto body = [&]() -> int {
-        for (int i = 0; i < 2; ++i) PHK_HIP(hipEventCreateWithFlags(&landed[i], hipEventDisableTiming));
-        const uint64_t nchunks = phk_div_up(bytes, BATCH_CHUNK);
-        auto issue = [&](uint64_t c) -> int {
-            const uint64_t o = c * BATCH_CHUNK, m = bytes - o < BATCH_CHUNK ? bytes - o : BATCH_CHUNK;
-            PHK_HIP(hipMemcpyAsync(ctx->stage[c & 1], (const char *)d_src + o, m, hipMemcpyDeviceToHost, ctx->stream));
-            PHK_HIP(hipEventRecord(landed[c & 1], ctx->stream));
-            return PHK_OK;
-        };
-        PHK_TRY(issue(0));
-        for (uint64_t c = 0; c < nchunks; ++c) {
-            PHK_HIP(hipEventSynchronize(landed[c & 1]));
-            if (c + 1 < nchunks) PHK_TRY(issue(c + 1));   // (into the other buffer, which the host is done with)
-            const uint64_t o = c * BATCH_CHUNK, m = bytes - o < BATCH_CHUNK ? bytes - o : BATCH_CHUNK;
-            const char *src = (const char *)ctx->stage[c & 1];
-            char *out = (char *)dst + o;
-            const uint64_t piece = 1ull << 20;
-            phk_parallel_for(phk_div_up(m, piece), [&](uint64_t i) {
-                const uint64_t a = i * piece, e = m - a < piece ? m - a : piece;
-                memcpy(out + a, src + a, e);
-            });
-        }
-        return PHK_OK;
-    };
-    rc = body();
-    (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 2; ++i)
-        if (landed[i]) (void)hipEventDestroy(landed[i]);
-    return rc;
-}
-
 extern "C" int phk_batch_counts_i64(phk_ctx *ctx, const phk_batch *b, int64_t *counts) {
     PHK_ENTER(ctx, "phk_batch_counts_i64");
     PHK_REQUIRE(b && (b->n == 0 || counts), "phk_batch_counts_i64: NULL");
@@ -317,7 +265,7 @@ extern "C" int phk_batch_counts_i64(phk_ctx *ctx, const phk_batch *b, int64_t *c
     for (uint64_t r = 0; r < b->n; r += rows_per) {
         const uint64_t m = b->n - r < rows_per ? b->n - r : rows_per;
         PHK_TRY(phk_launch_widen(ctx, b->d_counts + r * b->D, m * b->D, (int64_t *)d_wide));
-        PHK_TRY(copy_to_host_staged(ctx, counts + r * b->D, d_wide, m * b->D * 8));
+        PHK_TRY(phk_copy_to_host(ctx, counts + r * b->D, d_wide, m * b->D * 8));
     }
     return PHK_OK;
 }
@@ -326,7 +274,7 @@ extern "C" int phk_batch_counts_u32(phk_ctx *ctx, const phk_batch *b, uint32_t *
     PHK_ENTER(ctx, "phk_batch_counts_u32");
     PHK_REQUIRE(b && (b->n == 0 || counts), "phk_batch_counts_u32: NULL");
     if (b->n == 0) return PHK_OK;
-    return copy_to_host_staged(ctx, counts, b->d_counts, b->n * b->D * sizeof(uint32_t));
+    return phk_copy_to_host(ctx, counts, b->d_counts, b->n * b->D * sizeof(uint32_t));
 }
 
 extern "C" int phk_batch_normalized(phk_ctx *ctx, const phk_batch *b, double *rows) {
@@ -338,7 +286,7 @@ extern "C" int phk_batch_normalized(phk_ctx *ctx, const phk_batch *b, double *ro
     for (uint64_t r = 0; r < b->n; r += rows_per) {
         const uint64_t m = b->n - r < rows_per ? b->n - r : rows_per;
         PHK_TRY(phk_launch_normalize_u32(ctx, b->d_counts + r * b->D, m, b->D, (double *)d_q));
-        PHK_TRY(copy_to_host_staged(ctx, rows + r * b->D, d_q, m * b->D * 8));
+        PHK_TRY(phk_copy_to_host(ctx, rows + r * b->D, d_q, m * b->D * 8));
     }
     return PHK_OK;
 }

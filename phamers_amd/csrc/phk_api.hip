@@ -140,6 +140,99 @@ extern "C" int phk_destroy(phk_ctx *ctx) {
     return PHK_OK;
 }
 
+// Device -> host for the matrices a caller asks back (counts for the features cache, normalised rows): through the
+// context's two pinned staging buffers, copied on into the caller's array by host threads while the next chunk is on the
+// bus.  A plain hipMemcpy into pageable memory pins the destination's pages inside the runtime, and such an array then
+// costs ~0.07 s per GB to free (tools/diag/fasta_free_time.py measured the same for uploads) -- in the command line that
+// was the last thing the features-cache thread did before the run could end.
+int phk_copy_to_host(phk_ctx *ctx, void *dst, const void *d_src, uint64_t bytes) {
+    if (bytes < (2 * PHK_STAGE_BYTES)) {
+        PHK_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+        return PHK_OK;
+    }
+    if (!ctx->stage[0]) {
+        for (int i = 0; i < 2; ++i)
+            if (hipHostMalloc(&ctx->stage[i], PHK_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+                phk_set_error("phk_batch: cannot allocate the pinned staging buffers");
+                return PHK_ERR_NOMEM;
+            }
+        ctx->stage_bytes = PHK_STAGE_BYTES;
+    }
+    hipEvent_t landed[2] = {nullptr, nullptr};
+    int rc = PHK_OK;
+    auto body = [&]() -> int {
+        for (int i = 0; i < 2; ++i) PHK_HIP(hipEventCreateWithFlags(&landed[i], hipEventDisableTiming));
+        const uint64_t nchunks = phk_div_up(bytes, PHK_STAGE_BYTES);
+        auto issue = [&](uint64_t c) -> int {
+            const uint64_t o = c * PHK_STAGE_BYTES, m = bytes - o < PHK_STAGE_BYTES ? bytes - o : PHK_STAGE_BYTES;
+            PHK_HIP(hipMemcpyAsync(ctx->stage[c & 1], (const char *)d_src + o, m, hipMemcpyDeviceToHost, ctx->stream));
+            PHK_HIP(hipEventRecord(landed[c & 1], ctx->stream));
+            return PHK_OK;
+        };
+        PHK_TRY(issue(0));
+        for (uint64_t c = 0; c < nchunks; ++c) {
+            PHK_HIP(hipEventSynchronize(landed[c & 1]));
+            if (c + 1 < nchunks) PHK_TRY(issue(c + 1));   // (into the other buffer, which the host is done with)
+            const uint64_t o = c * PHK_STAGE_BYTES, m = bytes - o < PHK_STAGE_BYTES ? bytes - o : PHK_STAGE_BYTES;
+            const char *src = (const char *)ctx->stage[c & 1];
+            char *out = (char *)dst + o;
+            const uint64_t piece = 1ull << 20;
+            phk_parallel_for(phk_div_up(m, piece), [&](uint64_t i) {
+                const uint64_t a = i * piece, e = m - a < piece ? m - a : piece;
+                memcpy(out + a, src + a, e);
+            });
+        }
+        return PHK_OK;
+    };
+    rc = body();
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; ++i)
+        if (landed[i]) (void)hipEventDestroy(landed[i]);
+    return rc;
+}
+
+
+// Host -> device, the same way round: host threads fill a staging buffer while the previous one is on the bus.
+int phk_copy_to_device(phk_ctx *ctx, void *d_dst, const void *src, uint64_t bytes) {
+    if (bytes < (2 * PHK_STAGE_BYTES)) {
+        PHK_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return PHK_OK;   // (stream ordered, as the callers' small copies always were)
+    }
+    if (!ctx->stage[0]) {
+        for (int i = 0; i < 2; ++i)
+            if (hipHostMalloc(&ctx->stage[i], PHK_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+                phk_set_error("phk_batch: cannot allocate the pinned staging buffers");
+                return PHK_ERR_NOMEM;
+            }
+        ctx->stage_bytes = PHK_STAGE_BYTES;
+    }
+    hipEvent_t gone[2] = {nullptr, nullptr};
+    auto body = [&]() -> int {
+        for (int i = 0; i < 2; ++i) PHK_HIP(hipEventCreateWithFlags(&gone[i], hipEventDisableTiming));
+        const uint64_t nchunks = phk_div_up(bytes, PHK_STAGE_BYTES);
+        for (uint64_t c = 0; c < nchunks; ++c) {
+            const uint64_t o = c * PHK_STAGE_BYTES, m = bytes - o < PHK_STAGE_BYTES ? bytes - o : PHK_STAGE_BYTES;
+            if (c >= 2) PHK_HIP(hipEventSynchronize(gone[c & 1]));   // the bus is done with this staging buffer
+            char *st = (char *)ctx->stage[c & 1];
+            const char *in = (const char *)src + o;
+            const uint64_t piece = 1ull << 20;
+            phk_parallel_for(phk_div_up(m, piece), [&](uint64_t i) {
+                const uint64_t a = i * piece, e = m - a < piece ? m - a : piece;
+                memcpy(st + a, in + a, e);
+            });
+            PHK_HIP(hipMemcpyAsync((char *)d_dst + o, st, m, hipMemcpyHostToDevice, ctx->stream));
+            PHK_HIP(hipEventRecord(gone[c & 1], ctx->stream));
+        }
+        return PHK_OK;
+    };
+    const int rc = body();
+    (void)hipStreamSynchronize(ctx->stream);   // (the staging buffers are free again when this returns)
+    for (int i = 0; i < 2; ++i)
+        if (gone[i]) (void)hipEventDestroy(gone[i]);
+    return rc;
+}
+
 extern "C" int phk_sync(phk_ctx *ctx) {
     PHK_ENTER(ctx, "phk_sync");
     PHK_HIP(hipStreamSynchronize(ctx->stream));
@@ -189,7 +282,7 @@ extern "C" int phk_memcpy_h2d(phk_ctx *ctx, void *dst, const void *src, uint64_t
     PHK_ENTER(ctx, "phk_memcpy_h2d");
     PHK_REQUIRE(bytes == 0 || (dst && src), "phk_memcpy_h2d: NULL");
     if (bytes) {
-        PHK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        PHK_TRY(phk_copy_to_device(ctx, dst, src, bytes));
         PHK_HIP(hipStreamSynchronize(ctx->stream));
     }
     return PHK_OK;
@@ -197,10 +290,7 @@ extern "C" int phk_memcpy_h2d(phk_ctx *ctx, void *dst, const void *src, uint64_t
 extern "C" int phk_memcpy_d2h(phk_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     PHK_ENTER(ctx, "phk_memcpy_d2h");
     PHK_REQUIRE(bytes == 0 || (dst && src), "phk_memcpy_d2h: NULL");
-    if (bytes) {
-        PHK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        PHK_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    if (bytes) PHK_TRY(phk_copy_to_host(ctx, dst, src, bytes));
     return PHK_OK;
 }
 
@@ -318,7 +408,7 @@ extern "C" int phk_count_ascii(phk_ctx *ctx, const char *bases, const uint64_t *
     PHK_TRY(phk_ws(ctx, WS_COUNTS, n * D * 4, &d_counts));
     PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &d_wide));
     PHK_TRY(phk_ws(ctx, WS_FLAGS, 64, &d_flags));
-    if (T) PHK_HIP(hipMemcpyAsync(d_ascii, bases, T, hipMemcpyHostToDevice, ctx->stream));
+    if (T) PHK_TRY(phk_copy_to_device(ctx, d_ascii, bases, T));
     PHK_HIP(hipMemcpyAsync(d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     PHK_TRY(phk_launch_pack(ctx, (const char *)d_ascii, T, sym, (uint32_t *)d_packed, (uint32_t *)d_mask,
                             (uint32_t *)d_flags));
@@ -328,9 +418,7 @@ extern "C" int phk_count_ascii(phk_ctx *ctx, const char *bases, const uint64_t *
     PHK_TRY(phk_launch_count(ctx, (const uint32_t *)d_packed, any_invalid ? (const uint32_t *)d_mask : nullptr,
                              T, (const uint64_t *)d_off, n, k, (uint32_t *)d_counts, nullptr));
     PHK_TRY(phk_launch_widen(ctx, (const uint32_t *)d_counts, n * D, (int64_t *)d_wide));
-    PHK_HIP(hipMemcpyAsync(counts, d_wide, n * D * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PHK_HIP(hipStreamSynchronize(ctx->stream));
-    return PHK_OK;
+    return phk_copy_to_host(ctx, counts, d_wide, n * D * 8);
 }
 
 extern "C" int phk_normalize_i64(phk_ctx *ctx, const int64_t *counts, uint64_t n, uint64_t D, double *out) {
@@ -340,11 +428,9 @@ extern "C" int phk_normalize_i64(phk_ctx *ctx, const int64_t *counts, uint64_t n
     void *d_in, *d_out;
     PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &d_in));
     PHK_TRY(phk_ws(ctx, WS_Q64, n * D * 8, &d_out));
-    PHK_HIP(hipMemcpyAsync(d_in, counts, n * D * 8, hipMemcpyHostToDevice, ctx->stream));
+    PHK_TRY(phk_copy_to_device(ctx, d_in, counts, n * D * 8));
     PHK_TRY(phk_launch_normalize_i64(ctx, (const int64_t *)d_in, n, D, (double *)d_out));
-    PHK_HIP(hipMemcpyAsync(out, d_out, n * D * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PHK_HIP(hipStreamSynchronize(ctx->stream));
-    return PHK_OK;
+    return phk_copy_to_host(ctx, out, d_out, n * D * 8);
 }
 
 extern "C" int phk_normalize_f64(phk_ctx *ctx, const double *rows, uint64_t n, uint64_t D, double *out) {
@@ -354,11 +440,9 @@ extern "C" int phk_normalize_f64(phk_ctx *ctx, const double *rows, uint64_t n, u
     void *d_in, *d_out;
     PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &d_in));
     PHK_TRY(phk_ws(ctx, WS_Q64, n * D * 8, &d_out));
-    PHK_HIP(hipMemcpyAsync(d_in, rows, n * D * 8, hipMemcpyHostToDevice, ctx->stream));
+    PHK_TRY(phk_copy_to_device(ctx, d_in, rows, n * D * 8));
     PHK_TRY(phk_launch_normalize_f64(ctx, (const double *)d_in, n, D, (double *)d_out));
-    PHK_HIP(hipMemcpyAsync(out, d_out, n * D * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PHK_HIP(hipStreamSynchronize(ctx->stream));
-    return PHK_OK;
+    return phk_copy_to_host(ctx, out, d_out, n * D * 8);
 }
 
 extern "C" int phk_permute_columns_i64(phk_ctx *ctx, const int64_t *rows, uint64_t n, uint64_t D, const uint32_t *perm,
@@ -371,12 +455,10 @@ extern "C" int phk_permute_columns_i64(phk_ctx *ctx, const int64_t *rows, uint64
     PHK_TRY(phk_ws(ctx, WS_WIDE, n * D * 8, &d_in));
     PHK_TRY(phk_ws(ctx, WS_Q64, n * D * 8, &d_out));
     PHK_TRY(phk_ws(ctx, WS_OFFSETS, D * 4, &d_perm));
-    PHK_HIP(hipMemcpyAsync(d_in, rows, n * D * 8, hipMemcpyHostToDevice, ctx->stream));
+    PHK_TRY(phk_copy_to_device(ctx, d_in, rows, n * D * 8));
     PHK_HIP(hipMemcpyAsync(d_perm, perm, D * 4, hipMemcpyHostToDevice, ctx->stream));
     PHK_TRY(phk_launch_permute_columns(ctx, (const int64_t *)d_in, n, D, (const uint32_t *)d_perm, (int64_t *)d_out));
-    PHK_HIP(hipMemcpyAsync(out, d_out, n * D * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PHK_HIP(hipStreamSynchronize(ctx->stream));
-    return PHK_OK;
+    return phk_copy_to_host(ctx, out, d_out, n * D * 8);
 }
 
 extern "C" int phk_score(phk_ctx *ctx, const phk_model *model, const double *Q, uint64_t N, int method,
@@ -390,7 +472,7 @@ extern "C" int phk_score(phk_ctx *ctx, const phk_model *model, const double *Q, 
     PHK_TRY(phk_ws(ctx, WS_WIDE, N * D * 8, &d_q));
     PHK_TRY(phk_ws(ctx, WS_COUNTS, N * 8, &d_s));
     PHK_TRY(phk_ws(ctx, WS_FLAGS, 64, &d_flags));
-    PHK_HIP(hipMemcpyAsync(d_q, Q, N * D * 8, hipMemcpyHostToDevice, ctx->stream));
+    PHK_TRY(phk_copy_to_device(ctx, d_q, Q, N * D * 8));
     PHK_TRY(phk_score_rows(ctx, model, (const double *)d_q, nullptr, nullptr, N, method, (double *)d_s,
                            (uint32_t *)d_flags));
     uint32_t nan_rows = 0;

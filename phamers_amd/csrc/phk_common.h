@@ -151,6 +151,14 @@ struct phk_ctx {
 
 int phk_ws(phk_ctx *ctx, int slot, uint64_t bytes, void **out);
 
+// Large transfers between caller arrays and the device go through the context's two pinned staging buffers (64 MB each),
+// host threads copying on one side while the bus works on the other: an array handed to hipMemcpy as it is has its pages
+// pinned inside the runtime and costs 0.05 - 0.1 s per GB to free afterwards (tools/diag/fasta_free_time.py).  Below 128 MB
+// a plain stream-ordered copy.  phk_copy_to_host returns with the data in place; phk_copy_to_device is stream ordered.
+#define PHK_STAGE_BYTES (64ull << 20)
+int phk_copy_to_host(phk_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
+int phk_copy_to_device(phk_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
+
 // kernel timing: PHK_LAUNCH(ctx, "name", kernel<<<...>>>(...)) brackets the launch with HIP
 // events on the context's stream when profiling is on.
 int phk_prof_begin(phk_ctx *ctx, const char *name, int *slot);
