@@ -516,3 +516,17 @@ def test_multi_chunk_upload_through_the_staging_buffers(ctx):
     sample = sorted(set(on_cuts + [0, n - 1] + rng.integers(0, n, size=60).tolist()))
     seqs = [bases[int(offsets[c]):int(offsets[c + 1])].tobytes().decode() for c in sample]
     assert np.array_equal(got[sample].astype(np.int64), oracle.count(seqs, k))
+
+
+@pytest.mark.gpu
+def test_large_copies_through_the_staging_buffers_round_trip(ctx):
+    """phk_memcpy_h2d / _d2h above 128 MB go through the two pinned 64 MB staging buffers in chunks (host threads on one
+    side, the bus on the other): sizes that end inside a chunk, on a chunk's last byte and one past it come back as sent."""
+    from phamers_amd import device
+    rng = np.random.default_rng(99)
+    chunk = 64 << 20
+    for nbytes in (2 * chunk, 2 * chunk + 1, 3 * chunk - 1, 4 * chunk + 12345):
+        src = rng.integers(0, 256, size=nbytes, dtype=np.uint8)
+        d = device.DeviceArray.from_host(ctx, src)
+        back = d.to_host()
+        assert back.shape == src.shape and np.array_equal(back, src), nbytes
