@@ -195,6 +195,12 @@ int phk_features_close(phk_features *f);
 int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n, int k,
                          const char *symbols4, phk_batch **out);
 int phk_batch_from_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *symbols4, phk_batch **out);
+/* FASTA file -> device-resident batch in one call (kmer.count_file as load_data uses it, scripts/kmer.py:114-140,
+ * scripts/phamer.py:131): the records are measured in one pass over the file and their sequences then written straight into
+ * the upload's pinned staging buffers, chunk by chunk, overlapped with the bus and the packer -- no host copy of the
+ * sequences exists.  *index_out: titles, ids and lengths as phk_fasta_index gives them (free with phk_fasta_free). */
+int phk_batch_from_fasta_file(phk_ctx *ctx, const char *path, int k, const char *symbols4, int threads,
+                              phk_fasta **index_out, phk_batch **out);
 /* A batch from a count matrix on the host -- the features cache read back by fileIO.read_feature_file
  * (scripts/phamer.py:132-136, scripts/fileIO.py:134-166): counts[n][D] int64 row-major, D = 4^k.  The run then scores from
  * the same resident integers as one that counted the FASTA file (the reference normalises the cached counts to float rows

@@ -55,6 +55,7 @@ SIGNATURES = {
     "phk_batch_from_ascii": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, c_int, c_char_p, P(c_void_p)]),
     "phk_batch_from_fasta": (c_int, [c_void_p, c_void_p, c_int, c_char_p, P(c_void_p)]),
     "phk_batch_from_counts": (c_int, [c_void_p, c_void_p, c_u64, c_u64, P(c_void_p)]),
+    "phk_batch_from_fasta_file": (c_int, [c_void_p, c_char_p, c_int, c_char_p, c_int, P(c_void_p), P(c_void_p)]),
     "phk_batch_shape": (c_int, [c_void_p, P(c_u64), P(c_u64), P(c_u64), P(c_int)]),
     "phk_batch_device_ptrs": (c_int, [c_void_p, P(c_void_p), P(c_void_p)]),
     "phk_batch_counts_i64": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -424,6 +425,9 @@ class Fasta(object):
         if rc == PHK_ERR_IO:
             raise IOError(self.lib.phk_last_error().decode("utf-8", "replace"))
         check(rc)
+        self._attach(h)
+
+    def _attach(self, h):
         self.handle = h
         n, t, tb = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
         check(self.lib.phk_fasta_shape(h, ctypes.byref(n), ctypes.byref(t), ctypes.byref(tb)))
@@ -431,6 +435,22 @@ class Fasta(object):
         b, o, ti, to = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
         check(self.lib.phk_fasta_data(h, ctypes.byref(b), ctypes.byref(o), ctypes.byref(ti), ctypes.byref(to)))
         self._bases, self._offsets, self._titles, self._title_off = b.value, o.value, ti.value, to.value
+
+    @classmethod
+    def count_file(cls, ctx, path, kmer_length, symbols=b"ATGC", threads=0):
+        """(index, batch) of a FASTA file in one call (phk_batch_from_fasta_file): the sequences are parsed straight into the
+        upload's staging buffers -- no host copy of them exists; ``index`` is a Fasta as ``index_only=True`` gives it (titles,
+        ids, lengths).  IOError when the file cannot be read."""
+        self = cls.__new__(cls)
+        self.lib = load()
+        h, hb = ctypes.c_void_p(), ctypes.c_void_p()
+        rc = self.lib.phk_batch_from_fasta_file(ctx.handle, os.fsencode(path), int(kmer_length), symbols, int(threads),
+                                                ctypes.byref(h), ctypes.byref(hb))
+        if rc == PHK_ERR_IO:
+            raise IOError(self.lib.phk_last_error().decode("utf-8", "replace"))
+        check(rc)
+        self._attach(h)
+        return self, Batch(ctx, hb)
 
     def offsets(self):
         return np.ctypeslib.as_array(ctypes.cast(self._offsets, ctypes.POINTER(ctypes.c_uint64)),

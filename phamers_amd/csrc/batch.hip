@@ -8,6 +8,7 @@
 // back: the scores, and the counts once for the features cache.
 #include <string.h>
 
+#include <functional>
 #include <vector>
 
 #include "phk_common.h"
@@ -32,9 +33,12 @@ static void batch_release(phk_batch *b) {
     delete b;
 }
 
-extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n, int k,
-                                    const char *symbols4, phk_batch **out) {
-    PHK_ENTER(ctx, "phk_batch_from_ascii");
+// The sequence bytes of a batch -> device, packed, counted.  `bases` (when the caller holds them in one buffer) or `fill`
+// (when they are produced chunk by chunk: phk_batch_from_fasta_file parses the file straight into the staging buffers)
+// supplies the bytes: fill(o, len, dst) writes bases [o, o + len) of the concatenated sequences to dst; it is called for
+// consecutive chunks in increasing order, from this thread.
+int phk_batch_build(phk_ctx *ctx, const char *bases, const std::function<void(uint64_t, uint64_t, char *)> *fill,
+                    const uint64_t *offsets, uint64_t n, int k, const char *symbols4, phk_batch **out) {
     PHK_REQUIRE(out, "phk_batch_from_ascii: NULL out");
     PHK_REQUIRE(k >= 1, "phk_batch_from_ascii: k must be >= 1 (got %d)", k);
     if (k > PHK_MAX_K) {
@@ -50,7 +54,7 @@ extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint6
             PHK_REQUIRE(offsets[c + 1] >= offsets[c], "phk_batch_from_ascii: offsets must be non-decreasing");
     }
     const uint64_t T = n ? offsets[n] : 0;
-    PHK_REQUIRE(T == 0 || bases, "phk_batch_from_ascii: NULL bases");
+    PHK_REQUIRE(T == 0 || bases || fill, "phk_batch_from_ascii: NULL bases");
     phk_batch *b = new phk_batch();
     b->n = n;
     b->k = k;
@@ -89,7 +93,7 @@ extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint6
             // it either (the runtime then pins the pages itself): a 5 GB buffer the device has once been given costs
             // 0.26-0.6 s to free afterwards instead of 0.05 (measured, tools/diag/fasta_free_time.py), with every HIP call
             // of the process waiting meanwhile.
-            const bool staged = nchunks > 1;
+            const bool staged = nchunks > 1 || !bases;
             if (staged && !ctx->stage[0]) {
                 for (int i = 0; i < 2; ++i)
                     if (hipHostMalloc(&ctx->stage[i], BATCH_CHUNK, hipHostMallocDefault) != hipSuccess) {
@@ -107,15 +111,19 @@ extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint6
                 const int s = (int)(c & 1);
                 const uint64_t o = c * BATCH_CHUNK, len = T - o < BATCH_CHUNK ? T - o : BATCH_CHUNK;
                 if (c >= 2) PHK_HIP(hipStreamWaitEvent(copy_stream, packed_ev[s], 0));   // the packer is done with this buffer
-                const char *src = bases + o;
+                const char *src = bases ? bases + o : nullptr;
                 if (staged) {
                     if (c >= 2) PHK_HIP(hipEventSynchronize(copied[s]));   // the bus is done with this staging buffer
                     char *dst = (char *)ctx->stage[s];
-                    const uint64_t piece = 1ull << 20;
-                    phk_parallel_for(phk_div_up(len, piece), [&](uint64_t i) {
-                        const uint64_t a = i * piece, m = len - a < piece ? len - a : piece;
-                        memcpy(dst + a, src + a, m);
-                    });
+                    if (fill) {
+                        (*fill)(o, len, dst);
+                    } else {
+                        const uint64_t piece = 1ull << 20;
+                        phk_parallel_for(phk_div_up(len, piece), [&](uint64_t i) {
+                            const uint64_t a = i * piece, m = len - a < piece ? len - a : piece;
+                            memcpy(dst + a, src + a, m);
+                        });
+                    }
                     src = dst;
                 }
                 PHK_HIP(hipMemcpyAsync(d_chunk[s], src, len, hipMemcpyHostToDevice, copy_stream));
@@ -151,6 +159,12 @@ extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint6
     }
     *out = b;
     return PHK_OK;
+}
+
+extern "C" int phk_batch_from_ascii(phk_ctx *ctx, const char *bases, const uint64_t *offsets, uint64_t n, int k,
+                                    const char *symbols4, phk_batch **out) {
+    PHK_ENTER(ctx, "phk_batch_from_ascii");
+    return phk_batch_build(ctx, bases, nullptr, offsets, n, k, symbols4, out);
 }
 
 __global__ void phk_rowsum_kernel(const uint32_t *__restrict__ counts, uint64_t N, uint64_t D, uint32_t *__restrict__ out);

@@ -22,6 +22,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <functional>
 #include <memory>
 #include <string>
 #include <thread>
@@ -405,7 +406,8 @@ static size_t next_record_start(const char *b, size_t n, size_t from) {
     return n;
 }
 
-static int parse_fasta_bytes(const char *b, size_t n, int threads, phk_fasta **out, bool with_bases = true);
+static int parse_fasta_bytes(const char *b, size_t n, int threads, phk_fasta **out, bool with_bases = true,
+                             std::vector<size_t> *starts_out = nullptr);
 
 extern "C" int phk_fasta_read(const char *path, int threads, phk_fasta **out) {
     PHK_REQUIRE(path && out, "phk_fasta_read: NULL argument");
@@ -452,7 +454,8 @@ extern "C" int phk_fasta_read_part(const char *path, uint32_t part, uint32_t n_p
     return parse_fasta_bytes(fb.data + lo, hi > lo ? hi - lo : 0, threads, out);
 }
 
-static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fasta **out, const bool with_bases) {
+static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fasta **out, const bool with_bases,
+                             std::vector<size_t> *starts_out) {
     if (threads < 1) threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
     // One pass finds the records and measures them: the file is cut into one slice per thread (a slice begins at the
     // first line start at or after its cut); each thread lists the '>' line starts inside its slice with the title length
@@ -576,6 +579,7 @@ static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fas
             at += chunk[t].size();
         }
     }
+    if (starts_out) starts_out->swap(starts);
     *out = f;
     return PHK_OK;
 }
@@ -616,6 +620,115 @@ extern "C" int phk_fasta_data(const phk_fasta *f, const char **bases, const uint
     if (offsets) *offsets = f->offsets.data();
     if (titles) *titles = f->titles.data();
     if (title_offsets) *title_offsets = f->title_off.data();
+    return PHK_OK;
+}
+
+// Sequence characters of one record from file position p (a line start, or inside a line when an earlier call stopped
+// there) up to `room` of them: trailing white space of a line, ' ' and '\r' dropped as write_record does.  Returns the number
+// written; p is where the next call continues.
+static size_t write_sequence_part(const char *b, size_t &p, size_t end, char *out, size_t room) {
+    size_t done = 0;
+    while (p < end && done < room) {
+        size_t fs;
+        const size_t eol = scan_line(b, p, end, &fs);
+        size_t l_end = eol;
+        while (l_end > p && is_space(b[l_end - 1])) --l_end;
+        if (fs >= l_end) {
+            const size_t len = l_end - p, take = len < room - done ? len : room - done;
+            memcpy(out + done, b + p, take);
+            done += take;
+            if (take < len) {   // the chunk ends inside this line
+                p += take;
+                return done;
+            }
+        } else {
+            size_t i = p;
+            for (; i < l_end && done < room; ++i)
+                if (b[i] != ' ' && b[i] != '\r') out[done++] = b[i];
+            if (i < l_end) {
+                // (stopped inside the line: what is left may be nothing but characters that are dropped -- the next call finds out)
+                p = i;
+                return done;
+            }
+        }
+        p = eol < end ? eol + 1 : end;
+    }
+    return done;
+}
+
+// FASTA file -> device-resident batch in one go (kmer.count_file, scripts/kmer.py:114-140, as the command line's load_data
+// uses it, scripts/phamer.py:131): the scan pass measures the records, then the copy pass writes the sequences STRAIGHT INTO
+// the pinned staging buffers of the upload, chunk by chunk, while the previous chunk is on the bus and the packer works on
+// the one before -- no 5 GB host buffer between the parser and the device, no second copy, nothing to free afterwards.
+// *index_out is the file's index (titles, ids, lengths; no sequences: as phk_fasta_index), *out the batch.
+extern "C" int phk_batch_from_fasta_file(phk_ctx *ctx, const char *path, int k, const char *symbols4, int threads,
+                                         phk_fasta **index_out, phk_batch **out) {
+    PHK_REQUIRE(ctx && path && index_out && out, "phk_batch_from_fasta_file: NULL argument");
+    FileBytes fb;
+    PHK_TRY(open_fasta_bytes(path, fb));
+    std::vector<size_t> starts;
+    phk_fasta *f = nullptr;
+    PHK_TRY(parse_fasta_bytes(fb.data, fb.size, threads, &f, false, &starts));
+    const char *b = fb.data;
+    const size_t n = fb.size, nrec = starts.size();
+    const std::vector<uint64_t> &off = f->offsets;
+    auto rec_end = [&](size_t r) { return r + 1 < nrec ? starts[r + 1] : n; };
+    auto seq_begin = [&](size_t r) {   // the line after the title line
+        const size_t p = starts[r] + 1, e = rec_end(r);
+        const char *nl = (const char *)memchr(b + p, '\n', e - p);
+        return nl ? (size_t)(nl - b) + 1 : e;
+    };
+    size_t cut_rec = 0, cut_pos = 0;   // a record the previous chunk's end cut: where its copy continues
+    bool cut = false;
+    std::function<void(uint64_t, uint64_t, char *)> fill = [&](uint64_t o, uint64_t len, char *dst) {
+        const uint64_t end = o + len;
+        // r: the record that holds base o (the last one that begins at or before it: empty records before it are passed)
+        size_t r = (size_t)(std::upper_bound(off.begin(), off.end(), o) - off.begin()) - 1;
+        if (off[r] < o) {   // it began in an earlier chunk
+            const uint64_t upto = off[r + 1] < end ? off[r + 1] : end;
+            size_t p = cut && cut_rec == r ? cut_pos : seq_begin(r);
+            if (!(cut && cut_rec == r)) {   // (cannot happen: chunks come in order -- but then skip, slowly, from the record's start)
+                std::vector<char> skip(1 << 16);
+                for (uint64_t left = o - off[r]; left;) {
+                    const size_t got = write_sequence_part(b, p, rec_end(r), skip.data(), left < skip.size() ? (size_t)left : skip.size());
+                    if (!got) break;
+                    left -= got;
+                }
+            }
+            write_sequence_part(b, p, rec_end(r), dst, (size_t)(upto - o));
+            if (off[r + 1] > end) {   // and goes on beyond this one
+                cut = true; cut_rec = r; cut_pos = p;
+                return;
+            }
+            cut = false;
+            ++r;
+        }
+        // records that begin in [o, end): r .. rl - 1; the last one may be cut by the chunk's end
+        size_t rl = (size_t)(std::lower_bound(off.begin(), off.end(), end) - off.begin());
+        if (rl > nrec) rl = nrec;
+        size_t full_hi = rl;
+        if (rl > r && off[rl] > end) full_hi = rl - 1;
+        if (full_hi > r)
+            phk_parallel_for(full_hi - r, [&](uint64_t i) {
+                const size_t x = r + (size_t)i;
+                size_t p = seq_begin(x);
+                write_sequence_part(b, p, rec_end(x), dst + (off[x] - o), (size_t)(off[x + 1] - off[x]));
+            });
+        if (full_hi < rl) {
+            const size_t x = rl - 1;
+            size_t p = seq_begin(x);
+            write_sequence_part(b, p, rec_end(x), dst + (off[x] - o), (size_t)(end - off[x]));
+            cut = true; cut_rec = x; cut_pos = p;
+        }
+    };
+    phk_batch *batch = nullptr;
+    const int rc = phk_batch_build(ctx, nullptr, &fill, off.data(), nrec, k, symbols4, &batch);
+    if (rc != PHK_OK) {
+        delete f;
+        return rc;
+    }
+    *index_out = f;
+    *out = batch;
     return PHK_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string>
 #include <thread>
+#include <functional>
 #include <vector>
 
 #include "../../include/phamers_hip.h"
@@ -155,6 +156,10 @@ int phk_ws(phk_ctx *ctx, int slot, uint64_t bytes, void **out);
 // host threads copying on one side while the bus works on the other: an array handed to hipMemcpy as it is has its pages
 // pinned inside the runtime and costs 0.05 - 0.1 s per GB to free afterwards (tools/diag/fasta_free_time.py).  Below 128 MB
 // a plain stream-ordered copy.  phk_copy_to_host returns with the data in place; phk_copy_to_device is stream ordered.
+struct phk_batch;
+// (batch.hip) the sequence bytes of a batch -> device, packed and counted; see there
+int phk_batch_build(phk_ctx *ctx, const char *bases, const std::function<void(uint64_t, uint64_t, char *)> *fill,
+                    const uint64_t *offsets, uint64_t n, int k, const char *symbols4, phk_batch **out);
 #define PHK_STAGE_BYTES (64ull << 20)
 int phk_copy_to_host(phk_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
 int phk_copy_to_device(phk_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);

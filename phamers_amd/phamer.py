@@ -161,22 +161,20 @@ class phamer_scorer(object):
 
     def _count_fasta_on_device(self):
         ctx = _lib.get_context()
-        fasta = _lib.Fasta(self.fasta_file)
-        _lap("FASTA parsed")
+        self._drop_batch()
+        self._rows = None
+        # the file is parsed straight into the upload's staging buffers (phk_batch_from_fasta_file): no host copy of the
+        # sequences, nothing to free afterwards; the k-means thread starts beside it
         self._start_pending_centroids()
+        fasta, self._batch = _lib.Fasta.count_file(ctx, self.fasta_file, self.kmer_length)
+        _lap("FASTA parsed, uploaded, counted")
         try:
             self.data_ids = fasta.phamers_ids()
             lengths = fasta.lengths()
-            self._drop_batch()
-            self._rows = None
-            self._batch = _lib.Batch.from_fasta(ctx, fasta, self.kmer_length)
-            _lap("uploaded + counted")
             counts = self._batch.counts_u32()
             _lap("counts on the host")
         finally:
-            # (on a helper thread, and only now: unmapping the file's 5 GB beside the page faults of the count matrix's
-            # first touch made that download six times slower)
-            fasta.close(wait=False)
+            fasta.close()
         self.features_file = "{base}_features.csv".format(base=os.path.splitext(self.fasta_file)[0])
         ids, path = self.data_ids, self.features_file
         if self._defer_io:

@@ -429,3 +429,44 @@ def test_fasta_line_scanner_simd_and_plain_agree(tmp_path):
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip() == mine
+
+
+@pytest.mark.gpu
+def test_fasta_file_straight_into_the_upload_equals_read_then_upload(tmp_path):
+    """phk_batch_from_fasta_file (the command line's cold path: sequences parsed straight into the 64 MB staging buffers of
+    the upload) against phk_fasta_read + phk_batch_from_fasta on a 150 MB file: records of every size -- some longer than
+    a staging buffer, so that they are cut by one or two chunk ends --, lines with blanks and CR inside (a chunk end inside
+    such a line), empty records, non-symbols.  Counts, ids, titles and lengths must be identical."""
+    from phamers_amd import _lib
+    rng = np.random.default_rng(31)
+    alphabet = np.frombuffer(b"ATGCN", dtype=np.uint8)
+    path = tmp_path / "big.fasta"
+    sizes = [70 << 20, 0, 5000, 300, 66 << 20, 1, 12 << 20] + [int(x) for x in rng.integers(0, 20000, size=300)]
+    with open(path, "w") as f:
+        f.write("text before the first record\n")
+        for c, n in enumerate(sizes):
+            seq = alphabet[rng.integers(0, 5 if c % 3 == 0 else 4, size=n)].tobytes().decode()
+            w = 70 if n > (1 << 20) else int(rng.integers(1, 200))
+            f.write(">contig_%d_length_%d_ID_%d some words\n" % (c, n, c))
+            if c % 4 == 1 or n > (60 << 20):       # blanks and CR inside / at the end of lines
+                body = "\n".join(seq[i:i + w // 2] + " " + seq[i + w // 2:i + w] + "\r" for i in range(0, n, w))
+            else:
+                body = "\n".join(seq[i:i + w] for i in range(0, n, w))
+            f.write(body + ("\n\n" if c % 5 == 0 else "\n"))
+    ctx = _lib.get_context()
+    fa = _lib.Fasta(str(path))
+    want_batch = _lib.Batch.from_fasta(ctx, fa, 4)
+    want = want_batch.counts_u32()
+    want_batch.close()
+    idx, batch = _lib.Fasta.count_file(ctx, str(path), 4)
+    try:
+        assert batch.n == fa.n_records == len(sizes) and batch.total_bases == fa.total_bases == sum(sizes)
+        assert np.array_equal(batch.counts_u32(), want)
+        assert idx.titles() == fa.titles() and np.array_equal(idx.lengths(), fa.lengths())
+        assert idx.phamers_ids().tolist() == fa.phamers_ids().tolist()
+    finally:
+        batch.close()
+        idx.close()
+        fa.close()
+    with pytest.raises(IOError):
+        _lib.Fasta.count_file(ctx, str(tmp_path / "missing.fasta"), 4)
