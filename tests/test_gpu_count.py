@@ -530,3 +530,34 @@ def test_large_copies_through_the_staging_buffers_round_trip(ctx):
         d = device.DeviceArray.from_host(ctx, src)
         back = d.to_host()
         assert back.shape == src.shape and np.array_equal(back, src), nbytes
+
+
+@pytest.mark.gpu
+def test_staged_copies_from_two_host_threads_at_once():
+    """Two host threads, each with a context (and so staging buffers) of its own, copy 200 MB to the device and back five
+    times each at the same time; every round trip is exact.  (A persistent pool for the copies' host-side loops was measured
+    against threads started per chunk: no difference, not kept.)"""
+    import threading
+    from phamers_amd import _lib, device
+    errors = []
+
+    def work(seed):
+        try:
+            ctx = _lib.Context(_lib.default_device())
+            rng = np.random.default_rng(seed)
+            src = rng.integers(0, 256, size=(200 << 20) + seed, dtype=np.uint8)
+            for _ in range(5):
+                d = device.DeviceArray.from_host(ctx, src)
+                if not np.array_equal(d.to_host(), src):
+                    errors.append("mismatch in thread %d" % seed)
+                del d
+            ctx.close()
+        except Exception as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+    threads = [threading.Thread(target=work, args=(s,)) for s in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a copy thread hangs"
+    assert not errors, errors
