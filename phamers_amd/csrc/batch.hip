@@ -24,7 +24,7 @@ struct phk_batch {
     std::vector<uint64_t> len;      // [n] bases per contig (host): what a selection's total_bases is summed from
 };
 
-#define BATCH_CHUNK (64ull << 20)    // bases per upload chunk (a multiple of 32: chunks pack independently)
+#define BATCH_CHUNK PHK_STAGE_BYTES   // bases per upload chunk = one staging buffer (a multiple of 32: chunks pack independently)
 
 static void batch_release(phk_batch *b) {
     if (!b) return;
@@ -39,6 +39,7 @@ static void batch_release(phk_batch *b) {
 // consecutive chunks in increasing order, from this thread.
 int phk_batch_build(phk_ctx *ctx, const char *bases, const std::function<void(uint64_t, uint64_t, char *)> *fill,
                     const uint64_t *offsets, uint64_t n, int k, const char *symbols4, phk_batch **out) {
+    PHK_ENTER(ctx, "phk_batch_build");   // (every caller's device work starts here: phk_batch_from_ascii, _from_fasta, _from_fasta_file)
     PHK_REQUIRE(out, "phk_batch_from_ascii: NULL out");
     PHK_REQUIRE(k >= 1, "phk_batch_from_ascii: k must be >= 1 (got %d)", k);
     if (k > PHK_MAX_K) {
@@ -94,14 +95,7 @@ int phk_batch_build(phk_ctx *ctx, const char *bases, const std::function<void(ui
             // 0.26-0.6 s to free afterwards instead of 0.05 (measured, tools/diag/fasta_free_time.py), with every HIP call
             // of the process waiting meanwhile.
             const bool staged = nchunks > 1 || !bases;
-            if (staged && !ctx->stage[0]) {
-                for (int i = 0; i < 2; ++i)
-                    if (hipHostMalloc(&ctx->stage[i], BATCH_CHUNK, hipHostMallocDefault) != hipSuccess) {
-                        phk_set_error("phk_batch: cannot allocate the pinned staging buffers");
-                        return PHK_ERR_NOMEM;
-                    }
-                ctx->stage_bytes = BATCH_CHUNK;
-            }
+            if (staged) PHK_TRY(phk_stage_ensure(ctx));
             PHK_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
             for (int i = 0; i < 2; ++i) {
                 PHK_HIP(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming));
@@ -199,14 +193,7 @@ extern "C" int phk_batch_from_counts(phk_ctx *ctx, const int64_t *counts, uint64
             phk_set_error("phk_batch: cannot allocate %llu x %llu counts on the device", (unsigned long long)n, (unsigned long long)D);
             return PHK_ERR_NOMEM;
         }
-        if (!ctx->stage[0]) {
-            for (int i = 0; i < 2; ++i)
-                if (hipHostMalloc(&ctx->stage[i], BATCH_CHUNK, hipHostMallocDefault) != hipSuccess) {
-                    phk_set_error("phk_batch: cannot allocate the pinned staging buffers");
-                    return PHK_ERR_NOMEM;
-                }
-            ctx->stage_bytes = BATCH_CHUNK;
-        }
+        PHK_TRY(phk_stage_ensure(ctx));
         for (int i = 0; i < 2; ++i) PHK_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
         const uint64_t total = n * D, per = BATCH_CHUNK / sizeof(uint32_t), nchunks = phk_div_up(total, per);
         std::vector<uint8_t> bad(nchunks, 0);

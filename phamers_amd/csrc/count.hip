@@ -1395,6 +1395,11 @@ int phk_count_init_device(phk_ctx *ctx) {
 int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t T,
                      const uint64_t *d_offsets, uint64_t n, int k, uint32_t *d_counts,
                      uint32_t *d_nwin, uint64_t mean_bases) {
+    // phk_count_score_dev may have armed the int8 operand hand-over (PhkPrep8): it stays armed for the scorer ONLY if the one
+    // kernel that writes the fragments is launched below -- every other way out of this function (tiny batches, empty batches,
+    // knobs, the wave-per-contig kernel) leaves it disarmed, and the scorer prepares its operand itself
+    const bool prep8_asked = ctx->prep8.armed;
+    ctx->prep8.armed = false;
     PHK_REQUIRE(k >= 1, "phk_count: k must be >= 1 (got %d)", k);
     if (k > PHK_MAX_K) {
         phk_set_error("phk_count: k=%d is above PHK_MAX_K=%d (4^k bins no longer fit LDS)", k, PHK_MAX_K);
@@ -1484,7 +1489,7 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         // At k = 5 without a mask it also writes the scorer's int8 operand when phk_count_score_dev armed it for this matrix.
         if (lanes_knob != '1' && lanes_knob != '2') {
             PhkPrep8 &pp = ctx->prep8;
-            const bool prep = k == 5 && !d_mask && pp.armed && pp.counts == d_counts && pp.n == n && pp.D == 1024;
+            const bool prep = k == 5 && !d_mask && prep8_asked && pp.counts == d_counts && pp.n == n && pp.D == 1024;
             uint4 *frag8 = prep ? (uint4 *)pp.frag : nullptr;
             uint32_t *big8 = prep ? pp.big : nullptr;
             pp.armed = prep;   // (stays armed only if the kernel that prepares it is launched)

@@ -140,6 +140,28 @@ extern "C" int phk_destroy(phk_ctx *ctx) {
     return PHK_OK;
 }
 
+int phk_stage_ensure(phk_ctx *ctx) {
+    if (ctx->stage[0] && ctx->stage[1] && ctx->stage_bytes == PHK_STAGE_BYTES) return PHK_OK;
+    for (void *&p : ctx->stage) {   // (a size other than the one every user assumes cannot occur; were it to, start over)
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+    }
+    ctx->stage_bytes = 0;
+    for (int i = 0; i < 2; ++i)
+        if (hipHostMalloc(&ctx->stage[i], PHK_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->stage[i] = nullptr;
+            if (i == 1) {
+                (void)hipHostFree(ctx->stage[0]);
+                ctx->stage[0] = nullptr;
+            }
+            phk_set_error("cannot allocate the pinned staging buffers (2 x %llu bytes)", (unsigned long long)PHK_STAGE_BYTES);
+            return PHK_ERR_NOMEM;
+        }
+    ctx->stage_bytes = PHK_STAGE_BYTES;
+    return PHK_OK;
+}
+
 // Device -> host for the matrices a caller asks back (counts for the features cache, normalised rows): through the
 // context's two pinned staging buffers, copied on into the caller's array by host threads while the next chunk is on the
 // bus.  A plain hipMemcpy into pageable memory pins the destination's pages inside the runtime, and such an array then
@@ -151,14 +173,7 @@ int phk_copy_to_host(phk_ctx *ctx, void *dst, const void *d_src, uint64_t bytes)
         PHK_HIP(hipStreamSynchronize(ctx->stream));
         return PHK_OK;
     }
-    if (!ctx->stage[0]) {
-        for (int i = 0; i < 2; ++i)
-            if (hipHostMalloc(&ctx->stage[i], PHK_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
-                phk_set_error("phk_batch: cannot allocate the pinned staging buffers");
-                return PHK_ERR_NOMEM;
-            }
-        ctx->stage_bytes = PHK_STAGE_BYTES;
-    }
+    PHK_TRY(phk_stage_ensure(ctx));
     hipEvent_t landed[2] = {nullptr, nullptr};
     int rc = PHK_OK;
     auto body = [&]() -> int {
@@ -199,14 +214,7 @@ int phk_copy_to_device(phk_ctx *ctx, void *d_dst, const void *src, uint64_t byte
         PHK_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
         return PHK_OK;   // (stream ordered, as the callers' small copies always were)
     }
-    if (!ctx->stage[0]) {
-        for (int i = 0; i < 2; ++i)
-            if (hipHostMalloc(&ctx->stage[i], PHK_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
-                phk_set_error("phk_batch: cannot allocate the pinned staging buffers");
-                return PHK_ERR_NOMEM;
-            }
-        ctx->stage_bytes = PHK_STAGE_BYTES;
-    }
+    PHK_TRY(phk_stage_ensure(ctx));
     hipEvent_t gone[2] = {nullptr, nullptr};
     auto body = [&]() -> int {
         for (int i = 0; i < 2; ++i) PHK_HIP(hipEventCreateWithFlags(&gone[i], hipEventDisableTiming));

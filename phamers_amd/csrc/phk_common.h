@@ -161,6 +161,9 @@ struct phk_batch;
 int phk_batch_build(phk_ctx *ctx, const char *bases, const std::function<void(uint64_t, uint64_t, char *)> *fill,
                     const uint64_t *offsets, uint64_t n, int k, const char *symbols4, phk_batch **out);
 #define PHK_STAGE_BYTES (64ull << 20)
+// the context's two pinned staging buffers of PHK_STAGE_BYTES each, allocated on first use by whichever transfer needs them;
+// a partial failure frees what it got (the next call starts from nothing) and returns PHK_ERR_NOMEM
+int phk_stage_ensure(phk_ctx *ctx);
 int phk_copy_to_host(phk_ctx *ctx, void *dst, const void *d_src, uint64_t bytes);
 int phk_copy_to_device(phk_ctx *ctx, void *d_dst, const void *src, uint64_t bytes);
 

@@ -295,9 +295,12 @@ class phamer_scorer(object):
         exception) to this Future BEFORE it closes that context -- freeing the context's buffers waits for the device,
         0.2 s beside the main thread's upload."""
         _lap("k-means: begin")
-        ctx = _lib.Context(_lib.default_device()) if deliver is not None else None
+        ctx = None
         try:
             try:
+                # (inside the guarded block: a context that cannot be created -- no memory for its streams, a HIP error --
+                # must reach the Future as an exception, or the main thread waits for this result for ever)
+                ctx = _lib.Context(_lib.default_device()) if deliver is not None else None
                 out = []
                 for d in (pos, neg):
                     out.append(learning.get_centroids(d, learning.kmeans(d, k_clusters, _ctx=ctx)))

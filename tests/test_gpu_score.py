@@ -1220,6 +1220,73 @@ def test_count_score_k5_with_the_operand_prepared_by_the_count_kernel():
 
 
 @pytest.mark.gpu
+def test_count_score_k5_tiny_and_empty_batches_do_not_take_a_stale_operand():
+    """phk_count_score_dev at k = 5 arms the count kernel's int8 operand hand-over (PhkPrep8).  Batches that never reach the
+    kernel that writes the fragments -- a few short contigs (at most 1024 bases in all: the wave-per-contig kernel counts
+    them), a batch of empty contigs only -- must leave it disarmed: the scorer then prepares the operand itself.  (Round 4
+    left it armed there and the sweep multiplied whatever the workspace held.)  A large batch goes FIRST so that the
+    workspace holds another batch's fragments when the tiny ones are scored.  Counts and scores must equal counting and
+    scoring in two separate calls, bit for bit; zero-count rows are NaN and flagged either way."""
+    from phamers_amd import _lib, device
+    ctx = _lib.get_context()
+    k, D, n_ref = 5, 1024, 600
+    rng = np.random.default_rng(77)
+    ref = rng.gamma(4.0, 1.0, (n_ref, D))
+    ref[: n_ref // 2] *= 1.0 + 0.3 * np.sin(np.arange(D) * 0.37)
+    ref /= ref.sum(axis=1, keepdims=True)
+    pos, neg = ref[: n_ref // 2], ref[n_ref // 2:]
+    cpos = np.stack([pos[i::8].mean(axis=0) for i in range(8)])
+    cneg = np.stack([neg[i::8].mean(axis=0) for i in range(8)])
+    model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
+    cases = [("large first", [9000] * 300 + [10000] * 100),
+             ("one short contig", [700]),
+             ("three short contigs", [300, 5, 600]),
+             ("short with empties", [0, 400, 0, 4, 500]),
+             ("1024 bases exactly", [512, 512]),
+             ("all empty", [0, 0, 0]),
+             ("just above the bypass", [600, 500])]
+    for name, lens in cases:
+        n = len(lens)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lens)
+        T = int(offs[-1])
+        d_off = device.DeviceArray.from_host(ctx, offs)
+        d_packed = device.DeviceArray(ctx, device.packed_words(max(T, 1)), np.uint32)
+        d_mask = device.DeviceArray(ctx, device.mask_words(max(T, 1)), np.uint32)
+        if T:
+            device.synth_ragged(ctx, 23, 0, n, d_off, T, d_packed, d_mask, gc_spread_permille=300, invalid_ppm=0)
+        d_counts = device.DeviceArray.from_host(ctx, np.full((n, D), 0xABCD, np.uint32))
+        d_scores = device.DeviceArray.from_host(ctx, np.full(n, 7.0))
+        d_status = device.DeviceArray.from_host(ctx, np.zeros(1, np.uint32))
+        device.count_score(ctx, model, d_packed, None, T, d_off, n, k, "combo", d_counts, d_scores, d_status)
+        fused_counts, fused, fused_status = d_counts.to_host(), d_scores.to_host(), int(d_status.to_host()[0])
+        d_counts2 = device.DeviceArray.from_host(ctx, np.full((n, D), 0x1234, np.uint32))
+        d_scores2 = device.DeviceArray.from_host(ctx, np.full(n, 9.0))
+        d_status2 = device.DeviceArray.from_host(ctx, np.zeros(1, np.uint32))
+        device.count(ctx, d_packed, None, T, d_off, n, k, d_counts2)
+        device.score_counts(ctx, model, d_counts2, n, "combo", d_scores2, d_status2)
+        two_counts, two = d_counts2.to_host(), d_scores2.to_host()
+        assert np.array_equal(fused_counts, two_counts), name
+        want_rowsum = np.array([max(0, x - k + 1) for x in lens])
+        assert np.array_equal(fused_counts.sum(axis=1), want_rowsum), name
+        assert np.array_equal(np.isnan(fused), np.isnan(two)), (name, fused, two)
+        assert np.array_equal(np.isnan(fused), want_rowsum == 0), (name, fused)
+        ok = ~np.isnan(two)
+        assert np.array_equal(fused[ok], two[ok]), (name, fused, two)
+        assert fused_status == int(d_status2.to_host()[0]) == int((want_rowsum == 0).sum()), name
+        # and against the float64 brute-force path of the same library (independent of the int8 operand)
+        ctx.set_option("force_exact", "1")
+        try:
+            d_scores3 = device.DeviceArray.from_host(ctx, np.full(n, 5.0))
+            device.score_counts(ctx, model, d_counts2, n, "combo", d_scores3, None)
+            ex = d_scores3.to_host()
+        finally:
+            ctx.set_option("force_exact", "0")
+        assert np.allclose(fused[ok], ex[ok], rtol=1e-6, atol=0), (name, fused, ex)
+    model.close()
+
+
+@pytest.mark.gpu
 def test_reference_kmeans_labels_from_the_device_lloyd():
     """learning.kmeans (scripts/learning.py:131-146) without the host fit: scikit-learn's seeding on the host, its Lloyd
     iteration on the device (phk_kmeans_lloyd) -- labels equal to oracle.kmeans_lloyd_seeded from the same seeds and to
