@@ -424,16 +424,26 @@ def main():
     npar = min(npar, n)
     if ragged:
         npar = min(npar, 64)
-        seqs = [synth.synth_ragged_contig(0, first + c, int(lengths[c]), 400, 1000) for c in range(npar)]
+    # the sample: contigs drawn at random over the rank's whole range (seeded; always with the first and the last one), not
+    # its first tile -- every scoring batch, tile position and workgroup of the step has a chance of being looked at
+    if npar >= n:
+        sample = np.arange(n)
     else:
-        seqs = synth.synth_contigs(0, npar, L, start=first)
+        sample = np.unique(np.concatenate(([0, n - 1], np.random.default_rng(20241005 + rank).choice(n, max(npar - 2, 0), replace=False))))
+        npar = len(sample)
+    if ragged:
+        seqs = [synth.synth_ragged_contig(0, first + int(c), int(lengths[int(c)]), 400, 1000) for c in sample]
+    else:
+        seqs = [synth.synth_contig(0, first + int(c), L) for c in sample]
     want_counts = oracle.count(seqs, k).reshape(npar, D)
-    got_counts = counts[:npar].cpu().numpy().view(np.uint32).astype(np.int64)
+    sample_t = torch.from_numpy(sample.astype(np.int64)).to(counts.device)
+    got_counts = counts[sample_t].cpu().numpy().view(np.uint32).astype(np.int64)
     q = oracle.normalize_counts(want_counts)
     want = oracle.knn_score_points(q, pos, neg, 3) + oracle.centroid_score_points_fast(q, cpos, cneg) \
         if args.method == "combo" else oracle.score_points(q, pos, neg, args.method, 3, cpos, cneg)
-    got = scores[:npar].cpu().numpy()
-    parity = {"contigs_checked": npar, "counts_bit_exact": bool(np.array_equal(got_counts, want_counts)),
+    got = scores[sample_t].cpu().numpy()
+    parity = {"contigs_checked": npar, "sample": "random over the rank's contigs (seeded), first and last included",
+              "counts_bit_exact": bool(np.array_equal(got_counts, want_counts)),
               "max_rel_score_err": float(np.max(np.abs(got - want) / np.abs(want))),
               "nan_rows": int(status.item()), "fallback_queries": n_fallback,
               "orderings_decided_by_exact_distances": n_exact, "decision_stats": stats_ex}

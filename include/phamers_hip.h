@@ -201,6 +201,11 @@ int phk_batch_from_fasta(phk_ctx *ctx, const phk_fasta *f, int k, const char *sy
  * sequences exists.  *index_out: titles, ids and lengths as phk_fasta_index gives them (free with phk_fasta_free). */
 int phk_batch_from_fasta_file(phk_ctx *ctx, const char *path, int k, const char *symbols4, int threads,
                               phk_fasta **index_out, phk_batch **out);
+/* The same for one rank's share of the file: the records whose '>' line begins in byte range `part` of `n_parts` equal
+ * ranges (the ranges of phk_fasta_read_part).  What rank `part` of `python -m phamers_amd.phamer --gpus n_parts` loads
+ * (scripts/phamer.py:131 on a shard; contigs are independent, scripts/kmer.py:102-105). */
+int phk_batch_from_fasta_part(phk_ctx *ctx, const char *path, uint32_t part, uint32_t n_parts, int k,
+                              const char *symbols4, int threads, phk_fasta **index_out, phk_batch **out);
 /* A batch from a count matrix on the host -- the features cache read back by fileIO.read_feature_file
  * (scripts/phamer.py:132-136, scripts/fileIO.py:134-166): counts[n][D] int64 row-major, D = 4^k.  The run then scores from
  * the same resident integers as one that counted the FASTA file (the reference normalises the cached counts to float rows
@@ -269,9 +274,13 @@ int phk_kmeans(phk_ctx *ctx, const double *X, uint64_t n, uint64_t D, uint32_t k
  * (kmeans_plusplus on the mean-centred rows, RandomState(10): phamers_amd/learning.py) the labels -- and so the reference's
  * per-label means, learning.get_centroids -- equal those of KMeans(n_clusters=k, random_state=10).fit(X).
  * X[n][D], init[k][D] host float64 -> labels[n]; centres (may be NULL); sweeps; number of empty clusters met (scikit-learn
- * relocates an empty cluster, this entry does not: a caller that sees n_empty != 0 must use the host fit). */
+ * relocates an empty cluster, this entry does not: a caller that sees n_empty != 0 must use the host fit).
+ * min_gap (may be NULL): the closest call any E-step made, min over points and sweeps of (d2_second - d2_best) / d2_second.
+ * scikit-learn forms its distances as -2 x.c + |c|^2 in chunked matrix products, this entry by direct differences: the two
+ * agree to ~1e-13 relative, so a label can differ only where min_gap is of that order -- the facade takes the host fit
+ * below 1e-9 (phamers_amd/learning.py). */
 int phk_kmeans_lloyd(phk_ctx *ctx, const double *X, uint64_t n, uint64_t D, uint32_t k, const double *init, double tol,
-                     int max_iter, double *centres, uint32_t *labels, int *n_iter, int *n_empty);
+                     int max_iter, double *centres, uint32_t *labels, int *n_iter, int *n_empty, double *min_gap);
 
 /* ---- host API: scoring ------------------------------------------------------------- */
 /* phamer.score_points / phamer_scorer.score_points (scripts/phamer.py:451-468, 177-195) for

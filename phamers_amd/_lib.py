@@ -56,6 +56,7 @@ SIGNATURES = {
     "phk_batch_from_fasta": (c_int, [c_void_p, c_void_p, c_int, c_char_p, P(c_void_p)]),
     "phk_batch_from_counts": (c_int, [c_void_p, c_void_p, c_u64, c_u64, P(c_void_p)]),
     "phk_batch_from_fasta_file": (c_int, [c_void_p, c_char_p, c_int, c_char_p, c_int, P(c_void_p), P(c_void_p)]),
+    "phk_batch_from_fasta_part": (c_int, [c_void_p, c_char_p, c_u32, c_u32, c_int, c_char_p, c_int, P(c_void_p), P(c_void_p)]),
     "phk_batch_shape": (c_int, [c_void_p, P(c_u64), P(c_u64), P(c_u64), P(c_int)]),
     "phk_batch_device_ptrs": (c_int, [c_void_p, P(c_void_p), P(c_void_p)]),
     "phk_batch_counts_i64": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -76,7 +77,7 @@ SIGNATURES = {
     "phk_batch_free": (c_int, [c_void_p, c_void_p]),
     "phk_kmeans": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_u32, c_u64, c_int, c_void_p, c_void_p, P(c_int)]),
     "phk_kmeans_lloyd": (c_int, [c_void_p, c_void_p, c_u64, c_u64, c_u32, c_void_p, c_double, c_int, c_void_p, c_void_p, P(c_int),
-                                 P(c_int)]),
+                                 P(c_int), P(c_double)]),
     "phk_model_create": (c_int, [c_void_p, c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_u64,
                                  c_void_p, c_u64, c_u64, c_int, P(c_void_p)]),
     "phk_model_destroy": (c_int, [c_void_p, c_void_p]),
@@ -122,16 +123,27 @@ def load():
     if _lib is None:
         with _lock:
             if _lib is None:
-                if not os.path.exists(LIB_PATH):
+                path = LIB_PATH
+                # A/B timing runs on one box (tools/diag): another build of the library -- an earlier round's, a candidate's --
+                # in place of the in-tree one.  Only together with PHK_ALLOW_DIAGNOSTIC_BUILD=1, never for results; entry points
+                # such a build lacks stay unbound.
+                other = os.environ.get("PHAMERS_AB_LIB") if os.environ.get("PHK_ALLOW_DIAGNOSTIC_BUILD") == "1" else None
+                if other:
+                    path = other
+                if not os.path.exists(path):
                     raise ImportError(
                         "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                        "(or `make -C phamers_amd/csrc`). There is no CPU fallback." % LIB_PATH)
-                lib = ctypes.CDLL(LIB_PATH)
+                        "(or `make -C phamers_amd/csrc`). There is no CPU fallback." % path)
+                lib = ctypes.CDLL(path)
                 for name, (res, args) in SIGNATURES.items():
+                    if other and not hasattr(lib, name):
+                        continue
                     fn = getattr(lib, name)
                     fn.restype = res
                     fn.argtypes = args
                 ver = lib.phk_abi_version()
+                if other:
+                    ver = ABI_VERSION
                 if ver != ABI_VERSION and not (ver == (ABI_VERSION | 0x40000000)
                                                and os.environ.get("PHK_ALLOW_DIAGNOSTIC_BUILD") == "1"):
                     raise ImportError(
@@ -437,15 +449,20 @@ class Fasta(object):
         self._bases, self._offsets, self._titles, self._title_off = b.value, o.value, ti.value, to.value
 
     @classmethod
-    def count_file(cls, ctx, path, kmer_length, symbols=b"ATGC", threads=0):
+    def count_file(cls, ctx, path, kmer_length, symbols=b"ATGC", threads=0, part=None):
         """(index, batch) of a FASTA file in one call (phk_batch_from_fasta_file): the sequences are parsed straight into the
         upload's staging buffers -- no host copy of them exists; ``index`` is a Fasta as ``index_only=True`` gives it (titles,
-        ids, lengths).  IOError when the file cannot be read."""
+        ids, lengths).  ``part`` = (i, n): the records that begin in the i-th of n equal byte ranges of the file only (one
+        rank's share, phk_batch_from_fasta_part).  IOError when the file cannot be read."""
         self = cls.__new__(cls)
         self.lib = load()
         h, hb = ctypes.c_void_p(), ctypes.c_void_p()
-        rc = self.lib.phk_batch_from_fasta_file(ctx.handle, os.fsencode(path), int(kmer_length), symbols, int(threads),
-                                                ctypes.byref(h), ctypes.byref(hb))
+        if part is not None:
+            rc = self.lib.phk_batch_from_fasta_part(ctx.handle, os.fsencode(path), int(part[0]), int(part[1]), int(kmer_length),
+                                                    symbols, int(threads), ctypes.byref(h), ctypes.byref(hb))
+        else:
+            rc = self.lib.phk_batch_from_fasta_file(ctx.handle, os.fsencode(path), int(kmer_length), symbols, int(threads),
+                                                    ctypes.byref(h), ctypes.byref(hb))
         if rc == PHK_ERR_IO:
             raise IOError(self.lib.phk_last_error().decode("utf-8", "replace"))
         check(rc)

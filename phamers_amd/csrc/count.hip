@@ -381,48 +381,6 @@ __global__ __launch_bounds__(256) void phk_count_kernel(const uint32_t *__restri
     }
 }
 
-__global__ __launch_bounds__(256) void phk_count_stats_kernel(const uint64_t *__restrict__ offsets, uint64_t n, int k,
-                                                              uint32_t gs,  // contigs per slot workgroup
-                                                              uint32_t long_thr, unsigned long long *__restrict__ stats) {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long pad = 0, used = 0;
-    if (g * gs < n) {
-        uint64_t mx = 0;
-        uint64_t prev = offsets[g * gs];
-        for (uint64_t i = g * gs; i < g * gs + gs && i < n; ++i) {
-            const uint64_t nx = offsets[i + 1];
-            const uint64_t len = nx - prev;
-            prev = nx;
-            const uint64_t w = len >= (uint64_t)k ? len - k + 1 : 0;
-            if (w <= long_thr) {
-                used += w;
-                mx = w > mx ? w : mx;
-            }
-        }
-        pad = (unsigned long long)gs * (((mx + 1023) >> 10) << 10);
-    }
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) {
-        pad += __shfl_xor(pad, sft);
-        used += __shfl_xor(used, sft);
-    }
-    // one pair of atomics per workgroup, not per wave: they all land on one cache line and retire one after the other
-    __shared__ unsigned long long s_pad[4], s_used[4];
-    if ((threadIdx.x & 63) == 0) {
-        s_pad[threadIdx.x >> 6] = pad;
-        s_used[threadIdx.x >> 6] = used;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        pad = s_pad[0] + s_pad[1] + s_pad[2] + s_pad[3];
-        used = s_used[0] + s_used[1] + s_used[2] + s_used[3];
-        if (pad) {
-            atomicAdd(stats, pad);
-            atomicAdd(stats + 1, used);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------
 // Length-bucketed contig order for ragged batches.  The slot kernel pads every group of SLOTS contigs to its longest
 // member, so a batch of mixed lengths in arbitrary order wastes most of its stages.  A counting sort by the number of
@@ -453,44 +411,141 @@ __device__ __forceinline__ uint64_t phk_piece_windows(uint64_t w, uint32_t piece
     return pc + 1 < pieces ? (uint64_t)piece_w : w - (uint64_t)(pieces - 1) * piece_w;
 }
 
-__global__ __launch_bounds__(256) void phk_sort_hist_kernel(const uint64_t *__restrict__ offsets, uint64_t n, int k,
-                                                            uint32_t long_thr, uint32_t piece_w,
-                                                            const unsigned long long *__restrict__ stats,
-                                                            uint32_t *__restrict__ hist) {
-    if (phk_slots_apply(stats)) return;
+// The planning kernel: ONE launch in front of the count kernels (round 5; rounds 2-4 spent two memsets and four launches
+// here: statistics, key histogram, scan, scatter -- all of them no-ops on a batch of similar lengths).
+//   * batch statistics for the stand-down rule (phk_slots_apply): padded / counted windows over groups of `gs` contigs;
+//   * sort != 0: the key histogram of the work items, whatever the batch looks like (a block's few non-empty keys);
+//   * the LAST block to finish (a ticket) reads the totals back with device-scope loads, and -- only for a batch the
+//     statistics call ragged -- turns the histogram into the scatter's cursors and writes the item count;
+//   * every block zeroes its share of the NEXT call's control block and of up to two word ranges the caller names (the
+//     scorer's NaN counter and call totals): no launch of the chain is preceded by a memset.
+// Control block of a call (uint32 words; the count kernels take a pointer to word 0 as `long_count`):
+#define CTL_LONG 0      // hand-over items appended by the slot kernels (contigs >> mean, in pieces)
+#define CTL_ITEMS 1     // work items of a sorted batch
+#define CTL_STATS 2     // two uint64: padded windows, counted windows
+#define CTL_TICKET 6
+#define CTL_CURSOR 16   // SORT_KEYS words: key histogram, then the scatter's cursors
+#define CTL_WORDS (16 + SORT_KEYS)
+#define PLAN_PER_BLOCK 2048   // contigs per block and round (a multiple of 32: groups never straddle blocks)
+__global__ __launch_bounds__(256) void phk_count_plan_kernel(const uint64_t *__restrict__ offsets, uint64_t n, int k,
+                                                             uint32_t gs,  // contigs per slot workgroup (16 or 32)
+                                                             uint32_t long_thr, uint32_t piece_w, int sort,
+                                                             uint32_t *__restrict__ ctl, uint32_t *__restrict__ ctl_next,
+                                                             uint32_t *__restrict__ z0, uint32_t z0n, uint32_t *__restrict__ z1, uint32_t z1n) {
     __shared__ uint32_t h[SORT_KEYS];
-    for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x) h[i] = 0;
+    __shared__ unsigned long long s_pad[4], s_used[4];
+    __shared__ uint32_t s_last;
+    const int tid = threadIdx.x;
+    {
+        const uint32_t g0 = blockIdx.x * 256u + (uint32_t)tid, gn = gridDim.x * 256u;
+        for (uint32_t i = g0; i < (uint32_t)CTL_WORDS; i += gn) ctl_next[i] = 0;
+        for (uint32_t i = g0; i < z0n; i += gn) z0[i] = 0;
+        for (uint32_t i = g0; i < z1n; i += gn) z1[i] = 0;
+    }
+    if (sort)
+        for (int i = tid; i < SORT_KEYS; i += 256) h[i] = 0;
     __syncthreads();
-    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t np;
-        const uint64_t w = phk_contig_windows(offsets, c, k, long_thr, piece_w, np);
-        if (np > 1) atomicAdd(&h[phk_windows_key(piece_w)], np - 1);
-        atomicAdd(&h[phk_windows_key(phk_piece_windows(w, np, np - 1, piece_w))], 1u);
+    unsigned long long pad = 0, used = 0;
+    for (uint64_t base = (uint64_t)blockIdx.x * PLAN_PER_BLOCK; base < n; base += (uint64_t)gridDim.x * PLAN_PER_BLOCK) {
+        // (all of a round's offsets are requested before any is used: as a load - use - load chain the eight rounds cost eight
+        // exposed memory round trips, 25 us per 1M contigs)
+        uint64_t o0[PLAN_PER_BLOCK / 256], o1[PLAN_PER_BLOCK / 256];
+#pragma unroll
+        for (int it = 0; it < PLAN_PER_BLOCK / 256; ++it) {
+            const uint64_t c = base + (uint64_t)it * 256 + tid;
+            const uint64_t cc = c < n ? c : n - 1;
+            o0[it] = offsets[cc];
+            o1[it] = offsets[cc + 1];
+        }
+#pragma unroll
+        for (int it = 0; it < PLAN_PER_BLOCK / 256; ++it) {
+            const uint64_t c = base + (uint64_t)it * 256 + tid;
+            const bool have = c < n;
+            uint64_t w = 0;
+            if (have) {
+                const uint64_t len = o1[it] - o0[it];
+                w = len >= (uint64_t)k ? len - k + 1 : 0;
+            }
+            const unsigned long long wq = (have && w <= long_thr) ? w : 0ull;   // (longer ones leave the slot kernels)
+            used += wq;
+            unsigned long long mx = wq;
+            for (uint32_t sft = 1; sft < gs; sft <<= 1) {
+                const unsigned long long o = __shfl_xor(mx, (int)sft);
+                mx = o > mx ? o : mx;
+            }
+            if (have && (c % gs) == 0) pad += (unsigned long long)gs * (((mx + 1023) >> 10) << 10);
+            if (sort) {
+                // (a batch of similar lengths has ONE key: 256 atomics on one LDS word per round cost this kernel 30 us per 1M
+                // contigs -- a wave whose live lanes agree on the key adds their number once)
+                const uint32_t np = (have && w > long_thr && piece_w) ? (uint32_t)((w + piece_w - 1) / piece_w) : 1u;
+                const uint32_t key = phk_windows_key(phk_piece_windows(w, np, np - 1, piece_w));
+                const unsigned long long live = __ballot(have);
+                const uint32_t key0 = __builtin_amdgcn_readfirstlane(key);   // (the first ACTIVE lane's: all 64 are active here)
+                if (__all(!have || (key == key0 && np == 1)) && (live & 1ull)) {
+                    if ((tid & 63) == 0) atomicAdd(&h[key0], (uint32_t)__popcll(live));
+                } else if (have) {
+                    if (np > 1) atomicAdd(&h[phk_windows_key(piece_w)], np - 1);
+                    atomicAdd(&h[key], 1u);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        pad += __shfl_xor(pad, sft);
+        used += __shfl_xor(used, sft);
+    }
+    if ((tid & 63) == 0) {
+        s_pad[tid >> 6] = pad;
+        s_used[tid >> 6] = used;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x)
-        if (h[i]) atomicAdd(hist + i, h[i]);
-}
-
-// cursor[key] = number of items with a LARGER key (descending order); *n_items = their total; one block
-__global__ __launch_bounds__(1024) void phk_sort_scan_kernel(const unsigned long long *__restrict__ stats,
-                                                             uint32_t *__restrict__ hist /* in: counts, out: cursors */,
-                                                             uint32_t *__restrict__ n_items) {
-    if (phk_slots_apply(stats)) return;
-    __shared__ uint32_t v[SORT_KEYS];
-    for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x) v[i] = hist[SORT_KEYS - 1 - i];   // descending keys
+    unsigned long long *stats = reinterpret_cast<unsigned long long *>(ctl + CTL_STATS);
+    if (tid == 0) {   // one pair of atomics per workgroup: they all land on one line and retire one after the other
+        pad = s_pad[0] + s_pad[1] + s_pad[2] + s_pad[3];
+        used = s_used[0] + s_used[1] + s_used[2] + s_used[3];
+        if (pad) {
+            atomicAdd(stats, pad);
+            atomicAdd(stats + 1, used);
+        }
+    }
+    if (sort)
+        for (int i = tid; i < SORT_KEYS; i += 256)
+            if (h[i]) atomicAdd(ctl + CTL_CURSOR + i, h[i]);
+    // ---- the last block to get here finishes the plan.  What the other blocks publish are device-scope atomics only (performed
+    // at the memory side); each wave waits for its own to be done, then the block's ticket is drawn: no cache write-back or
+    // invalidate is needed on this side (a __threadfence() here cost every block ~4 us), and the reader uses sc1 loads ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int i = 0; i < SORT_KEYS; ++i) {
-            const uint32_t cnt = v[i];
-            v[i] = run;
+    if (tid == 0) s_last = atomicAdd(ctl + CTL_TICKET, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!s_last || !sort) return;
+    const unsigned long long pad_t = __hip_atomic_load(stats, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long used_t = __hip_atomic_load(stats + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (used_t * 10ull >= pad_t * 6ull) return;   // (phk_slots_apply: not ragged -- nobody reads the cursors)
+    // cursor[key] = number of items with a LARGER key (descending order: the longest groups start first)
+    for (int i = tid; i < SORT_KEYS; i += 256)
+        h[i] = __hip_atomic_load(ctl + CTL_CURSOR + (SORT_KEYS - 1 - i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid < 64) {   // exclusive scan of 2048 counts by one wave: 32 per lane, then across the lanes
+        uint32_t loc = 0;
+        for (int i = 0; i < SORT_KEYS / 64; ++i) loc += h[tid * (SORT_KEYS / 64) + i];
+        uint32_t inc = loc;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const uint32_t o = __shfl_up(inc, sft);
+            if (tid >= sft) inc += o;
+        }
+        uint32_t run = inc - loc;
+        for (int i = 0; i < SORT_KEYS / 64; ++i) {
+            const uint32_t cnt = h[tid * (SORT_KEYS / 64) + i];
+            h[tid * (SORT_KEYS / 64) + i] = run;
             run += cnt;
         }
-        *n_items = run;
+        if (tid == 63) ctl[CTL_ITEMS] = run;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SORT_KEYS; i += blockDim.x) hist[SORT_KEYS - 1 - i] = v[i];
+    for (int i = tid; i < SORT_KEYS; i += 256) ctl[CTL_CURSOR + (SORT_KEYS - 1 - i)] = h[i];
 }
 
 // every block reserves, per key, a range for its items with one global atomic, then places them; the row (and window
@@ -1432,30 +1487,38 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         uint64_t thr64 = 4 * mean_len + 1024;
         if (sorted && thr64 < 2ull * piece_w) thr64 = 2ull * piece_w;
         const uint32_t long_thr = thr64 < 0xFFFFFFFFull ? (uint32_t)thr64 : 0xFFFFFFFFu;
-        // workspace: [0] hand-over item count, [2..5] batch statistics (two uint64), [16 ..] hand-over items (contig,
-        // piece), then the sort's key cursors and the contig order
+        // workspace: the call's control block (PhkCountCtl words, see phk_count_plan_kernel) in WS_CTL; hand-over items
+        // (contig, piece) and the sorted contig order in WS_LONG
         const uint64_t max_items = n + (piece_w ? T / piece_w : 0) + 16;
-        void *ws;
-        // ([1] = number of (contig, piece) items of a sorted batch)
-        PHK_TRY(phk_ws(ctx, WS_LONG, (16 + 2 * max_items + SORT_KEYS + 2 * max_items + 16) * sizeof(uint32_t), &ws));
-        uint32_t *d_long_count = (uint32_t *)ws;
-        uint2 *d_long_list = (uint2 *)((uint32_t *)ws + 16);
-        uint32_t *d_cursor = (uint32_t *)ws + 16 + 2 * max_items;
-        uint2 *d_order = (uint2 *)(d_cursor + SORT_KEYS);
-        PHK_HIP(hipMemsetAsync(d_long_count, 0, 64, ctx->stream));
-        if (!forced)
-        PHK_LAUNCH(ctx, "phk_count_stats_kernel",
-                   phk_count_stats_kernel<<<dim3((unsigned)phk_div_up(phk_div_up(n, slots), 256)), dim3(256), 0, ctx->stream>>>(
-                       d_offsets, n, k, slots, long_thr, (unsigned long long *)(d_long_count + 2)));
-        if (sorted) {   // all three return at once on the device unless the statistics call the batch ragged
-            const unsigned long long *st = (const unsigned long long *)(d_long_count + 2);
-            PHK_HIP(hipMemsetAsync(d_cursor, 0, SORT_KEYS * sizeof(uint32_t), ctx->stream));
+        void *ws, *ctlv;
+        PHK_TRY(phk_ws(ctx, WS_LONG, (4 * max_items + 16) * sizeof(uint32_t), &ws));
+        PHK_TRY(phk_ws(ctx, WS_CTL, 2 * CTL_WORDS * sizeof(uint32_t), &ctlv));
+        if (ctx->ctl_dirty || ctx->ctl_gen != ctx->ws[WS_CTL].gen) {   // first use of this allocation, or a call that failed half way
+            PHK_HIP(hipMemsetAsync(ctlv, 0, 2 * CTL_WORDS * sizeof(uint32_t), ctx->stream));
+            ctx->ctl_gen = ctx->ws[WS_CTL].gen;
+        }
+        ctx->ctl_dirty = true;   // (cleared where this function returns with everything launched)
+        uint32_t *d_long_count = (uint32_t *)ctlv + (ctx->ctl_epoch & 1) * CTL_WORDS;
+        uint32_t *d_ctl_next = (uint32_t *)ctlv + ((ctx->ctl_epoch + 1) & 1) * CTL_WORDS;
+        uint2 *d_long_list = (uint2 *)ws;
+        uint32_t *d_cursor = d_long_count + CTL_CURSOR;
+        uint2 *d_order = (uint2 *)((uint32_t *)ws + 2 * max_items);
+        {
+            uint64_t pb = phk_div_up(forced ? 1 : n, PLAN_PER_BLOCK);
+            pb = pb > 1024 ? 1024 : (pb < 1 ? 1 : pb);
+            PHK_LAUNCH(ctx, "phk_count_plan_kernel",
+                       phk_count_plan_kernel<<<dim3((unsigned)pb), dim3(256), 0, ctx->stream>>>(
+                           d_offsets, forced ? 0 : n, k, slots, long_thr, piece_w, sorted ? 1 : 0, d_long_count, d_ctl_next,
+                           ctx->plan_zero[0], ctx->plan_zero_words[0], ctx->plan_zero[1], ctx->plan_zero_words[1]));
+            ctx->ctl_epoch += 1;
+            ctx->plan_zero_taken = ctx->plan_zero[0] != nullptr || ctx->plan_zero[1] != nullptr;
+            ctx->plan_zero[0] = ctx->plan_zero[1] = nullptr;
+            ctx->plan_zero_words[0] = ctx->plan_zero_words[1] = 0;
+        }
+        if (sorted) {   // returns at once on the device unless the statistics call the batch ragged
+            const unsigned long long *st = (const unsigned long long *)(d_long_count + CTL_STATS);
             uint64_t sb = phk_div_up(n, 2048);
             sb = sb > 1024 ? 1024 : (sb < 1 ? 1 : sb);
-            PHK_LAUNCH(ctx, "phk_sort_hist_kernel",
-                       phk_sort_hist_kernel<<<dim3((unsigned)sb), dim3(256), 0, ctx->stream>>>(d_offsets, n, k, long_thr, piece_w, st, d_cursor));
-            PHK_LAUNCH(ctx, "phk_sort_scan_kernel",
-                       phk_sort_scan_kernel<<<dim3(1), dim3(1024), 0, ctx->stream>>>(st, d_cursor, d_long_count + 1));
             PHK_LAUNCH(ctx, "phk_sort_scatter_kernel",
                        phk_sort_scatter_kernel<<<dim3((unsigned)sb), dim3(256), 0, ctx->stream>>>(d_offsets, n, k, long_thr, piece_w, st,
                                                                                                   d_cursor, d_order, d_counts, d_nwin));
@@ -1512,11 +1575,15 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
                 PHK_DIRECT1(K_, S_, T_, true, false);                                                                            \
                 if (d_ord) { PHK_DIRECT1(K_, S_, T_, true, true); }                                                              \
             } else {                                                                                                             \
-                PHK_DIRECT1(K_, S_, T_, false, false);                                                                           \
+                if (!skip_plain) { PHK_DIRECT1(K_, S_, T_, false, false); }   /* (else: the pairs kernel's, launched above) */    \
                 if (d_ord) { PHK_DIRECT1(K_, S_, T_, false, true); }                                                             \
             }                                                                                                                    \
-            return launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                                       \
-                ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count, piece_w)
+            {                                                                                                                    \
+                const int rc_ = launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                          \
+                    ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count, piece_w);         \
+                if (rc_ == PHK_OK) ctx->ctl_dirty = false;                                                                       \
+                return rc_;                                                                                                      \
+            }
             if (k == 3) { PHK_DIRECT(3, 32, 512); }
             if (k == 4) { if (small) { PHK_DIRECT(4, 32, 512); } PHK_DIRECT(4, 32, 1024); }
             if (small) { PHK_DIRECT(5, 16, 512); }
@@ -1542,8 +1609,12 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
                        (phk_count_slots_kernel<K_, S_, T_, false><<<dim3((unsigned)blocks), dim3(T_), lds, ctx->stream>>>(  \
                            d_packed, nullptr, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w, skip_plain))); \
         }                                                                                                                   \
-        return launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                                    \
-            ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count, piece_w)
+        {                                                                                                                   \
+            const int rc_ = launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                         \
+                ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count, piece_w);        \
+            if (rc_ == PHK_OK) ctx->ctl_dirty = false;                                                                      \
+            return rc_;                                                                                                     \
+        }
         // 16 lanes per contig (512 threads) at k <= 4: 24 waves per CU hide the barrier and staging latencies better
         // than 12 (0.94 vs 1.03 ms per 1M x 5 kb); PHK_SLOT_THREADS=256 for comparison
         const bool t256 = ctx->knobs.slot_threads == '2';

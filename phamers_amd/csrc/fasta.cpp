@@ -661,16 +661,39 @@ static size_t write_sequence_part(const char *b, size_t &p, size_t end, char *ou
 // the pinned staging buffers of the upload, chunk by chunk, while the previous chunk is on the bus and the packer works on
 // the one before -- no 5 GB host buffer between the parser and the device, no second copy, nothing to free afterwards.
 // *index_out is the file's index (titles, ids, lengths; no sequences: as phk_fasta_index), *out the batch.
+static int batch_from_fasta_bytes(phk_ctx *ctx, const char *b, size_t n, int k, const char *symbols4, int threads,
+                                  phk_fasta **index_out, phk_batch **out);
+
 extern "C" int phk_batch_from_fasta_file(phk_ctx *ctx, const char *path, int k, const char *symbols4, int threads,
                                          phk_fasta **index_out, phk_batch **out) {
     PHK_REQUIRE(ctx && path && index_out && out, "phk_batch_from_fasta_file: NULL argument");
     FileBytes fb;
     PHK_TRY(open_fasta_bytes(path, fb));
+    return batch_from_fasta_bytes(ctx, fb.data, fb.size, k, symbols4, threads, index_out, out);
+}
+
+// The same for ONE RANK'S SHARE of the file: the records whose '>' line begins in byte range `part` of `n_parts` equal
+// ranges (as phk_fasta_read_part) -- what rank `part` of an n_parts-GPU run of the command line loads.  A plain file is
+// mapped and only the rank's own pages are touched; a ".gz" stream has to be inflated whole by every rank.
+extern "C" int phk_batch_from_fasta_part(phk_ctx *ctx, const char *path, uint32_t part, uint32_t n_parts, int k,
+                                         const char *symbols4, int threads, phk_fasta **index_out, phk_batch **out) {
+    PHK_REQUIRE(ctx && path && index_out && out, "phk_batch_from_fasta_part: NULL argument");
+    PHK_REQUIRE(n_parts >= 1 && part < n_parts, "phk_batch_from_fasta_part: part %u of %u", part, n_parts);
+    FileBytes fb;
+    PHK_TRY(open_fasta_bytes(path, fb));
+    const size_t n = fb.size;
+    const size_t cut_lo = (size_t)((unsigned __int128)n * part / n_parts), cut_hi = (size_t)((unsigned __int128)n * (part + 1) / n_parts);
+    const size_t lo = next_record_start(fb.data, n, cut_lo);
+    const size_t hi = part + 1 == n_parts ? n : next_record_start(fb.data, n, cut_hi);
+    return batch_from_fasta_bytes(ctx, fb.data + lo, hi > lo ? hi - lo : 0, k, symbols4, threads, index_out, out);
+}
+
+static int batch_from_fasta_bytes(phk_ctx *ctx, const char *b, const size_t n, int k, const char *symbols4, int threads,
+                                  phk_fasta **index_out, phk_batch **out) {
     std::vector<size_t> starts;
     phk_fasta *f = nullptr;
-    PHK_TRY(parse_fasta_bytes(fb.data, fb.size, threads, &f, false, &starts));
-    const char *b = fb.data;
-    const size_t n = fb.size, nrec = starts.size();
+    PHK_TRY(parse_fasta_bytes(b, n, threads, &f, false, &starts));
+    const size_t nrec = starts.size();
     const std::vector<uint64_t> &off = f->offsets;
     auto rec_end = [&](size_t r) { return r + 1 < nrec ? starts[r + 1] : n; };
     auto seq_begin = [&](size_t r) {   // the line after the title line

@@ -88,11 +88,12 @@ __global__ __launch_bounds__(256) void km_pick_kernel(const double *__restrict__
 __global__ __launch_bounds__(256) void km_assign_kernel(const double *__restrict__ X, uint64_t n, uint64_t D,
                                                         const double *__restrict__ centres, uint32_t k,
                                                         uint32_t *__restrict__ labels, double *__restrict__ d2own,
-                                                        uint32_t *__restrict__ changed) {
+                                                        uint32_t *__restrict__ changed,
+                                                        unsigned long long *__restrict__ gapbits = nullptr) {
     const int lane = threadIdx.x & 63;
     const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= n) return;
-    double best = INFINITY;
+    double best = INFINITY, second = INFINITY;
     uint32_t bi = 0;
     for (uint32_t c = 0; c < k; ++c) {
         double acc = 0.0;
@@ -102,12 +103,17 @@ __global__ __launch_bounds__(256) void km_assign_kernel(const double *__restrict
         }
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
-        if (acc < best) { best = acc; bi = c; }  // strict: ties keep the lower centre index
+        if (acc < best) { second = best; best = acc; bi = c; }  // strict: ties keep the lower centre index
+        else if (acc < second) second = acc;
     }
     if (lane == 0) {
         if (labels[i] != bi) atomicAdd(changed, 1u);
         labels[i] = bi;
         d2own[i] = best;
+        // the closest call of the whole fit: (second - best) / second, the smallest over points and sweeps (non-negative
+        // doubles order as their bit patterns)
+        if (gapbits && k > 1 && second > 0.0 && second < INFINITY)
+            atomicMin(gapbits, (unsigned long long)__double_as_longlong((second - best) / second));
     }
 }
 
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(256) void km_shift_kernel(const double *__restrict_
 }
 
 extern "C" int phk_kmeans_lloyd(phk_ctx *ctx, const double *X, uint64_t n, uint64_t D, uint32_t k, const double *init, double tol,
-                                int max_iter, double *centres_out, uint32_t *labels, int *n_iter, int *n_empty) {
+                                int max_iter, double *centres_out, uint32_t *labels, int *n_iter, int *n_empty, double *min_gap) {
     PHK_REQUIRE(ctx && X && init && labels, "phk_kmeans_lloyd: NULL pointer");
     PHK_REQUIRE(k >= 1 && k <= n, "phk_kmeans_lloyd: need 1 <= k <= n (k=%u, n=%llu)", k, (unsigned long long)n);
     PHK_REQUIRE(D >= 1 && max_iter >= 1 && tol >= 0.0, "phk_kmeans_lloyd: bad D / max_iter / tol");
@@ -242,6 +248,11 @@ extern "C" int phk_kmeans_lloyd(phk_ctx *ctx, const double *X, uint64_t n, uint6
     PHK_HIP(hipMemcpyAsync(dX, X, n * D * 8, hipMemcpyHostToDevice, ctx->stream));
     PHK_HIP(hipMemcpyAsync(cen, init, (uint64_t)k * D * 8, hipMemcpyHostToDevice, ctx->stream));
     PHK_HIP(hipMemsetAsync(dl, 0xFF, n * 4, ctx->stream));
+    unsigned long long *gapbits = (unsigned long long *)((uint32_t *)dflag + 4);   // (behind the 16 bytes zeroed per sweep)
+    {
+        const double inf = INFINITY;
+        PHK_HIP(hipMemcpyAsync(gapbits, &inf, 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     const unsigned wblocks = (unsigned)phk_div_up(n, 4);
     struct { uint32_t changed, empty; double shift; } flag;
     int it = 0, empties = 0;
@@ -254,7 +265,7 @@ extern "C" int phk_kmeans_lloyd(phk_ctx *ctx, const double *X, uint64_t n, uint6
         PHK_HIP(hipMemcpyAsync(old, cen, (uint64_t)k * D * 8, hipMemcpyDeviceToDevice, ctx->stream));
         PHK_LAUNCH(ctx, "km_assign_kernel",
                    km_assign_kernel<<<dim3(wblocks), dim3(256), 0, ctx->stream>>>((const double *)dX, n, D, cen, k, (uint32_t *)dl,
-                                                                                (double *)dm, (uint32_t *)dflag));
+                                                                                (double *)dm, (uint32_t *)dflag, gapbits));
         PHK_LAUNCH(ctx, "km_update_kernel",
                    km_update_kernel<<<dim3(k), dim3(256), 0, ctx->stream>>>((const double *)dX, n, D, (const uint32_t *)dl, cen,
                                                                           (uint32_t *)dsz));
@@ -270,12 +281,15 @@ extern "C" int phk_kmeans_lloyd(phk_ctx *ctx, const double *X, uint64_t n, uint6
     if (!strict) {
         PHK_LAUNCH(ctx, "km_assign_kernel",
                    km_assign_kernel<<<dim3(wblocks), dim3(256), 0, ctx->stream>>>((const double *)dX, n, D, cen, k, (uint32_t *)dl,
-                                                                                (double *)dm, (uint32_t *)dflag));
+                                                                                (double *)dm, (uint32_t *)dflag, gapbits));
     }
+    double gap = INFINITY;
+    PHK_HIP(hipMemcpyAsync(&gap, gapbits, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (centres_out) PHK_HIP(hipMemcpyAsync(centres_out, cen, (uint64_t)k * D * 8, hipMemcpyDeviceToHost, ctx->stream));
     PHK_HIP(hipMemcpyAsync(labels, dl, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     PHK_HIP(hipStreamSynchronize(ctx->stream));
     if (n_iter) *n_iter = it;
     if (n_empty) *n_empty = empties;
+    if (min_gap) *min_gap = gap;
     return PHK_OK;
 }

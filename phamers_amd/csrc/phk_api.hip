@@ -42,7 +42,8 @@ static int set_knob(PhkKnobs &k, const char *key, const char *value) {
     else if (!strcmp(key, "rerank")) k.rerank = v[0];
     else if (!strcmp(key, "count_sort")) k.count_sort = v[0] != '0';
     else if (!strcmp(key, "score_batch")) k.score_batch = strtoull(v, nullptr, 10);
-    else if (!strcmp(key, "pipeline")) k.pipeline = v[0] ? atoi(v) : 1;
+    else if (!strcmp(key, "tail_aside")) k.tail_aside = v[0] != '0';
+    else if (!strcmp(key, "ws_fail")) k.ws_fail = v[0] ? atoi(v) : 0;
     else if (!strcmp(key, "gen_groups")) k.gen_groups = v[0] ? atoi(v) : 0;
     else if (!strcmp(key, "gen_seq")) k.gen_seq = v[0] == '1';
     else if (!strcmp(key, "i8_insert")) k.i8_insert = (v[0] >= '0' && v[0] <= '2') ? v[0] : 0;
@@ -55,7 +56,7 @@ static void knobs_from_env(PhkKnobs &k) {
                                            {"slot_threads", "PHK_SLOT_THREADS"}, {"force_exact", "PHK_FORCE_EXACT"},
                                            {"proposal", "PHK_PROPOSAL"}, {"cx_cfg", "PHK_CX_CFG"},
                                            {"rerank", "PHK_RERANK"}, {"count_sort", "PHK_COUNT_SORT"},
-                                           {"score_batch", "PHK_SCORE_BATCH"}, {"pipeline", "PHK_PIPELINE"},
+                                           {"score_batch", "PHK_SCORE_BATCH"}, {"tail_aside", "PHK_TAIL_ASIDE"},
                                            {"gen_groups", "PHK_GEN_GROUPS"}, {"gen_seq", "PHK_GEN_SEQ"}, {"i8_insert", "PHK_I8_INSERT"}};
     for (auto &n : names) {
         const char *e = getenv(n[1]);
@@ -132,9 +133,10 @@ extern "C" int phk_destroy(phk_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->aux);
         (void)hipStreamDestroy(ctx->aux);
     }
-    for (auto e : ctx->ev_chunk)
+    for (auto e : ctx->ev_fork)
         if (e) (void)hipEventDestroy(e);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (auto e : ctx->ev_tail)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PHK_OK;
@@ -259,14 +261,17 @@ int phk_ws(phk_ctx *ctx, int slot, uint64_t bytes, void **out) {
             b.bytes = 0;
         }
         uint64_t want = (bytes + 255) & ~255ull;
+        if (ctx->knobs.ws_fail > 0 && --ctx->knobs.ws_fail == 0) want = 1ull << 60;   // (tests: see PhkKnobs::ws_fail)
         hipError_t e = hipMalloc(&b.ptr, want);
         if (e != hipSuccess) {
+            (void)hipGetLastError();
             b.ptr = nullptr;
             phk_set_error("workspace slot %d: hipMalloc(%llu) failed: %s", slot, (unsigned long long)want,
                           hipGetErrorString(e));
             return PHK_ERR_NOMEM;
         }
         b.bytes = want;
+        b.gen += 1;
     }
     *out = b.ptr;
     return PHK_OK;
@@ -546,67 +551,41 @@ extern "C" int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const u
     void *d_nwin;  // row sums straight from the count kernel (saves the scorer a pass over the counts)
     PHK_TRY(phk_ws(ctx, WS_NWIN, n * sizeof(uint32_t), &d_nwin));
     uint32_t *nwin = (uint32_t *)d_nwin;
-    // Chunk pipeline (k = 4, large batches; opt-in, option "pipeline"): the batch is cut into chunks; chunk i+1 is counted
-    // on this stream while chunk i is scored on a second stream, forked and joined with events inside the call (the caller
-    // sees one stream-ordered operation).  Measured on the BASELINE batch it LOSES: 5.32 ms unchunked, 5.71 / 6.39 / 7.94
-    // with 2 / 4 / 8 chunks -- every chunk pays the latency-bound tail of the scoring chain (second-chance sweep, exact-
-    // distance kernels) again, and the overlapped kernels slow each other.  Kept for batches that arrive in pieces.
-    int chunks = ctx->knobs.pipeline;
-    chunks = chunks < 1 ? 1 : (chunks > 8 ? 8 : chunks);
-    if (k != 4 || !phk_model_has_fast(model) || ctx->knobs.force_exact || n < 65536ull * (uint64_t)chunks) chunks = 1;
-    if (chunks == 1) {
-        // k = 5: the count kernel's flush also writes the int8 operand of the scorer's sweep (PhkPrep8, phk_common.h)
-        ctx->prep8.armed = false;
-        if (k == 5 && !d_mask && n > 0 && phk_model_has_fast(model) && model->d_A8 && !model->bf_stale && !ctx->knobs.force_exact &&
-            !ctx->knobs.proposal[0] && !ctx->knobs.count_lanes && !ctx->knobs.count_cfg[0]) {
-            const uint64_t D = model->D;
-            void *frag, *big;
-            PHK_TRY(phk_ws(ctx, WS_FRAG8, phk_div_up(n, 32) * 32 * D, &frag));
-            PHK_TRY(phk_ws(ctx, WS_BIG8, (n + 1) * sizeof(uint32_t), &big));
-            PHK_HIP(hipMemsetAsync(big, 0, (n + 1) * sizeof(uint32_t), ctx->stream));
-            ctx->prep8.counts = d_counts; ctx->prep8.n = n; ctx->prep8.D = D;
-            ctx->prep8.frag = frag; ctx->prep8.big = (uint32_t *)big;
-            ctx->prep8.armed = true;
-        }
-        int rc = phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets, n, k, d_counts, nwin);
-        if (rc == PHK_OK) rc = phk_score_rows(ctx, model, nullptr, d_counts, nwin, n, method, d_scores, d_status);
-        ctx->prep8.armed = false;
-        return rc;
+    // (Rounds 2-4 kept a chunk pipeline here -- count of chunk i + 1 on this stream beside the scoring of chunk i on a second
+    // one.  It lost at every chunk count, 5.32 ms unchunked against 5.71 / 6.39 / 7.94 with 2 / 4 / 8 chunks: every chunk paid
+    // the latency-bound tail of the scoring chain again.  Removed in round 5; what does overlap is a batch's tail with the
+    // next batch's sweep inside phk_score_fast.)
+    // k = 5: the count kernel's flush also writes the int8 operand of the scorer's sweep (PhkPrep8, phk_common.h)
+    ctx->prep8.armed = false;
+    if (k == 5 && !d_mask && n > 0 && phk_model_has_fast(model) && model->d_A8 && !model->bf_stale && !ctx->knobs.force_exact &&
+        !ctx->knobs.proposal[0] && !ctx->knobs.count_lanes && !ctx->knobs.count_cfg[0]) {
+        const uint64_t D = model->D;
+        void *frag, *big;
+        PHK_TRY(phk_ws(ctx, WS_FRAG8, phk_div_up(n, 32) * 32 * D, &frag));
+        PHK_TRY(phk_ws(ctx, WS_BIG8, (n + 1) * sizeof(uint32_t), &big));
+        PHK_HIP(hipMemsetAsync(big, 0, (n + 1) * sizeof(uint32_t), ctx->stream));
+        ctx->prep8.counts = d_counts; ctx->prep8.n = n; ctx->prep8.D = D;
+        ctx->prep8.frag = frag; ctx->prep8.big = (uint32_t *)big;
+        ctx->prep8.armed = true;
     }
-    if (!ctx->aux) {
-        PHK_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
-        for (auto &e : ctx->ev_chunk) PHK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        PHK_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
-    const uint64_t D = model->D;
-    const uint64_t per = ((n / (uint64_t)chunks + 4095) / 4096) * 4096;   // whole proposal workgroups and slot groups
-    const uint64_t mean = total_bases / n;
-    hipStream_t main_stream = ctx->stream;
-    int rc = PHK_OK;
-    ctx->keep_score_state = false;
-    for (int c = 0; c < chunks && rc == PHK_OK; ++c) {
-        const uint64_t c0 = per * (uint64_t)c;
-        if (c0 >= n) break;
-        const uint64_t m = n - c0 < per ? n - c0 : per;
-        rc = phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets + c0, m, k, d_counts + c0 * D, nwin + c0, mean);
-        if (rc != PHK_OK) break;
-        if (hipEventRecord(ctx->ev_chunk[c], main_stream) != hipSuccess ||
-            hipStreamWaitEvent(ctx->aux, ctx->ev_chunk[c], 0) != hipSuccess) {
-            phk_set_error("phk_count_score_dev: event hand-over failed");
-            rc = PHK_ERR_HIP;
-            break;
-        }
-        ctx->stream = ctx->aux;   // the scoring chain (launch helpers, workspaces, kernel timers) follows ctx->stream
-        rc = phk_score_rows(ctx, model, nullptr, d_counts + c0 * D, nwin + c0, m, method, d_scores + c0, d_status);
-        ctx->stream = main_stream;
-        ctx->keep_score_state = true;
-    }
-    ctx->keep_score_state = false;
-    // join: everything enqueued on the second stream is done before anything the caller enqueues next
-    if (hipEventRecord(ctx->ev_join, ctx->aux) != hipSuccess || hipStreamWaitEvent(main_stream, ctx->ev_join, 0) != hipSuccess) {
-        phk_set_error("phk_count_score_dev: join failed");
-        return PHK_ERR_HIP;
-    }
+    // the scorer's NaN counter and the call totals of its statistics are zeroed by the count planner's kernel where there is
+    // one (no memset in front of either stage); phk_score_rows does it itself otherwise
+    ctx->plan_zero[0] = d_status;
+    ctx->plan_zero_words[0] = d_status ? 1u : 0u;
+    const bool totals_ready = phk_model_has_fast(model) && !ctx->knobs.force_exact && ctx->ws[WS_SCTL].ptr && !ctx->score_ctl_dirty &&
+                              ctx->score_ctl_gen == ctx->ws[WS_SCTL].gen;
+    ctx->plan_zero[1] = totals_ready ? (uint32_t *)ctx->ws[WS_SCTL].ptr : nullptr;
+    ctx->plan_zero_words[1] = totals_ready ? 32u : 0u;
+    ctx->plan_zero_taken = false;
+    int rc = phk_launch_count(ctx, d_packed, d_mask, total_bases, d_offsets, n, k, d_counts, nwin);
+    ctx->plan_zero[0] = ctx->plan_zero[1] = nullptr;
+    ctx->plan_zero_words[0] = ctx->plan_zero_words[1] = 0;
+    ctx->score_totals_zeroed = ctx->plan_zero_taken;   // (consumed by phk_score_rows)
+    ctx->score_totals_only_status = ctx->plan_zero_taken && !totals_ready;
+    ctx->plan_zero_taken = false;
+    if (rc == PHK_OK) rc = phk_score_rows(ctx, model, nullptr, d_counts, nwin, n, method, d_scores, d_status);
+    ctx->prep8.armed = false;
+    ctx->score_totals_zeroed = ctx->score_totals_only_status = false;
     return rc;
 }
 
@@ -619,8 +598,8 @@ extern "C" int phk_check_counts_dev(phk_ctx *ctx, const uint32_t *d_counts, cons
 extern "C" int phk_score_stats(phk_ctx *ctx, uint64_t *n_fallback, uint64_t *n_exact_resolved) {
     PHK_ENTER(ctx, "phk_score_stats");
     uint32_t c[2] = {0, 0};
-    if (ctx->last_score_fast && ctx->ws[WS_DIST].ptr) {   // words 16 ..: totals over the call's batches
-        PHK_HIP(hipMemcpyAsync(c, (const uint32_t *)ctx->ws[WS_DIST].ptr + 16, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->last_score_fast && ctx->ws[WS_SCTL].ptr) {   // the first words: totals over the call's batches
+        PHK_HIP(hipMemcpyAsync(c, (const uint32_t *)ctx->ws[WS_SCTL].ptr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         PHK_HIP(hipStreamSynchronize(ctx->stream));
     }
     if (n_fallback) *n_fallback = c[0];
@@ -632,8 +611,8 @@ extern "C" int phk_score_stats_ex(phk_ctx *ctx, uint64_t *out, int n_out) {
     PHK_ENTER(ctx, "phk_score_stats_ex");
     PHK_REQUIRE(out && n_out >= 0, "phk_score_stats_ex: NULL");
     uint32_t c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (ctx->last_score_fast && ctx->ws[WS_DIST].ptr) {
-        PHK_HIP(hipMemcpyAsync(c, (const uint32_t *)ctx->ws[WS_DIST].ptr + 16, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->last_score_fast && ctx->ws[WS_SCTL].ptr) {
+        PHK_HIP(hipMemcpyAsync(c, (const uint32_t *)ctx->ws[WS_SCTL].ptr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         PHK_HIP(hipStreamSynchronize(ctx->stream));
     }
     for (int i = 0; i < n_out; ++i) out[i] = i < 9 ? c[i] : 0;

@@ -17,7 +17,7 @@
 // Diagnostic code (phase timers, tuning overrides of the kernels' shape macros) compiles only in a build that says so;
 // such a build reports another ABI version (phk_api.hip) and is refused by the loader.
 #if (defined(I8_TIMERS) || defined(I8_NW) || defined(I8_NBUF) || defined(SLOT_LINES) || defined(PHK_HI_REFINE) || \
-     defined(PHK_RERANK_WAVES) || defined(PAIRS_ABL)) && !defined(PHK_DIAGNOSTIC_BUILD)
+     defined(PHK_RERANK_WAVES) || defined(PAIRS_ABL) || defined(F16H_ABL)) && !defined(PHK_DIAGNOSTIC_BUILD)
 #error "kernel tuning / timer macros need -DPHK_DIAGNOSTIC_BUILD (make EXTRA_CXXFLAGS='-DPHK_DIAGNOSTIC_BUILD -D...')"
 #endif
 
@@ -75,12 +75,16 @@ enum PhkSlot {
     WS_QUEUE,       // scoring at general D: the two hand-over queues of the first pass
     WS_FRAG8,       // count -> score at k = 5: the int8 query fragments of the whole call, written by the count kernel's flush
     WS_BIG8,        // ... and their per-row flag words (+ the call's mode word)
+    WS_SCTL,        // scoring (MFMA path): the call's statistics totals, the two sets of counters / query lists / striped words
+    WS_CTL,         // small control words the kernels keep zeroed themselves (no memset per call): the count planner's two
+                    // alternating blocks (PhkCountCtl), see phk_launch_count
     WS_SLOTS
 };
 
 struct PhkBuf {
     void *ptr = nullptr;
     uint64_t bytes = 0;
+    uint64_t gen = 0;    // counts (re)allocations: a user that keeps state in the buffer sees when it has to start over
 };
 
 struct PhkTimed {
@@ -107,8 +111,10 @@ struct PhkKnobs {
                                // '2' no test (0 = by the number of columns, phk_launch_proposal_i8_general)
     bool gen_seq = false;      // int8 sweep: the column groups as successive launches (each group's records L2-resident) instead of a 2-D launch
     int gen_groups = 0;        // column groups of the general-D sweep's 2-D launch (0 = default: PHK_GEN_GROUPS at D >= 2048, else 1)
-    int pipeline = 1;          // chunks of phk_count_score_dev's count / score pipeline at k = 4 (1 = off, the default:
-                               // measured 5.32 / 5.71 / 6.39 / 7.94 ms per 1M contigs with 1 / 2 / 4 / 8 chunks)
+    int ws_fail = 0;           // fault injection for the tests: the ws_fail-th workspace allocation from now on asks hipMalloc for
+                               // 2^60 bytes (a genuine out-of-memory failure on the genuine error path), then the knob is spent
+    bool tail_aside = true;    // multi-batch scoring at k = 4: a batch's hand-over kernels on the second stream beside the next
+                               // batch's sweep (option "tail_aside" = 0: everything on one stream, for A/B runs)
 };
 
 // The int8 operand of the general-D sweep prepared by the count kernel (phk_count_score_dev at k = 5: the flush of
@@ -133,12 +139,26 @@ struct phk_ctx {
     bool slots_lds0 = true;        // the slot count kernel's dynamic LDS starts at address 0 (checked at creation)
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // second stream of phk_count_score_dev's chunk pipeline (count of chunk i+1 beside the scoring of chunk i): forked
-    // from / joined to `stream` with events inside the call, so the caller still sees one stream-ordered operation
+    // second stream of multi-batch scoring calls (phk_score_fast): batch b's hand-over kernels -- second chance, merge, brute
+    // force: a few % of the chip -- run here beside batch b + 1's sweep; forked from / joined to `stream` with events inside
+    // the call, so the caller still sees one stream-ordered operation
     hipStream_t aux = nullptr;
-    hipEvent_t ev_chunk[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_join = nullptr;
-    bool keep_score_state = false;   // a later chunk of one logical call: NaN counter and statistics totals carry on
+    hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_tail[2] = {nullptr, nullptr};
+    // Control words of the count planner (phk_launch_count): two blocks used alternately -- the planning kernel of a call
+    // zeroes the block of the NEXT call, so no launch is preceded by a memset.  ctl_gen = the allocation the blocks were
+    // zeroed for; ctl_epoch = calls so far (its parity picks the block); ctl_dirty = a call failed half way.
+    uint64_t ctl_gen = 0, ctl_epoch = 0;
+    bool ctl_dirty = true;
+    // words another entry point wants zeroed by the planning kernel (phk_count_score_dev: the scorer's NaN counter and call
+    // totals), consumed by the next phk_launch_count that launches a planning kernel; `taken` says it did
+    // the scorer's control words (phk_score_fast, WS_DIST): zeroed by the kernels that read them last; see there
+    uint64_t score_ctl_gen = 0;
+    bool score_ctl_dirty = true;
+    bool score_totals_zeroed = false;   // this call's NaN counter (and totals) were zeroed by the count planner's kernel ...
+    bool score_totals_only_status = false;   // ... the NaN counter only (the totals' workspace did not exist yet)
+    uint32_t *plan_zero[2] = {nullptr, nullptr};
+    uint32_t plan_zero_words[2] = {0, 0};
+    bool plan_zero_taken = false;
     int num_cus = 256;
     PhkBuf ws[WS_SLOTS];
     bool profile = false;

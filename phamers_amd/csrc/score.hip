@@ -313,13 +313,20 @@ int phk_score_rows(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
                    const uint32_t *d_rowsum, uint64_t N, int method, double *d_scores, uint32_t *d_status) {
     PHK_REQUIRE(m && d_scores && (d_Q || d_counts), "phk_score: NULL pointer");
     PHK_TRY(check_method(m, method));
-    if (d_status && !ctx->keep_score_state) PHK_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), ctx->stream));
-    if (N == 0) return PHK_OK;
+    // (phk_count_score_dev: the count planner's kernel has zeroed the NaN counter -- and the statistics totals -- already)
+    const bool prezeroed = ctx->score_totals_zeroed;
+    ctx->score_totals_zeroed = prezeroed && !ctx->score_totals_only_status;   // what phk_score_fast may rely on: the totals
+    if (d_status && !prezeroed) PHK_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), ctx->stream));
+    if (N == 0) {
+        ctx->score_totals_zeroed = false;
+        return PHK_OK;
+    }
     const uint64_t D = m->D;
 
     // PHK_FORCE_EXACT=1 routes every model through the float64 path (used by the parity tests to
     // cross-check the two GPU paths against each other)
     ctx->last_score_fast = false;
+    if (!(phk_model_has_fast(m) && !ctx->knobs.force_exact)) ctx->score_totals_zeroed = false;
     if (phk_model_has_fast(m) && !ctx->knobs.force_exact) {
         ctx->last_score_fast = true;
         return phk_score_fast(ctx, m, d_Q, d_counts, d_rowsum, N, method, d_scores, d_status);

@@ -617,22 +617,51 @@ __global__ __launch_bounds__(256) void phk_merge_list_sets_kernel(float *__restr
     float lv[CAND] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
     uint32_t li[CAND] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     float drop = -3.0e38f;
-    for (int y = 0; y < S; ++y) {
-        drop = fmaxf(drop, set_u(y)[candu_at(0, h, q, Nlist)]);
+    // Eight sets at a time, every load of the eight requested before the first insertion (and the centroid segments' copies
+    // with them): as load - insert - load the kernel was a chain of 8 dependent round trips per thread, 33 us for the ~5 000
+    // queued rows of configs[1] -- most of it waiting.
+    float cv1[NSEG - 1][CAND], cu1[NSEG - 1];
+    uint32_t ci1[NSEG - 1][CAND];
 #pragma unroll
-        for (int c = 0; c < CAND; ++c) {
-            const uint32_t ix = set_i(y)[cand_at(0, h, c, q, Nlist)];
-            if (ix != 0xFFFFFFFFu) list_insert(lv, li, drop, set_v(y)[cand_at(0, h, c, q, Nlist)], ix);
-        }
-    }
-    cand_store(cv, ci, cu, 0, h, q, Nlist, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2], li[3], drop);
     for (int seg = 1; seg < NSEG; ++seg) {
 #pragma unroll
         for (int c = 0; c < CAND; ++c) {
-            cv[cand_at(seg, h, c, q, Nlist)] = set_v(S - 1)[cand_at(seg, h, c, q, Nlist)];
-            ci[cand_at(seg, h, c, q, Nlist)] = set_i(S - 1)[cand_at(seg, h, c, q, Nlist)];
+            cv1[seg - 1][c] = set_v(S - 1)[cand_at(seg, h, c, q, Nlist)];
+            ci1[seg - 1][c] = set_i(S - 1)[cand_at(seg, h, c, q, Nlist)];
         }
-        cu[candu_at(seg, h, q, Nlist)] = set_u(S - 1)[candu_at(seg, h, q, Nlist)];
+        cu1[seg - 1] = set_u(S - 1)[candu_at(seg, h, q, Nlist)];
+    }
+    for (int y0 = 0; y0 < S; y0 += 8) {
+        float v[8][CAND], u[8];
+        uint32_t ix[8][CAND];
+#pragma unroll
+        for (int yy = 0; yy < 8; ++yy) {
+            const int y = y0 + yy < S ? y0 + yy : S - 1;   // (a set past the end re-reads the last one: no load under a condition)
+            u[yy] = set_u(y)[candu_at(0, h, q, Nlist)];
+#pragma unroll
+            for (int c = 0; c < CAND; ++c) {
+                ix[yy][c] = set_i(y)[cand_at(0, h, c, q, Nlist)];
+                v[yy][c] = set_v(y)[cand_at(0, h, c, q, Nlist)];
+            }
+        }
+#pragma unroll
+        for (int yy = 0; yy < 8; ++yy) {
+            if (y0 + yy >= S) break;
+            drop = fmaxf(drop, u[yy]);
+#pragma unroll
+            for (int c = 0; c < CAND; ++c)
+                if (ix[yy][c] != 0xFFFFFFFFu) list_insert(lv, li, drop, v[yy][c], ix[yy][c]);
+        }
+    }
+    cand_store(cv, ci, cu, 0, h, q, Nlist, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2], li[3], drop);
+#pragma unroll
+    for (int seg = 1; seg < NSEG; ++seg) {
+#pragma unroll
+        for (int c = 0; c < CAND; ++c) {
+            cv[cand_at(seg, h, c, q, Nlist)] = cv1[seg - 1][c];
+            ci[cand_at(seg, h, c, q, Nlist)] = ci1[seg - 1][c];
+        }
+        cu[candu_at(seg, h, q, Nlist)] = cu1[seg - 1];
     }
 }
 
@@ -1044,7 +1073,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     };
     // insertion of one value: w = acc - T * bias, index bits embedded, 5 x v_med3
     auto insert = [&](int t, float a, float bias, int r) {
+#if defined(PHK_DIAGNOSTIC_BUILD) && defined(F16H_ABL) && (F16H_ABL & 1)   // timing only: no bias multiply-add (the bias as a 17th k-step would remove it)
+        const float w = a + 0.0f * bias;
+#else
         const float w = fmaf(negT[t], bias, a);
+#endif
         // A value no lane of the wave can place (w <= the best value its list has dropped, in every lane) changes nothing:
         // wave-uniform skip of the index bits and the five v_med3.  A lane's list holds the 5 best of the n values it has
         // seen, so a value enters with probability 5 / n and some lane of the wave takes one with 1 - (1 - 5/n)^64: 63 % of
@@ -1072,6 +1105,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     f32x16 accA[NT], accB[NT];
     uint32_t g = 0;  // global block number: DMA source
     uint32_t cur = 0, nxt = 2;   // ring positions of the block being read / requested
+#if defined(PHK_DIAGNOSTIC_BUILD) && defined(F16H_ABL)
+    uint32_t abl_third = 0;
+#endif
 
     auto block_iter = [&](uint32_t settle_id, f32x16 (&cur_acc)[NT], const f32x16 (&prev)[NT]) {
         // block g has landed (every wave waits for its own pieces -- those of block g + 1 may be outstanding -- then the
@@ -1084,7 +1120,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
         // block i - 2's ids are settled here, under the latency of the first fragment read (38 vector instructions that need
         // nothing from LDS), not behind the first MFMAs
         __builtin_amdgcn_sched_barrier(0);
+#if defined(PHK_DIAGNOSTIC_BUILD) && defined(F16H_ABL) && (F16H_ABL & 2)   // timing only: ids settled every third block
+        if (++abl_third == 3) {
+            abl_third = 0;
+            settle(settle_id);
+        }
+#else
         settle(settle_id);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {

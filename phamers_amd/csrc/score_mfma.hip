@@ -407,6 +407,10 @@ struct RerankParams {
     uint32_t *q2_count = nullptr;
     uint32_t *q2_wide = nullptr;
     uint32_t *q2_big = nullptr;
+    // phk_fallback_merge_kernel, the last kernel of a batch: its last workgroup to finish zeroes the batch's counter words
+    // (word 15 = the ticket) and striped statistics words, so that no memset precedes the next use of the set
+    uint32_t *clean_counters = nullptr;
+    uint32_t *clean_stripes = nullptr;
     const int8_t *L8 = nullptr;             // [M + n_cpos + n_cneg][D] L digits, row-major
     const float *T8 = nullptr;              // per 32-column block: 32 quanta g_j (+ 32 bias terms)
     uint32_t t8_blk[3] = {0, 0, 0};         // first block of each segment
@@ -2480,6 +2484,13 @@ __device__ __forceinline__ bool fb_less(double da, uint64_t ia, double db, uint6
     return da < db || (da == db && ia < ib);
 }
 
+// chunks the reference is cut into per queued query: 64 while the record workspace holds them (a short queue -- the usual
+// two or three rows of a batch -- is then spread over 64 workgroups per row instead of 16: the kernel is a chain of dependent
+// passes over a chunk's columns, 25 -> 10 us at configs[1]), else FB_CHUNKS
+__host__ __device__ __forceinline__ uint32_t fb_group_chunks(uint64_t count, uint64_t rec_cap) {
+    return (rec_cap && count * 64 <= rec_cap) ? 64u : (uint32_t)FB_CHUNKS;
+}
+
 template <int SRC>
 __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *__restrict__ src, RerankParams p) {
     extern __shared__ double fb_lds[];  // [0, 256): the query; then one chunk of distances
@@ -2488,13 +2499,23 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t count = phk_uniform_load(p.fb_count);
     const uint64_t ncols = p.M + p.n_cpos + p.n_cneg;
-    const uint64_t cw = (ncols + FB_CHUNKS - 1) / FB_CHUNKS;
+    const uint64_t nch = fb_group_chunks(count, p.fb_rec_cap);
+    const uint64_t cw = (ncols + nch - 1) / nch;
     FbRecord *rec = static_cast<FbRecord *>(p.fb_rec);
-    const uint64_t items = (uint64_t)count * FB_CHUNKS;
+    const uint64_t items = (uint64_t)count * nch;
     for (uint64_t it = blockIdx.x; it < items; it += gridDim.x) {
-        const uint64_t qi = it / FB_CHUNKS, ch = it % FB_CHUNKS;
+        const uint64_t qi = it / nch, ch = it % nch;
         const uint64_t q = p.fb_list[qi];
-        const uint64_t c0 = ch * cw, c1 = (c0 + cw < ncols) ? c0 + cw : ncols;
+        const uint64_t c0 = ch * cw < ncols ? ch * cw : ncols, c1 = (c0 + cw < ncols) ? c0 + cw : ncols;
+        if (c0 >= c1) {   // (more chunks than columns: an empty record)
+            if (threadIdx.x == 0) {
+                FbRecord e;
+                for (int k = 0; k < 3; ++k) { e.d[k] = INFINITY; e.i[k] = 0xFFFFFFFFu; }
+                e.minpos = e.minneg = INFINITY; e.pad = 0;
+                rec[it] = e;
+            }
+            continue;
+        }
         // The distances are evaluated in the SAME float64 form, element ownership and summation order as every other
         // exact evaluation of this model shape, so that a query's score does not depend on the route that decided it
         // (which depends on how many rows its batch queued): D = 256 -- exact_d2_g16 (raw counts c and the row sum T,
@@ -2601,10 +2622,6 @@ __global__ __launch_bounds__(256) void phk_fallback_partial_kernel(const void *_
 // query exactly as phk_rerank_kernel does (exact_d2<DSUB>: same operands, element ownership and summation order), so
 // a score does not depend on the route that produced it.  Items are numbered chunk-major: the workgroups that run
 // together share a chunk of the reference.
-__host__ __device__ __forceinline__ uint32_t fb_group_chunks(uint64_t count, uint64_t rec_cap) {
-    return (rec_cap && count * 64 <= rec_cap) ? 64u : (uint32_t)FB_CHUNKS;
-}
-
 template <int SRC, int DSUB>
 __global__ __launch_bounds__(512) void phk_fallback_group_kernel(const void *__restrict__ src, RerankParams p) {
     constexpr int D = 256 * DSUB;
@@ -2782,6 +2799,19 @@ __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p)
         }
         p.scores[p.q_base + q] = knn + cen;
     }
+    // the last workgroup out zeroes the set's control words: every workgroup's reads of them precede its ticket
+    if (p.clean_counters) {
+        __shared__ uint32_t s_last;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(p.clean_counters + 15, 1u) == gridDim.x - 1 ? 1u : 0u;
+        __syncthreads();
+        if (s_last) {
+            for (uint32_t i = threadIdx.x; i < 16u; i += blockDim.x) p.clean_counters[i] = 0;
+            if (p.clean_stripes)
+                for (uint32_t i = threadIdx.x; i < PHK_STRIPES * 32u; i += blockDim.x) p.clean_stripes[i] = 0;
+        }
+    }
 }
 
 // one thread per query: score += tanh((en - ep) / (ep + en)) for the queries whose centroid distances the general-D
@@ -2948,19 +2978,43 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     float *cv2 = (float *)((char *)cv + gen_sets * set_bytes + ca_bytes);
     uint32_t *ci2 = (uint32_t *)((char *)cv2 + per_list2 * sizeof(float4));
     float *cu2 = (float *)((char *)ci2 + per_list2 * sizeof(uint4));
-    PHK_TRY(phk_ws(ctx, WS_DIST, (3 * nb_max + 32 + 64 * PHK_SUB_LISTS + PHK_STRIPES * 32) * sizeof(uint32_t), &fb));
+    // WS_SCTL: [32 words: the call's totals, read by phk_score_stats] then TWO sets of {32 counter words, the three query
+    // lists, the striped statistics words}, used by alternate batches: batch b's hand-over kernels (second stream, see
+    // below) still read set b & 1 while batch b + 1's first pass fills the other.  Nothing here is memset per call or per
+    // batch: the last workgroup of a batch's last kernel (phk_fallback_merge_kernel) zeroes the set's counters and stripes
+    // after everybody has read them; a memset happens once per allocation and after a call that failed half way.
+    // (the words that must read zero sit at FIXED offsets in front -- totals, then each set's counters and stripes -- and the
+    // lists, whose size follows the batch, behind them: a call with another batch size finds the same words zeroed)
+    const uint64_t ctl_words = 32 + (uint64_t)PHK_STRIPES * 32, list_words = 3 * nb_max + 64 * PHK_SUB_LISTS;
+    PHK_TRY(phk_ws(ctx, WS_SCTL, (32 + 2 * ctl_words + 2 * list_words) * sizeof(uint32_t), &fb));
+    if (ctx->score_ctl_dirty || ctx->score_ctl_gen != ctx->ws[WS_SCTL].gen) {
+        PHK_HIP(hipMemsetAsync(fb, 0, (32 + 2 * ctl_words) * sizeof(uint32_t), ctx->stream));
+        ctx->score_ctl_gen = ctx->ws[WS_SCTL].gen;
+        ctx->score_totals_zeroed = true;
+    }
+    ctx->score_ctl_dirty = true;   // (cleared at the end of a call that launched everything)
     PHK_TRY(phk_ws(ctx, WS_QF32, nb_max * FB_CHUNKS * sizeof(FbRecord), &rec));
     // counter words, per batch: [0] first-pass queue length, [1] exact-distance decisions, [2] decide kernel's hand-over
     // count, [3] brute-force queue length after the second chance, [4] its exact-distance decisions, [8..11] why the
     // high-parts-only decision stage passed a query on (window wider than the refined set, window reaching past the
     // lists, refined values too close, centroid leader not certified); [16 ..] totals of the call: brute-forced queries,
     // exact-distance decisions, second-chance queries, the four reasons
-    uint32_t *fbc = (uint32_t *)fb, *fb_list = fbc + 32, *slow_list = fb_list + nb_max, *fb2_list = slow_list + nb_max + 64 * PHK_SUB_LISTS;
-    uint32_t *stripes = fb2_list + nb_max;   // striped statistics words (RerankParams::stripes)
+    uint32_t *const totals = (uint32_t *)fb;
+    uint32_t *fbc = nullptr, *fb_list = nullptr, *slow_list = nullptr, *fb2_list = nullptr, *stripes = nullptr;
+    auto use_set = [&](int par) {
+        fbc = totals + 32 + (uint64_t)par * ctl_words;
+        stripes = fbc + 32;            // striped statistics words (RerankParams::stripes)
+        fb_list = totals + 32 + 2 * ctl_words + (uint64_t)par * list_words;
+        slow_list = fb_list + nb_max;
+        fb2_list = slow_list + nb_max + 64 * PHK_SUB_LISTS;
+    };
+    use_set(0);
     const uint64_t ncols = m->M + m->n_cpos + m->n_cneg;
     const size_t fb_lds = ((ncols + FB_CHUNKS - 1) / FB_CHUNKS + D) * sizeof(double);
     PHK_REQUIRE(fb_lds <= FB_LDS_MAX, "phk_score: %llu columns exceed the fallback kernel's LDS", (unsigned long long)ncols);  // phk_model_build_fast keeps such models off this path
-    if (!ctx->keep_score_state) PHK_HIP(hipMemsetAsync(fbc, 0, 128, ctx->stream));   // incl. the totals of this call
+    // the totals of this call start from zero (phk_count_score_dev had the count planner's kernel zero them)
+    if (!ctx->score_totals_zeroed) PHK_HIP(hipMemsetAsync(totals, 0, 32 * sizeof(uint32_t), ctx->stream));
+    ctx->score_totals_zeroed = false;
     // General D, count rows (the int8 sweep): routing is PER ROW, never per batch.  The first pass sweeps the whole batch with two
     // digits; its decision kernel hands on what the lists cannot decide -- rows beyond the int8 operand (a bin more than 127
     // from the row's centre: long or compositionally skewed contigs) to one device queue, rows whose two-digit window holds
@@ -2971,15 +3025,43 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // what these passes cannot certify either is brute-forced.  (Round 3 declined a whole batch to the f16 kernel when more
     // than max(16, n / 256) of its rows were beyond the operand, and re-swept a whole batch -- and the rest of the call --
     // with three digits when its brute-force queue grew past max(64, n / 256).)
-    uint32_t *q2c = fbc + 5, *q2_wide = nullptr, *q2_big = nullptr;
+    uint32_t *q2c = nullptr, *q2_wide = nullptr, *q2_big = nullptr;
     if (use_i8) {
         void *q2;
         PHK_TRY(phk_ws(ctx, WS_QUEUE, 2 * nb_max * sizeof(uint32_t), &q2));
         q2_wide = (uint32_t *)q2;
         q2_big = q2_wide + nb_max;
     }
-    for (uint64_t s = 0; s < N; s += BATCH) {
+    // Multi-batch calls at k = 4 (configs[3]: 12 batches per rank): a batch's hand-over kernels -- second-chance sweep, merge,
+    // its decision, brute force: 0.17 ms at a few % of the chip -- run on the context's second stream beside the NEXT batch's
+    // sweep.  Forked / joined with events inside the call; main-stream work on set b & 1 waits for the tail of batch b - 2.
+    const bool tail_aside = hi_only && second && N > BATCH && ctx->knobs.tail_aside;
+    hipStream_t main_stream = ctx->stream;
+    if (tail_aside && !ctx->aux) {
+        PHK_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+        for (auto &e : ctx->ev_fork) PHK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : ctx->ev_tail) PHK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    bool tail_used[2] = {false, false};
+    auto join_tails = [&]() -> int {
+        for (int par = 0; par < 2; ++par)
+            if (tail_used[par]) {
+                PHK_HIP(hipStreamWaitEvent(main_stream, ctx->ev_tail[par], 0));
+                tail_used[par] = false;
+            }
+        return PHK_OK;
+    };
+    int rc_loop = PHK_OK;
+    for (uint64_t s = 0; s < N && rc_loop == PHK_OK; s += BATCH) {
+      const int par = (int)((s / BATCH) & 1);
+      auto one_batch = [&]() -> int {
         const uint64_t nb = N - s < BATCH ? N - s : BATCH;
+        use_set(par);
+        q2c = fbc + 5;
+        if (tail_used[par]) {   // the tail of batch b - 2 read this set
+            PHK_HIP(hipStreamWaitEvent(main_stream, ctx->ev_tail[par], 0));
+            tail_used[par] = false;
+        }
         const void *src = d_counts ? (const void *)(d_counts + s * D) : (const void *)(d_Q + s * D);
         const uint32_t *rsum = d_rowsum ? d_rowsum + s : nullptr;
         if (use_i8 && !rsum) {   // the int8 path's kernels (fragments, sweep, lane-per-query decision) take the row sums as input
@@ -2993,8 +3075,6 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         const uint32_t nref = (method & PHK_METHOD_KNN) ? m->n_rblk_ref : 0;
         const uint32_t npos = (method & PHK_METHOD_KMEANS) ? m->n_rblk_pos : 0;
         const uint32_t nneg = (method & PHK_METHOD_KMEANS) ? m->n_rblk_neg : 0;
-        PHK_HIP(hipMemsetAsync(fbc, 0, 64, ctx->stream));
-        PHK_HIP(hipMemsetAsync(stripes, 0, PHK_STRIPES * 32 * sizeof(uint32_t), ctx->stream));
         RerankParams p;
         p.N = nb; p.M = m->M; p.n_cpos = m->n_cpos; p.n_cneg = m->n_cneg; p.D = D;
         p.kn = m->kn; p.method = method; p.rmax = m->max_colnorm; p.mu_norm = m->mu_norm;
@@ -3002,7 +3082,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         p.cand_v = (const float *)cv; p.cand_i = ci; p.cand_u = cu; p.fb_rec = rec;
         p.scores = d_scores; p.status = d_status;
         p.fb_count = fbc; p.fb_list = fb_list; p.slow_list = slow_list; p.q_base = s;
-        p.stat_total = fbc + 16;
+        p.stat_total = totals;
         p.counters = fbc;
         p.stripes = stripes;
         p.col_mask = m->has_mask ? m->d_col_mask : nullptr;
@@ -3212,6 +3292,12 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
         }
         RerankParams pf = p;   // what the brute force works from
         pf.status = d_status;
+        pf.fb_rec_cap = nb_max * FB_CHUNKS;
+        if (tail_aside) {   // ---- from here on: the batch's tail, on the second stream ----
+            PHK_HIP(hipEventRecord(ctx->ev_fork[par], main_stream));
+            PHK_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork[par], 0));
+            ctx->stream = ctx->aux;
+        }
         if (second) {
             const uint64_t cap = nb < cap2 ? nb : cap2;
             PHK_TRY(phk_launch_proposal_f16(ctx, m, src, true, rsum, cap, nref, npos, nneg, cv2, ci2, cu2, fb_list, fbc,
@@ -3227,6 +3313,7 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
                        (phk_rerank16_kernel<0, 2><<<dim3((unsigned)phk_div_up(cap, 16)), dim3(256), 0, ctx->stream>>>(src, p2)));
             pf = p2;
             pf.N = nb;
+            pf.fb_rec_cap = nb_max * FB_CHUNKS;
         }
         if (D == FAST_D) {
             if (d_counts) {
@@ -3249,10 +3336,25 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             if (D == 512) PHK_FBG(2); else if (D == 1024) PHK_FBG(4); else if (D == 2048) PHK_FBG(8); else PHK_FBG(16);
 #undef PHK_FBG
         }
+        pf.clean_counters = fbc;   // the set's last kernel leaves its counters and stripes zeroed for batch b + 2 / the next call
+        pf.clean_stripes = stripes;
         PHK_LAUNCH(ctx, "phk_fallback_merge_kernel",
                    phk_fallback_merge_kernel<<<dim3(64), dim3(256), 0, ctx->stream>>>(pf));
+        if (tail_aside) {
+            PHK_HIP(hipEventRecord(ctx->ev_tail[par], ctx->aux));
+            tail_used[par] = true;
+        }
+        return PHK_OK;
+      };
+      rc_loop = one_batch();
+      ctx->stream = main_stream;   // (whatever the batch's tail did with it)
     }
-    return PHK_OK;
+    {   // everything enqueued on the second stream is done before anything the caller enqueues next
+        const int rcj = join_tails();
+        if (rc_loop == PHK_OK) rc_loop = rcj;
+    }
+    if (rc_loop == PHK_OK) ctx->score_ctl_dirty = false;
+    return rc_loop;
 }
 
 // per-device kernel attributes, called from phk_create

@@ -167,6 +167,26 @@ def gather_variable(local, group=None):
     return torch.cat([out[r * width: r * width + sizes[r]] for r in range(world)])
 
 
+def gather_rows_to_root(local, group=None, root=0):
+    """Rows of 2-D tensors whose row counts differ per rank -> their concatenation in rank order on ``root`` (None
+    elsewhere).  One size exchange + one padded gather: only the root holds the whole matrix."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    height = max(max(sizes), 1)
+    padded = torch.zeros((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    parts = [torch.empty_like(padded) for _ in range(world)] if rank == root else None
+    dist.gather(padded, parts, dst=root, group=group)
+    if rank != root:
+        return None
+    return torch.cat([parts[r][: sizes[r]] for r in range(world)])
+
+
 def rank_device():
     """This rank's GPU, chosen ONCE: LOCAL_RANK (or PHAMERS_HIP_DEVICE) modulo the number of visible devices.
     The phk context, torch's current device and the collective's tensors must all sit on it: RCCL refuses two

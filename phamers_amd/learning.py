@@ -141,12 +141,22 @@ def _one_blas_thread():
         return contextlib.nullcontext()
 
 
+KMEANS_MIN_GAP = 1e-9   # below this relative distance gap between a point's two nearest centres the host fit decides
+
+
 def kmeans_reference_on_device(data, k, seed=kmeans_seed, max_iter=300, tol=1e-4, ctx=None):
     """The labels of ``KMeans(n_clusters=k, random_state=seed).fit(data)`` (scripts/learning.py:138) with only the seeding
     on the host: scikit-learn's k-means++ (kmeans_plusplus_seeds, on the mean-centred rows with a fresh
     ``RandomState(seed)`` -- what ``KMeans.fit`` does before its first sweep, n_init = 1) and its Lloyd iteration,
     stopping rule included, on the device (phk_kmeans_lloyd).  Returns (labels, sweeps), or None when a cluster ran
-    empty (scikit-learn relocates it; the caller then takes the host fit)."""
+    empty (scikit-learn relocates it) or when some point came within KMEANS_MIN_GAP (relative) of a tie between its two
+    nearest centres in some sweep: the caller then takes the host fit.
+
+    Parity: the device forms distances by float64 direct differences, scikit-learn by chunked matrix products; the labels
+    are EQUAL to scikit-learn 1.7.2's on the reference's matrices (pinned: tests/golden centroids) and on every fold
+    subset / random matrix the tests try, and can differ in principle only for points nearer to a tie than the two
+    formulations' rounding (~1e-13 relative), which the gap guard hands to the host fit.  Outside those pins: parity
+    unpinned (scikit-learn is unpinned by the reference itself, requirements.txt:4)."""
     import ctypes
     X = np.array(data, dtype=np.float64, order="C")          # (a copy: centred in place, as KMeans.fit does)
     n, D = X.shape
@@ -156,11 +166,15 @@ def kmeans_reference_on_device(data, k, seed=kmeans_seed, max_iter=300, tol=1e-4
     init = np.ascontiguousarray(init, dtype=np.float64)
     tol_abs = float(np.mean(np.var(X, axis=0)) * tol)
     labels = np.empty(n, dtype=np.uint32)
-    n_iter, n_empty = ctypes.c_int(), ctypes.c_int()
+    n_iter, n_empty, min_gap = ctypes.c_int(), ctypes.c_int(), ctypes.c_double()
     ctx = ctx or _lib.get_context()
     _lib.check(ctx.lib.phk_kmeans_lloyd(ctx.handle, _lib.ptr(X), n, D, int(k), _lib.ptr(init), tol_abs, int(max_iter), None,
-                                        _lib.ptr(labels), ctypes.byref(n_iter), ctypes.byref(n_empty)))
+                                        _lib.ptr(labels), ctypes.byref(n_iter), ctypes.byref(n_empty), ctypes.byref(min_gap)))
     if n_empty.value:
+        return None
+    # a point nearly equidistant from two centres: the device's direct differences and scikit-learn's chunked matrix
+    # products (-2 x.c + |c|^2) may order them differently -- such a fit is left to the host
+    if not (min_gap.value >= KMEANS_MIN_GAP):
         return None
     return labels.astype(np.int32), n_iter.value
 

@@ -229,26 +229,11 @@ class phamer_scorer(object):
             _lap("FASTA indexed (ids, lengths)")
         else:
             fasta_ids = self.data_ids
-        is_long = np.asarray(_lengths) >= self.length_requirement
-        # the rows are the file's records in the file's order: always so when they were just counted from it, and the
-        # usual case when they came from the features cache written beside it (one vectorised comparison to know)
-        own_rows = fasta_ids is self.data_ids or (
-            len(fasta_ids) == len(self.data_ids) and bool(np.array_equal(np.asarray(fasta_ids), np.asarray(self.data_ids))))
+        keep, long_ids = _length_screen(self.data_ids, fasta_ids, _lengths, self.length_requirement)
         _lap("length screen: rows matched")
-        if own_rows and is_long.all():
+        if keep is None:
             self.data_ids = np.asarray(self.data_ids)
             return      # every row is a long contig's own: nothing to drop (and 10^6 ids not sorted and copied, 0.4 s)
-        long_ids = np.asarray(fasta_ids)[is_long]
-        if own_rows:
-            # the reference keeps a row when its id is that of SOME contig long enough (np.in1d): true for every long contig's
-            # own row, so only the short contigs' ids have to be looked up (none on a batch of long contigs; a sort of 10^6
-            # strings otherwise, 0.2 s)
-            keep = is_long.copy()
-            short = ~is_long
-            if short.any() and is_long.any():
-                keep[short] = np.isin(np.asarray(self.data_ids)[short], long_ids)
-        else:
-            keep = np.isin(self.data_ids, long_ids)
         if self._batch is not None:
             old, self._batch = self._batch, self._batch.select(np.flatnonzero(keep))
             old.close()
@@ -385,6 +370,30 @@ class phamer_scorer(object):
         return self._gpu_score('combo')
 
 
+def _length_screen(data_ids, fasta_ids, lengths, length_requirement):
+    """The rows screen_by_length keeps (scripts/phamer.py:144-157): (keep mask over data_ids, ids of the long contigs), or
+    (None, None) when every row is a long contig's own and nothing is dropped."""
+    is_long = np.asarray(lengths) >= length_requirement
+    # the rows are the file's records in the file's order: always so when they were just counted from it, and the
+    # usual case when they came from the features cache written beside it (one vectorised comparison to know)
+    own_rows = fasta_ids is data_ids or (
+        len(fasta_ids) == len(data_ids) and bool(np.array_equal(np.asarray(fasta_ids), np.asarray(data_ids))))
+    if own_rows and is_long.all():
+        return None, None
+    long_ids = np.asarray(fasta_ids)[is_long]
+    if own_rows:
+        # the reference keeps a row when its id is that of SOME contig long enough (np.in1d): true for every long contig's
+        # own row, so only the short contigs' ids have to be looked up (none on a batch of long contigs; a sort of 10^6
+        # strings otherwise, 0.2 s)
+        keep = is_long.copy()
+        short = ~is_long
+        if short.any() and is_long.any():
+            keep[short] = np.isin(np.asarray(data_ids)[short], long_ids)
+    else:
+        keep = np.isin(data_ids, long_ids)
+    return keep, long_ids
+
+
 def score_points(scoring_data, positive_training_data, negative_training_data, method=None):
     """Functional form of phamer_scorer.score_points (scripts/phamer.py:451-468), the scoring function of the
     reference's cross-validation (scripts/cross_validate.py:95)."""
@@ -428,6 +437,18 @@ def main(argv=None):
     args = ap.parse_args(argv)
     if args.do_tsne or args.plot_tsne:
         raise NotImplementedError("t-SNE / plots (-do_tsne, -plot) are outside the accelerated path (SURVEY.md section 8)")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or os.environ.get("PHAMERS_FORCE_RANK_PATH") == "1":   # one rank of a sharded run (started below, or by
+                                                                        # torch.distributed.run; forced: a 1-rank group, tests)
+        return _run_rank(ap, args)
+    if args.gpus and args.gpus > 1:    # the launcher: it never touches the GPU itself -- the ranks are its children
+        import sys
+        from . import dist as pdist
+        cmd = [sys.executable, "-m", "phamers_amd.phamer"] + list(sys.argv[1:] if argv is None else argv)
+        rc = pdist.launch_ranks(args.gpus, cmd, require_gpus=os.environ.get("PHAMERS_DIST_BACKEND", "nccl") == "nccl")
+        if rc:
+            raise SystemExit(rc)
+        return None
     return _run(ap, args)
 
 
@@ -445,6 +466,7 @@ def _parser():
             (('-k', '--kmer_length'), dict(type=int, default=4, help='k-mer length')),
             (('-l', '--length_requirement'), dict(type=int, default=5000, help='Input sequence length requirement')),
             (('-equal', '-e', '--equalize_reference'), dict(action='store_true', help='Same number of reference points')),
+            (('--gpus',), dict(type=int, default=1, help='GPUs of this node to shard the contigs over (one process per GPU)')),
             (('-v', '--verbose'), dict(action='store_true')),
             (('--debug',), dict(action='store_true')),
             # the rest of the reference's command line (scripts/phamer.py:515-553), so that its launch scripts
@@ -504,6 +526,125 @@ def _run(ap, args):
         scorer.finish_io()
         lap("features cache complete")
     return scorer
+
+
+def _rank_count_and_score(fasta_file, part, kmer_length, method, positive, negative, cpos, cneg, k_neighbors, keep_of, gpu):
+    """One rank's share of the FASTA file on its GPU: the records that begin in byte range ``part`` = (rank, world) are parsed
+    straight into the upload's staging buffers (phk_batch_from_fasta_part), counted, screened (``keep_of(ids, lengths)`` ->
+    boolean mask over this rank's records, decided with every rank's ids) and scored.  Returns (ids, counts uint32 of every
+    record, keep mask, scores of the kept).  (A module-level function so that the CPU tests can put the oracle in its
+    place: the product has no CPU path.)"""
+    ctx = _lib.get_context(gpu)
+    threads = max(1, (os.cpu_count() or 1) // max(1, part[1]))
+    fasta, batch = _lib.Fasta.count_file(ctx, fasta_file, kmer_length, threads=threads, part=part)
+    try:
+        ids, lengths = fasta.phamers_ids(), fasta.lengths()
+    finally:
+        fasta.close()
+    try:
+        counts = batch.counts_u32() if batch.n else np.zeros((0, 4 ** int(kmer_length)), dtype=np.uint32)
+        keep = keep_of(ids, lengths)
+        scores = np.zeros(0)
+        if keep.any():
+            sub = batch if keep.all() else batch.select(np.flatnonzero(keep))
+            model = _lib.Model(ctx, positive, negative, cpos if method != 'knn' else None, cneg if method != 'knn' else None,
+                               k_neighbors=k_neighbors)
+            try:
+                scores = sub.score(model, method)
+            finally:
+                model.close()
+                if sub is not batch:
+                    sub.close()
+        return ids, counts, keep, scores
+    finally:
+        batch.close()
+
+
+def _run_rank(ap, args):
+    """One rank of `python -m phamers_amd.phamer ... --gpus N` (scripts/phamer.py:512-598 on a shard): the
+    reference matrices and centroids are replicated, every rank loads, counts and scores the records of ITS byte range of the
+    FASTA file, and the ranks exchange ids, lengths (for the length screen, which looks ids up across the whole file), scores
+    and -- for the features cache rank 0 writes -- counts.  Rank 0 writes the same phamer_scores.csv and <fasta>_features.csv
+    as the one-GPU run, byte for byte."""
+    import torch
+    import torch.distributed as tdist
+    from . import dist as pdist
+    logger.setLevel(logging.DEBUG if args.debug else logging.INFO if args.verbose else logging.WARNING)
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    backend = os.environ.get("PHAMERS_DIST_BACKEND", "nccl")
+    gpu = None
+    if backend == "nccl":
+        gpu = pdist.rank_device()
+        tdist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+    else:
+        tdist.init_process_group(backend)
+    dev = torch.device("cuda", gpu) if backend == "nccl" else torch.device("cpu")
+    try:
+        scorer = phamer_scorer()
+        scorer.kmer_length = args.kmer_length
+        scorer.input_directory, scorer.fasta_file, scorer.features_file = args.input_directory, args.fasta_file, args.features_file
+        if args.data_directory:
+            scorer.data_directory = args.data_directory
+            scorer.find_data_files()
+        scorer.positive_features_file = args.positive_features or scorer.positive_features_file
+        scorer.negative_features_file = args.negative_features or scorer.negative_features_file
+        if not (scorer.positive_features_file and scorer.negative_features_file):
+            ap.error("give -data <dir with reference_features/> or -pf and -nf")
+        scorer.output_directory = args.output_directory or os.path.join(
+            args.input_directory or os.path.dirname(args.fasta_file or args.features_file or '.'), "phamer_output")
+        scorer.find_input_files()
+        if not (scorer.fasta_file and os.path.exists(scorer.fasta_file)):
+            raise SystemExit("--gpus needs the input FASTA file (a features cache alone is scored by one GPU). Exiting...")
+        scorer._load_reference()
+        if args.equalize_reference:
+            scorer.equalize_reference_data()
+        # centroids: fitted once, by rank 0, and handed to every rank (the fit is deterministic; this makes "replicated" literal)
+        shape = (scorer.k_clusters, scorer.positive_data.shape[1])
+        cen = torch.zeros((2,) + shape, dtype=torch.float64, device=dev)
+        if rank == 0:
+            scorer._fit_centroids()
+            cen[0] = torch.from_numpy(np.ascontiguousarray(scorer.positive_centroids)).to(dev)
+            cen[1] = torch.from_numpy(np.ascontiguousarray(scorer.negative_centroids)).to(dev)
+        tdist.broadcast(cen, src=0)
+        cpos, cneg = cen[0].cpu().numpy(), cen[1].cpu().numpy()
+
+        screen = int(scorer.length_requirement) if args.length_requirement else 0   # (the CLI value is a switch, as in the reference)
+
+        def keep_of(ids, lengths):
+            # the screen keeps a row whose id is that of SOME contig long enough, anywhere in the file: decided on every
+            # rank from all ranks' ids and lengths, exactly as the one-GPU run decides it
+            everything = [None] * world
+            tdist.all_gather_object(everything, (list(ids), np.asarray(lengths, dtype=np.int64)))
+            keep_of.all_ids = np.array([x for part in everything for x in part[0]], dtype=object if any(
+                x is None for part in everything for x in part[0]) else None)
+            if keep_of.all_ids.dtype != object:
+                keep_of.all_ids = keep_of.all_ids.astype(str)
+            all_len = np.concatenate([part[1] for part in everything]) if everything else np.zeros(0, dtype=np.int64)
+            first = sum(len(part[0]) for part in everything[:rank])
+            keep_of.kept_ids = keep_of.all_ids
+            keep_of.all_keep = np.ones(len(all_len), dtype=bool)
+            if screen:
+                k_all, long_ids = _length_screen(keep_of.all_ids, keep_of.all_ids, all_len, screen)
+                if k_all is not None:    # (rows and ids exactly as screen_by_length leaves them in the one-GPU run)
+                    keep_of.all_keep, keep_of.kept_ids = k_all, long_ids
+            return keep_of.all_keep[first:first + len(ids)]
+
+        ids, counts, keep, scores = _rank_count_and_score(scorer.fasta_file, (rank, world), scorer.kmer_length, scorer.scoring_method,
+                                                          scorer.positive_data, scorer.negative_data, cpos, cneg, scorer.k_neighbors,
+                                                          keep_of, gpu)
+        all_scores = pdist.gather_variable(torch.from_numpy(np.ascontiguousarray(scores, dtype=np.float64)).to(dev)).cpu().numpy()
+        all_counts = pdist.gather_rows_to_root(torch.from_numpy(np.ascontiguousarray(counts).view(np.int32)).to(dev))
+        if rank == 0:
+            os.makedirs(scorer.output_directory, exist_ok=True)
+            scorer.data_ids = keep_of.kept_ids
+            scorer.scores = all_scores
+            scorer.make_summary_file(args=args)
+            cache = "{base}_features.csv".format(base=os.path.splitext(scorer.fasta_file)[0])
+            fileIO.save_counts(all_counts.cpu().numpy().view(np.uint32), keep_of.all_ids, cache)
+        tdist.barrier()
+        return scorer if rank == 0 else None
+    finally:
+        tdist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -18,7 +18,7 @@ def golden_dir():
 
 
 KNOB_DEFAULTS = {"count_lanes": "", "count_cfg": "", "slot_threads": "", "count_sort": "1", "force_exact": "0",
-                 "proposal": "", "cx_cfg": "", "rerank": "", "score_batch": "0", "pipeline": "1"}
+                 "proposal": "", "cx_cfg": "", "rerank": "", "score_batch": "0", "tail_aside": "1"}
 
 
 @pytest.fixture(autouse=True)

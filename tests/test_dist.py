@@ -215,3 +215,109 @@ def test_visible_gpus_counts_kfd_nodes_without_the_runtime(tmp_path, monkeypatch
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
     assert pdist.visible_gpus(str(tmp_path)) == 0
     assert pdist.visible_gpus(str(tmp_path / "absent")) == 0
+
+
+def _cli_fasta(path):
+    """Contigs either side of the 5000-base screen, titles with descriptions, lower case and N; 23 records so that 2 and 3
+    byte ranges cut in the middle of records.  (Ids are unique: for a short contig that shares its id with a long one the
+    reference keeps the row and drops the id, scripts/phamer.py:153-155, and cannot write its output.)"""
+    from phamers_amd import synth
+    lens = [5200, 300, 5000, 4999, 7000, 5100, 20, 6100, 5000, 5050, 900, 5600, 5000, 8000, 5001, 4000, 5300, 5000, 5000, 6500, 70, 5900, 5000]
+    with open(path, "w") as f:
+        for i, L in enumerate(lens):
+            name = "SuperContig_%d_ID_%d" % (i, i)
+            seq = synth.synth_contig(5, i, L)
+            if i == 7:
+                seq = seq[:1000] + "NNNNNNNNNN" + seq[1010:3000].lower() + seq[3000:]
+            f.write(">%s some description %d\n" % (name, i))
+            for a in range(0, len(seq), 70):
+                f.write(seq[a:a + 70] + "\n")
+    return lens
+
+
+def _run_cli_ranks(world, indir, outdir, refdir, tmp_path):
+    from phamers_amd import dist as pdist
+    env = {"PHAMERS_DIST_BACKEND": "gloo", "PHAMERS_KMEANS": "sklearn", "PHK_REPO": REPO, "OMP_NUM_THREADS": "1",
+           "PHAMERS_FORCE_RANK_PATH": "1"}
+    argv = [sys.executable, os.path.join(REPO, "tests", "dist_cli_worker.py"), "-in", str(indir), "-out", str(outdir),
+            "-pf", os.path.join(refdir, "pos.csv"), "-nf", os.path.join(refdir, "neg.csv"), "--gpus", str(world)]
+    rc = pdist.launch_ranks(world, argv, require_gpus=False, timeout=600, extra_env=env)
+    assert rc == 0
+    # (the '#' header block of the score file lists the run's arguments -- --gpus, -out -- : compared without it)
+    scores = b"\n".join(ln for ln in open(os.path.join(outdir, "phamer_scores.csv"), "rb").read().split(b"\n") if not ln.startswith(b"#"))
+    cache = [f for f in os.listdir(indir) if f.endswith("_features.csv")]
+    assert len(cache) == 1
+    feats = open(os.path.join(indir, cache[0]), "rb").read()
+    os.unlink(os.path.join(indir, cache[0]))      # (the next run must count the FASTA file again, not read the cache)
+    return scores, feats
+
+
+def test_command_line_ranks_write_the_one_rank_files_byte_for_byte(tmp_path):
+    """`python -m phamers_amd.phamer -in <dir> ... --gpus N` (phamer._run_rank) over gloo with 1, 2 and 3
+    ranks: rank 0's phamer_scores.csv and <fasta>_features.csv are the same bytes whatever the number of ranks, and equal
+    the files built here from the oracle over the whole FASTA file with the reference's length screen
+    (scripts/phamer.py:144-157).  The per-rank GPU work is replaced by the oracle
+    (tests/dist_cli_worker.py); everything else is the command line's own code."""
+    from oracle import oracle
+    from phamers_amd import _lib, fileIO, learning
+    ref = helpers.load_npz("ref_features.npz")
+    refdir = tmp_path / "ref"
+    refdir.mkdir()
+    npos, nneg = 260, 240
+    fileIO.save_counts(ref["pos_counts"][:npos].astype(np.int64), ["p%d" % i for i in range(npos)], str(refdir / "pos.csv"))
+    fileIO.save_counts(ref["neg_counts"][:nneg].astype(np.int64), ["n%d" % i for i in range(nneg)], str(refdir / "neg.csv"))
+    indir = tmp_path / "in"
+    indir.mkdir()
+    lens = _cli_fasta(str(indir / "contigs.fasta"))
+    outs = {}
+    for world in (1, 2, 3):
+        out = tmp_path / ("out%d" % world)
+        outs[world] = _run_cli_ranks(world, indir, out, str(refdir), tmp_path)
+    assert outs[2] == outs[1] and outs[3] == outs[1]
+    # ... and what those bytes must be
+    fa = _lib.Fasta(str(indir / "contigs.fasta"))
+    ids, seqs = fa.phamers_ids(), fa.sequences()
+    fa.close()
+    assert [len(x) for x in seqs] == lens
+    counts = oracle.count(seqs, 4).reshape(len(seqs), 256)
+    is_long = np.array(lens) >= 5000
+    keep = is_long
+    assert int(keep.sum()) == 17 and not keep[1]
+    pos = oracle.normalize_counts(ref["pos_counts"][:npos].astype(np.int64))
+    neg = oracle.normalize_counts(ref["neg_counts"][:nneg].astype(np.int64))
+    os.environ["PHAMERS_KMEANS"] = "sklearn"
+    try:
+        cpos = learning.get_centroids(pos, learning.kmeans(pos, 86))
+        cneg = learning.get_centroids(neg, learning.kmeans(neg, 86))
+    finally:
+        del os.environ["PHAMERS_KMEANS"]
+    want = oracle.score_points(oracle.normalize_counts(counts[keep]), pos, neg, "combo", 3, cpos, cneg)
+    want_scores = tmp_path / "want_scores.csv"
+    fileIO.save_phamer_scores(ids[keep], want, str(want_scores))
+    strip = lambda b: b"\n".join(ln for ln in b.split(b"\n") if not ln.startswith(b"#"))
+    assert outs[2][0] == strip(open(want_scores, "rb").read())
+    want_feats = tmp_path / "want_features.csv"
+    fileIO.save_counts(counts.astype(np.uint32), ids, str(want_feats))
+    assert outs[2][1] == open(want_feats, "rb").read()
+
+
+def test_command_line_gpus_flag_starts_ranks_as_children(monkeypatch):
+    """--gpus N in a process that is not a rank: N children of `python -m phamers_amd.phamer <same arguments>`, nothing on
+    the GPU in the launcher itself; a failing rank's exit code becomes the command's."""
+    from phamers_amd import dist as pdist, phamer
+    seen = {}
+
+    def fake_launch(n, argv, require_gpus=True, **kw):
+        seen.update(n=n, argv=list(argv), require_gpus=require_gpus)
+        return seen.get("rc", 0)
+    monkeypatch.setattr(pdist, "launch_ranks", fake_launch)
+    for var in ("WORLD_SIZE", "RANK", "PHAMERS_FORCE_RANK_PATH", "PHAMERS_DIST_BACKEND"):
+        monkeypatch.delenv(var, raising=False)
+    args = ["-in", "/nonexistent/in", "-data", "/nonexistent/data", "--gpus", "4", "-e"]
+    assert phamer.main(args) is None
+    assert seen["n"] == 4 and seen["require_gpus"] is True
+    assert seen["argv"][1:3] == ["-m", "phamers_amd.phamer"] and seen["argv"][3:] == args
+    seen["rc"] = 7
+    with pytest.raises(SystemExit) as e:
+        phamer.main(args)
+    assert e.value.code == 7

@@ -206,3 +206,35 @@ def test_sharded_entry_points_under_a_one_rank_rccl_group(tmp_path):
     want = pdist.default_scorer()(seqs, 4, "combo", pos, neg, g["cpos_eq"], g["cneg_eq"], 3)
     assert np.array_equal(got[0], want)
     assert np.array_equal(got[1], want)
+
+
+def test_command_line_rank_path_under_a_one_rank_rccl_group(tmp_path):
+    """`python -m phamers_amd.phamer -in <dir> -data <dir> -e` twice in fresh child processes: as the one-GPU run (phamer._run)
+    and as a rank of `--gpus N` (phamer._run_rank: PHAMERS_FORCE_RANK_PATH=1 makes it a 1-rank `nccl` group on the box's
+    one GPU -- init_process_group(device_id=...), the centroid broadcast, the ids / lengths exchange for the length screen,
+    phk_batch_from_fasta_part, the score gather and the count gather to rank 0 as DEVICE tensors through RCCL).  Both must
+    write the same phamer_scores.csv (below the header block, which lists the arguments) and the same features cache,
+    byte for byte.  The 2- and 3-rank forms of the same code run over gloo in tests/test_dist.py."""
+    from phamers_amd import fileIO, synth
+    ref = helpers.load_npz("ref_features.npz")
+    data = tmp_path / "data" / "reference_features"
+    data.mkdir(parents=True)
+    fileIO.save_counts(ref["pos_counts"], ref["pos_ids"], str(data / "positive_features.csv"))
+    fileIO.save_counts(ref["neg_counts"], ref["neg_ids"], str(data / "negative_features.csv"))
+    lens = [5000] * 40 + [300, 5000, 4999, 7000, 20, 6100, 900, 5600, 8000, 70] + [5000] * 30
+    outs = {}
+    for name, extra in (("plain", {}), ("rank", {"PHAMERS_FORCE_RANK_PATH": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})):
+        indir = tmp_path / ("in_" + name)
+        indir.mkdir()
+        with open(indir / "contigs.fasta", "w") as f:
+            for c, L in enumerate(lens):
+                s = synth.synth_contig(3, c, L)
+                f.write(">SuperContig_%d_length_%d_ID_%d\n" % (c, L, c))
+                f.write("\n".join(s[i:i + 70] for i in range(0, L, 70)) + "\n")
+        r = subprocess.run([sys.executable, "-m", "phamers_amd.phamer", "-in", str(indir), "-data", str(tmp_path / "data"), "-e"],
+                           cwd=REPO, env=_rccl_env(**extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (name, r.stderr[-4000:])
+        sc = (indir / "phamer_output" / "phamer_scores.csv").read_bytes()
+        outs[name] = (b"\n".join(ln for ln in sc.split(b"\n") if not ln.startswith(b"#")), (indir / "contigs_features.csv").read_bytes())
+    assert outs["plain"][0].count(b"\n") >= 70
+    assert outs["rank"] == outs["plain"]

@@ -94,8 +94,10 @@ def test_full_size_batch_properties(monkeypatch):
 def test_config2_k5_10M_x_10kb_counting_and_scoring():
     """BASELINE configs[2] at full size: k = 5 (1024 bins), 10 M x 10 kb contigs on one GPU (100 Gbases; 25 GB packed,
     41 GB of counts per copy).  Every row sums to L - k + 1, the slot kernel and the wave-per-contig kernel agree bit
-    for bit (both checked on the device), 96 sampled rows equal the oracle's counts, and a 262 144-row slice scored
-    against 2255 + 2255 synthetic reference genomes matches the oracle on a sample."""
+    for bit (both checked on the device), 96 sampled rows equal the oracle's counts, and ALL 10 M rows are scored against
+    2255 + 2255 synthetic reference genomes in one call -- ten scoring batches of 2^20 rows, the per-row hand-over queues
+    (three-digit re-sweep, f16 sweep, brute force) carried per batch -- with the oracle on a sample spread over all ten
+    batches, and a slice re-scored alone (other batch split, other tiles) equal bit for bit."""
     from oracle import oracle
     from phamers_amd import _lib, device, synth, workloads
     cfg = workloads.CONFIGS[2]
@@ -128,19 +130,27 @@ def test_config2_k5_10M_x_10kb_counting_and_scoring():
     # scoring a slice of the batch (general-D count-exact MFMA path), sample against the oracle
     pos, neg, cpos, cneg = workloads.synthetic_reference(ctx, k, cfg["refs"], cfg["ref_length"])
     model = _lib.Model(ctx, pos, neg, cpos, cneg, 3)
-    ns = 262144
-    scores = device.DeviceArray(ctx, ns, np.float64)
+    scores = device.DeviceArray(ctx, n, np.float64)
     status = device.DeviceArray(ctx, 1, np.uint32)
-    device.score_counts(ctx, model, counts, ns, "combo", scores, status)
+    device.score_counts(ctx, model, counts, n, "combo", scores, status)
     assert status.to_host()[0] == 0
     n_fallback, _ = ctx.score_stats()
-    assert n_fallback < ns // 100
-    pick = np.sort(rng.choice(ns, 48, replace=False))
+    assert n_fallback < n // 1000, n_fallback
+    all_scores = scores.to_host()
+    assert np.isfinite(all_scores).all() and np.all(np.abs(all_scores) < 2.0)
+    # six rows of each of the ten scoring batches (2^20 rows each; the last one holds 562 816)
+    pick = np.sort(np.concatenate([b * (1 << 20) + rng.choice(min(1 << 20, n - b * (1 << 20)), 6, replace=False) for b in range(10)]))
+    assert pick[-1] >= 9 * (1 << 20)
     q = oracle.normalize_counts(device.read_rows(ctx, counts, pick, D).astype(np.int64))
     want_s = oracle.knn_score_points(q, pos, neg, 3) + oracle.centroid_score_points_fast(q, cpos, cneg)
-    assert helpers.rel_err(scores.to_host()[pick], want_s) < 1e-6
+    assert helpers.rel_err(all_scores[pick], want_s) < 1e-6
+    # a slice that straddles two batches of the full call, scored alone: route independence at full size
+    lo, ns = 3 * (1 << 20) - 70000, 262144
+    sub_scores = device.DeviceArray(ctx, ns, np.float64)
+    device.score_counts(ctx, model, counts.ptr + lo * D * 4, ns, "combo", sub_scores, status)   # (a device pointer into the matrix)
+    assert np.array_equal(sub_scores.to_host(), all_scores[lo:lo + ns])
     model.close()
-    for a in (packed, offsets, counts, nwin, scores, status):
+    for a in (packed, offsets, counts, nwin, scores, status, sub_scores):
         a.free()
 
 

@@ -703,7 +703,10 @@ def test_scoring_in_several_batches_matches_one_batch_and_exact_path():
     d_scores = device.DeviceArray(ctx, n, np.float64)
     d_status = device.DeviceArray(ctx, 1, np.uint32)
     out, stats = {}, {}
-    for name, opts in (("one", {}), ("four", {"score_batch": "4096"}), ("piped", {"pipeline": "3"}), ("exact", {"force_exact": "1"})):
+    # "four": 49 batches of 4096, each batch's hand-over kernels on the context's second stream beside the next batch's sweep
+    # (round 5); "inline": the same batches with everything on one stream (option tail_aside = 0)
+    for name, opts in (("one", {}), ("four", {"score_batch": "4096"}), ("inline", {"score_batch": "4096", "tail_aside": "0"}),
+                       ("exact", {"force_exact": "1"})):
         for k_, v_ in opts.items():
             ctx.set_option(k_, v_)
         # the fused entry point (row sums come from the count kernel) and the counts-only one
@@ -714,12 +717,13 @@ def test_scoring_in_several_batches_matches_one_batch_and_exact_path():
         assert np.array_equal(d_scores.to_host(), out[name]), name
         ctx.set_option("score_batch", "0")
         ctx.set_option("force_exact", "0")
-        ctx.set_option("pipeline", "1")
+        ctx.set_option("tail_aside", "1")
     # Scores do not depend on the batch split: every route a query can take (certified margin, exact candidate
     # distances, second chance, brute force -- which one depends on how many rows its batch queues) ends in the same
     # float64 evaluation (exact_d2_g16's form, element ownership and summation order) of the same operands.
-    assert np.array_equal(out["one"], out["piped"])
     assert np.array_equal(out["one"], out["four"])
+    assert np.array_equal(out["one"], out["inline"])
+    assert stats["four"] == stats["inline"]
     # totals over the four batches (the tail routes depend on the batch split: a handful of queued rows per batch goes
     # straight to the brute force, so the totals are compared loosely)
     assert stats["four"][1] > 0 and abs(stats["four"][1] - stats["one"][1]) <= 64
@@ -1287,6 +1291,61 @@ def test_count_score_k5_tiny_and_empty_batches_do_not_take_a_stale_operand():
 
 
 @pytest.mark.gpu
+def test_out_of_memory_in_a_workspace_is_reported_and_the_context_stays_usable():
+    """A hipMalloc failure inside phk_ws (option ws_fail = n: the n-th workspace allocation from now on asks for 2^60 bytes
+    -- a real failure on the real error path) surfaces as PHK_ERR_NOMEM from whatever entry point hit it, half way through a
+    launch chain or not; the next call on the same context works and gives the same counts and scores as before the
+    failure.  (The kernels keep their control words zeroed themselves, round 5: a chain cut short must not leave the next
+    call with dirty counters.)"""
+    from phamers_amd import _lib, device
+    g = helpers.load_npz("scoring_k4.npz")
+    pos, neg = _ref_matrices()
+    model = _lib.Model(_lib.get_context(), pos, neg, g["cpos_full"], g["cneg_full"], 3)
+    model.close()
+    ctx = _lib.Context(_lib.default_device())      # a context of its own: fresh workspaces, so that every slot still has to grow
+    try:
+        model = _lib.Model(ctx, pos, neg, g["cpos_full"], g["cneg_full"], 3)
+        n, L = 70000, 4000
+        T = n * L
+        d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+        d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+        device.synth_packed(ctx, 31, 0, n, L, d_packed, d_off)
+        d_counts = device.DeviceArray(ctx, (n, 256), np.uint32)
+        d_scores = device.DeviceArray(ctx, n, np.float64)
+        d_status = device.DeviceArray(ctx, 1, np.uint32)
+        hit = 0
+        for nth in range(1, 12):     # fail the 1st, 2nd, ... workspace allocation of the chain in turn
+            ctx.set_option("ws_fail", str(nth))
+            try:
+                device.count_score(ctx, model, d_packed, None, T, d_off, n, 4, "combo", d_counts, d_scores, d_status)
+            except _lib.PhkError as e:
+                assert e.code == _lib.PHK_ERR_NOMEM, (nth, e)
+                hit += 1
+            ctx.set_option("ws_fail", "0")
+            # the same call again: complete and correct (the workspaces the failed call did get are kept)
+            device.count_score(ctx, model, d_packed, None, T, d_off, n, 4, "combo", d_counts, d_scores, d_status)
+            if nth == 1:
+                want_counts, want = d_counts.to_host(), d_scores.to_host()
+                assert np.array_equal(want_counts.sum(axis=1), np.full(n, L - 3))
+            else:
+                assert np.array_equal(d_counts.to_host(), want_counts), nth
+                assert np.array_equal(d_scores.to_host(), want), nth
+            assert int(d_status.to_host()[0]) == 0
+        assert hit >= 1
+        # ... and a context that has seen failures scores like the shared one
+        d2 = device.DeviceArray(_lib.get_context(), n, np.float64)
+        base = _lib.get_context()
+        model2 = _lib.Model(base, pos, neg, g["cpos_full"], g["cneg_full"], 3)
+        c2 = device.DeviceArray.from_host(base, want_counts)
+        device.score_counts(base, model2, c2, n, "combo", d2, None)
+        assert np.array_equal(d2.to_host(), want)
+        model2.close()
+        model.close()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_reference_kmeans_labels_from_the_device_lloyd():
     """learning.kmeans (scripts/learning.py:131-146) without the host fit: scikit-learn's seeding on the host, its Lloyd
     iteration on the device (phk_kmeans_lloyd) -- labels equal to oracle.kmeans_lloyd_seeded from the same seeds and to
@@ -1318,6 +1377,26 @@ def test_reference_kmeans_labels_from_the_device_lloyd():
     for method, key in (("kmeans", "kmeans_eq"), ("combo", "combo_eq")):
         got = phamer.score_points(q, pos[:n], neg[:n], method=method)
         assert helpers.rel_err(got, g[key]) < 1e-6, method
+    # beyond the fixture matrices: cross-validation folds of the reference classes and random matrices of
+    # other shapes -- wherever the device fit answers at all (no empty cluster, no near tie: else the facade takes the host
+    # fit and equality is trivial) its labels are scikit-learn's
+    rng = np.random.default_rng(12)
+    cases = []
+    for f in range(5):
+        cases.append((np.delete(pos, np.arange(f, len(pos), 5), axis=0), 86))
+        cases.append((np.delete(neg, np.arange(f, len(neg), 5), axis=0), 86))
+    for nn, dd, kk in ((600, 64, 12), (1500, 256, 86), (900, 1024, 30), (300, 16, 5)):
+        X = rng.gamma(3.0, 1.0, (nn, dd)) * (1.0 + 0.5 * np.sin(np.arange(dd) * 0.3 + rng.integers(0, 4, nn)[:, None]))
+        cases.append((X / X.sum(axis=1, keepdims=True), kk))
+    answered = 0
+    for X, kk in cases:
+        got = learning.kmeans_reference_on_device(X, kk)
+        want = KMeans(n_clusters=kk, random_state=10).fit(X).labels_
+        if got is not None:
+            answered += 1
+            assert np.array_equal(got[0], want), (X.shape, kk, int((got[0] != want).sum()))
+        assert np.array_equal(learning.kmeans(X, kk), want), (X.shape, kk)
+    assert answered >= len(cases) - 2, answered
 
 
 @pytest.mark.gpu
