@@ -8,6 +8,7 @@
 // back: the scores, and the counts once for the features cache.
 #include <string.h>
 
+#include <chrono>
 #include <functional>
 #include <vector>
 
@@ -147,6 +148,106 @@ int phk_batch_build(phk_ctx *ctx, const char *bases, const std::function<void(ui
         if (packed_ev[i]) (void)hipEventDestroy(packed_ev[i]);
         if (d_chunk[i]) (void)hipFree(d_chunk[i]);
     }
+    if (rc != PHK_OK) {
+        batch_release(b);
+        return rc;
+    }
+    *out = b;
+    return PHK_OK;
+}
+
+// The batch of a FASTA file from its RAW bytes (phk_batch_from_fasta_file / _part since round 5): the file goes up as it is --
+// host threads only copy it into the pinned staging buffers, at memory speed, while the previous chunk is on the bus -- and
+// phk_deline_pack_kernel reads the sequences out of it on the device.  The raw buffer (the file's size) lives on the device
+// until the packed stream exists.
+int phk_raw_to_device(phk_ctx *ctx, const char *raw, uint64_t raw_bytes, const uint8_t **d_raw) {
+    PHK_ENTER(ctx, "phk_raw_to_device");
+    void *d = nullptr;
+    PHK_TRY(phk_ws(ctx, WS_ASCII, raw_bytes + 64, &d));
+    if (raw_bytes) {
+        PHK_TRY(phk_copy_to_device(ctx, d, raw, raw_bytes));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *d_raw = (const uint8_t *)d;
+    return PHK_OK;
+}
+
+int phk_batch_build_raw(phk_ctx *ctx, const uint8_t *d_raw, const char *side, uint64_t side_bytes,
+                        const uint64_t *rbegin, const uint32_t *rlw, const uint32_t *rtl, const uint64_t *offsets, uint64_t n,
+                        int k, const char *symbols4, phk_batch **out) {
+    PHK_ENTER(ctx, "phk_batch_build_raw");
+    PHK_REQUIRE(out, "phk_batch: NULL out");
+    PHK_REQUIRE(k >= 1, "phk_batch: k must be >= 1 (got %d)", k);
+    if (k > PHK_MAX_K) {
+        phk_set_error("phk_batch: k=%d is above PHK_MAX_K=%d", k, PHK_MAX_K);
+        return PHK_ERR_UNSUPPORTED;
+    }
+    const char *sym = symbols4 ? symbols4 : "ATGC";
+    PHK_REQUIRE(strlen(sym) == 4, "phk_batch: symbols must be exactly 4 characters");
+    const uint64_t T = n ? offsets[n] : 0;
+    phk_batch *b = new phk_batch();
+    b->n = n;
+    b->k = k;
+    b->D = phk_pow4(k);
+    b->T = T;
+    b->len.resize(n);
+    for (uint64_t c = 0; c < n; ++c) b->len[c] = offsets[c + 1] - offsets[c];
+    if (n == 0) {
+        *out = b;
+        return PHK_OK;
+    }
+    void *d_meta = nullptr;
+    const bool timing = getenv("PHK_INGEST_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (timing) {
+            (void)hipStreamSynchronize(ctx->stream);
+            fprintf(stderr, "[phk ingest]   %-26s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
+    };
+    auto body = [&]() -> int {
+        if (hipMalloc(&b->d_counts, n * b->D * sizeof(uint32_t)) != hipSuccess ||
+            hipMalloc(&b->d_nwin, n * sizeof(uint32_t)) != hipSuccess) {
+            phk_set_error("phk_batch: cannot allocate %llu x %llu counts on the device", (unsigned long long)n,
+                          (unsigned long long)b->D);
+            return PHK_ERR_NOMEM;
+        }
+        void *d_packed, *d_mask, *d_off, *d_flags;
+        PHK_TRY(phk_ws(ctx, WS_PACKED, (phk_div_up(T, 16) + 1) * 4, &d_packed));
+        PHK_TRY(phk_ws(ctx, WS_MASK, (phk_div_up(T, 32) + 1) * 4, &d_mask));
+        PHK_TRY(phk_ws(ctx, WS_OFFSETS, (n + 1) * 8, &d_off));
+        PHK_TRY(phk_ws(ctx, WS_FLAGS, 64, &d_flags));
+        if (hipMalloc(&d_meta, n * 16 + side_bytes + 64) != hipSuccess) {
+            phk_set_error("phk_batch: cannot allocate %llu bytes for the record layout on the device", (unsigned long long)(n * 16 + side_bytes));
+            return PHK_ERR_NOMEM;
+        }
+        lap("device allocations");
+        uint64_t *d_rbegin = (uint64_t *)d_meta;
+        uint32_t *d_rlw = (uint32_t *)(d_rbegin + n), *d_rtl = d_rlw + n;
+        uint8_t *d_side = (uint8_t *)(d_rtl + n);
+        PHK_HIP(hipMemcpyAsync(d_off, offsets, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        PHK_HIP(hipMemcpyAsync(d_rbegin, rbegin, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        PHK_HIP(hipMemcpyAsync(d_rlw, rlw, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        PHK_HIP(hipMemcpyAsync(d_rtl, rtl, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (side_bytes) PHK_TRY(phk_copy_to_device(ctx, d_side, side, side_bytes));
+        lap("layout + side on the device");
+        PHK_TRY(phk_launch_deline_pack(ctx, d_raw, d_side, (const uint64_t *)d_off, n, d_rbegin, d_rlw, d_rtl, T, sym,
+                                       (uint32_t *)d_packed, (uint32_t *)d_mask, (uint32_t *)d_flags));
+        uint32_t flag = 0;
+        PHK_HIP(hipMemcpyAsync(&flag, d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+        b->any_invalid = flag != 0;
+        lap("de-lined and packed");
+        PHK_TRY(phk_launch_count(ctx, (const uint32_t *)d_packed, b->any_invalid ? (const uint32_t *)d_mask : nullptr, T,
+                                 (const uint64_t *)d_off, n, k, b->d_counts, b->d_nwin));
+        PHK_HIP(hipStreamSynchronize(ctx->stream));
+        lap("counted");
+        return PHK_OK;
+    };
+    const int rc = body();
+    if (rc != PHK_OK) (void)hipStreamSynchronize(ctx->stream);
+    if (d_meta) (void)hipFree(d_meta);
+    lap("layout freed");
     if (rc != PHK_OK) {
         batch_release(b);
         return rc;

@@ -82,6 +82,91 @@ int phk_launch_pack(phk_ctx *ctx, const char *d_bases, uint64_t T, const char *s
 }
 
 // ------------------------------------------------------------------------------------
+// de-line + pack (round 5): the packer fed by the RAW bytes of a FASTA file.  The host no longer copies every sequence
+// line into the upload's staging buffers (0.25 s per 5 GB on 16 cores, the largest piece of the command line's load):
+// the file's bytes go up as they are, and this kernel finds base i of record r at
+//     raw[ begin[r] + (i / lw[r]) * (lw[r] + tl[r]) + i % lw[r] ]
+// -- lw = bases per line, tl = bytes between a line's last base and the next line's first (trailing white space + '\n'),
+// both fixed within a record: what the host's index scan checks line by line anyway.  A record it finds irregular
+// (lines of different widths, a blank or a '\r' inside a line, a record cut by the scan's thread slices) is written
+// de-lined by the host into a side buffer and described as one line of it (lw = 2^32 - 1: the kernel then reads `side`).
+// One thread per 32 output bases: its record by binary search in the offsets, then a walk (position, column).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void phk_deline_pack_kernel(const uint8_t *__restrict__ raw, const uint8_t *__restrict__ side,
+                                                              const uint64_t *__restrict__ offsets,
+                                                              uint64_t n, const uint64_t *__restrict__ rbegin,
+                                                              const uint32_t *__restrict__ rlw, const uint32_t *__restrict__ rtl,
+                                                              uint64_t T, uint32_t sym, uint32_t *__restrict__ packed,
+                                                              uint32_t *__restrict__ mask, uint64_t packed_words,
+                                                              uint64_t mask_words, uint32_t *any_invalid) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= mask_words) return;
+    const uint64_t g0 = t * 32;
+    uint32_t w[2] = {0u, 0u};
+    uint32_t m = 0u;
+    bool bad = false;
+    if (g0 < T) {
+        // record of base g0: the last r with offsets[r] <= g0 (empty records before it are passed)
+        uint64_t lo = 0, hi = n;
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (offsets[mid] <= g0) lo = mid; else hi = mid;
+        }
+        uint64_t r = lo, end = offsets[r + 1];
+        uint32_t lw = rlw[r], tl = rtl[r];
+        const uint64_t i0 = g0 - offsets[r];
+        uint64_t line = i0 / lw;
+        uint32_t col = (uint32_t)(i0 - line * lw);
+        uint64_t pos = rbegin[r] + line * ((uint64_t)lw + tl) + col;
+        const uint8_t *src = lw == 0xFFFFFFFFu ? side : raw;   // (a record the host de-lined: one line in the side buffer)
+        for (int b = 0; b < 32; ++b) {
+            const uint64_t g = g0 + b;
+            if (g >= T) break;
+            while (g >= end) {   // next record with bases
+                ++r;
+                end = offsets[r + 1];
+                if (g < end) {
+                    lw = rlw[r];
+                    tl = rtl[r];
+                    pos = rbegin[r];
+                    col = 0;
+                    src = lw == 0xFFFFFFFFu ? side : raw;
+                }
+            }
+            const int code = phk_code_of(src[pos], sym);
+            const bool ok = code >= 0;
+            bad |= !ok;
+            w[b >> 4] |= (uint32_t)(ok ? code : 0) << (30 - 2 * (b & 15));
+            m |= (uint32_t)ok << (31 - b);
+            ++pos;
+            if (++col == lw) {
+                col = 0;
+                pos += tl;
+            }
+        }
+    }
+    mask[t] = m;
+    if (2 * t < packed_words) packed[2 * t] = w[0];
+    if (2 * t + 1 < packed_words) packed[2 * t + 1] = w[1];
+    if (bad && any_invalid) atomicOr(any_invalid, 1u);
+}
+
+int phk_launch_deline_pack(phk_ctx *ctx, const uint8_t *d_raw, const uint8_t *d_side, const uint64_t *d_offsets, uint64_t n, const uint64_t *d_rbegin,
+                           const uint32_t *d_rlw, const uint32_t *d_rtl, uint64_t T, const char *symbols4, uint32_t *d_packed,
+                           uint32_t *d_mask, uint32_t *d_any_invalid) {
+    PHK_REQUIRE(d_packed && d_mask && d_offsets, "phk_deline_pack: NULL output / offsets");
+    PHK_REQUIRE(T == 0 || (d_raw && d_rbegin && d_rlw && d_rtl && n > 0), "phk_deline_pack: NULL input");
+    const uint32_t sym = (uint32_t)(uint8_t)symbols4[0] | ((uint32_t)(uint8_t)symbols4[1] << 8) |
+                         ((uint32_t)(uint8_t)symbols4[2] << 16) | ((uint32_t)(uint8_t)symbols4[3] << 24);
+    const uint64_t packed_words = phk_div_up(T, 16) + 1, mask_words = phk_div_up(T, 32) + 1;
+    if (d_any_invalid) PHK_HIP(hipMemsetAsync(d_any_invalid, 0, sizeof(uint32_t), ctx->stream));
+    PHK_LAUNCH(ctx, "phk_deline_pack_kernel",
+               phk_deline_pack_kernel<<<dim3((unsigned)phk_div_up(mask_words, 256)), dim3(256), 0, ctx->stream>>>(
+                   d_raw, d_side, d_offsets, n, d_rbegin, d_rlw, d_rtl, T, sym, d_packed, d_mask, packed_words, mask_words, d_any_invalid));
+    return PHK_OK;
+}
+
+// ------------------------------------------------------------------------------------
 // count: one wavefront per contig; per-wave LDS histogram replicated over COPIES lanes
 // ------------------------------------------------------------------------------------
 // Lane l of a wave-iteration owns packed word w = w0 + l (16 window starts) and reads word

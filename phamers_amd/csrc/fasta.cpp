@@ -22,6 +22,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <memory>
 #include <string>
@@ -273,7 +274,23 @@ struct FileBytes {
     size_t map_len = 0;
     std::vector<char> owned;
     ~FileBytes() {
-        if (map) munmap(map, map_len);
+        if (!map) return;
+        if (map_len >= ((size_t)256u << 20)) {
+            // tearing down a multi-GB mapping: the page tables are emptied in slices from several threads under the SHARED
+            // address-space lock (MADV_DONTNEED), so that the munmap, which holds it exclusively -- every page fault of the
+            // process waits meanwhile: a detached munmap made the caller's next 1 GB array three times slower -- finds nothing
+            // left to do
+            const size_t page = (size_t)2u << 20, pages = map_len / page;
+            const unsigned nt = std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+            std::vector<std::thread> pool;
+            char *base = (char *)map;
+            for (unsigned t = 0; t < nt; ++t) {
+                const size_t lo = pages * t / nt * page, hi = (t + 1 == nt) ? map_len : pages * (t + 1) / nt * page;
+                if (hi > lo) pool.emplace_back([base, lo, hi]() { (void)madvise(base + lo, hi - lo, MADV_DONTNEED); });
+            }
+            for (auto &th : pool) th.join();
+        }
+        munmap(map, map_len);
     }
 };
 
@@ -406,8 +423,17 @@ static size_t next_record_start(const char *b, size_t n, size_t from) {
     return n;
 }
 
+// Where a record's sequence sits in the file, for the device's de-lining (phk_deline_pack_kernel): base i of a REGULAR record
+// is byte  seq_begin + (i / lw) * (lw + tl) + i % lw  -- every sequence line but the last holds lw bases and is followed by tl
+// bytes (trailing white space + the line end) before the next one begins, and no line holds a ' ' or '\r' inside.
+struct RecLayout {
+    size_t seq_begin = 0;     // first byte of the line after the title line
+    uint32_t lw = 0, tl = 0;  // bases per line; bytes from a line's last base to the next line's first
+    bool regular = true;
+};
+
 static int parse_fasta_bytes(const char *b, size_t n, int threads, phk_fasta **out, bool with_bases = true,
-                             std::vector<size_t> *starts_out = nullptr);
+                             std::vector<size_t> *starts_out = nullptr, std::vector<RecLayout> *layout_out = nullptr);
 
 extern "C" int phk_fasta_read(const char *path, int threads, phk_fasta **out) {
     PHK_REQUIRE(path && out, "phk_fasta_read: NULL argument");
@@ -455,13 +481,13 @@ extern "C" int phk_fasta_read_part(const char *path, uint32_t part, uint32_t n_p
 }
 
 static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fasta **out, const bool with_bases,
-                             std::vector<size_t> *starts_out) {
+                             std::vector<size_t> *starts_out, std::vector<RecLayout> *layout_out) {
     if (threads < 1) threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
     // One pass finds the records and measures them: the file is cut into one slice per thread (a slice begins at the
     // first line start at or after its cut); each thread lists the '>' line starts inside its slice with the title length
     // and the number of bases of the record's lines INSIDE the slice, plus the bases of the lines before its first '>'
     // (they belong to the last record of an earlier slice).
-    struct RecInfo { size_t start; uint64_t n_title, n_bases; };
+    struct RecInfo { size_t start; uint64_t n_title, n_bases; RecLayout lay; bool closed; };   // closed: a line that must be the last was seen
     const int nt = (int)std::min<size_t>((size_t)threads, std::max<size_t>(n >> 20, 1));
     std::vector<std::vector<RecInfo>> part((size_t)nt);
     std::vector<uint64_t> lead((size_t)nt, 0);
@@ -479,21 +505,48 @@ static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fas
                     hi = hi ? (nl ? (size_t)(nl - b) + 1 : n) : 0;
                 }
                 uint64_t *acc = &lead[t];
+                RecInfo *cur = nullptr;      // the record the lines belong to (none: the slice begins inside an earlier slice's record)
                 for (size_t p = lo; p < hi;) {
                     size_t fs;
                     const size_t eol = scan_line(b, p, n, &fs);
                     size_t l_end = eol;
                     while (l_end > p && is_space(b[l_end - 1])) --l_end;
+                    const size_t next = eol < n ? eol + 1 : n;
                     if (b[p] == '>') {
-                        part[t].push_back(RecInfo{p, (uint64_t)(l_end > p + 1 ? l_end - (p + 1) : 0), 0});
-                        acc = &part[t].back().n_bases;
-                    } else if (fs >= l_end) {
-                        *acc += l_end - p;                      // the usual line: nothing to drop
+                        part[t].push_back(RecInfo{p, (uint64_t)(l_end > p + 1 ? l_end - (p + 1) : 0), 0, RecLayout(), false});
+                        cur = &part[t].back();
+                        cur->lay.seq_begin = next;
+                        acc = &cur->n_bases;
                     } else {
-                        for (size_t i = p; i < l_end; ++i) *acc += (b[i] != ' ' && b[i] != '\r');
+                        const size_t len = l_end - p;
+                        if (fs >= l_end) {
+                            *acc += len;                        // the usual line: nothing to drop
+                        } else {
+                            for (size_t i = p; i < l_end; ++i) *acc += (b[i] != ' ' && b[i] != '\r');
+                            if (cur) cur->lay.regular = false;  // something inside the line is dropped: positions are not arithmetic
+                        }
+                        if (cur && cur->lay.regular && len) {   // (a line without bases moves nothing: the next base is not there yet)
+                            RecLayout &L = cur->lay;
+                            const size_t gap = next - l_end;    // bytes to the next line's first base
+                            if (cur->closed || len > 0xFFFFFFFEull || gap > 0xFFFFFFFFull) {
+                                L.regular = false;              // bases after a line that had to be the last
+                            } else if (L.lw == 0) {
+                                if (p != L.seq_begin) L.regular = false;   // (blank lines in front of the sequence)
+                                L.lw = (uint32_t)len;
+                                L.tl = (uint32_t)gap;
+                            } else if (len != L.lw || gap != L.tl) {
+                                if (len > L.lw) L.regular = false;
+                                cur->closed = true;             // shorter, or ended differently: fine if nothing follows
+                            }
+                        } else if (cur && cur->lay.regular && !len && cur->lay.lw) {
+                            cur->closed = true;                 // a blank line inside the sequence: nothing may follow it
+                        }
                     }
-                    p = eol < n ? eol + 1 : n;
+                    p = next;
                 }
+                // the slice's last record may go on in the next slice (whose thread adds those bases as its `lead`): its
+                // lines were not all seen here
+                if (t + 1 < nt && !part[t].empty()) part[t].back().lay.regular = false;
             });
         for (auto &th : pool) th.join();
     }
@@ -502,6 +555,7 @@ static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fas
         size_t total = 0;
         for (auto &v : part) total += v.size();
         starts.reserve(total);
+        if (layout_out) layout_out->reserve(total);
     }
     phk_fasta *f = new phk_fasta();
     f->offsets.push_back(0);
@@ -512,6 +566,7 @@ static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fas
             starts.push_back(ri.start);
             f->offsets.push_back(ri.n_bases);
             f->title_off.push_back(ri.n_title);
+            if (layout_out) layout_out->push_back(ri.lay);
         }
     }
     const size_t nrec = starts.size();
@@ -690,62 +745,71 @@ extern "C" int phk_batch_from_fasta_part(phk_ctx *ctx, const char *path, uint32_
 
 static int batch_from_fasta_bytes(phk_ctx *ctx, const char *b, const size_t n, int k, const char *symbols4, int threads,
                                   phk_fasta **index_out, phk_batch **out) {
+    // Index scan (ids, titles, lengths, each record's line layout), then the file's bytes go to the device AS THEY ARE and
+    // the sequences are read out of them there (phk_batch_build_raw).  Rounds 3-4 copied every sequence line into the pinned
+    // staging buffers on the host (0.25 s of 16 cores per 5 GB).  Only the records the scan finds irregular -- lines of
+    // different widths, blanks inside a line, a record the scan's thread slices cut -- are de-lined here, into a side buffer.
     std::vector<size_t> starts;
+    std::vector<RecLayout> lay;
     phk_fasta *f = nullptr;
-    PHK_TRY(parse_fasta_bytes(b, n, threads, &f, false, &starts));
+    const bool timing = getenv("PHK_INGEST_TIMING") != nullptr;   // (stage times on stderr; diagnostics)
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "[phk ingest] %-28s %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    };
+    // the file's bytes go to the device on a thread of their own, beside the index scan (which needs nothing from the device)
+    const uint8_t *d_raw = nullptr;
+    int rc_up = PHK_OK;
+    char up_err[512] = "";
+    std::thread uploader([&]() {
+        rc_up = phk_raw_to_device(ctx, b, n, &d_raw);
+        if (rc_up != PHK_OK) snprintf(up_err, sizeof(up_err), "%s", phk_last_error());   // (the message is per thread)
+        if (timing) fprintf(stderr, "[phk ingest] %-28s %.3f s\n", "(raw bytes on the device)", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    });
+    const int rc_scan = parse_fasta_bytes(b, n, threads, &f, false, &starts, &lay);
+    lap("index scan + ids");
+    uploader.join();
+    if (rc_scan != PHK_OK || rc_up != PHK_OK) {
+        delete f;
+        if (rc_scan == PHK_OK) phk_set_error("%s", up_err);
+        return rc_scan != PHK_OK ? rc_scan : rc_up;
+    }
+    lap("upload joined");
     const size_t nrec = starts.size();
     const std::vector<uint64_t> &off = f->offsets;
     auto rec_end = [&](size_t r) { return r + 1 < nrec ? starts[r + 1] : n; };
-    auto seq_begin = [&](size_t r) {   // the line after the title line
-        const size_t p = starts[r] + 1, e = rec_end(r);
-        const char *nl = (const char *)memchr(b + p, '\n', e - p);
-        return nl ? (size_t)(nl - b) + 1 : e;
-    };
-    size_t cut_rec = 0, cut_pos = 0;   // a record the previous chunk's end cut: where its copy continues
-    bool cut = false;
-    std::function<void(uint64_t, uint64_t, char *)> fill = [&](uint64_t o, uint64_t len, char *dst) {
-        const uint64_t end = o + len;
-        // r: the record that holds base o (the last one that begins at or before it: empty records before it are passed)
-        size_t r = (size_t)(std::upper_bound(off.begin(), off.end(), o) - off.begin()) - 1;
-        if (off[r] < o) {   // it began in an earlier chunk
-            const uint64_t upto = off[r + 1] < end ? off[r + 1] : end;
-            size_t p = cut && cut_rec == r ? cut_pos : seq_begin(r);
-            if (!(cut && cut_rec == r)) {   // (cannot happen: chunks come in order -- but then skip, slowly, from the record's start)
-                std::vector<char> skip(1 << 16);
-                for (uint64_t left = o - off[r]; left;) {
-                    const size_t got = write_sequence_part(b, p, rec_end(r), skip.data(), left < skip.size() ? (size_t)left : skip.size());
-                    if (!got) break;
-                    left -= got;
-                }
-            }
-            write_sequence_part(b, p, rec_end(r), dst, (size_t)(upto - o));
-            if (off[r + 1] > end) {   // and goes on beyond this one
-                cut = true; cut_rec = r; cut_pos = p;
-                return;
-            }
-            cut = false;
-            ++r;
+    std::vector<uint64_t> rbegin(nrec);
+    std::vector<uint32_t> rlw(nrec), rtl(nrec);
+    std::vector<size_t> odd;           // the irregular records that hold bases
+    uint64_t side_bytes = 0;
+    for (size_t r = 0; r < nrec; ++r) {
+        const uint64_t nb = off[r + 1] - off[r];
+        if (lay[r].regular || nb == 0) {
+            rbegin[r] = lay[r].seq_begin;
+            rlw[r] = lay[r].lw ? lay[r].lw : 1u;
+            rtl[r] = lay[r].tl;
+        } else {
+            rbegin[r] = side_bytes;
+            rlw[r] = 0xFFFFFFFFu;
+            rtl[r] = 0;
+            odd.push_back(r);
+            side_bytes += nb;
         }
-        // records that begin in [o, end): r .. rl - 1; the last one may be cut by the chunk's end
-        size_t rl = (size_t)(std::lower_bound(off.begin(), off.end(), end) - off.begin());
-        if (rl > nrec) rl = nrec;
-        size_t full_hi = rl;
-        if (rl > r && off[rl] > end) full_hi = rl - 1;
-        if (full_hi > r)
-            phk_parallel_for(full_hi - r, [&](uint64_t i) {
-                const size_t x = r + (size_t)i;
-                size_t p = seq_begin(x);
-                write_sequence_part(b, p, rec_end(x), dst + (off[x] - o), (size_t)(off[x + 1] - off[x]));
-            });
-        if (full_hi < rl) {
-            const size_t x = rl - 1;
-            size_t p = seq_begin(x);
-            write_sequence_part(b, p, rec_end(x), dst + (off[x] - o), (size_t)(end - off[x]));
-            cut = true; cut_rec = x; cut_pos = p;
-        }
-    };
+    }
+    std::vector<char> side(side_bytes + 1);
+    phk_parallel_for(odd.size(), [&](uint64_t i) {
+        const size_t r = odd[(size_t)i];
+        const size_t p0 = starts[r] + 1, e = rec_end(r);
+        const char *nl = (const char *)memchr(b + p0, '\n', e - p0);
+        size_t p = nl ? (size_t)(nl - b) + 1 : e;
+        write_sequence_part(b, p, e, side.data() + rbegin[r], (size_t)(off[r + 1] - off[r]));
+    });
+    lap("layout + irregular records");
     phk_batch *batch = nullptr;
-    const int rc = phk_batch_build(ctx, nullptr, &fill, off.data(), nrec, k, symbols4, &batch);
+    const int rc = phk_batch_build_raw(ctx, d_raw, side.data(), side_bytes, rbegin.data(), rlw.data(), rtl.data(), off.data(), nrec, k,
+                                       symbols4, &batch);
+    lap("de-line + count");
+    if (timing) fprintf(stderr, "[phk ingest] %zu records, %zu irregular, %llu side bytes\n", nrec, odd.size(), (unsigned long long)side_bytes);
     if (rc != PHK_OK) {
         delete f;
         return rc;

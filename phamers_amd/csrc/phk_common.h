@@ -180,6 +180,15 @@ struct phk_batch;
 // (batch.hip) the sequence bytes of a batch -> device, packed and counted; see there
 int phk_batch_build(phk_ctx *ctx, const char *bases, const std::function<void(uint64_t, uint64_t, char *)> *fill,
                     const uint64_t *offsets, uint64_t n, int k, const char *symbols4, phk_batch **out);
+// (batch.hip) the same from the RAW bytes of a FASTA file (title lines, line ends and all) + one layout entry per record:
+// the bytes go up as they are and the device drops what is not sequence (phk_deline_pack_kernel, count.hip).
+// phk_raw_to_device puts the file's bytes into the context's WS_ASCII workspace (staged copies; it may run on a thread of its
+// own beside the host's index scan -- nothing else uses the context meanwhile); phk_batch_build_raw then takes the record
+// layout and the side buffer of the irregular records (rbegin[r] indexes the raw bytes, or `side` where rlw[r] = 2^32 - 1).
+int phk_raw_to_device(phk_ctx *ctx, const char *raw, uint64_t raw_bytes, const uint8_t **d_raw);
+int phk_batch_build_raw(phk_ctx *ctx, const uint8_t *d_raw, const char *side, uint64_t side_bytes,
+                        const uint64_t *rbegin, const uint32_t *rlw, const uint32_t *rtl, const uint64_t *offsets, uint64_t n,
+                        int k, const char *symbols4, phk_batch **out);
 #define PHK_STAGE_BYTES (64ull << 20)
 // the context's two pinned staging buffers of PHK_STAGE_BYTES each, allocated on first use by whichever transfer needs them;
 // a partial failure frees what it got (the next call starts from nothing) and returns PHK_ERR_NOMEM
@@ -247,6 +256,9 @@ int phk_score_mfma_init_device(phk_ctx *ctx);  // score_mfma.hip
 // count.hip
 int phk_launch_pack(phk_ctx *ctx, const char *d_bases, uint64_t T, const char *symbols4,
                     uint32_t *d_packed, uint32_t *d_mask, uint32_t *d_any_invalid);
+int phk_launch_deline_pack(phk_ctx *ctx, const uint8_t *d_raw, const uint8_t *d_side, const uint64_t *d_offsets, uint64_t n, const uint64_t *d_rbegin,
+                           const uint32_t *d_rlw, const uint32_t *d_rtl, uint64_t T, const char *symbols4, uint32_t *d_packed,
+                           uint32_t *d_mask, uint32_t *d_any_invalid);
 int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask, uint64_t T,
                      const uint64_t *d_offsets, uint64_t n, int k, uint32_t *d_counts,
                      uint32_t *d_nwin, uint64_t mean_bases = 0);

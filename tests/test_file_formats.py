@@ -470,3 +470,82 @@ def test_fasta_file_straight_into_the_upload_equals_read_then_upload(tmp_path):
         fa.close()
     with pytest.raises(IOError):
         _lib.Fasta.count_file(ctx, str(tmp_path / "missing.fasta"), 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("threads", [0, 1, 3])
+def test_device_delining_of_every_line_layout(tmp_path, threads):
+    """phk_batch_from_fasta_file since round 5: the file's raw bytes go to the device and phk_deline_pack_kernel reads base i
+    of a record at  begin + (i / lw) (lw + tl) + i % lw; records the index scan finds irregular are de-lined by the host into a
+    side buffer.  Every layout the scan has to tell apart, against the host reader + phk_pack_kernel (phk_fasta_read +
+    phk_batch_from_fasta): LF and CRLF line ends, trailing blanks / tabs (the same on every line: regular; different: not),
+    a shorter last line, a last line without line end, one-line records, a blank line before / inside / after the sequence,
+    lines of varying width, a wider line after a narrow one, ' ' and CR inside a line, '>' inside a line, title-only and
+    empty records, a record whose only line is longer than any other -- with 1, 3 and all scan threads (slices cut records at
+    other places)."""
+    from phamers_amd import _lib, synth
+    rng = np.random.default_rng(5)
+    recs = []
+
+    def seq(n):
+        return "".join("ATGCNatgcRY"[i] for i in rng.integers(0, 11 if n % 3 == 0 else 4, size=n))
+
+    def lines(s, w, end="\n", last_end=None):
+        parts = [s[i:i + w] for i in range(0, len(s), w)] or [""]
+        return end.join(parts) + (end if last_end is None else last_end)
+    recs.append(lines(seq(1000), 70))                                   # the usual record
+    recs.append(lines(seq(1400), 70, "\r\n"))                           # CRLF throughout
+    recs.append(lines(seq(700), 60, " \t\n"))                           # the same trailing blanks on every line
+    recs.append(lines(seq(350), 70))                                    # last line full
+    recs.append(seq(5000) + "\n")                                       # one line
+    recs.append("\n" + lines(seq(300), 50))                             # blank line before the sequence
+    recs.append(lines(seq(200), 50) + "\n" + lines(seq(120), 50))       # blank line inside
+    recs.append(lines(seq(260), 50) + "\n\n")                           # blank lines after
+    recs.append(seq(40) + "\n" + seq(90) + "\n" + seq(40) + "\n")       # a wider line after a narrow one
+    recs.append(seq(90) + "\n" + seq(40) + "\n" + seq(90) + "\n")       # bases after a short line
+    s = seq(210)
+    recs.append(s[:30] + " " + s[30:70] + "\n" + s[70:140] + "\r\n" + s[140:] + "\n")   # blank inside, mixed ends
+    recs.append(seq(70) + "\n" + seq(35) + ">" + seq(34) + "\n" + seq(10) + "\n")       # '>' inside a line
+    recs.append("")                                                     # title only
+    recs.append("\n\n")                                                 # blank lines only
+    recs.append(lines(seq(3), 70))
+    recs.append(lines(seq(211), 1))                                     # one base per line
+    recs.append(lines(seq(500), 70, "\n", last_end="\r\n"))             # only the last line ends differently
+    recs.append(lines(seq(140), 70, "\r\n", last_end="\n"))
+    recs.append(lines(seq(141), 70, "\n", last_end="  \n"))
+    for _ in range(400):                                                # bulk: many records, so that several scan threads have work
+        recs.append(lines(seq(int(rng.integers(0, 12000))), int(rng.integers(20, 120)), "\n" if rng.random() < 0.8 else "\r\n"))
+    recs.append(lines(seq(333), 80, "\n", last_end=""))                 # the file ends without a line end
+    path = tmp_path / "layouts.fasta"
+    with open(path, "w", newline="") as f:
+        f.write("junk before the first record\nmore junk\n")
+        for c, body in enumerate(recs):
+            f.write(">rec_%d_ID_%d words\n" % (c, c))
+            f.write(body)
+    assert os.path.getsize(path) > (2 << 20)                            # (> 1 MB per scan thread: the slices really are cut)
+    ctx = _lib.get_context()
+    fa = _lib.Fasta(str(path), threads=threads)
+    want_batch = _lib.Batch.from_fasta(ctx, fa, 4)
+    want = want_batch.counts_u32()
+    want_batch.close()
+    assert fa.n_records == len(recs)
+    idx, batch = _lib.Fasta.count_file(ctx, str(path), 4, threads=threads)
+    try:
+        assert batch.n == fa.n_records and batch.total_bases == fa.total_bases
+        assert np.array_equal(idx.lengths(), fa.lengths())
+        got = batch.counts_u32()
+        bad = np.flatnonzero((got != want).any(axis=1))
+        assert bad.size == 0, (bad[:10], [repr(recs[int(i)][:80]) for i in bad[:3]])
+        assert idx.titles() == fa.titles()
+        # ... and one rank's share of the same file, for 3 ranks (phk_batch_from_fasta_part)
+        rows = []
+        for part in range(3):
+            pidx, pbatch = _lib.Fasta.count_file(ctx, str(path), 4, threads=threads, part=(part, 3))
+            rows.append(pbatch.counts_u32() if pbatch.n else np.zeros((0, 256), np.uint32))
+            pbatch.close()
+            pidx.close()
+        assert np.array_equal(np.concatenate(rows), want)
+    finally:
+        batch.close()
+        idx.close()
+        fa.close()
