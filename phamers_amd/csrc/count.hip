@@ -671,328 +671,27 @@ __global__ __launch_bounds__(256) void phk_sort_scatter_kernel(const uint64_t *_
 }
 
 // ------------------------------------------------------------------------------------
-// Slot kernel (k = 3, 4; all bases valid): a workgroup of 4 waves counts 32 contigs at a time, 8 lanes
-// per contig, each contig in a histogram COLUMN of its own.
+// The slot kernels: one histogram COLUMN per contig.
 //
-// The wave-per-contig kernel above is bound by LDS bank conflicts: its 64 lanes add into ONE
-// histogram, so a wave-wide ds_add lands on random banks (about 7.7 LDS cycles per instruction at the
-// best replication, profiles/r01/count_lds_study.md), and replicas have to be summed again at the
-// flush.  Here the 32 histograms in a workgroup's LDS belong to 32 DIFFERENT contigs,
+// The wave-per-contig kernel above is bound by LDS bank conflicts: its 64 lanes add into ONE histogram, so a wave-wide
+// ds_add lands on random banks (about 7.7 LDS cycles per instruction at the best replication,
+// profiles/r01/count_lds_study.md), and replicas have to be summed again at the flush.  In the kernels below the 32
+// histograms in a workgroup's LDS belong to 32 DIFFERENT contigs,
 //     bins[code][slot]   (slot = lane & 31, so the LDS bank of an add is its lane's slot, whatever the code)
-// every ds_add is conflict free (2 LDS cycles per wave instruction), there is nothing to reduce at the
-// flush, and the address of a bin costs two VALU operations: ((word >> s) & (D-1) << 7) | slot * 4.
-// The input is staged through LDS so that global loads stay coalesced: per stage the workgroup loads the
-// next 128 bytes (32 words, 512 bases) of each of its 32 contigs -- 8 adjacent lanes fetch one contig's
-// line -- and each of the 8 lanes that serve a contig then counts the 64 windows starting in one 4-word
-// chunk of it.  Chunks are word aligned, so no funnel shift is needed; windows outside [start, last
-// window] only occur in a contig's first and last chunk, which take a predicated copy of the loop.
-// A workgroup runs as many stages as its longest contig needs.  In a batch of similar lengths the few contigs much
-// longer than the mean are appended to `long_list` for the wave-per-contig kernel, which follows; a ragged batch is
-// walked as a sorted list of (contig, piece) items, a long contig being cut into pieces that are columns like any other.
+// every ds_add is conflict free (2 LDS cycles per wave instruction), there is nothing to reduce at the flush, and the
+// address of a bin costs two VALU operations: ((word >> s) & (D-1) << 7) | slot * 4.  k = 5: 16 contigs per workgroup
+// (a 1024-bin column set of 32 would not fit; bank = slot + 16 (code & 1): 3 LDS cycles per instruction on average).
+// A lane reads its 64-base units straight from memory (the vector cache serves the other lanes' pieces of a line) and no
+// wave waits for another before the flush.  In a batch of similar lengths the few contigs much longer than the mean are
+// appended to `long_list` for the wave-per-contig kernel, which follows; a ragged batch is walked as a sorted list of
+// (contig, piece) items, a long contig being cut into pieces that are columns like any other.
+// (Rounds 2-4 also kept the first form of these kernels, which staged the input through LDS with a barrier per stage --
+// phk_count_slots_kernel, 0.90 ms per 1M x 5 kb against 0.66 -- behind count_lanes = 1 / 2 for comparison; removed in
+// round 5, the record is in profiles/r04/README.md.)
 // ------------------------------------------------------------------------------------
-#define PHK_PAIRS_DEFAULT 'P'   // count_lanes unset: the two-windows-per-add kernel (1024 threads) for k = 4 batches without a mask; '1' = the slot kernel
-#ifndef SLOT_LINES
-#define SLOT_LINES 2                       // 128-byte lines per contig and stage
-#endif
-#define SLOT_ROW (32 * SLOT_LINES + 4)     // staging row stride in words (data + 1 look-ahead + pad: conflict-free b128 reads)
-// LDS-only workgroup barrier: waits for this wave's LDS operations, NOT for its global loads (a
-// __syncthreads() would also drain the prefetch of the next stage, issued just before)
+#define PHK_PAIRS_DEFAULT 'P'   // count_lanes unset: the two-windows-per-add kernel (1024 threads) for k = 4 batches without a mask
+// LDS-only workgroup barrier: waits for this wave's LDS operations, NOT for its global loads
 __device__ __forceinline__ void phk_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// The same between two counting stages: LDS operations of a wave complete in order, so once at most 15 are
-// outstanding everything older than the last 15 -- the staging writes, issued before the stage's 128 adds --
-// has been performed; the adds themselves only have to be complete at the flush (full barrier there).
-__device__ __forceinline__ void phk_stage_barrier() { asm volatile("s_waitcnt lgkmcnt(15)\n\ts_barrier" ::: "memory"); }
-
-// SLOTS = contigs per workgroup: 32 (k <= 4: bank = slot, conflict free) or 16 (k = 5: a 1024-bin column set of
-// 32 contigs would not fit; bank = slot + 16 (code & 1), so the two lanes of a half-wave that share a slot
-// collide only when their codes have the same parity -- 3 LDS cycles per instruction on average instead of 2).
-// MASK: validity bits are read straight from global memory (three words per chunk, fetched a stage ahead); a chunk
-// that is interior to its contig and all valid still takes the predicate-free loop, every other one adds the bit
-// "window starts inside the contig and its k bases are valid"; the per-contig number of counted windows goes
-// through an LDS counter.
-template <int K, int SLOTS, int NTH, bool MASK>
-__global__ __launch_bounds__(NTH) void phk_count_slots_kernel(const uint32_t *__restrict__ packed,
-                                                             const uint32_t *__restrict__ mask,
-                                                             const uint64_t *__restrict__ offsets, uint64_t n,
-                                                             uint64_t max_word, uint32_t long_thr,
-                                                             uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin,
-                                                             uint2 *__restrict__ long_list,
-                                                             uint32_t *__restrict__ long_count,
-                                                             const uint2 *__restrict__ order,      // length-bucketed (contig, piece) items (ragged batches), or NULL
-                                                             uint32_t piece_w,                     // windows per piece (0: whole contigs)
-                                                             uint32_t skip_plain = 0) {            // 1: a batch that is not ragged was counted by phk_count_pairs_kernel
-    constexpr uint32_t D = 1u << (2 * K);
-    constexpr int CH = 8 * SLOT_LINES;      // 4-word chunks per contig and stage
-    constexpr int PARTS = NTH / SLOTS;      // lanes per contig
-    constexpr int CPL = CH / PARTS;         // chunks per lane and stage
-    constexpr int LPT = (SLOTS * CH + NTH - 1) / NTH;   // staging loads per thread and stage (the last may be partial)
-    constexpr int SHB = SLOTS == 32 ? 7 : 6;  // log2 of a bin row in bytes
-    static_assert(CH % PARTS == 0, "stage geometry");
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [D][SLOTS] | staging [2][SLOTS][SLOT_ROW] | smax
-    uint32_t *stage = lds + D * SLOTS;
-    uint32_t *smax_p = stage + 2 * SLOTS * SLOT_ROW;
-    uint32_t *nwin_s = smax_p + 4;   // [SLOTS] counted windows per contig (MASK)
-    uint32_t *split_s = nwin_s + SLOTS;   // [SLOTS] contig id + 1 of a slot that holds a PIECE (its column is added atomically), else 0
-    // a batch in arbitrary order whose groups of SLOTS contigs are ragged is walked in the length-bucketed order the
-    // sort kernels prepared; without one (count_sort off) the kernel stands down and the wave-per-contig kernel counts
-    if (phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2))) {
-        if (skip_plain) return;
-        order = nullptr;
-    } else if (!order) return;
-    if (order) n = long_count[1];   // the work list of a ragged batch: items, counted by the sort kernels
-    const int t = threadIdx.x, lane = t & 63;
-    const int slot = t & (SLOTS - 1), part = t / SLOTS;          // counting role: contig slot, chunk (mod PARTS) within the stage
-    for (uint32_t b = t * 4; b < D * SLOTS; b += 4 * NTH) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
-    if (t == 0) *smax_p = 0;
-    if (MASK && t < SLOTS) nwin_s[t] = 0;
-    __syncthreads();
-    const uint32_t colb = (uint32_t)slot * 4u;
-    const uint64_t wmax4 = max_word - 2;  // highest start of a 4-word load inside the stream (+ pad word)
-    // the integer bin addresses below assume the dynamic LDS array starts at address 0: true while the kernel has no
-    // static LDS, which phk_count_init_device verifies on the host (hipFuncGetAttributes) before this kernel is ever used
-
-    // LDS byte address of the bin of the window starting at base jw of `src` (jw < 8).
-    // The bins sit at LDS address 0 (the kernel has no static LDS), so the byte address is formed as an integer --
-    // shift, then v_and_or with the slot -- and used as an LDS pointer directly; going through `lds + index`
-    // costs a third instruction per window (the add of the array's link-time base).
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    auto bin = [&](uint32_t src, int jw) {
-        constexpr uint32_t msk = (D - 1u) << SHB;
-        const int sh = 32 - 2 * K - 2 * jw - SHB;   // >= 0 for jw < 8, k <= 5
-        const uint32_t a = ((src >> sh) & msk) | colb;
-        return (lds_u32 *)(uintptr_t)a;
-    };
-    auto add1 = [&](lds_u32 *p, uint32_t val) {
-        __hip_atomic_fetch_add(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-
-    for (uint64_t batch = blockIdx.x; batch * SLOTS < n; batch += gridDim.x) {
-        // ---- counting role: this lane's contig ----
-        const uint64_t ci = batch * SLOTS + slot;
-        const bool have = ci < n;
-        const uint2 item = (have && order) ? order[ci] : make_uint2(0, 0);
-        const uint64_t c = have ? (order ? (uint64_t)item.x : ci) : 0;
-        uint64_t st = have ? offsets[c] : 0;
-        const uint64_t en = have ? offsets[c + 1] : 0;
-        const uint64_t len = en - st;
-        uint32_t W = len >= (uint64_t)K ? (uint32_t)((len - K + 1) < 0xFFFFFFFFull ? (len - K + 1) : 0xFFFFFFFFull) : 0;
-        // an item of the sorted work list is a whole contig or one piece of a long one: the piece's windows start at
-        // st + piece * piece_w, and its histogram is added onto the contig's row (zeroed by the sort) at the flush
-        const bool split = order && piece_w && W > long_thr;
-        if (split) {
-            const uint64_t first = (uint64_t)item.y * piece_w;
-            st += first;
-            W = (uint32_t)((uint64_t)W - first < piece_w ? (uint64_t)W - first : piece_w);
-        }
-        const bool handed_over = !order && W > long_thr;
-        if (order && part == 0) split_s[slot] = split ? (uint32_t)c + 1u : 0u;
-        if (handed_over) {
-            if (part == 0) {   // as pieces of piece_w windows (each its own work item of the wave-per-contig kernel) or whole
-                const uint32_t np = piece_w ? (W + piece_w - 1) / piece_w : 1u;
-                const uint32_t base = atomicAdd(long_count, np);
-                for (uint32_t pc = 0; pc < np; ++pc) long_list[base + pc] = make_uint2((uint32_t)c, pc);
-            }
-            W = 0;
-        }
-        const uint64_t last = st + W - 1;                     // last window start (W > 0)
-        const uint64_t q0 = st >> 6;                          // first 4-word chunk
-        const uint32_t nchunk = W ? (uint32_t)((last >> 6) - q0 + 1) : 0;
-        const uint32_t nseg = (nchunk + CH - 1) / CH;
-        // stages this batch needs
-        uint32_t m = nseg;
-#pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) {
-            const uint32_t o = __shfl_xor(m, sft);
-            m = m > o ? m : o;
-        }
-        if (lane == 0) atomicMax(smax_p, m);
-        phk_lds_barrier();
-        const uint32_t smax = *smax_p;
-
-        // ---- loading role: staging element e = t + 256 i  ->  contig e / CH, chunk e % CH of the stage ----
-        uint64_t lw0[LPT];
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const uint64_t cl = batch * SLOTS + (uint32_t)(t + NTH * i) / CH;
-            uint64_t first = 0;   // first base of the item whose lines this thread stages
-            if (cl < n) {
-                if (order) {
-                    const uint2 it = order[cl];
-                    const uint64_t s0 = offsets[it.x], ln = offsets[it.x + 1] - s0;
-                    const bool cut = piece_w && ln >= (uint64_t)K && ln - K + 1 > long_thr;
-                    first = s0 + (cut ? (uint64_t)it.y * piece_w : 0);
-                } else {
-                    first = offsets[cl];
-                }
-            }
-            lw0[i] = (first >> 6) * 4;   // first word of its first chunk
-        }
-        auto gload = [&](uint32_t s, uint4 (&v)[LPT], uint32_t (&la)[LPT]) {   // 16 bytes each (+ a look-ahead word)
-#pragma unroll
-            for (int i = 0; i < LPT; ++i) {
-                const uint32_t ch = (uint32_t)(t + NTH * i) % CH;
-                const uint64_t w = lw0[i] + (4ull * CH) * s + 4u * ch;
-                if (w <= wmax4) {
-                    v[i] = *reinterpret_cast<const uint4 *>(packed + w);
-                } else {  // the last words of the whole stream (one pad word follows it): word by word, clamped
-                    const uint64_t e = max_word + 1;
-                    v[i] = make_uint4(packed[w < e ? w : e], packed[w + 1 < e ? w + 1 : e], packed[w + 2 < e ? w + 2 : e],
-                                      packed[w + 3 < e ? w + 3 : e]);
-                }
-                const uint64_t wl = lw0[i] + (4ull * CH) * (s + 1);  // word after the stage's lines
-                la[i] = packed[wl <= max_word + 1 ? wl : max_word + 1];
-            }
-        };
-        auto swrite = [&](uint32_t buf, const uint4 (&v)[LPT], const uint32_t (&la)[LPT]) {
-#pragma unroll
-            for (int i = 0; i < LPT; ++i) {
-                const uint32_t e = (uint32_t)(t + NTH * i);
-                if (e >= (uint32_t)(SLOTS * CH)) continue;
-                uint32_t *row = stage + (buf * SLOTS + e / CH) * SLOT_ROW;
-                *reinterpret_cast<uint4 *>(row + 4 * (e % CH)) = v[i];
-                if (e % CH == CH - 1) row[4 * CH] = la[i];
-            }
-        };
-        uint4 v[LPT];
-        uint32_t la[LPT];
-        if (smax) {
-            gload(0, v, la);
-            swrite(0, v, la);
-            if (smax > 1) gload(1, v, la);
-        }
-        // MASK: validity words of this lane's chunks (word 2 q .. 2 q + 2 of the mask), one stage ahead
-        const uint64_t mmax = (max_word >> 1) + 1;   // last mask word that exists (ceil(T/32) + 1 words)
-        uint32_t mk[CPL][3], mkn[CPL][3];
-        uint32_t cnt_ok = 0;
-        auto mload = [&](uint32_t s, uint32_t (&m)[CPL][3]) {
-#pragma unroll
-            for (int ln = 0; ln < CPL; ++ln) {
-                const uint64_t mw = 2 * (q0 + (uint64_t)CH * s + (uint32_t)(PARTS * ln + part));
-#pragma unroll
-                for (int j = 0; j < 3; ++j) m[ln][j] = mask[mw + j <= mmax ? mw + j : mmax];
-            }
-        };
-        if (MASK && smax) mload(0, mkn);
-        phk_lds_barrier();
-        for (uint32_t s = 0; s < smax; ++s) {
-            const uint32_t *row = stage + ((s & 1) * SLOTS + slot) * SLOT_ROW + 4 * part;
-            uint4 cw[CPL];
-            uint32_t nx[CPL];
-#pragma unroll
-            for (int ln = 0; ln < CPL; ++ln) {
-                cw[ln] = *reinterpret_cast<const uint4 *>(row + 4 * PARTS * ln);
-                nx[ln] = row[4 * PARTS * ln + 4];
-            }
-            if (s + 1 < smax) {
-                swrite((s + 1) & 1, v, la);
-                if (s + 2 < smax) gload(s + 2, v, la);
-            }
-            if (MASK) {
-#pragma unroll
-                for (int ln = 0; ln < CPL; ++ln)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) mk[ln][j] = mkn[ln][j];
-                if (s + 1 < smax) mload(s + 1, mkn);
-            }
-            bool issued = false;   // (wave-uniform) this wave issued a chunk's 64 adds after its staging writes
-            // take delivery of ALL the stage's staging reads here: a read waited for after the first adds have been
-            // issued costs a full drain of the add queue (the LDS counter is in order and saturates at 15)
-#pragma unroll
-            for (int ln = 0; ln < CPL; ++ln)
-                asm volatile("" ::"v"(cw[ln].x), "v"(cw[ln].y), "v"(cw[ln].z), "v"(cw[ln].w), "v"(nx[ln]));
-#pragma unroll
-            for (int ln = 0; ln < CPL; ++ln) {
-                const uint64_t q = q0 + (uint64_t)CH * s + (uint32_t)(PARTS * ln + part);   // this lane's chunk; bases 64 q .. 64 q + 63
-                const uint64_t fb = q << 6;
-                const bool any = W && fb + 63 >= st && fb <= last;
-                bool all = W && fb >= st && fb + 63 <= last;
-                // bit 63 - i of wv: window i of the chunk is counted (inside the contig; MASK: its k bases valid)
-                uint64_t wv = 0;
-                if (any) {
-                    const uint32_t lo = st > fb ? (uint32_t)(st - fb) : 0u;              // first window of the chunk inside the contig
-                    const uint32_t hi = last - fb < 63 ? (uint32_t)(last - fb) : 63u;    // last one
-                    wv = ((hi - lo == 63u) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << (63 - hi)));
-                    if (MASK) {
-                        const uint64_t vb = ((uint64_t)mk[ln][0] << 32) | mk[ln][1];   // bit 63 - i: base i of the chunk valid
-                        uint64_t w = vb;
-#pragma unroll
-                        for (int j = 1; j < K; ++j) w &= (vb << j) | ((uint64_t)mk[ln][2] >> (32 - j));
-                        wv &= w;
-                        all = all && w == ~0ull;
-                        cnt_ok += (uint32_t)__popcll(wv);
-                    }
-                }
-                const uint32_t wds[5] = {cw[ln].x, cw[ln].y, cw[ln].z, cw[ln].w, nx[ln]};
-                issued = issued || __any(any);
-                if (!__any(any && !all)) {   // wave-uniform: every lane's chunk is interior to its contig (and all valid) or empty
-                    if (all) {
-#pragma unroll
-                        for (int wd = 0; wd < 4; ++wd) {
-                            const uint32_t y = wds[wd], u = __builtin_amdgcn_alignbit(y, wds[wd + 1], 16);
-#pragma unroll
-                            for (int jw = 0; jw < 16; ++jw) add1(bin(jw < 8 ? y : u, jw & 7), 1u);
-                        }
-                    }
-                } else if (any) {            // some lane is at an edge / sees an invalid base: add the window's bit instead of 1
-                    const uint32_t vhi = (uint32_t)(wv >> 32), vlo = (uint32_t)wv;
-#pragma unroll
-                    for (int wd = 0; wd < 4; ++wd) {
-                        const uint32_t y = wds[wd], u = __builtin_amdgcn_alignbit(y, wds[wd + 1], 16);
-#pragma unroll
-                        for (int jw = 0; jw < 16; ++jw) {
-                            const int wi = 16 * wd + jw;
-                            add1(bin(jw < 8 ? y : u, jw & 7), __builtin_amdgcn_ubfe(wi < 32 ? vhi : vlo, 31 - (wi & 31), 1));
-                        }
-                    }
-                }
-            }
-            // (a wave that issued no adds in this stage -- all its contigs have ended -- has its staging writes among its
-            // youngest LDS operations: it waits for all of them)
-            if (issued) phk_stage_barrier();
-            else phk_lds_barrier();
-        }
-        if (MASK && cnt_ok) atomicAdd(nwin_s + slot, cnt_ok);
-        phk_lds_barrier();  // every wave's adds have landed
-        // ---- pieces first: wave w adds the columns of slots w, w + NTH/64, .. onto their contigs' rows, 64 consecutive
-        // codes per instruction (the reads of a column are a 64-way bank conflict -- 4 KB per column, a few thousand LDS
-        // cycles per batch -- but the global atomics are coalesced: from the per-(slot, group) threads below they went
-        // out as 8192 scattered single-dword atomics per batch, which tripled the time of a batch of pieces)
-        if (order) {
-            for (int sl = t >> 6; sl < SLOTS; sl += NTH / 64) {
-                const uint32_t cs = split_s[sl];
-                if (!cs) continue;
-                uint32_t *rowp = counts + (uint64_t)(cs - 1u) * D;
-                for (uint32_t code = lane; code < D; code += 64) {
-                    const uint32_t v = lds[code * SLOTS + sl];
-                    if (v) atomicAdd(rowp + code, v);
-                }
-            }
-            phk_lds_barrier();
-        }
-        // ---- flush: thread (slot, group g) writes codes [g D/PARTS, (g+1) D/PARTS) of contig `slot` and clears them ----
-        {
-            const int g = part;
-            uint32_t *cellb = lds + (g * (D / PARTS)) * SLOTS + slot;
-            uint32_t *rowo = counts + c * D + g * (D / PARTS);
-#pragma unroll 8
-            for (uint32_t i = 0; i < D / PARTS / 4; ++i) {
-                uint32_t *cell = cellb + 4 * i * SLOTS;
-                const uint4 o = make_uint4(cell[0], cell[SLOTS], cell[2 * SLOTS], cell[3 * SLOTS]);
-                cell[0] = 0; cell[SLOTS] = 0; cell[2 * SLOTS] = 0; cell[3 * SLOTS] = 0;
-                // (a contig handed over in pieces gets its zero row here: the pieces are added onto it atomically)
-                if (!split && have && (!handed_over || piece_w)) *reinterpret_cast<uint4 *>(rowo + 4 * i) = o;
-            }
-            if (nwin && have && g == 0) {
-                if (split) atomicAdd(nwin + c, MASK ? nwin_s[slot] : W);
-                else if (!handed_over || piece_w) nwin[c] = MASK ? nwin_s[slot] : W;
-            }
-        }
-        phk_lds_barrier();
-        if (MASK && t < SLOTS) nwin_s[t] = 0;
-        if (t == 0) *smax_p = 0;
-        phk_lds_barrier();
-    }
-}
 
 // ------------------------------------------------------------------------------------
 // TWO WINDOWS PER ADD (k = 4, no validity mask, batches the statistics do not call ragged; round 4).
@@ -1188,7 +887,7 @@ __global__ __launch_bounds__(NTH) void phk_count_pairs_kernel(const uint32_t *__
 // ------------------------------------------------------------------------------------
 // The slot kernel WITHOUT staging and stage barriers (k = 5, no validity mask, batches the statistics do not call ragged;
 // round 4): what made the two-windows-per-add kernel above fast was, as much as its halved adds, that a lane reads its
-// words straight from memory and no wave waits for another before the flush.  Same bins as phk_count_slots_kernel
+// words straight from memory and no wave waits for another before the flush.  The bins described above
 // (bins[code][slot], 16 contigs per workgroup at k = 5), one add per window, 64 windows per lane and round.
 // ------------------------------------------------------------------------------------
 template <int K, int SLOTS, int NTH, bool MASK, bool ORDERED>
@@ -1211,7 +910,7 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
     uint32_t *nwin_s = lds + D * SLOTS;
     uint32_t *split_s = nwin_s + SLOTS;
     // Two instances are launched back to back and decide on the device which of them counts the batch: the plain walk
-    // (ORDERED = false) when the statistics allow it, else the sorted work list (ORDERED = true; as phk_count_slots_kernel).
+    // (ORDERED = false) when the statistics allow it, else the sorted work list (ORDERED = true).
     // The plain instance carries none of the sorted walk's code: with it the k = 5 kernel ran 15 % slower.
     const bool plain = phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2));
     if (ORDERED) {
@@ -1351,7 +1050,7 @@ __global__ __launch_bounds__(NTH) void phk_count_direct_kernel(const uint32_t *_
         if (MASK && cnt_ok) atomicAdd(nwin_s + slot, cnt_ok);
         phk_lds_barrier();  // every wave's adds have landed
         // ---- pieces first: wave w adds the columns of slots w, w + NTH / 64, .. onto their contigs' rows, 64 consecutive codes per
-        // instruction (coalesced global atomics; see phk_count_slots_kernel)
+        // instruction (coalesced global atomics)
         if (ORDERED) {
             for (int sl = t >> 6; sl < SLOTS; sl += NTH / 64) {
                 const uint32_t cs = split_s[sl];
@@ -1465,19 +1164,8 @@ template <int K>
 static int launch_count_k(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_mask,
                           const uint64_t *d_offsets, uint64_t n, uint64_t max_word, uint32_t *d_counts,
                           uint32_t *d_nwin) {
-    // tuning knob for the LDS replication study: PHK_COUNT_CFG="<copies>,<pack16>", k = 4 / 5 / 6 only
-    if (K == 4 || K == 5 || K == 6) {
-        const char *cfg = ctx->knobs.count_cfg;
-        int copies = 0, p16 = 0;
-        if (cfg[0] && sscanf(cfg, "%d,%d", &copies, &p16) == 2) {
-#define PHK_CFG(C, P) if (copies == C && p16 == P) return launch_count_cfg<(K == 4 || K == 5 || K == 6) ? K : 4, C, P != 0>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin)
-            PHK_CFG(1, 0); PHK_CFG(2, 0); PHK_CFG(4, 0); PHK_CFG(8, 0); PHK_CFG(16, 0);
-            PHK_CFG(1, 1); PHK_CFG(4, 1); PHK_CFG(8, 1); PHK_CFG(16, 1);
-#undef PHK_CFG
-            phk_set_error("PHK_COUNT_CFG=%s is not one of the built variants", cfg);
-            return PHK_ERR_ARG;
-        }
-    }
+    // (the replication / packing of a k was settled by the LDS study of round 1, profiles/r01/count_lds_study.md; the knob that
+    // selected other built variants -- 60 kernel instances -- is gone since round 5)
     return launch_count_cfg<K, PhkCountCfg<K>::copies, PhkCountCfg<K>::pack16>(ctx, d_packed, d_mask, d_offsets, n,
                                                                               max_word, d_counts, d_nwin);
 }
@@ -1496,8 +1184,6 @@ static int slots_instance_ok(Kern kern, bool *ok) {
 }
 
 int phk_count_init_device(phk_ctx *ctx) {
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_slots_kernel<5, 16, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     bool ok = true;
@@ -1516,16 +1202,6 @@ int phk_count_init_device(phk_ctx *ctx) {
 #undef PHK_DIRECT_INIT1
     PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<512>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<1024>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 256, false>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 256, true>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 512, false>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<3, 32, 512, true>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<4, 32, 256, false>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<4, 32, 256, true>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<4, 32, 512, false>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<4, 32, 512, true>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<5, 16, 256, false>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_slots_kernel<5, 16, 256, true>, &ok));
     ctx->slots_lds0 = ok;
     return PHK_OK;
 }
@@ -1557,12 +1233,11 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
     // k = 3, 4 without invalid bases: slot kernel (32 contigs per workgroup, conflict-free LDS adds); contigs
     // more than 4x the batch mean go on to the wave-per-contig kernel through a device list
     const char lanes_knob = ctx->knobs.count_lanes;
-    if (k >= 3 && k <= 5 && max_word >= 64 && n < (1ull << 32) && lanes_knob != '0' && ctx->slots_lds0 &&
-        !ctx->knobs.count_cfg[0]) {
+    if (k >= 3 && k <= 5 && max_word >= 64 && n < (1ull << 32) && lanes_knob != '0' && ctx->slots_lds0) {
         const uint32_t slots = k == 5 ? 16u : 32u;
-        // count_lanes: '2' = slot kernel whatever the batch looks like (tests), 'q' / 'Q' = the same with the two-windows-per-add
+        // count_lanes: 'f' = the unstaged slot kernel whatever the batch looks like (tests), 'q' / 'Q' = the same with the two-windows-per-add
         // kernel (512 / 1024 threads) for k = 4 without a mask; 'p' / 'P' = that kernel where the statistics allow
-        const bool forced = lanes_knob == '2' || lanes_knob == 'q' || lanes_knob == 'Q' || lanes_knob == 'f';   // ('f': the unstaged slot kernel, forced)
+        const bool forced = lanes_knob == 'q' || lanes_knob == 'Q' || lanes_knob == 'f';   // ('f': the unstaged slot kernel, forced)
         const bool sorted = ctx->knobs.count_sort && !forced;
         // contigs much longer than the batch mean leave the slot kernel (a workgroup runs as many stages as its longest
         // contig): with count_sort they go to the wave-per-contig kernel as PIECES of 32768 windows, each its own work
@@ -1633,9 +1308,9 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
             skip_plain = 1;
         }
         // The unstaged slot kernel (phk_count_direct_kernel) for everything else the slot kernel used to count: masked batches,
-        // the sorted walk of ragged batches, k = 3 and k = 5 (count_lanes '1' / '2' keep phk_count_slots_kernel, for comparison).
+        // the sorted walk of ragged batches, k = 3 and k = 5.
         // At k = 5 without a mask it also writes the scorer's int8 operand when phk_count_score_dev armed it for this matrix.
-        if (lanes_knob != '1' && lanes_knob != '2') {
+        {
             PhkPrep8 &pp = ctx->prep8;
             const bool prep = k == 5 && !d_mask && prep8_asked && pp.counts == d_counts && pp.n == n && pp.D == 1024;
             uint4 *frag8 = prep ? (uint4 *)pp.frag : nullptr;
@@ -1676,37 +1351,6 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
 #undef PHK_DIRECT
 #undef PHK_DIRECT1
         }
-        ctx->prep8.armed = false;
-        const size_t lds = (size_t)phk_pow4(k) * slots * 4 + 2 * slots * SLOT_ROW * 4 + 16 + 2 * slots * 4;
-        // resident blocks per CU: the LDS allocation granule keeps a block that would exactly fill the 160 KiB out
-        const unsigned fit = (unsigned)((160u * 1024u - 1024u) / lds);
-        const unsigned per_cu = fit > 8 ? 8 : fit;
-        uint64_t blocks = phk_div_up(sorted ? max_items : n, slots);   // (a sorted batch works on items; surplus workgroups leave)
-        const uint64_t cap = (uint64_t)ctx->num_cus * per_cu;
-        if (blocks > cap) blocks = cap;
-#define PHK_SLOTS(K_, S_, T_)                                                                                               \
-        if (d_mask) {                                                                                                       \
-            PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                       \
-                       (phk_count_slots_kernel<K_, S_, T_, true><<<dim3((unsigned)blocks), dim3(T_), lds, ctx->stream>>>(   \
-                           d_packed, d_mask, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w, skip_plain))); \
-        } else {                                                                                                            \
-            PHK_LAUNCH(ctx, "phk_count_slots_kernel",                                                                       \
-                       (phk_count_slots_kernel<K_, S_, T_, false><<<dim3((unsigned)blocks), dim3(T_), lds, ctx->stream>>>(  \
-                           d_packed, nullptr, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w, skip_plain))); \
-        }                                                                                                                   \
-        {                                                                                                                   \
-            const int rc_ = launch_count_cfg<K_, PhkCountCfg<K_>::copies, PhkCountCfg<K_>::pack16>(                         \
-                ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count, piece_w);        \
-            if (rc_ == PHK_OK) ctx->ctl_dirty = false;                                                                      \
-            return rc_;                                                                                                     \
-        }
-        // 16 lanes per contig (512 threads) at k <= 4: 24 waves per CU hide the barrier and staging latencies better
-        // than 12 (0.94 vs 1.03 ms per 1M x 5 kb); PHK_SLOT_THREADS=256 for comparison
-        const bool t256 = ctx->knobs.slot_threads == '2';
-        if (k == 3) { if (t256) { PHK_SLOTS(3, 32, 256); } PHK_SLOTS(3, 32, 512); }
-        if (k == 4) { if (t256) { PHK_SLOTS(4, 32, 256); } PHK_SLOTS(4, 32, 512); }
-        PHK_SLOTS(5, 16, 256);
-#undef PHK_SLOTS
     }
     switch (k) {
         case 1: return launch_count_k<1>(ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin);
@@ -1761,36 +1405,75 @@ __global__ __launch_bounds__(256) void phk_normalize_int_kernel(const T *__restr
 // float rows: the row sum follows NumPy's pairwise summation (what np.sum does on a
 // contiguous float64 row: 8 running partial sums per <=128-element block, blocks combined by
 // halving) so that renormalising float rows matches the reference bit for bit.
-__device__ double phk_np_pairwise_sum(const double *a, uint64_t n) {
+// (The halving is a recursion in NumPy; here its frames live in an explicit stack in LDS, one per wave, walked by lane 0:
+// as a recursive device function it was the library's last kernel with a call stack in scratch memory.)
+__device__ __forceinline__ double phk_np_pairwise_leaf(const double *a, uint64_t n) {   // n <= 128
     if (n < 8) {
         double r = 0.0;  // NumPy starts from the first element; 0.0 + a0 is exact
         for (uint64_t i = 0; i < n; ++i) r += a[i];
         return r;
-    } else if (n <= 128) {
-        double r[8];
-        for (int j = 0; j < 8; ++j) r[j] = a[j];
-        uint64_t i;
-        for (i = 8; i < n - (n % 8); i += 8)
-            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; ++i) res += a[i];
-        return res;
-    } else {
-        uint64_t n2 = n / 2;
-        n2 -= n2 % 8;
-        return phk_np_pairwise_sum(a, n2) + phk_np_pairwise_sum(a + n2, n - n2);
     }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    uint64_t i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+#define PW_DEPTH 48   // frames: a row of 2^40 elements halves 34 times
+struct PwStack {
+    uint64_t off[PW_DEPTH], len[PW_DEPTH];
+    double left[PW_DEPTH];
+    uint32_t state[PW_DEPTH];   // 0 new, 1 waiting for the left half, 2 waiting for the right half
+};
+
+__device__ double phk_np_pairwise_sum(const double *a, uint64_t n, PwStack &st) {
+    int sp = 0;
+    st.off[0] = 0; st.len[0] = n; st.state[0] = 0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        const uint64_t o = st.off[sp], m = st.len[sp];
+        const uint32_t state = st.state[sp];
+        if (state == 0) {
+            if (m <= 128) {
+                ret = phk_np_pairwise_leaf(a + o, m);
+                --sp;
+            } else {
+                uint64_t n2 = m / 2;
+                n2 -= n2 % 8;
+                st.state[sp] = 1;
+                ++sp;
+                st.off[sp] = o; st.len[sp] = n2; st.state[sp] = 0;
+            }
+        } else if (state == 1) {
+            uint64_t n2 = m / 2;
+            n2 -= n2 % 8;
+            st.left[sp] = ret;
+            st.state[sp] = 2;
+            ++sp;
+            st.off[sp] = o + n2; st.len[sp] = m - n2; st.state[sp] = 0;
+        } else {
+            ret = st.left[sp] + ret;
+            --sp;
+        }
+    }
+    return ret;
 }
 
 __global__ __launch_bounds__(256) void phk_normalize_f64_kernel(const double *__restrict__ rows, uint64_t n,
                                                                 uint64_t D, double *__restrict__ out) {
+    __shared__ PwStack stacks[4];
     const int lane = threadIdx.x & 63;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t total = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     for (uint64_t r = wave; r < n; r += total) {
         const double *row = rows + r * D;
         double s = 0.0;
-        if (lane == 0) s = phk_np_pairwise_sum(row, D);
+        if (lane == 0) s = phk_np_pairwise_sum(row, D, stacks[threadIdx.x >> 6]);
         s = __shfl(s, 0);
         for (uint64_t j = lane; j < D; j += 64) out[r * D + j] = row[j] / s;
     }

@@ -22,6 +22,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <functional>
 #include <memory>
@@ -272,7 +273,9 @@ struct FileBytes {
     size_t size = 0;
     void *map = nullptr;
     size_t map_len = 0;
-    std::vector<char> owned;
+    RawBytes owned;           // an inflated ".gz" stream (or the part of it a rank needs)
+    // a partial read (BGZF ".gz", one rank's byte range): data[0] is byte `base` of the uncompressed stream of `total` bytes
+    size_t base = 0, total = 0;
     ~FileBytes() {
         if (!map) return;
         if (map_len >= ((size_t)256u << 20)) {
@@ -318,49 +321,161 @@ static int map_plain_file(const char *path, FileBytes &fb) {
     return PHK_OK;
 }
 
-static int read_whole_file(const char *path, std::vector<char> &buf) {
-    const size_t plen = strlen(path);
-    const bool gz = plen > 3 && strcmp(path + plen - 3, ".gz") == 0;
-    if (gz) {
-        gzFile f = gzopen(path, "rb");
-        if (!f) return PHK_ERR_IO;
-        gzbuffer(f, 1 << 20);
-        size_t used = 0;
-        buf.resize(1 << 24);
-        for (;;) {
-            if (buf.size() - used < (1 << 22)) buf.resize(buf.size() * 2);
-            const int got = gzread(f, buf.data() + used, (unsigned)std::min<size_t>(buf.size() - used, 1u << 30));
-            if (got < 0) {
-                gzclose(f);
-                return PHK_ERR_IO;
-            }
-            if (got == 0) break;
-            used += (size_t)got;
+// ---- ".gz" input (scripts/kmer.py:131-134, scripts/fileIO.py:34,53,68,86 accept zipped FASTA everywhere) -------------------
+// The compressed file is mapped and inflated straight into ONE buffer (rounds 1-4: gzread into a std::vector that doubled --
+// every doubling a copy of all that was read so far, every resize a zero-fill).  Two shapes:
+//   * BGZF (bgzip: what genomics tools write; every <= 64 KiB block a gzip member that carries its compressed size in an
+//     extra field and its uncompressed size in its trailer): the block table is read from the headers alone, so the blocks
+//     are inflated IN PARALLEL, each to its final place -- and one rank of a sharded run inflates only the blocks of its
+//     byte range (open_gz_range);
+//   * any other gzip stream (one member or several): zlib's inflate is serial -- ~0.4 GB/s, which bounds such a file whatever
+//     follows -- into a buffer sized by the ISIZE trailer of the last member, grown when that was not the whole story.
+struct BgzfBlock { size_t coff, csize, uoff; uint32_t usize; };
+
+static bool bgzf_index(const uint8_t *z, size_t zn, std::vector<BgzfBlock> &blocks) {
+    size_t p = 0, u = 0;
+    while (p < zn) {
+        if (zn - p < 28) return false;
+        if (z[p] != 0x1f || z[p + 1] != 0x8b || z[p + 2] != 8 || !(z[p + 3] & 4)) return false;
+        const size_t xlen = (size_t)z[p + 10] | ((size_t)z[p + 11] << 8);
+        if (zn - p < 12 + xlen + 8) return false;
+        size_t bsize = 0;
+        for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) {   // the extra subfields: 'B' 'C' len=2 BSIZE-1
+            const size_t slen = (size_t)z[q + 2] | ((size_t)z[q + 3] << 8);
+            if (z[q] == 'B' && z[q + 1] == 'C' && slen == 2 && q + 6 <= p + 12 + xlen) bsize = ((size_t)z[q + 4] | ((size_t)z[q + 5] << 8)) + 1;
+            q += 4 + slen;
         }
-        gzclose(f);
-        buf.resize(used);
-        return PHK_OK;
+        if (bsize < 12 + xlen + 8 || bsize > zn - p) return false;
+        const uint8_t *t = z + p + bsize - 4;
+        const uint32_t usize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (usize > 65536u) return false;
+        blocks.push_back(BgzfBlock{p, bsize, u, usize});
+        u += usize;
+        p += bsize;
     }
+    return !blocks.empty();
+}
+
+// one whole gzip member (header, deflate stream, CRC and size checked by zlib) -> dst; the bytes it produced
+static int inflate_member(const uint8_t *src, size_t n, char *dst, size_t cap, size_t *produced) {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) return PHK_ERR_IO;
+    zs.next_in = const_cast<Bytef *>(src);
+    zs.avail_in = (uInt)n;
+    zs.next_out = (Bytef *)dst;
+    zs.avail_out = (uInt)cap;
+    const int rc = inflate(&zs, Z_FINISH);
+    *produced = cap - zs.avail_out;
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END ? PHK_OK : PHK_ERR_IO;
+}
+
+static int inflate_bgzf_blocks(const uint8_t *z, const std::vector<BgzfBlock> &blocks, size_t b_lo, size_t b_hi, char *dst, size_t dst_u0) {
+    std::atomic<int> failed(0);
+    phk_parallel_for(b_hi - b_lo, [&](uint64_t i) {
+        const BgzfBlock &bk = blocks[b_lo + (size_t)i];
+        size_t got = 0;
+        if (inflate_member(z + bk.coff, bk.csize, dst + (bk.uoff - dst_u0), bk.usize, &got) != PHK_OK || got != bk.usize) failed.store(1);
+    });
+    return failed.load() ? PHK_ERR_IO : PHK_OK;
+}
+
+static int inflate_gz_serial(const uint8_t *z, size_t zn, RawBytes &out, size_t *size) {
+    size_t cap = 0;
+    if (zn >= 4) cap = (size_t)z[zn - 4] | ((size_t)z[zn - 3] << 8) | ((size_t)z[zn - 2] << 16) | ((size_t)z[zn - 1] << 24);
+    if (cap < zn) cap = 4 * zn;         // (several members, or more than 4 GB: the trailer is not the size)
+    cap += 64;
+    out.resize(cap);
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) return PHK_ERR_IO;
+    size_t in_at = 0, used = 0;
+    int rc = Z_OK;
+    for (;;) {
+        if (zs.avail_in == 0 && in_at < zn) {
+            const size_t take = std::min<size_t>(zn - in_at, (size_t)1 << 30);
+            zs.next_in = const_cast<Bytef *>(z + in_at);
+            zs.avail_in = (uInt)take;
+            in_at += take;
+        }
+        if (used == cap) {   // the guess was short: a larger buffer, one copy
+            RawBytes bigger;
+            bigger.resize(cap * 2);
+            memcpy(bigger.data(), out.data(), used);
+            std::swap(out.p, bigger.p); std::swap(out.n, bigger.n); std::swap(out.mapped, bigger.mapped);
+            cap *= 2;
+        }
+        const size_t room = std::min<size_t>(cap - used, (size_t)1 << 30);
+        zs.next_out = (Bytef *)(out.data() + used);
+        zs.avail_out = (uInt)room;
+        rc = inflate(&zs, Z_NO_FLUSH);
+        used += room - zs.avail_out;
+        if (rc == Z_STREAM_END) {
+            if (zs.avail_in == 0 && in_at >= zn) break;          // the last member
+            if (inflateReset(&zs) != Z_OK) { rc = Z_DATA_ERROR; break; }   // the next member of a multi-member file
+            continue;
+        }
+        if (rc != Z_OK && rc != Z_BUF_ERROR) break;
+        if (rc == Z_BUF_ERROR && zs.avail_in == 0 && in_at >= zn) break;   // truncated stream
+    }
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END) return PHK_ERR_IO;
+    *size = used;
+    return PHK_OK;
+}
+
+struct GzMap {
+    const uint8_t *z = nullptr;
+    size_t zn = 0;
+    ~GzMap() { if (z && zn) munmap(const_cast<uint8_t *>(z), zn); }
+};
+static int map_gz(const char *path, GzMap &g) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return PHK_ERR_IO;
     struct stat st;
-    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
-        close(fd);
-        return PHK_ERR_IO;
-    }
-    buf.resize((size_t)st.st_size);
-    size_t used = 0;
-    while (used < buf.size()) {
-        const ssize_t got = read(fd, buf.data() + used, std::min<size_t>(buf.size() - used, 1u << 30));
-        if (got < 0) {
-            close(fd);
-            return PHK_ERR_IO;
-        }
-        if (got == 0) break;
-        used += (size_t)got;
-    }
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return PHK_ERR_IO; }
+    g.zn = (size_t)st.st_size;
+    if (g.zn == 0) { close(fd); return PHK_ERR_IO; }     // (an empty file is not a gzip stream: gzopen would read it as empty text)
+    void *p = mmap(nullptr, g.zn, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
-    buf.resize(used);
+    if (p == MAP_FAILED) { g.zn = 0; return PHK_ERR_IO; }
+    g.z = (const uint8_t *)p;
+    return PHK_OK;
+}
+
+// the whole stream
+static int read_gz_file(const char *path, FileBytes &fb) {
+    GzMap g;
+    {
+        struct stat st;
+        if (stat(path, &st) == 0 && S_ISREG(st.st_mode) && st.st_size == 0) {   // as gzopen: an empty file reads as no text
+            fb.data = "";
+            fb.size = fb.total = 0;
+            return PHK_OK;
+        }
+    }
+    PHK_TRY(map_gz(path, g));
+    if (g.zn < 2 || g.z[0] != 0x1f || g.z[1] != 0x8b) {   // not gzip at all: gzopen would pass the bytes through
+        fb.owned.resize(g.zn + 64);
+        memcpy(fb.owned.data(), g.z, g.zn);
+        fb.data = fb.owned.data();
+        fb.size = fb.total = g.zn;
+        return PHK_OK;
+    }
+    std::vector<BgzfBlock> blocks;
+    if (bgzf_index(g.z, g.zn, blocks)) {
+        const size_t total = blocks.back().uoff + blocks.back().usize;
+        fb.owned.resize(total + 64);
+        PHK_TRY(inflate_bgzf_blocks(g.z, blocks, 0, blocks.size(), fb.owned.data(), 0));
+        fb.data = fb.owned.data();
+        fb.size = fb.total = total;
+        return PHK_OK;
+    }
+    size_t size = 0;
+    PHK_TRY(inflate_gz_serial(g.z, g.zn, fb.owned, &size));
+    fb.data = fb.owned.data();
+    fb.size = fb.total = size;
     return PHK_OK;
 }
 
@@ -395,11 +510,10 @@ static int open_fasta_bytes(const char *path, FileBytes &fb) {
     const size_t plen = strlen(path);
     int rc;
     if (plen > 3 && strcmp(path + plen - 3, ".gz") == 0) {
-        rc = read_whole_file(path, fb.owned);
-        fb.data = fb.owned.data();
-        fb.size = fb.owned.size();
+        rc = read_gz_file(path, fb);
     } else {
         rc = map_plain_file(path, fb);
+        fb.total = fb.size;
     }
     if (rc != PHK_OK) phk_set_error("phk_fasta_read: cannot read %s", path);
     return rc;
@@ -432,6 +546,72 @@ struct RecLayout {
     bool regular = true;
 };
 
+// The bytes of one byte range of the file's (uncompressed) stream -- the records whose '>' line begins in [cut_lo, cut_hi),
+// cuts given as fractions num / den of the stream or as absolute positions (den = 0) -- as *b / *n.  A plain file is mapped
+// and only the range's pages are touched; a BGZF ".gz" is inflated for the blocks of the range alone (in parallel), extended
+// block by block until the first record of the next range is found; any other ".gz" has to be inflated whole.
+static int open_fasta_cut(const char *path, uint64_t lo_num, uint64_t hi_num, uint64_t den, FileBytes &fb, const char **b, size_t *n) {
+    const size_t plen = strlen(path);
+    std::vector<BgzfBlock> blocks;
+    GzMap g;
+    bool bgzf = false;
+    if (plen > 3 && strcmp(path + plen - 3, ".gz") == 0 && map_gz(path, g) == PHK_OK) bgzf = bgzf_index(g.z, g.zn, blocks);
+    if (!bgzf) {
+        PHK_TRY(open_fasta_bytes(path, fb));
+        const size_t tot = fb.size;
+        const size_t cut_lo = den ? (size_t)((unsigned __int128)tot * lo_num / den) : (lo_num < tot ? (size_t)lo_num : tot);
+        const size_t cut_hi = den ? (size_t)((unsigned __int128)tot * hi_num / den) : (hi_num < tot ? (size_t)hi_num : tot);
+        const size_t lo = next_record_start(fb.data, tot, cut_lo);
+        const size_t hi = cut_hi >= tot ? tot : next_record_start(fb.data, tot, cut_hi);
+        *b = fb.data + lo;
+        *n = hi > lo ? hi - lo : 0;
+        return PHK_OK;
+    }
+    const size_t tot = blocks.back().uoff + blocks.back().usize;
+    const size_t cut_lo = den ? (size_t)((unsigned __int128)tot * lo_num / den) : (lo_num < tot ? (size_t)lo_num : tot);
+    const size_t cut_hi = den ? (size_t)((unsigned __int128)tot * hi_num / den) : (hi_num < tot ? (size_t)hi_num : tot);
+    fb.total = tot;
+    if (cut_lo >= tot) {
+        *b = "";
+        *n = 0;
+        return PHK_OK;
+    }
+    auto block_of = [&](size_t u) {   // the block that holds stream byte u (u < tot)
+        size_t a = 0, z = blocks.size();
+        while (z - a > 1) {
+            const size_t mid = (a + z) / 2;
+            if (blocks[mid].uoff <= u) a = mid; else z = mid;
+        }
+        return a;
+    };
+    const size_t b_lo = block_of(cut_lo ? cut_lo - 1 : 0);     // (the byte before the cut says whether the cut is a line start)
+    for (size_t ahead = (size_t)4 << 20;; ahead *= 8) {
+        const size_t want_end = cut_hi >= tot ? tot : std::min(tot, cut_hi + ahead);
+        const size_t b_hi = want_end >= tot ? blocks.size() : block_of(want_end - 1) + 1;
+        const size_t u0 = blocks[b_lo].uoff, u1 = b_hi < blocks.size() ? blocks[b_hi].uoff : tot;
+        fb.owned.resize(u1 - u0 + 64);
+        if (inflate_bgzf_blocks(g.z, blocks, b_lo, b_hi, fb.owned.data(), u0) != PHK_OK) {
+            phk_set_error("phk_fasta_read: cannot inflate %s", path);
+            return PHK_ERR_IO;
+        }
+        const char *d = fb.owned.data();
+        const size_t len = u1 - u0;
+        const size_t lo = next_record_start(d, len, cut_lo - u0);
+        size_t hi;
+        if (cut_hi >= tot) hi = len;
+        else {
+            hi = cut_hi >= u1 ? len : next_record_start(d, len, cut_hi - u0);
+            if (hi == len && u1 < tot) continue;               // the next range's first record lies further on: more blocks
+        }
+        fb.base = u0;
+        fb.data = d;
+        fb.size = len;
+        *b = d + lo;
+        *n = hi > lo ? hi - lo : 0;
+        return PHK_OK;
+    }
+}
+
 static int parse_fasta_bytes(const char *b, size_t n, int threads, phk_fasta **out, bool with_bases = true,
                              std::vector<size_t> *starts_out = nullptr, std::vector<RecLayout> *layout_out = nullptr);
 
@@ -460,11 +640,10 @@ extern "C" int phk_fasta_read_range(const char *path, uint64_t byte_lo, uint64_t
     PHK_REQUIRE(path && out, "phk_fasta_read_range: NULL argument");
     PHK_REQUIRE(byte_lo <= byte_hi, "phk_fasta_read_range: byte_lo > byte_hi");
     FileBytes fb;
-    PHK_TRY(open_fasta_bytes(path, fb));
-    const size_t n = fb.size;
-    const size_t lo = next_record_start(fb.data, n, byte_lo < n ? (size_t)byte_lo : n);
-    const size_t hi = byte_hi >= n ? n : next_record_start(fb.data, n, (size_t)byte_hi);
-    return parse_fasta_bytes(fb.data + lo, hi > lo ? hi - lo : 0, threads, out);
+    const char *b = nullptr;
+    size_t n = 0;
+    PHK_TRY(open_fasta_cut(path, byte_lo, byte_hi, 0, fb, &b, &n));
+    return parse_fasta_bytes(b, n, threads, out);
 }
 
 // part `part` of `n_parts` equal byte ranges of the file (what rank `part` of `n_parts` reads)
@@ -472,12 +651,10 @@ extern "C" int phk_fasta_read_part(const char *path, uint32_t part, uint32_t n_p
     PHK_REQUIRE(path && out, "phk_fasta_read_part: NULL argument");
     PHK_REQUIRE(n_parts >= 1 && part < n_parts, "phk_fasta_read_part: part %u of %u", part, n_parts);
     FileBytes fb;
-    PHK_TRY(open_fasta_bytes(path, fb));
-    const size_t n = fb.size;
-    const size_t cut_lo = (size_t)((unsigned __int128)n * part / n_parts), cut_hi = (size_t)((unsigned __int128)n * (part + 1) / n_parts);
-    const size_t lo = next_record_start(fb.data, n, cut_lo);
-    const size_t hi = part + 1 == n_parts ? n : next_record_start(fb.data, n, cut_hi);
-    return parse_fasta_bytes(fb.data + lo, hi > lo ? hi - lo : 0, threads, out);
+    const char *b = nullptr;
+    size_t n = 0;
+    PHK_TRY(open_fasta_cut(path, part, (uint64_t)part + 1, n_parts, fb, &b, &n));
+    return parse_fasta_bytes(b, n, threads, out);
 }
 
 static int parse_fasta_bytes(const char *b, const size_t n, int threads, phk_fasta **out, const bool with_bases,
@@ -735,12 +912,10 @@ extern "C" int phk_batch_from_fasta_part(phk_ctx *ctx, const char *path, uint32_
     PHK_REQUIRE(ctx && path && index_out && out, "phk_batch_from_fasta_part: NULL argument");
     PHK_REQUIRE(n_parts >= 1 && part < n_parts, "phk_batch_from_fasta_part: part %u of %u", part, n_parts);
     FileBytes fb;
-    PHK_TRY(open_fasta_bytes(path, fb));
-    const size_t n = fb.size;
-    const size_t cut_lo = (size_t)((unsigned __int128)n * part / n_parts), cut_hi = (size_t)((unsigned __int128)n * (part + 1) / n_parts);
-    const size_t lo = next_record_start(fb.data, n, cut_lo);
-    const size_t hi = part + 1 == n_parts ? n : next_record_start(fb.data, n, cut_hi);
-    return batch_from_fasta_bytes(ctx, fb.data + lo, hi > lo ? hi - lo : 0, k, symbols4, threads, index_out, out);
+    const char *b = nullptr;
+    size_t n = 0;
+    PHK_TRY(open_fasta_cut(path, part, (uint64_t)part + 1, n_parts, fb, &b, &n));
+    return batch_from_fasta_bytes(ctx, b, n, k, symbols4, threads, index_out, out);
 }
 
 static int batch_from_fasta_bytes(phk_ctx *ctx, const char *b, const size_t n, int k, const char *symbols4, int threads,

@@ -33,9 +33,7 @@ extern "C" int phk_device_count(int *count) {
 // one knob by name (the part after PHK_ of its environment variable, lower case)
 static int set_knob(PhkKnobs &k, const char *key, const char *value) {
     const char *v = value ? value : "";
-    if (!strcmp(key, "count_cfg")) snprintf(k.count_cfg, sizeof(k.count_cfg), "%s", v);
-    else if (!strcmp(key, "count_lanes")) k.count_lanes = v[0];
-    else if (!strcmp(key, "slot_threads")) k.slot_threads = v[0];
+    if (!strcmp(key, "count_lanes")) k.count_lanes = v[0];
     else if (!strcmp(key, "force_exact")) k.force_exact = v[0] == '1';
     else if (!strcmp(key, "proposal")) snprintf(k.proposal, sizeof(k.proposal), "%s", v);
     else if (!strcmp(key, "cx_cfg")) snprintf(k.cx_cfg, sizeof(k.cx_cfg), "%s", v);
@@ -52,8 +50,7 @@ static int set_knob(PhkKnobs &k, const char *key, const char *value) {
 }
 
 static void knobs_from_env(PhkKnobs &k) {
-    static const char *const names[][2] = {{"count_cfg", "PHK_COUNT_CFG"}, {"count_lanes", "PHK_COUNT_LANES"},
-                                           {"slot_threads", "PHK_SLOT_THREADS"}, {"force_exact", "PHK_FORCE_EXACT"},
+    static const char *const names[][2] = {{"count_lanes", "PHK_COUNT_LANES"}, {"force_exact", "PHK_FORCE_EXACT"},
                                            {"proposal", "PHK_PROPOSAL"}, {"cx_cfg", "PHK_CX_CFG"},
                                            {"rerank", "PHK_RERANK"}, {"count_sort", "PHK_COUNT_SORT"},
                                            {"score_batch", "PHK_SCORE_BATCH"}, {"tail_aside", "PHK_TAIL_ASIDE"},
@@ -558,7 +555,7 @@ extern "C" int phk_count_score_dev(phk_ctx *ctx, const phk_model *model, const u
     // k = 5: the count kernel's flush also writes the int8 operand of the scorer's sweep (PhkPrep8, phk_common.h)
     ctx->prep8.armed = false;
     if (k == 5 && !d_mask && n > 0 && phk_model_has_fast(model) && model->d_A8 && !model->bf_stale && !ctx->knobs.force_exact &&
-        !ctx->knobs.proposal[0] && !ctx->knobs.count_lanes && !ctx->knobs.count_cfg[0]) {
+        !ctx->knobs.proposal[0] && !ctx->knobs.count_lanes) {
         const uint64_t D = model->D;
         void *frag, *big;
         PHK_TRY(phk_ws(ctx, WS_FRAG8, phk_div_up(n, 32) * 32 * D, &frag));

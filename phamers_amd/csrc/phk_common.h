@@ -16,7 +16,7 @@
 
 // Diagnostic code (phase timers, tuning overrides of the kernels' shape macros) compiles only in a build that says so;
 // such a build reports another ABI version (phk_api.hip) and is refused by the loader.
-#if (defined(I8_TIMERS) || defined(I8_NW) || defined(I8_NBUF) || defined(SLOT_LINES) || defined(PHK_HI_REFINE) || \
+#if (defined(I8_TIMERS) || defined(I8_NW) || defined(I8_NBUF) || defined(PHK_HI_REFINE) || \
      defined(PHK_RERANK_WAVES) || defined(PAIRS_ABL) || defined(F16H_ABL)) && !defined(PHK_DIAGNOSTIC_BUILD)
 #error "kernel tuning / timer macros need -DPHK_DIAGNOSTIC_BUILD (make EXTRA_CXXFLAGS='-DPHK_DIAGNOSTIC_BUILD -D...')"
 #endif
@@ -97,10 +97,8 @@ struct PhkTimed {
 // Tuning / diagnostic knobs.  Read ONCE from the environment when the context is created (PHK_<NAME>), changed
 // afterwards only through phk_set_option(): no launch path calls getenv.
 struct PhkKnobs {
-    char count_cfg[32] = "";   // "<copies>,<pack16>": a built variant of the wave-per-contig count kernel (LDS study)
     char count_lanes = 0;      // '0' wave-per-contig kernel only, '1' slot kernel by the batch statistics, '2' slot kernel whatever the
                                // batch looks like, 'p' / 'P' (forced: 'q' / 'Q') two-windows-per-add kernel with 512 / 1024 threads (k = 4, no mask)
-    char slot_threads = 0;     // '2' = 256-thread slot workgroups (default 512 at k <= 4)
     bool force_exact = false;  // every model through the float64 path
     char proposal[8] = "";     // "f32" fp32 MFMA, "f16" split-query f16, "cx2" count-exact with 2 MFMAs per k-step
     char cx_cfg[8] = "";       // "<tiles per wave><waves per workgroup>": 14, 24, 28

@@ -692,7 +692,7 @@ int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, b
 }
 
 // ====================================================================================
-// Count-exact proposal kernel (k = 4, queries given as uint32 counts).
+// Count-exact proposal (k = 4, queries given as uint32 counts): the idea the kernel below builds on.
 //
 // The query operand is the count vector ITSELF: integers <= 2048 are exact in fp16, so no split and no
 // normalisation are needed on the query side and a k-step costs 2 MFMAs (c.r_hi, c.r_lo) instead of 3.
@@ -709,242 +709,6 @@ int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, b
 // The 31-ulp perturbation is part of the decision stage's error bound.
 // ====================================================================================
 #define CX_SENT 0x03FFFFFFu
-template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW, (NT == 1 && NW == 4) ? 2 : 1) void phk_knn_f16c_kernel(
-    const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rowsum, uint64_t N, const uint4 *__restrict__ Af,
-    uint32_t nblk_ref, uint32_t nblk_pos, uint32_t nblk_neg, float *__restrict__ cand_v, uint32_t *__restrict__ cand_i,
-    float *__restrict__ cand_u) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 x F16_BLOCK_BYTES
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    const uint64_t q0 = ((uint64_t)blockIdx.x * NW + wave) * (32 * NT);
-    const uint32_t total = nblk_ref + nblk_pos + nblk_neg;
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem;
-    auto dma_block = [&](uint32_t blk, int buf) {
-        const uint4 *g = Af + (uint64_t)blk * (F16_BLOCK_BYTES / 16) + lane;
-        const uint32_t l = lds_base + (uint32_t)buf * F16_BLOCK_BYTES;
-        // 32 / NW + 1 pieces per wave, no loop (a loop here splits the hot loop into basic blocks and hipcc then sinks the
-        // insertions away from the MFMAs they are meant to hide behind); piece 32 is fetched by every wave
-#pragma unroll
-        for (int k = 0; k < 32 / NW + 1; ++k) {
-            const int p = k < 32 / NW ? wave + NW * k : 32;
-            const uint4 *gp = g + p * 64;
-            const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gp), "s"(lp) : "memory");
-        }
-    };
-    if (total) dma_block(0, 0);
-
-    // ---- prologue: centred counts -> fp16 (exact up to 2048 in magnitude), row sum (from the caller) ----
-    half8 bq[NT][16];
-    float negT[NT];
-    bool big[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const uint64_t qi = q0 + 32 * t + j;
-        const uint64_t qrow = qi < N ? qi : N - 1;
-        const uint4 *row = reinterpret_cast<const uint4 *>(counts + qrow * FAST_D + 128 * h);
-        // the operand is the count minus the row's centre (phk_row_center): an integer of magnitude <= 2048, exact in fp16
-        const uint32_t tot = rowsum[qrow];
-        const int cen = (int)phk_row_center(tot, FAST_D);
-        uint32_t mx = 0;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const uint4 c0 = row[2 * s], c1 = row[2 * s + 1];
-            const uint32_t c[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int d = (int)c[e] - cen;           // (a count above 2^31 wraps to a negative d: the row is `big` below)
-                const uint32_t ad = (uint32_t)(d < 0 ? -d : d);
-                mx = max(mx, max(ad, c[e] >> 31 ? 0xFFFFFFFFu : 0u));
-                bq[t][s][e] = (_Float16)(float)(d < -2048 ? -2048 : (d > 2048 ? 2048 : d));
-            }
-        }
-        const uint32_t mo = __shfl_xor(mx, 32);
-        big[t] = (mx > mo ? mx : mo) > 2048u;
-        negT[t] = -(float)tot;
-    }
-
-    float lv[NT][5];
-    uint32_t lb[NT][4];
-    const float vempty = __uint_as_float(__float_as_uint(-3.0e38f) & ~31u);  // empty slot: fresh bit clear
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int c = 0; c < 5; ++c) lv[t][c] = vempty;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) lb[t][c] = CX_SENT;
-    }
-    const float fbig = 3.3e38f;  // above every value: med3(v0, x, fbig) = max(v0, x) without the canonicalising v_max pair
-
-    // after a block's 16 insertions: block number -> id list at the fresh positions, fresh bits cleared.
-    // A no-op when no fresh bit is set.
-    auto settle = [&](uint32_t cur) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            uint32_t m[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m[c]) : "v"(lv[t][c]));  // 0 / ~0 from bit 0
-            lb[t][3] = phk_bfi_hw(m[0], lb[t][2], lb[t][3]);
-            lb[t][2] = phk_bfi_hw(m[0], lb[t][1], lb[t][2]);
-            lb[t][1] = phk_bfi_hw(m[0], lb[t][0], lb[t][1]);
-            lb[t][0] = phk_bfi_hw(m[0], cur, lb[t][0]);
-            lb[t][3] = phk_bfi_hw(m[1], lb[t][2], lb[t][3]);
-            lb[t][2] = phk_bfi_hw(m[1], lb[t][1], lb[t][2]);
-            lb[t][1] = phk_bfi_hw(m[1], cur, lb[t][1]);
-            lb[t][3] = phk_bfi_hw(m[2], lb[t][2], lb[t][3]);
-            lb[t][2] = phk_bfi_hw(m[2], cur, lb[t][2]);
-            lb[t][3] = phk_bfi_hw(m[3], cur, lb[t][3]);
-#pragma unroll
-            for (int c = 0; c < 5; ++c) lv[t][c] = __uint_as_float(__float_as_uint(lv[t][c]) & ~1u);
-        }
-    };
-    // insertion of one value: w = acc - T * bias, index bits embedded, 5 x v_med3
-    auto insert = [&](int t, float a, float bias, int r) {
-        const float w = fmaf(negT[t], bias, a);
-        const float x = __uint_as_float((__float_as_uint(w) & ~31u) | (uint32_t)(2 * r + 1));
-        const float n4 = __builtin_amdgcn_fmed3f(lv[t][3], lv[t][4], x);
-        const float n3 = __builtin_amdgcn_fmed3f(lv[t][2], lv[t][3], x);
-        const float n2 = __builtin_amdgcn_fmed3f(lv[t][1], lv[t][2], x);
-        const float n1 = __builtin_amdgcn_fmed3f(lv[t][0], lv[t][1], x);
-        lv[t][0] = __builtin_amdgcn_fmed3f(lv[t][0], x, fbig);
-        lv[t][1] = n1;
-        lv[t][2] = n2;
-        lv[t][3] = n3;
-        lv[t][4] = n4;
-    };
-
-    // Software pipeline inside the wave, per segment: while block i's MFMAs fill one accumulator set, the VALU
-    // inserts block i-1's values out of the other set (with its bias terms, held in 16 registers) and settles
-    // the ids of block i-2's insertions during the first k-step.  Nothing but the LDS reads of the next bias
-    // terms and the workgroup barrier is left outside the MFMA stream; the hot loop has no data-dependent
-    // control flow.  The pipeline drains at the end of a segment (3 times per sweep); the DMA stream does not.
-    float bias[16];
-    f32x16 accA[NT], accB[NT];
-    uint32_t g = 0;  // global block number: LDS buffer parity and DMA source
-
-    auto block_iter = [&](uint32_t settle_id, f32x16 (&cur)[NT], const f32x16 (&prev)[NT]) {
-        // block g has landed (every wave waits for its own pieces, then the barrier), and every wave is done
-        // reading the other buffer, which the next DMA overwrites
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        dma_block(g + 1, (g + 1) & 1);  // one past the end on the last block: the record array is padded
-        const uint8_t *buf = smem + (g & 1) * F16_BLOCK_BYTES;
-        ++g;
-        const half8 *fr = reinterpret_cast<const half8 *>(buf) + lane;
-        half8 ahn = fr[0], aln = fr[64];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const half8 ah = ahn, al = aln;
-            if (s < 15) {
-                ahn = fr[(2 * s + 2) * 64];
-                aln = fr[(2 * s + 3) * 64];
-            }
-            __builtin_amdgcn_sched_barrier(0);  // the reads stay up here, one step ahead of their MFMAs
-            if (s == 0) {
-                f32x16 z;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], z, 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], cur[t], 0, 0, 0);
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) cur[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bq[t][s], cur[t], 0, 0, 0);
-            if (s == 0) settle(settle_id);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) insert(t, prev[t][s], bias[s], s);
-            if (s == 0) {
-#pragma unroll
-                for (int gi = 0; gi < 2 * NT; ++gi) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);  // VALU (settle + insertion)
-                }
-            } else {
-#pragma unroll
-                for (int gi = 0; gi < 2 * NT; ++gi) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU (insertion)
-                }
-            }
-        }
-        // D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h'; its bias terms
-        // (the buffer is recycled after the next barrier)
-        const float4 *cn = reinterpret_cast<const float4 *>(buf + 32 * 1024 + 128) + h;
-#pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) {
-            const float4 c4 = cn[2 * m4];
-            bias[4 * m4 + 0] = c4.x;
-            bias[4 * m4 + 1] = c4.y;
-            bias[4 * m4 + 2] = c4.z;
-            bias[4 * m4 + 3] = c4.w;
-        }
-    };
-    // drain: the last block's values (in `last`, bias terms loaded), ids, then the segment's lists go out
-    auto finish = [&](int seg, uint32_t nb, const f32x16 (&last)[NT]) {
-        settle(nb - 2);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int s = 0; s < 16; ++s) insert(t, last[t][s], bias[s], s);
-        settle(nb - 1);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const uint64_t qi = q0 + 32 * t + j;
-            if (qi < N) {
-                                uint32_t ix[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t r = (__float_as_uint(lv[t][c]) >> 1) & 15u;
-                    ix[c] = (lb[t][c] == CX_SENT || big[t]) ? 0xFFFFFFFFu
-                                                             : lb[t][c] * 32u + (r & 3u) + 8u * (r >> 2) + 4u * (uint32_t)h;
-                }
-                cand_store(cand_v, cand_i, cand_u, seg, h, qi, N, lv[t][0], lv[t][1], lv[t][2], lv[t][3], ix[0], ix[1], ix[2], ix[3], big[t] ? 3.0e38f : lv[t][4]);
-            }
-        }
-    };
-#pragma unroll 1
-    for (int seg = 0; seg < NSEG; ++seg) {
-        const uint32_t nb = seg == 0 ? nblk_ref : seg == 1 ? nblk_pos : nblk_neg;
-        if (nb == 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint64_t qi = q0 + 32 * t + j;
-                if (qi < N) {
-                                        cand_store_empty(cand_v, cand_i, cand_u, seg, h, qi, N);
-                }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int c = 0; c < 5; ++c) lv[t][c] = vempty;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) lb[t][c] = CX_SENT;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accB[t][r] = -3.35e38f;  // "block -1": below the empty slots, never accepted
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bias[r] = 0.0f;
-        uint32_t i = 0;
-#pragma unroll 1
-        for (; i + 1 < nb; i += 2) {
-            block_iter(i - 2, accA, accB);
-            block_iter(i - 1, accB, accA);
-        }
-        if (i < nb) {
-            block_iter(i - 2, accA, accB);
-            finish(seg, nb, accA);
-        } else {
-            finish(seg, nb, accB);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the trailing prefetch before the LDS is released
-}
 
 // ====================================================================================
 // High-parts-only proposal kernel (k = 4, uint32 counts; the default first pass).
@@ -1243,31 +1007,6 @@ static int ensure_rowsum(phk_ctx *ctx, const uint32_t *d_counts, uint64_t nb, ui
     PHK_LAUNCH(ctx, "phk_rowsum_kernel",
                phk_rowsum_kernel<<<dim3((unsigned)phk_div_up(nb, 4)), dim3(256), 0, ctx->stream>>>(d_counts, nb, D, (uint32_t *)rs));
     d_rowsum = (const uint32_t *)rs;
-    return PHK_OK;
-}
-
-int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
-                             uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu) {
-    PHK_TRY(ensure_rowsum(ctx, d_counts, nb, m->D, d_rowsum));
-    const size_t lds = 2 * F16_BLOCK_BYTES;
-    int nt = 2, nw = 8;
-    const char *e = ctx->knobs.cx_cfg;  // "<tiles per wave><waves per workgroup>": 14, 24, 28 (default)
-    if (e[0] == '1') { nt = 1; nw = 4; }
-    if (e[0] == '2' && e[1] == '4') nw = 4;
-    const uint4 *af = (const uint4 *)m->d_Af16 + (uint64_t)(nref ? 0 : m->n_rblk_ref) * (F16_BLOCK_BYTES / 16);
-    const unsigned gblocks = (unsigned)phk_div_up(nb, 32 * nw * nt);
-#define PHK_CX_LAUNCH(NT_, NW_)                                                                             \
-    PHK_LAUNCH(ctx, "phk_knn_f16c_kernel",                                                                  \
-               (phk_knn_f16c_kernel<NT_, NW_><<<dim3(gblocks), dim3(64 * NW_), lds, ctx->stream>>>(         \
-                   d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu)))
-    if (nt == 1) {
-        PHK_CX_LAUNCH(1, 4);
-    } else if (nw == 4) {
-        PHK_CX_LAUNCH(2, 4);
-    } else {
-        PHK_CX_LAUNCH(2, 8);
-    }
-#undef PHK_CX_LAUNCH
     return PHK_OK;
 }
 
@@ -1730,9 +1469,6 @@ int phk_score_f16_init_device(phk_ctx *ctx) {
     const int lds = 2 * F16_BLOCK_BYTES;
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16c_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16h_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, F16H_NBUF * F16H_BLOCK_BYTES));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16h_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, F16H_NBUF * F16H_BLOCK_BYTES));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_knn_f16_general_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));

@@ -53,33 +53,6 @@ bool phk_fast_supports_dim(uint64_t D);
 // ------------------------------------------------------------------------------------
 // model build (host): centre, round to fp32, fragment-order, upload
 // ------------------------------------------------------------------------------------
-static void pack_segment(const double *rows, uint64_t n, const std::vector<double> &mu, std::vector<float> &bf,
-                         uint64_t cb0, double &max_norm, double *colnorm) {
-    const uint64_t nblk = phk_div_up(n, 32);
-    for (uint64_t b = 0; b < nblk; ++b) {
-        float *blk = bf.data() + (cb0 + b) * NG * 64 * 4;
-        for (int i = 0; i < 32; ++i) {
-            const uint64_t r = b * 32 + i;
-            if (r >= n) {  // padding column: zeros, never selectable
-                blk[(32 * 64 + i) * 4 + 0] = PAD_V;
-                continue;
-            }
-            double nrm2 = 0.0;
-            for (int h = 0; h < 2; ++h)
-                for (int s = 0; s < 128; ++s) {
-                    const int d = 128 * h + s;
-                    const float v = (float)(rows[r * FAST_D + d] - mu[d]);
-                    blk[((s >> 2) * 64 + h * 32 + i) * 4 + (s & 3)] = v;
-                    nrm2 += (double)v * (double)v;
-                }
-            blk[(32 * 64 + i) * 4 + 0] = (float)(-0.5 * nrm2);
-            const double nrm = std::sqrt(nrm2);
-            colnorm[r] = nrm;
-            if (nrm > max_norm) max_norm = nrm;
-        }
-    }
-}
-
 int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const double *neg,
                          const double *cpos, const double *cneg) {
     (void)ctx;
@@ -107,26 +80,9 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
     m->n_rblk_ref = (uint32_t)phk_div_up(m->M, 32);
     m->n_rblk_pos = (uint32_t)phk_div_up(m->n_cpos, 32);
     m->n_rblk_neg = (uint32_t)phk_div_up(m->n_cneg, 32);
-    const uint64_t nblk = (uint64_t)m->n_rblk_ref + m->n_rblk_pos + m->n_rblk_neg;
     double max_norm = 0.0;
     std::vector<double> colnorm(m->M + m->n_cpos + m->n_cneg + 1, 0.0);  // |r'| of every real column
-    if (D == FAST_D) {
-        // fp32 fragment-ordered operand of the fp32-input MFMA kernel (k = 4 only)
-        std::vector<float> bf((nblk * NG + 16) * 64 * 4, 0.0f);  // + 16 groups: the prefetch ring runs past the end
-        {
-            std::vector<double> train(m->M * FAST_D);
-            std::copy(pos, pos + m->n_pos * FAST_D, train.begin());
-            std::copy(neg, neg + m->n_neg * FAST_D, train.begin() + m->n_pos * FAST_D);
-            pack_segment(train.data(), m->M, mu, bf, 0, max_norm, colnorm.data());
-        }
-        if (m->n_cpos) pack_segment(cpos, m->n_cpos, mu, bf, m->n_rblk_ref, max_norm, colnorm.data() + m->M);
-        if (m->n_cneg)
-            pack_segment(cneg, m->n_cneg, mu, bf, (uint64_t)m->n_rblk_ref + m->n_rblk_pos, max_norm,
-                         colnorm.data() + m->M + m->n_cpos);
-        if (hipMalloc(&m->d_Bf, bf.size() * sizeof(float)) != hipSuccess) return PHK_ERR_NOMEM;
-        if (hipMemcpy(m->d_Bf, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
-            return PHK_ERR_HIP;
-    } else {
+    {   // |r'| of every column as the float32-rounded centred row gives it
         auto norms = [&](const double *rows, uint64_t n, double *out) {
             phk_parallel_for(n, [&](uint64_t r) {
                 double s2 = 0.0;
@@ -165,7 +121,6 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
 }
 
 void phk_model_free_fast(phk_model *m) {
-    if (m->d_Bf) (void)hipFree(m->d_Bf);
     if (m->d_colnorm) (void)hipFree(m->d_colnorm);
     if (m->d_Af16) (void)hipFree(m->d_Af16);
     m->d_Af16 = nullptr;
@@ -193,145 +148,9 @@ void phk_model_free_fast(phk_model *m) {
     m->d_cn16 = nullptr;
     if (m->d_mu32) (void)hipFree(m->d_mu32);
     if (m->d_mu64) (void)hipFree(m->d_mu64);
-    m->d_Bf = nullptr;
     m->d_colnorm = nullptr;
     m->d_mu32 = nullptr;
     m->d_mu64 = nullptr;
-}
-
-// ------------------------------------------------------------------------------------
-// 1. MFMA candidate search
-// ------------------------------------------------------------------------------------
-// SRC 0: uint32 count rows (normalised here as kmer.normalize_counts would, in fp32 for the
-// proposal pass);  SRC 1: float64 rows.
-template <int SRC>
-__global__ __launch_bounds__(256, 2) void phk_knn_mfma_kernel(const void *__restrict__ src, uint64_t N,
-                                                              const float4 *__restrict__ Bf,
-                                                              const float *__restrict__ mu32,
-                                                              const double *__restrict__ mu64,
-                                                              uint32_t nblk_ref, uint32_t nblk_pos,
-                                                              uint32_t nblk_neg,
-                                                              float *__restrict__ cand_v,
-                                                              uint32_t *__restrict__ cand_i,
-                                                              float *__restrict__ cand_u) {
-    const int lane = threadIdx.x & 63;
-    const int j = lane & 31, h = lane >> 5;
-    const uint64_t q0 = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
-    if (q0 >= N) return;
-    const uint64_t qrow = (q0 + j < N) ? q0 + j : N - 1;
-
-    // ---- prologue: this lane's 128 centred query elements q'[qrow][128h .. 128h+127] ----
-    float q[128];
-    if (SRC == 0) {
-        const uint4 *row = reinterpret_cast<const uint4 *>(static_cast<const uint32_t *>(src) + qrow * FAST_D + 128 * h);
-        uint32_t sum = 0;
-#pragma unroll
-        for (int g = 0; g < 32; ++g) {
-            const uint4 c = row[g];
-            sum += c.x + c.y + c.z + c.w;
-        }
-        const uint32_t tot = sum + __shfl_xor(sum, 32);
-        const float inv = (float)(1.0 / (double)tot);
-        const float4 *mp = reinterpret_cast<const float4 *>(mu32 + 128 * h);
-#pragma unroll
-        for (int g = 0; g < 32; ++g) {
-            const uint4 c = row[g];
-            const float4 mm = mp[g];
-            q[4 * g + 0] = fmaf((float)c.x, inv, -mm.x);
-            q[4 * g + 1] = fmaf((float)c.y, inv, -mm.y);
-            q[4 * g + 2] = fmaf((float)c.z, inv, -mm.z);
-            q[4 * g + 3] = fmaf((float)c.w, inv, -mm.w);
-        }
-    } else {
-        const double2 *row = reinterpret_cast<const double2 *>(static_cast<const double *>(src) + qrow * FAST_D + 128 * h);
-        const double2 *mp = reinterpret_cast<const double2 *>(mu64 + 128 * h);
-#pragma unroll
-        for (int g = 0; g < 64; ++g) {
-            const double2 c = row[g], mm = mp[g];
-            q[2 * g + 0] = (float)(c.x - mm.x);
-            q[2 * g + 1] = (float)(c.y - mm.y);
-        }
-    }
-    const float bone = h == 0 ? 1.0f : 0.0f;  // B operand of the norm step
-    const uint32_t seg_end0 = nblk_ref, seg_end1 = nblk_ref + nblk_pos, total = seg_end1 + nblk_neg;
-    const float4 *bp = Bf + lane;
-
-    // The A-fragment stream (33 x 1 KiB per column block, identical for every wave) is software
-    // pipelined through a ring of PF float4 registers: group g+PF is requested while group g feeds
-    // its 4 MFMAs, and the ring runs across column-block boundaries (Bf carries >= PF groups of tail
-    // padding), so L2 latency hides behind ~PF*4*64 MFMA cycles.
-    constexpr int PF = 11;  // divides NG = 33, so the ring needs no rotation between blocks
-    float4 ring[PF];
-#pragma unroll
-    for (int g = 0; g < PF; ++g) ring[g] = bp[g * 64];
-
-    float lv[CAND];
-    uint32_t li[CAND];
-    float ldrop = -3.0e38f;
-#pragma unroll
-    for (int c = 0; c < CAND; ++c) {
-        lv[c] = -3.0e38f;
-        li[c] = 0xFFFFFFFFu;
-    }
-    int seg = 0;
-    uint32_t seg_first = 0;  // first block of the current segment
-    // leading segments without columns (method 'kmeans' sweeps no train rows): empty lists
-    while (seg < NSEG && (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total) == 0) {
-        if (q0 + j < N) cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
-        ++seg;
-    }
-    for (uint32_t blk = 0; blk < total; ++blk, bp += NG * 64) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const float4 a = ring[g % PF];
-            ring[g % PF] = bp[(g + PF) * 64];  // group g+PF of this block, or the head of the next one
-            if (g < 32) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[4 * (g & 31) + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[4 * (g & 31) + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[4 * (g & 31) + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[4 * (g & 31) + 3], acc, 0, 0, 0);
-            } else {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bone, acc, 0, 0, 0);  // norm step
-            }
-        }
-        // pin the issue order hipcc would otherwise undo (it sinks the loads next to their use):
-        // one fragment load, then the 4 (or 1) MFMAs of the group loaded PF groups earlier
-#pragma unroll
-        for (int g = 0; g < 32; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMA
-        }
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        // epilogue: D[i][j] sits in lane (j, h') register r with i = (r&3) + 8(r>>2) + 4h'
-        const uint32_t cbase = 32u * (blk - seg_first) + 4u * (uint32_t)h;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) list_insert(lv, li, ldrop, acc[r], cbase + (uint32_t)((r & 3) + 8 * (r >> 2)));
-
-        // segment boundary: flush this (query, segment, half) list and start the next segment
-        while (seg < NSEG && blk + 1 == (seg == 0 ? seg_end0 : seg == 1 ? seg_end1 : total)) {
-            if (q0 + j < N) {
-                cand_store(cand_v, cand_i, cand_u, seg, h, q0 + j, N, lv[0], lv[1], lv[2], lv[3], li[0], li[1], li[2], li[3], ldrop);
-            }
-#pragma unroll
-            for (int c = 0; c < CAND; ++c) {
-                lv[c] = -3.0e38f;
-                li[c] = 0xFFFFFFFFu;
-            }
-            ldrop = -3.0e38f;
-            ++seg;
-            seg_first = blk + 1;
-        }
-    }
-    // segments with no blocks at all (method without that part) still get an (empty) list
-    for (; seg < NSEG; ++seg) {
-        if (q0 + j < N) {
-            cand_store_empty(cand_v, cand_i, cand_u, seg, h, q0 + j, N);
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -2923,23 +2742,17 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
     // batch: bounds the candidate (200 B/query), fallback (1 KiB/query) and split-query (4 D B/query) workspaces
     // proposal pass: split-f16 MFMA by default; proposal=f32 selects the fp32-input MFMA kernel (k = 4 only)
     const char *prop = ctx->knobs.proposal;
-    const bool use_f16 = D != FAST_D || !(prop[0] == 'f' && prop[1] == '3');
-    if (!use_f16 && m->bf_stale) {
-        phk_set_error("phk_score: the fp32 MFMA proposal (proposal=f32) does not follow phk_model_set_centroids / "
-                      "phk_model_set_column_mask; use the default proposal");
-        return PHK_ERR_UNSUPPORTED;
-    }
-    // counts at k = 4: the count-exact kernel (2 MFMAs per k-step); proposal=f16 keeps the split-query one
-    const bool use_cx = use_f16 && d_counts && !(prop[0] == 'f' && prop[1] == '1');
+    // count rows: the count-exact kernels (the integer counts are the MFMA operand); proposal=f16 keeps the split-query one
+    const bool use_cx = d_counts && !(prop[0] == 'f' && prop[1] == '1') && (D != FAST_D || m->d_Af16h);
     // Second chance (k = 4, count-exact first pass): what the first pass cannot decide -- rows holding a count above
     // 2048, which the fp16 count operand cannot carry (long or low-complexity contigs), and the rare query whose
     // candidate lists fail certification -- is NOT sent to the float64 brute force at once.  Those rows go through the
     // split-query MFMA kernel (any magnitude: the counts are normalised, centred and split on the fly) addressed through
     // the first pass's queue, with their own list set; only what that pass cannot certify either is brute-forced.
     const bool second = use_cx && D == FAST_D;
-    // first pass at k = 4: the high-parts-only kernel (1 MFMA per k-step) + its decision stage; proposal=cx2 keeps the
-    // count-exact kernel with both parts (2 MFMAs per k-step) and the margin-test decision kernels
-    const bool hi_only = second && m->d_Af16h && !(prop[0] == 'c' && prop[1] == 'x' && prop[2] == '2');
+    // first pass at k = 4: the high-parts-only kernel (1 MFMA per k-step) + its decision stage.  (Rounds 2-4 kept the kernel
+    // with both parts in the sweep, phk_knn_f16c_kernel, 2 MFMAs per k-step, behind proposal=cx2; removed in round 5.)
+    const bool hi_only = second;
     // general D (k = 5, 6): the same idea exists (HI flavour of the general kernel + phk_rerank_h_kernel) but is opt-in
     // (proposal=hi): on the BASELINE configurations' synthetic reference genomes, which are nearly equidistant from every
     // query, the high-part windows are wide -- 20 % of config 4's queries fell through to the brute force -- and the
@@ -3153,11 +2966,8 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             p.rowsum = rsum;
         } else if (use_cx) {
             cx_bound(p);
-        } else if (use_f16) {
-            split_f16_bound(p);
         } else {
-            p.vscale = 1.0;
-            p.eb_cA = 6.0; p.eb_cP = 264.0; p.eb_cR = 4.0; p.eb_abs = 0.0;
+            split_f16_bound(p);
         }
         if (i8_now) {
             // (launched above)
@@ -3166,23 +2976,9 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
                                                     (float *)cv, ci, cu, ca, hi_gen, (uint32_t)gen_sets, set_bytes));
         } else if (hi_only) {
             PHK_TRY(phk_launch_proposal_f16h(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu));
-        } else if (use_cx) {
-            PHK_TRY(phk_launch_proposal_f16c(ctx, m, (const uint32_t *)src, rsum, nb, nref, npos, nneg, (float *)cv, ci, cu));
-        } else if (use_f16) {
+        } else {
             PHK_TRY(phk_launch_proposal_f16(ctx, m, src, d_counts != nullptr, rsum, nb, nref, npos, nneg, (float *)cv,
                                             ci, cu));
-        } else {
-            const unsigned gblocks = (unsigned)phk_div_up(nb, 128);
-            const float4 *bf = (const float4 *)m->d_Bf + (uint64_t)(nref ? 0 : m->n_rblk_ref) * NG * 64;
-            if (d_counts) {
-                PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
-                           phk_knn_mfma_kernel<0><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
-                               src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float *)cv, ci, cu));
-            } else {
-                PHK_LAUNCH(ctx, "phk_knn_mfma_kernel",
-                           phk_knn_mfma_kernel<1><<<dim3(gblocks), dim3(256), 0, ctx->stream>>>(
-                               src, nb, bf, m->d_mu32, m->d_mu64, nref, npos, nneg, (float *)cv, ci, cu));
-            }
         }
         const unsigned rblocks = (unsigned)phk_div_up(nb, 4);
         if (hi_only) {

@@ -12,7 +12,6 @@ struct phk_model {
     double *d_C64 = nullptr;      // [n_cpos + n_cneg][D] centroids
     // MFMA path (score_mfma.hip); null when the shape is outside it
     bool fast = false;
-    float *d_Bf = nullptr;        // fragment-ordered centred fp32 columns (train rows, then centroids)
     double *d_colnorm = nullptr;  // |r'| per real column (train rows, pos centroids, neg centroids)
     void *d_Af16 = nullptr;       // split-f16 fragment-ordered block records (score_f16.hip)
     float *d_cn16 = nullptr;      // split-f16 norm terms per column slot (general-D kernel)
@@ -80,8 +79,6 @@ int phk_launch_proposal_f16(phk_ctx *ctx, const phk_model *m, const void *src, b
                             const uint32_t *d_rowsum, uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg,
                             float *cv, uint32_t *ci, float *cu, const uint32_t *qmap = nullptr,
                             const uint32_t *qcount = nullptr, int splits = 1, uint64_t set_bytes = 0);
-int phk_launch_proposal_f16c(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
-                             uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu);
 int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d_counts, const uint32_t *d_rowsum,
                              uint64_t nb, uint32_t nref, uint32_t npos, uint32_t nneg, float *cv, uint32_t *ci, float *cu);
 int phk_launch_proposal_f16_general(phk_ctx *ctx, const phk_model *m, const void *src, bool src_counts, bool count_exact,

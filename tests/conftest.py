@@ -17,7 +17,7 @@ def golden_dir():
     return os.path.join(REPO, "tests", "golden")
 
 
-KNOB_DEFAULTS = {"count_lanes": "", "count_cfg": "", "slot_threads": "", "count_sort": "1", "force_exact": "0",
+KNOB_DEFAULTS = {"count_lanes": "", "count_sort": "1", "force_exact": "0",
                  "proposal": "", "cx_cfg": "", "rerank": "", "score_batch": "0", "tail_aside": "1"}
 
 

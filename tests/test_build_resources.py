@@ -9,11 +9,7 @@ import pytest
 from phamers_amd import _codeobj, _lib
 
 # kernels allowed to use scratch, and why
-ALLOWED = {
-    r"phk_knn_f16c_kernelILi2ELi8E": "count-exact two-MFMA proposal, 8-wave shape: only behind proposal=cx2 (comparison runs)",
-    r"phk_knn_mfma_kernelILi[01]E": "fp32-MFMA proposal of round 1: only behind proposal=f32 (comparison runs)",
-    r"phk_normalize_f64_kernel": "NumPy's pairwise row sum is recursive: 48 bytes of call stack on lane 0",
-}
+ALLOWED = {}   # (round 5: none -- the last one, NumPy's recursive pairwise row sum, keeps its frames in LDS)
 
 
 @pytest.fixture(scope="module")

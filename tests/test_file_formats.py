@@ -549,3 +549,79 @@ def test_device_delining_of_every_line_layout(tmp_path, threads):
         batch.close()
         idx.close()
         fa.close()
+
+
+def _bgzf(data, block=65280, eof=True, level=6):
+    """`data` as a BGZF stream (bgzip's format: gzip members of at most 64 KiB, each with its compressed size in a 'BC'
+    extra field), optionally with bgzip's empty end-of-file block."""
+    import struct
+    import zlib
+    out = bytearray()
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof else [])
+    for chunk in chunks:
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = c.compress(chunk) + c.flush()
+        out += struct.pack("<BBBBIBBHBBHH", 0x1F, 0x8B, 8, 4, 0, 0, 0xFF, 6, 66, 67, 2, len(comp) + 25)
+        out += comp + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+def test_gzip_shapes_one_member_many_members_and_bgzf(tmp_path):
+    """".gz" input (scripts/kmer.py:131-134): a one-member gzip file, a multi-member one (`cat a.gz b.gz`, members cut at
+    awkward places), BGZF with and without its end-of-file block and with tiny blocks, a ".gz" that is not compressed at all
+    (gzopen reads it as it is) -- all give the plain file's records; byte ranges and parts of the BGZF stream, which inflate
+    only the blocks they need, give every record to exactly one range, as the plain file's do; a damaged member is an
+    IOError, not a short read."""
+    from phamers_amd import _lib, synth
+    text = "junk\n"
+    for c in range(300):
+        s = synth.synth_contig(9, c, 200 + 913 * (c % 17), invalid_ppm=5000)
+        w = 60 + c % 11
+        text += ">" + synth.contig_header(c, len(s)) + " d%d\n" % c + "\n".join(s[i:i + w] for i in range(0, len(s), w)) + "\n"
+    raw = text.encode()
+    assert len(raw) > (1 << 20)
+    plain = tmp_path / "x.fasta"
+    plain.write_bytes(raw)
+
+    def read(path, **kw):
+        f = _lib.Fasta(str(path), **kw)
+        out = (f.titles(), f.sequences())
+        f.close()
+        return out
+
+    want = read(plain)
+    assert len(want[0]) == 300
+    shapes = {"one": gzip.compress(raw),
+              "many": b"".join(gzip.compress(raw[a:b]) for a, b in ((0, 7), (7, 70001), (70001, 70002), (70002, len(raw)))),
+              "bgzf": _bgzf(raw), "bgzf_noeof": _bgzf(raw, eof=False), "bgzf_tiny": _bgzf(raw, block=997, level=1),
+              "stored": raw}
+    for name, blob in shapes.items():
+        p = tmp_path / (name + ".fasta.gz")
+        p.write_bytes(blob)
+        assert read(p) == want, name
+        assert read(p, threads=3) == want, name
+        for n in (2, 3, 7):
+            parts = [read(p, part=(i, n)) for i in range(n)]
+            assert sum((x[0] for x in parts), []) == want[0], (name, n)
+            assert sum((x[1] for x in parts), []) == want[1], (name, n)
+            if name.startswith("bgzf"):    # the same cuts as the plain file's: the fractions are of the uncompressed stream
+                assert parts == [read(plain, part=(i, n)) for i in range(n)], (name, n)
+        for cut in (0, 1, 5, 65279, 65280, 65281, 400000, len(raw) - 1, len(raw), len(raw) + 9):
+            a, b = read(p, byte_range=(0, cut)), read(p, byte_range=(cut, None))
+            assert a[0] + b[0] == want[0] and a[1] + b[1] == want[1], (name, cut)
+    # damage: a flipped byte in the middle of a member, a truncated file
+    for name in ("one", "bgzf"):
+        blob = bytearray(shapes[name])
+        blob[len(blob) // 2] ^= 0x5A
+        p = tmp_path / ("bad_" + name + ".fasta.gz")
+        p.write_bytes(bytes(blob))
+        with pytest.raises(IOError):
+            read(p)
+        p.write_bytes(shapes[name][: len(shapes[name]) // 2])
+        with pytest.raises(IOError):
+            read(p)
+    empty = tmp_path / "empty.fasta.gz"
+    empty.write_bytes(b"")
+    assert read(empty) == ([], [])
+    empty.write_bytes(gzip.compress(b""))
+    assert read(empty) == ([], [])

@@ -210,7 +210,7 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
     # slot kernel forced / chosen by the batch statistics / wave-per-contig kernel only; at k = 4 also the two-windows-per-add
     # kernel (5-mer pairs in 16-bit half bins, marginalised at the flush), forced and by the statistics, in both shapes
     # ("" = the library's own choice: those kernels where they apply; k = 5: "d" / "D" = the unstaged slot kernel, 512 / 1024 threads)
-    for lanes in ("2", "1", "0", "", "f", "d") + (("q", "Q", "p", "P") if k == 4 else ()) + (("D",) if k == 5 else ()):
+    for lanes in ("0", "", "f", "d") + (("q", "Q", "p", "P") if k == 4 else ()) + (("D",) if k == 5 else ()):
         ctx.set_option("count_lanes", lanes)
         try:
             d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 0xABCD, np.uint32))
@@ -234,7 +234,7 @@ def test_slot_count_kernel_ragged_and_handover(ctx, k):
     device.pack_ascii(ctx, d_raw_n, T, d_packed, d_mask, d_flag)
     assert d_flag.to_host()[0] != 0
     want_n = oracle.count(seqs_n, k)
-    for lanes in ("2", "0", "", "f", "d"):   # (masked: the classic slot kernel, the wave-per-contig kernel, the unstaged slot kernel)
+    for lanes in ("0", "", "f", "d"):   # (masked: the wave-per-contig kernel, the slot kernel by the statistics / forced / 512 threads)
         ctx.set_option("count_lanes", lanes)
         try:
             d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 0xABCD, np.uint32))
@@ -278,7 +278,7 @@ def test_slot_count_kernel_random_batches(ctx, seed):
     d_off = device.DeviceArray.from_host(ctx, offsets)
     want = oracle.count(seqs, k)
     D = 4 ** k
-    for lanes in ("2", "1", "q", "Q", "p", "d", "f", ""):   # (q / Q / p: the two-windows-per-add kernel where it applies -- k = 4, no mask; d: k = 5)
+    for lanes in ("0", "q", "Q", "p", "d", "f", ""):   # (q / Q / p: the two-windows-per-add kernel where it applies -- k = 4, no mask; d: k = 5)
         ctx.set_option("count_lanes", lanes)
         try:
             d_counts = device.DeviceArray.from_host(ctx, np.full((len(lens), D), 7, np.uint32))
@@ -421,7 +421,7 @@ def test_ragged_batch_sorted_slots_and_pieces(ctx, k, masked):
     assert (lens > 70000).sum() >= 4          # some contigs really are cut into pieces
     D = 4 ** k
     got = {}
-    for name, opts in (("sorted", {}), ("sorted, staged slot kernel", {"count_lanes": "1"}), ("standdown", {"count_sort": "0"}),
+    for name, opts in (("sorted", {}), ("standdown", {"count_sort": "0"}),
                        ("wave", {"count_lanes": "0"})):
         for key, val in opts.items():
             ctx.set_option(key, val)
