@@ -131,6 +131,50 @@ static void pack_segment_f16(const double *rows, uint64_t n, uint64_t D, const d
 #define F16H_BLOCK_BYTES (F16H_PIECES * 1024)
 #define F16H_NBUF 3      // LDS ring of block records in phk_knn_f16h_kernel
 
+// ---- the bias as a 17th k-step of the k = 4 sweep (round 5) ----
+// w = sum_i (c_i - c0) hi_ji - T b_j.  Rounds 3-4 subtracted T b_j with one v_fma per value after the MFMA chain; one value
+// per MFMA and lane, so that fma was a sixth of the kernel's vector instructions.  Now the MFMA does it: piece 16 of a block
+// record is one more A fragment, lane (column j, half 0) = [p0 p0 p0 p1 p1 p1 p2 p2], lane (j, half 1) = [p2 0 ..], with
+// p0 + p1 + p2 = -b_j 2^e on the 2^-14 grid (29 bits: three float16 pieces hold it exactly, none subnormal), and the query
+// side brings [t0 t1 t2 t0 t1 t2 t0 t1 | t2 0 ..], t0 + t1 + t2 = T 2^-e exactly: the nine products sum to -T b~_j.
+// e = the model's bias_e.  A padding / masked column carries -65504 (its value can enter no list of a real batch).
+__host__ __device__ __forceinline__ void phk_bias_pieces(float bias, double scale, _Float16 (&p)[3]) {
+    double x = -(double)bias * scale;
+    x = x > -65504.0 ? x : -65504.0;
+    x = x < 65504.0 ? x : 65504.0;
+    x = rint(x * 16384.0) * (1.0 / 16384.0);
+    p[0] = (_Float16)(float)x;
+    const double r = x - (double)p[0];
+    p[1] = (_Float16)(float)r;
+    p[2] = (_Float16)(float)(r - (double)p[1]);
+}
+// the 16 + 16 bytes of column i in piece 16 of its block record
+__host__ __device__ __forceinline__ void phk_bias_piece_store(uint8_t *block, int i, const _Float16 (&p)[3]) {
+    _Float16 *lo = reinterpret_cast<_Float16 *>(block + 16 * 1024 + i * 16), *hi = reinterpret_cast<_Float16 *>(block + 16 * 1024 + (32 + i) * 16);
+    lo[0] = p[0]; lo[1] = p[0]; lo[2] = p[0]; lo[3] = p[1]; lo[4] = p[1]; lo[5] = p[1]; lo[6] = p[2]; lo[7] = p[2];
+    hi[0] = p[2];
+    for (int j = 1; j < 8; ++j) hi[j] = (_Float16)0.0f;
+}
+static int bias_exponent(const std::vector<float> &betah, double *bmax_out) {
+    double bmax = 0.0;
+    for (float b : betah)
+        if (std::fabs((double)b) < 1.0e29) bmax = std::fabs((double)b) > bmax ? std::fabs((double)b) : bmax;   // (not the padding slots)
+    *bmax_out = bmax;
+    if (!(bmax > 0.0)) return 14;
+    int e = (int)std::floor(std::log2(32768.0 / bmax));
+    while (e > -20 && bmax * std::ldexp(1.0, e) > 32768.0) --e;
+    return e > 14 ? 14 : (e < -20 ? -20 : e);
+}
+static void write_bias_pieces(std::vector<uint8_t> &rech, const std::vector<float> &betah, uint64_t b0, uint64_t b1, int e) {
+    const double scale = std::ldexp(1.0, e);
+    for (uint64_t b = b0; b < b1; ++b)
+        for (int i = 0; i < 32; ++i) {
+            _Float16 p[3];
+            phk_bias_pieces(betah[b * 32 + i], scale, p);
+            phk_bias_piece_store(rech.data() + b * F16H_BLOCK_BYTES, i, p);
+        }
+}
+
 int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, const double *cpos,
                         const double *cneg, const double *mu, const double *colnorm) {
     const uint64_t D = m->D;
@@ -197,12 +241,14 @@ int phk_model_build_f16(phk_model *m, const double *pos, const double *neg, cons
     }
     if (hi_only && hi_records) {
         // 17-piece records: the 16 hi fragments of the full record + one piece of bias terms
-        std::vector<uint8_t> rech((nblk + 2) * F16H_BLOCK_BYTES, 0);   // (two padding records: the sweep's prefetch runs two blocks ahead)
-        for (uint64_t b = 0; b < nblk; ++b) {
+        std::vector<uint8_t> &rech = m->h_rech;
+        rech.assign((nblk + 2) * F16H_BLOCK_BYTES, 0);   // (two padding records: the sweep's prefetch runs two blocks ahead)
+        for (uint64_t b = 0; b < nblk; ++b)
             for (int st = 0; st < 16; ++st)
                 memcpy(rech.data() + b * F16H_BLOCK_BYTES + st * 1024, rec.data() + b * rec_bytes + (2 * st) * 1024, 1024);
-            memcpy(rech.data() + b * F16H_BLOCK_BYTES + 16 * 1024, betah_all.data() + b * 32, 32 * sizeof(float));
-        }
+        m->h_betah = betah_all;
+        m->bias_e = bias_exponent(m->h_betah, &m->bias_max);
+        write_bias_pieces(rech, m->h_betah, 0, nblk, m->bias_e);
         if (hipMalloc(&m->d_Af16h, rech.size()) != hipSuccess) return PHK_ERR_NOMEM;
         if (hipMemcpy(m->d_Af16h, rech.data(), rech.size(), hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
     }
@@ -272,14 +318,26 @@ int phk_model_update_centroids_f16(phk_model *m, const double *cpos, const doubl
         return PHK_ERR_HIP;
     if (hi_only) {
         if (m->d_Af16h) {
-            std::vector<uint8_t> rech(nbc * F16H_BLOCK_BYTES, 0);
-            for (uint64_t b = 0; b < nbc; ++b) {
+            // the centroid blocks of the host copy, then the bias pieces: of the centroid blocks alone while the model's
+            // exponent still fits the new biases, else of every block (NOTE: the train blocks then carry the biases as
+            // built -- a column mask is re-applied by the caller's next phk_model_set_column_mask / apply_mask)
+            std::vector<uint8_t> &rech = m->h_rech;
+            for (uint64_t b = 0; b < nbc; ++b)
                 for (int st = 0; st < 16; ++st)
-                    memcpy(rech.data() + b * F16H_BLOCK_BYTES + st * 1024, rec.data() + b * rec_bytes + (2 * st) * 1024, 1024);
-                memcpy(rech.data() + b * F16H_BLOCK_BYTES + 16 * 1024, betah_all.data() + b * 32, 32 * sizeof(float));
+                    memcpy(rech.data() + (b0 + b) * F16H_BLOCK_BYTES + st * 1024, rec.data() + b * rec_bytes + (2 * st) * 1024, 1024);
+            for (uint64_t i = 0; i < nbc * 32; ++i) m->h_betah[b0 * 32 + i] = betah_all[i];
+            const int e = bias_exponent(m->h_betah, &m->bias_max);
+            const uint64_t nblk = b0 + nbc;
+            if (e != m->bias_e) {
+                m->bias_e = e;
+                write_bias_pieces(rech, m->h_betah, 0, nblk, e);
+                if (hipMemcpy(m->d_Af16h, rech.data(), nblk * F16H_BLOCK_BYTES, hipMemcpyHostToDevice) != hipSuccess) return PHK_ERR_HIP;
+            } else {
+                write_bias_pieces(rech, m->h_betah, b0, nblk, e);
+                if (hipMemcpy((uint8_t *)m->d_Af16h + b0 * F16H_BLOCK_BYTES, rech.data() + b0 * F16H_BLOCK_BYTES, nbc * F16H_BLOCK_BYTES,
+                              hipMemcpyHostToDevice) != hipSuccess)
+                    return PHK_ERR_HIP;
             }
-            if (hipMemcpy((uint8_t *)m->d_Af16h + b0 * F16H_BLOCK_BYTES, rech.data(), rech.size(), hipMemcpyHostToDevice) != hipSuccess)
-                return PHK_ERR_HIP;
         }
         if (hipMemcpy(m->d_betah16 + b0 * 32, betah_all.data(), betah_all.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(m->d_lo16 + m->M * D, lo_rows.data(), lo_rows.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess)
@@ -312,7 +370,7 @@ __global__ __launch_bounds__(256) void phk_mask_terms_kernel(const uint8_t *__re
                                                              const float *__restrict__ orig, uint8_t *__restrict__ rec,
                                                              uint64_t rec_bytes, uint64_t term_off, uint8_t *__restrict__ rech,
                                                              float *__restrict__ cn16, float *__restrict__ beta16,
-                                                             float *__restrict__ betah16) {
+                                                             float *__restrict__ betah16, double bias_scale) {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nslots) return;
     const bool masked = s < M && mask && mask[s];
@@ -324,7 +382,11 @@ __global__ __launch_bounds__(256) void phk_mask_terms_kernel(const uint8_t *__re
     cn16[s] = cn;
     beta16[s] = be;
     if (betah16) betah16[s] = bh;
-    if (rech) reinterpret_cast<float *>(rech + b * F16H_BLOCK_BYTES + 16 * 1024)[i] = bh;
+    if (rech) {
+        _Float16 p[3];
+        phk_bias_pieces(bh, bias_scale, p);
+        phk_bias_piece_store(rech + b * F16H_BLOCK_BYTES, (int)i, p);
+    }
 }
 
 int phk_model_apply_mask_f16(phk_ctx *ctx, phk_model *m) {
@@ -334,7 +396,7 @@ int phk_model_apply_mask_f16(phk_ctx *ctx, phk_model *m) {
     PHK_LAUNCH(ctx, "phk_mask_terms_kernel",
                phk_mask_terms_kernel<<<dim3((unsigned)phk_div_up(ns, 256)), dim3(256), 0, ctx->stream>>>(
                    m->has_mask ? m->d_col_mask : nullptr, m->M, ns, m->d_term_orig, (uint8_t *)m->d_Af16, rec_bytes,
-                   (m->D / 256) * 32 * 1024, (uint8_t *)m->d_Af16h, m->d_cn16, m->d_beta16, m->d_betah16));
+                   (m->D / 256) * 32 * 1024, (uint8_t *)m->d_Af16h, m->d_cn16, m->d_beta16, m->d_betah16, std::ldexp(1.0, m->bias_e)));
     return PHK_OK;
 }
 
@@ -731,7 +793,7 @@ template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
     const uint32_t *__restrict__ counts, const uint32_t *__restrict__ rowsum, uint64_t N, const uint4 *__restrict__ Af,
     uint32_t nblk_ref, uint32_t nblk_pos, uint32_t nblk_neg, float *__restrict__ cand_v, uint32_t *__restrict__ cand_i,
-    float *__restrict__ cand_u) {
+    float *__restrict__ cand_u, float tscale /* 2^-bias_e */) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // F16H_NBUF x F16H_BLOCK_BYTES
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -755,9 +817,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
             const char *gp = g + p * 1024;
             const uint32_t lp = __builtin_amdgcn_readfirstlane(l + (uint32_t)p * 1024u);
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(gp), "s"(lp) : "memory");
-        } else {
-            const char *gp = g + 16 * 1024;
-            const uint32_t lp = __builtin_amdgcn_readfirstlane(l + 16u * 1024u);
+        } else {   // piece 16 (the bias fragment): 256 bytes of it per wave
+            const uint32_t quarter = 256u * ((uint32_t)wave & 3u);
+            const char *gp = g + 16 * 1024 + quarter;
+            const uint32_t lp = __builtin_amdgcn_readfirstlane(l + 16u * 1024u + quarter);
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(lane4), "s"(gp), "s"(lp) : "memory");
         }
     };
@@ -773,7 +836,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
 
     // ---- prologue: centred counts -> fp16 (exact up to 2048 in magnitude), row sum (from the caller) ----
     half8 bq[NT][16];
-    float negT[NT];
+    half8 bqx[NT];      // the 17th k-step's operand: the pieces of T 2^-e (see phk_bias_pieces)
     bool big[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -783,6 +846,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
         // the operand is the count minus the row's centre (phk_row_center): an integer of magnitude <= 2048, exact in fp16
         const uint32_t tot = rowsum[qrow];
         const int cen = (int)phk_row_center(tot, FAST_D);
+        // T 2^-e = t0 + t1 + t2 exactly, or the row is `big` (a row sum the pieces cannot carry: beyond 65504 x 2^e): the three
+        // bit fields of T, each at most 11 bits wide, times the power of two -- exact in float32 and, inside the float16 range
+        // (the lowest non-zero piece is >= 2^-e >= 2^-14), in float16.  (Formed before the row is read: nothing of it but the
+        // four registers of bqx stays live.)
+        bool fits;
+        {
+            const float f0 = (float)(tot & 0xFFE00000u) * tscale, f1 = (float)(tot & 0x001FFC00u) * tscale, f2 = (float)(tot & 0x000003FFu) * tscale;
+            fits = fmaxf(fmaxf(f0, f1), f2) < 65504.0f;
+            const _Float16 z16 = (_Float16)0.0f;
+            const _Float16 tp[3] = {fits ? (_Float16)f0 : z16, fits ? (_Float16)f1 : z16, fits ? (_Float16)f2 : z16};
+            if (h == 0) bqx[t] = half8{tp[0], tp[1], tp[2], tp[0], tp[1], tp[2], tp[0], tp[1]};
+            else bqx[t] = half8{tp[2], z16, z16, z16, z16, z16, z16, z16};
+        }
+        __builtin_amdgcn_sched_barrier(0);
         uint32_t mx = 0;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -797,8 +874,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
             }
         }
         const uint32_t mo = __shfl_xor(mx, 32);
-        big[t] = (mx > mo ? mx : mo) > 2048u;
-        negT[t] = -(float)tot;
+        big[t] = (mx > mo ? mx : mo) > 2048u || !fits;
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     float lv[NT][5];
@@ -835,13 +912,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
             for (int c = 0; c < 5; ++c) lv[t][c] = __uint_as_float(__float_as_uint(lv[t][c]) & ~1u);
         }
     };
-    // insertion of one value: w = acc - T * bias, index bits embedded, 5 x v_med3
-    auto insert = [&](int t, float a, float bias, int r) {
-#if defined(PHK_DIAGNOSTIC_BUILD) && defined(F16H_ABL) && (F16H_ABL & 1)   // timing only: no bias multiply-add (the bias as a 17th k-step would remove it)
-        const float w = a + 0.0f * bias;
-#else
-        const float w = fmaf(negT[t], bias, a);
-#endif
+    // insertion of one value (w = acc, the bias is in it since round 5: the MFMA's 17th k-step), index bits embedded, 5 x v_med3
+    auto insert = [&](int t, float w, int r) {
         // A value no lane of the wave can place (w <= the best value its list has dropped, in every lane) changes nothing:
         // wave-uniform skip of the index bits and the five v_med3.  A lane's list holds the 5 best of the n values it has
         // seen, so a value enters with probability 5 / n and some lane of the wave takes one with 1 - (1 - 5/n)^64: 63 % of
@@ -860,18 +932,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
         asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(lv[t][0]) : "v"(x), "v"(fbig));
     };
 
-    // Software pipeline inside the wave, per segment: while block i's MFMAs fill one accumulator set, the VALU
-    // inserts block i-1's values out of the other set (with its bias terms, held in 16 registers) and settles
-    // the ids of block i-2's insertions during the first k-step.  Nothing but the LDS reads of the next bias
-    // terms and the workgroup barrier is left outside the MFMA stream; the only data-dependent control
-    // flow of the hot loop is the wave-uniform skip inside insert().  The pipeline drains at the end of a segment (3 times per sweep); the DMA stream does not.
-    float bias[16];
+    // Software pipeline inside the wave, per segment: while block i's MFMAs fill one accumulator set (16 k-steps of the
+    // counts, then the bias step), the VALU inserts block i-1's values out of the other set and settles the ids of block
+    // i-2's insertions under the first fragment read.  Nothing but the workgroup barrier is left outside the MFMA stream;
+    // the only data-dependent control flow of the hot loop is the wave-uniform skip inside insert().  The pipeline drains at
+    // the end of a segment (3 times per sweep); the DMA stream does not.
     f32x16 accA[NT], accB[NT];
     uint32_t g = 0;  // global block number: DMA source
     uint32_t cur = 0, nxt = 2;   // ring positions of the block being read / requested
-#if defined(PHK_DIAGNOSTIC_BUILD) && defined(F16H_ABL)
-    uint32_t abl_third = 0;
-#endif
 
     auto block_iter = [&](uint32_t settle_id, f32x16 (&cur_acc)[NT], const f32x16 (&prev)[NT]) {
         // block g has landed (every wave waits for its own pieces -- those of block g + 1 may be outstanding -- then the
@@ -884,19 +952,12 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
         // block i - 2's ids are settled here, under the latency of the first fragment read (38 vector instructions that need
         // nothing from LDS), not behind the first MFMAs
         __builtin_amdgcn_sched_barrier(0);
-#if defined(PHK_DIAGNOSTIC_BUILD) && defined(F16H_ABL) && (F16H_ABL & 2)   // timing only: ids settled every third block
-        if (++abl_third == 3) {
-            abl_third = 0;
-            settle(settle_id);
-        }
-#else
         settle(settle_id);
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
+        for (int s = 0; s < 17; ++s) {
             const half8 ah = ahn;
-            if (s < 15) ahn = fr[(s + 1) * 64];
+            if (s < 16) ahn = fr[(s + 1) * 64];   // (piece 16: the bias fragment)
             __builtin_amdgcn_sched_barrier(0);  // the reads stay up here, one step ahead of their MFMAs (two steps ahead: 4 spilled registers, 2.17 ms instead of 2.10)
             // (also measured and not kept: s_setprio 2 around the two MFMAs, 2.42 ms against 2.21 on the same box; the first
             // tile's insertion between the two MFMAs instead of behind them, 2.19 against 2.21: within the noise)
@@ -906,36 +967,32 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
                 for (int r = 0; r < 16; ++r) z[r] = 0.0f;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) cur_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], z, 0, 0, 0);
-            } else {
+            } else if (s < 16) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) cur_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bq[t][s], cur_acc[t], 0, 0, 0);
+            } else {   // the bias: - T b~_j, LAST, so that the sixteen steps before it run on the small sums of the centred counts
+#pragma unroll
+                for (int t = 0; t < NT; ++t) cur_acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bqx[t], cur_acc[t], 0, 0, 0);
             }
             // block g + 2's pieces, one behind the MFMAs of every third k-step (one past the end on the last blocks: padded)
             if (s % 3 == 1 && s / 3 < NPW) dma_piece(g + 2, nxt, s / 3);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) insert(t, prev[t][s], bias[s], s);
-            // the bias terms of the block being computed replace those of the previous one four at a time, as soon as the
-            // insertions that read them are done: their LDS latency falls inside the loop, not in front of the next barrier
             // (D[i][j]: register r of lane (j, h') holds column row i = (r&3) + 8(r>>2) + 4h')
-            if (s % 4 == 3) {
-                const float4 c4 = (reinterpret_cast<const float4 *>(buf + 16 * 1024) + h)[2 * (s / 4)];
-                bias[s - 3] = c4.x;
-                bias[s - 2] = c4.y;
-                bias[s - 1] = c4.z;
-                bias[s] = c4.w;
+            if (s < 16) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) insert(t, prev[t][s], s);
             }
         }
         ++g;
         cur = cur == F16H_NBUF - 1 ? 0 : cur + 1;
         nxt = nxt == F16H_NBUF - 1 ? 0 : nxt + 1;
     };
-    // drain: the last block's values (in `last`, bias terms loaded), ids, then the segment's lists go out
+    // drain: the last block's values (in `last`), ids, then the segment's lists go out
     auto finish = [&](int seg, uint32_t nb, const f32x16 (&last)[NT]) {
         settle(nb - 2);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) insert(t, last[t][s], bias[s], s);
+            for (int s = 0; s < 16; ++s) insert(t, last[t][s], s);
         settle(nb - 1);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -980,8 +1037,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void phk_knn_f16h_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) accB[t][r] = -3.35e38f;  // "block -1": below the empty slots, never accepted
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) bias[r] = 0.0f;
         uint32_t i = 0;
 #pragma unroll 1
         for (; i + 1 < nb; i += 2) {
@@ -1020,14 +1075,15 @@ int phk_launch_proposal_f16h(phk_ctx *ctx, const phk_model *m, const uint32_t *d
     // (2.44 vs 2.62 ms on configs[1]; one wave per SIMD with 3 or 4 tiles, tried through AGPRs, ran 2.9 / 3.3 ms, and
     // 2-wave workgroups quadruple the L2 -> LDS record traffic: 13.6 ms).
     const char *e = ctx->knobs.cx_cfg;
+    const float tscale = std::ldexp(1.0f, -m->bias_e);
     if (e[0] == '2' && e[1] == '8') {
         PHK_LAUNCH(ctx, "phk_knn_f16h_kernel",
                    (phk_knn_f16h_kernel<2, 8><<<dim3((unsigned)phk_div_up(nb, 32 * 8 * 2)), dim3(64 * 8), lds, ctx->stream>>>(
-                       d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu)));
+                       d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu, tscale)));
     } else {
         PHK_LAUNCH(ctx, "phk_knn_f16h_kernel",
                    (phk_knn_f16h_kernel<2, 4><<<dim3((unsigned)phk_div_up(nb, 32 * 4 * 2)), dim3(64 * 4), lds, ctx->stream>>>(
-                       d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu)));
+                       d_counts, d_rowsum, nb, af, nref, npos, nneg, cv, ci, cu, tscale)));
     }
     return PHK_OK;
 }

@@ -116,6 +116,11 @@ int phk_model_build_fast(phk_ctx *ctx, phk_model *m, const double *pos, const do
         if (colnorm[c] > m->max_colnorm_train) m->max_colnorm_train = colnorm[c];
     m->max_colnorm = max_norm;
     m->mu_norm = std::sqrt(mu2);
+    {
+        double t2 = 0.0;
+        for (uint64_t d = 0; d < D; ++d) t2 += (mu[d] - 1.0 / (double)D) * (mu[d] - 1.0 / (double)D);
+        m->mu_tilde_norm = std::sqrt(t2) * (1.0 + 1.0e-12);
+    }
     m->fast = true;
     return PHK_OK;
 }
@@ -230,6 +235,8 @@ struct RerankParams {
     // (word 15 = the ticket) and striped statistics words, so that no memset precedes the next use of the set
     uint32_t *clean_counters = nullptr;
     uint32_t *clean_stripes = nullptr;
+    double eb_babs = 0.0;     // k = 4 high-parts-only lists: what the bias as the sweep's three float16 pieces can be off by, in v units (added to habs)
+    double eb_cM = 0.0, eb_M = 0.0;   // ... and the rounding of the bias step: coefficient of |mu - 1/D| (ErrBound::cM, M)
     const int8_t *L8 = nullptr;             // [M + n_cpos + n_cneg][D] L digits, row-major
     const float *T8 = nullptr;              // per 32-column block: 32 quanta g_j (+ 32 bias terms)
     uint32_t t8_blk[3] = {0, 0, 0};         // first block of each segment
@@ -414,9 +421,10 @@ struct ErrBound {
     double I = 0.0, cI = 0.0;
     double habs = 0.0;
     double cIf = 0.0;   // f16 chains: PHK_MFMA_PROD x instructions, WITHOUT rho_inf -- the floor of the nominal products, see above
+    double M = 0.0, cM = 0.0;   // |mu - 1/D| and its coefficient: the bias step of the k = 4 sweep (round 5; see phk_score_fast)
     __device__ double operator()(double R) const {
         const double f = 1.4901161193847656e-08;   // 2^-14 / S, S = 2^12: a float16 subnormal's nominal magnitude in operand units
-        return 5.9604644775390625e-08 * (R * (cA * A + cQ * Q + cI * I + cP * P + cR * R) + cIf * f * (I + R + f)) + cabs * (R + P) + habs;
+        return 5.9604644775390625e-08 * (R * (cA * A + cQ * Q + cI * I + cP * P + cR * R + cM * M) + cIf * f * (I + R + f)) + cabs * (R + P) + habs;
     }
 };
 
@@ -1171,9 +1179,10 @@ __global__ __launch_bounds__(256, 3) void phk_rerank16_kernel(const void *__rest
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
     eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI; eb.cIf = p.eb_cIf;
+    eb.cM = p.eb_cM; eb.M = p.eb_M;
     if (SRC == 0 && p.per_row_scale) {   // count-exact lists: the chain's query operand is c - c0 (see ErrBound)
         const CenteredOperand cop = phk_centered_operand(sumsq, nan_row ? 1.0 : Tq, (double)cmx, (double)cmn, (double)FAST_D, p.eb_hsum);
-        eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs;
+        eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs + p.eb_babs;
         eb.P = sqrt(nqp2 + cop.shift2);   // (high-parts-only lists: what the low parts multiply)
     } else {                             // split-f16 lists: the chain's query operand is q' (Tq = 1 for float64 rows)
         eb.Q = 0.0; eb.I = group16_max(am) / Tq;
@@ -1987,8 +1996,9 @@ __global__ __launch_bounds__(64) void phk_decide_h_kernel(const uint32_t *__rest
     ErrBound eb;
     eb.A = sqrt(nq2) + p.mu_norm;
     eb.P = sqrt(nqp2);
-    eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs;
+    eb.Q = cop.Q; eb.I = cop.I; eb.habs = cop.habs + p.eb_babs;
     eb.cA = p.eb_cA; eb.cP = p.eb_cP; eb.cR = p.eb_cR; eb.cabs = p.eb_abs; eb.cQ = p.eb_cQ; eb.cI = p.eb_cI; eb.cIf = p.eb_cIf;
+    eb.cM = p.eb_cM; eb.M = p.eb_M;
     const double nqp = eb.P;
     const double nqx = sqrt(nqp2 + cop.shift2);   // |q' - (c0/T - 1/D) 1|: what the low parts multiply (see phase B)
     auto e_hi = [&](int sg, double R) { return nqx * phk_lam_of(hp, sg, R) + eb(R); };
@@ -2999,6 +3009,20 @@ int phk_score_fast(phk_ctx *ctx, const phk_model *m, const double *d_Q, const ui
             pd.eb_cQ = PHK_MFMA_ACC * ((double)D / 16.0) + 3.0;
             pd.eb_cI = PHK_MFMA_PROD * ((double)D / 16.0) * rho;
             pd.eb_cIf = PHK_MFMA_PROD * ((double)D / 16.0);
+            // Round 5: the bias is the sweep's 17th MFMA step, - T b~_j as nine products of float16 pieces.  That instruction
+            // runs on |running sum| <= |counts' sum| + T |b~| and its largest nominal product is <= T |b~| (1 + 2^-11)^2:
+            // u (11 A + 18 p) adds 11 u on the counts' sum (the Q R term), and (11 + 18 (1 + 2^-10)) u on T |b~|, in v units
+            // |b~| / S per column as below.  The pieces carry the bias rounded to the 2^-14 2^-e grid: an absolute
+            // 2^-15 2^-e / S per value.
+            // (charged per column: |b_j| / S = |(mu - 1/D) . r~'_j + |r~'_j|^2 / 2| <= |mu - 1/D| R + R^2 / 2 with R >= |r'_j| (1 + 2^-21);
+            // by the model's largest bias, an absolute term, it cost the exact-distance kernel 26 % more queries -- outlying
+            // columns far from every query set it -- and by |mu| instead of |mu - 1/D| 16 %)
+            pd.eb_cQ += PHK_MFMA_ACC;
+            const double cb = (PHK_MFMA_ACC + PHK_MFMA_PROD * (1.0 + 1.0 / 1024.0)) * (1.0 + 1.0 / 512.0);   // (|hi_j| <= S |r'_j| (1 + 2^-11); the pieces' own rounding)
+            pd.eb_cM = cb;
+            pd.eb_M = m->mu_tilde_norm;
+            pd.eb_cR += 0.5 * cb;
+            pd.eb_babs = std::ldexp(1.0, -15 - m->bias_e) / 4096.0;
             if (d_knn && d_cen) {
                 PHK_LAUNCH(ctx, "phk_decide_h_kernel", (phk_decide_h_kernel<true, true><<<dg, db, 0, ctx->stream>>>((const uint32_t *)src, pd, hp)));
             } else if (d_knn) {

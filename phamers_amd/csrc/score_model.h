@@ -21,6 +21,13 @@ struct phk_model {
     // lam_tab[s][i] = max |lo_j| / S over segment s's columns with |r'_j| <= lam_r0[s] + i * lam_step[s] (error of a high-parts-only value)
     float *d_betah16 = nullptr;   // high-part bias terms per column slot (general-D kernel; mask restore target)
     void *d_Af16h = nullptr;
+    // (round 5) the bias enters the k = 4 sweep as a 17th k-step of the MFMA: piece 16 of a block record holds, per column,
+    // the three float16 pieces of  -bias x 2^bias_e  (on the 2^-14 grid) in fragment order; the kernel multiplies them by
+    // the three pieces of  T x 2^-bias_e.  bias_e: the largest exponent that keeps every real column's bias below 2^15.
+    int bias_e = 0;
+    double bias_max = 0.0;        // max |bias| over the real columns (what the 17th step's products are bounded by)
+    std::vector<float> h_betah;   // host copy of the high-part bias terms, per column slot (piece rebuilds)
+    std::vector<uint8_t> h_rech;  // host copy of the 17-piece records
     _Float16 *d_lo16 = nullptr;   // [M + n_cpos + n_cneg][D]
     double lam_tab[3][65] = {{0}};     // per segment (train rows, positive centroids, negative centroids)
     double lam_r0[3] = {0, 0, 0}, lam_step[3] = {1, 1, 1};
@@ -55,6 +62,7 @@ struct phk_model {
     double hsum_train = 0.0, hsum_cen = 0.0;   // max_j |sum_i r~'_ji| over the train rows / the centroids (see ErrBound: habs)
     double max_colnorm = 0.0;     // max ||r'|| over real columns (error bound)
     double mu_norm = 0.0;         // ||mu||
+    double mu_tilde_norm = 0.0;   // ||mu - 1/D||: what the count-exact bias terms multiply the column by
 };
 
 // second-chance pass of phk_score_fast: below this many queued rows the float64 brute force is the cheaper last resort

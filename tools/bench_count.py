@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Count-kernel microbenchmark (device-resident synthetic batch): ms per launch and algorithmic GB/s
-(packed input + offsets + uint32 counts), for the LDS replication / bank-conflict study.
-PHK_COUNT_CFG="<copies>,<pack16>" selects a built variant (k = 4, 5)."""
+(packed input + offsets + uint32 counts).  --lanes picks the count kernel (count_lanes): "" the library's choice, d / D / f the
+one-window-per-add slot kernel (512 / 1024 threads, forced), p / P / q / Q the two-windows-per-add kernels, 0 the wave-per-contig
+kernel; --invalid-ppm adds a validity mask."""
 import argparse, json, os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,7 +34,7 @@ for _ in range(a.iters):
     device.count(ctx, packed, mask, T, off, n, k, counts)
 ctx.sync()
 prof = ctx.profile()
-ms = sum(prof[name][0] for name in ("phk_count_slots_kernel", "phk_count_kernel", "phk_count_pairs_kernel", "phk_count_direct_kernel") if name in prof) / a.iters
+ms = sum(prof[name][0] for name in ("phk_count_kernel", "phk_count_pairs_kernel", "phk_count_pairs2_kernel", "phk_count_direct_kernel") if name in prof) / a.iters
 alg = n * ((L + 3) // 4 + 8 + 4 * D) + (n * ((L + 7) // 8) if mask else 0)
 ok = None
 if a.check:
@@ -43,6 +44,6 @@ if a.check:
     want = oracle.count(synth.synth_contigs(0, m, L, a.invalid_ppm), k).reshape(m, D)
     got = counts.to_host()[:m].astype(np.int64)
     ok = bool(np.array_equal(got, want))
-print(json.dumps({"cfg": os.environ.get("PHK_COUNT_CFG", "default"), "lanes": a.lanes, "per_kernel_ms": {kn: v[0] / a.iters for kn, v in prof.items()}, "kernels": sorted(prof), "k": k, "contigs": n, "length": L,
+print(json.dumps({"lanes": a.lanes, "invalid_ppm": a.invalid_ppm, "per_kernel_ms": {kn: v[0] / a.iters for kn, v in prof.items()}, "kernels": sorted(prof), "k": k, "contigs": n, "length": L,
                   "ms": ms, "GBps_algorithmic": alg / ms / 1e6, "Gbases_per_s": T / ms / 1e6,
                   "frac_hbm_peak": alg / ms / 1e6 / 8000.0, "bit_exact_vs_oracle": ok}))
