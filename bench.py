@@ -320,8 +320,11 @@ def main():
         offsets.copy_(torch.from_numpy(offs))
         mask = torch.empty(device.mask_words(T), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
+        ragged_ppm = int(os.environ.get("PHK_BENCH_RAGGED_PPM", "1000"))   # (diagnostic runs: 0 = the ragged batch without invalid bases)
         device.synth_ragged(ctx, 0, first, n, offsets.data_ptr(), T, packed.data_ptr(), mask.data_ptr(),
-                            gc_spread_permille=400, invalid_ppm=1000)
+                            gc_spread_permille=400, invalid_ppm=ragged_ppm)
+        if ragged_ppm == 0:
+            mask = None
     else:
         device.synth_packed(ctx, 0, first, n, L, packed.data_ptr(), offsets.data_ptr())
     mask_ptr = mask.data_ptr() if mask is not None else None
@@ -432,7 +435,7 @@ def main():
         sample = np.unique(np.concatenate(([0, n - 1], np.random.default_rng(20241005 + rank).choice(n, max(npar - 2, 0), replace=False))))
         npar = len(sample)
     if ragged:
-        seqs = [synth.synth_ragged_contig(0, first + int(c), int(lengths[int(c)]), 400, 1000) for c in sample]
+        seqs = [synth.synth_ragged_contig(0, first + int(c), int(lengths[int(c)]), 400, int(os.environ.get("PHK_BENCH_RAGGED_PPM", "1000"))) for c in sample]
     else:
         seqs = [synth.synth_contig(0, first + int(c), L) for c in sample]
     want_counts = oracle.count(seqs, k).reshape(npar, D)

@@ -885,259 +885,6 @@ __global__ __launch_bounds__(NTH) void phk_count_pairs_kernel(const uint32_t *__
 }
 
 // ------------------------------------------------------------------------------------
-// Two windows per add for batches with a VALIDITY MASK and for the SORTED WALK of ragged batches (k = 4; round 5).
-// Real contigs carry N and soft-masked lower case, which the reference drops (scripts/kmer.py:190-191, 49): rounds 3-4 counted
-// such batches one window per add (phk_count_direct_kernel, 1.00 ms per 1M x 5 kb against 0.66 for the kernel above).
-//   * A unit (64 bases, 32 pairs) whose windows are all valid and inside the contig takes the kernel above's loop unchanged.
-//   * Any other unit: window validity w(i) = the four bases from i on are valid, i inside the contig; pair p is added when
-//     BOTH its windows count (the increment times that bit); a pair of which exactly ONE window counts yields a SINGLE
-//     window -- beside an invalid base, at a contig's end (the unpaired last window of an odd number is one of these), at a
-//     piece's end.  Singles are rare (about one per run of invalid bases): their 4-mer codes go to a per-contig list in LDS
-//     (128 bytes per slot) and are added to the marginals at the flush.  A contig with more than 128 of them is counted
-//     by the wave-per-contig kernel instead (handed over at the flush, its row zeroed here).
-//   * ORDERED: the work items of the sort kernels -- whole contigs and pieces of long ones (a piece starts an even number of
-//     windows into its contig, so the pairing is the contig's) --, a piece's counts added onto the contig's zeroed row with
-//     atomics, as phk_count_direct_kernel does.
-// ------------------------------------------------------------------------------------
-#define PAIRS_SUB_CAP 128
-template <int NTH, bool MASK, bool ORDERED>
-__global__ __launch_bounds__(NTH) void phk_count_pairs2_kernel(const uint32_t *__restrict__ packed, const uint32_t *__restrict__ mask,
-                                                              const uint64_t *__restrict__ offsets, uint64_t n, uint64_t max_word,
-                                                              uint32_t long_thr, uint32_t *__restrict__ counts, uint32_t *__restrict__ nwin,
-                                                              uint2 *__restrict__ long_list, uint32_t *__restrict__ long_count,
-                                                              const uint2 *__restrict__ order, uint32_t piece_w) {
-    constexpr int K = 4;
-    constexpr uint32_t D = 256, NWORD = 512;
-    constexpr int SLOTS = 32;
-    constexpr int PARTS = NTH / SLOTS;
-    constexpr int XPT = (int)D / PARTS;
-    static_assert(XPT % 4 == 0, "flush geometry");
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins [NWORD][SLOTS] | windows [SLOTS] | piece owner [SLOTS] | singles [SLOTS] | codes [SLOTS][CAP]
-    uint32_t *nwin_s = lds + NWORD * SLOTS;
-    uint32_t *split_s = nwin_s + SLOTS;
-    uint32_t *scnt_s = split_s + SLOTS;
-    uint8_t *sub = reinterpret_cast<uint8_t *>(scnt_s + SLOTS);
-    const bool plain = phk_slots_apply(reinterpret_cast<const unsigned long long *>(long_count + 2));
-    if (ORDERED) {
-        if (plain || !order) return;
-        n = long_count[1];   // items, counted by the planning kernel
-    } else if (!plain) return;
-    const int t = threadIdx.x;
-    const int slot = t & (SLOTS - 1), part = t / SLOTS;
-    for (uint32_t b = t * 4; b < NWORD * SLOTS; b += 4 * NTH) *reinterpret_cast<uint4 *>(lds + b) = make_uint4(0, 0, 0, 0);
-    if (t < SLOTS) { nwin_s[t] = 0; scnt_s[t] = 0; split_s[t] = 0; }
-    __syncthreads();
-    const uint32_t colb = (uint32_t)slot * 4u;
-    const uint32_t pthr = long_thr < 131070u ? long_thr : 131070u;   // a 16-bit half holds W / 2
-    typedef __attribute__((address_space(3))) uint32_t lds_u32;
-    auto pair_addr = [&](uint32_t src, int o) { return (lds_u32 *)(uintptr_t)(((src >> (16 - 2 * o)) & (0x1FFu << 7)) | colb); };
-    auto pair_inc = [&](uint32_t src, int o) {
-        uint32_t bit, inc;
-        asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(bit) : "v"(src), "n"(22 - 2 * o));
-        asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc) : "v"(bit), "v"(65535u));
-        return inc;
-    };
-    auto add1 = [&](lds_u32 *p, uint32_t val) { __hip_atomic_fetch_add(p, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-    const uint64_t wlast = max_word + 1;          // the pad word: the last one that exists
-    const uint64_t mlast = (max_word >> 1) + 1;   // last mask word that exists (ceil(T / 32) + 1 words)
-
-    for (uint64_t batch = blockIdx.x; batch * SLOTS < n; batch += gridDim.x) {
-        const uint64_t ci = batch * SLOTS + slot;
-        const bool have = ci < n;
-        const uint2 item = (ORDERED && have) ? order[ci] : make_uint2(0, 0);
-        const uint64_t c = have ? (ORDERED ? (uint64_t)item.x : ci) : 0;
-        uint64_t st = have ? offsets[c] : 0;
-        const uint64_t en = have ? offsets[c + 1] : 0;
-        const uint64_t len = en - st;
-        uint32_t W = len >= (uint64_t)K ? (uint32_t)((len - K + 1) < 0xFFFFFFFFull ? (len - K + 1) : 0xFFFFFFFFull) : 0;
-        const uint32_t W_all = W;
-        const bool split = ORDERED && piece_w && W > long_thr;
-        if (split) {
-            const uint64_t first = (uint64_t)item.y * piece_w;
-            st += first;
-            W = (uint32_t)((uint64_t)W - first < piece_w ? (uint64_t)W - first : piece_w);
-        }
-        const bool handed_over = !ORDERED && W > pthr;
-        if (part == 0) split_s[slot] = split ? (uint32_t)c + 1u : 0u;
-        if (handed_over) {
-            if (part == 0) {
-                const uint32_t np = piece_w ? (W + piece_w - 1) / piece_w : 1u;
-                const uint32_t base = atomicAdd(long_count, np);
-                for (uint32_t pc = 0; pc < np; ++pc) long_list[base + pc] = make_uint2((uint32_t)c, pc);
-            }
-            W = 0;
-        }
-        const uint32_t par = (uint32_t)st & 1u;
-        const uint64_t U0 = st >> 6;
-        const uint32_t rst = (uint32_t)(st - (U0 << 6));                 // the first window
-        const uint32_t rlast = rst + W - 1u;                             // the last one (W > 0)
-        const uint32_t nunit = W ? ((rlast - par) >> 6) + 1u : 0u;       // unit j: windows 64 j + par .. + 63 (relative to the first unit)
-        const uint32_t *pc = packed + 4 * U0;
-        const uint32_t wlim = (uint32_t)((wlast - 4 * U0) < 0x7FFFFFFFull ? (wlast - 4 * U0) : 0x7FFFFFFFull);
-        const uint32_t *pm = MASK ? mask + 2 * U0 : nullptr;
-        const uint32_t mlim = MASK ? (uint32_t)((mlast - 2 * U0) < 0x7FFFFFFFull ? (mlast - 2 * U0) : 0x7FFFFFFFull) : 0u;
-        auto load5 = [&](uint32_t j, uint32_t (&w)[5], uint32_t (&mk)[3]) {
-            const uint32_t w0 = 4u * j;
-            if (w0 + 3 <= wlim) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(pc + w0);
-                w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
-            } else {   // the last words of the whole stream
-                w[0] = pc[w0]; w[1] = pc[w0 + 1 < wlim ? w0 + 1 : wlim]; w[2] = pc[w0 + 2 < wlim ? w0 + 2 : wlim]; w[3] = pc[wlim];
-            }
-            w[4] = pc[w0 + 4 < wlim ? w0 + 4 : wlim];
-            if (MASK) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) mk[i] = pm[2 * j + i < mlim ? 2 * j + i : mlim];
-            }
-        };
-        uint32_t cur[5] = {0, 0, 0, 0, 0}, nxt[5] = {0, 0, 0, 0, 0}, mcur[3] = {0, 0, 0}, mnxt[3] = {0, 0, 0};
-        uint32_t cnt_ok = 0;
-        uint32_t j = (uint32_t)part;
-        if (j < nunit) load5(j, cur, mcur);
-        while (__any(j < nunit)) {
-            const bool live = j < nunit;
-            if (j + PARTS < nunit) load5(j + PARTS, nxt, mnxt);
-            const uint32_t s0 = 64u * j + par;                            // the unit's first window
-            // window i of the (re-aligned) unit counts: inside the contig / piece and, with a mask, its four bases valid
-            uint64_t wv = 0;                                              // bit 63 - i
-            if (live) {
-                const uint32_t lo = rst > s0 ? rst - s0 : 0u;
-                const uint32_t hi = rlast - s0 < 63u ? rlast - s0 : 63u;
-                wv = (hi - lo == 63u) ? ~0ull : (((1ull << (hi - lo + 1)) - 1ull) << (63 - hi));
-                if (MASK) {
-                    const uint64_t vb = ((uint64_t)mcur[0] << 32) | mcur[1];   // bit 63 - i: base i of the unit valid
-                    uint64_t w = vb;
-#pragma unroll
-                    for (int jj = 1; jj < K; ++jj) w &= (vb << jj) | ((uint64_t)mcur[2] >> (32 - jj));
-                    const uint64_t w64 = (mcur[2] >> 28) == 0xFu ? 1ull : 0ull;   // the window at base 64 (the next unit's first)
-                    wv &= par ? ((w << 1) | w64) : w;
-                }
-                cnt_ok += (uint32_t)__popcll(wv);
-            }
-            const uint64_t EV = 0xAAAAAAAAAAAAAAAAull;                    // bit 63 - 2 p: pair p
-            const uint64_t both = wv & (wv << 1) & EV;
-            const bool all = live && both == EV;
-            uint32_t sw[5];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sw[i] = par ? __builtin_amdgcn_alignbit(cur[i], cur[i + 1], 30) : cur[i];
-            sw[4] = par ? cur[4] << 2 : cur[4];
-            if (!__any(live && !all)) {   // wave-uniform: every live lane's unit is whole
-                if (all) {
-#pragma unroll
-                    for (int wd = 0; wd < 4; ++wd) {
-                        const uint32_t y = sw[wd], u = __builtin_amdgcn_alignbit(y, sw[wd + 1], 16);
-#pragma unroll
-                        for (int jp = 0; jp < 8; ++jp) {
-                            const uint32_t src = jp < 5 ? y : u;
-                            const int o = jp < 5 ? 2 * jp : 2 * jp - 8;
-                            add1(pair_addr(src, o), pair_inc(src, o));
-                        }
-                    }
-                }
-            } else if (live) {
-                const uint32_t bhi = (uint32_t)(both >> 32), blo = (uint32_t)both;
-#pragma unroll
-                for (int wd = 0; wd < 4; ++wd) {
-                    const uint32_t y = sw[wd], u = __builtin_amdgcn_alignbit(y, sw[wd + 1], 16);
-#pragma unroll
-                    for (int jp = 0; jp < 8; ++jp) {
-                        const uint32_t src = jp < 5 ? y : u;
-                        const int o = jp < 5 ? 2 * jp : 2 * jp - 8;
-                        const int pidx = 8 * wd + jp;
-                        add1(pair_addr(src, o), pair_inc(src, o) * __builtin_amdgcn_ubfe(pidx < 16 ? bhi : blo, 31 - 2 * (pidx & 15), 1));
-                    }
-                }
-                // single windows: the first of a pair alone (bit 63 - 2 p), the second alone (bit 62 - 2 p)
-                uint64_t sm = (wv & ~(wv << 1) & EV) | ((~wv & (wv << 1) & EV) >> 1);
-                while (sm) {
-                    const uint32_t i = (uint32_t)__builtin_clzll(sm);
-                    sm &= ~(1ull << (63 - i));
-                    const uint32_t wi = i >> 4, o = i & 15u;
-                    const uint32_t hw = wi == 0 ? sw[0] : wi == 1 ? sw[1] : wi == 2 ? sw[2] : sw[3];
-                    const uint32_t lw = wi == 0 ? sw[1] : wi == 1 ? sw[2] : wi == 2 ? sw[3] : sw[4];
-                    const uint32_t code = (uint32_t)((((uint64_t)hw << 32) | lw) >> (56 - 2 * o)) & 0xFFu;
-                    const uint32_t at = atomicAdd(scnt_s + slot, 1u);
-                    if (at < PAIRS_SUB_CAP) sub[slot * PAIRS_SUB_CAP + at] = (uint8_t)code;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 5; ++i) cur[i] = nxt[i];
-            if (MASK) {
-#pragma unroll
-                for (int i = 0; i < 3; ++i) mcur[i] = mnxt[i];
-            }
-            j += PARTS;
-        }
-        if (cnt_ok) atomicAdd(nwin_s + slot, cnt_ok);
-        phk_lds_barrier();  // every wave's adds, single lists and window counts have landed
-        {
-            const uint32_t x0 = (uint32_t)part * XPT;
-            uint32_t out[XPT];
-            const uint32_t *col = lds + slot;
-#pragma unroll
-            for (int i = 0; i < XPT; ++i) {
-                const uint32_t w0 = col[(2 * (x0 + i)) * SLOTS], w1 = col[(2 * (x0 + i) + 1) * SLOTS];
-                out[i] = __builtin_amdgcn_sad_u16(w1, 0u, __builtin_amdgcn_sad_u16(w0, 0u, 0u));
-            }
-            const uint32_t one = 1u;
-#pragma unroll
-            for (int mm = 0; mm < XPT / 2; ++mm)
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const uint32_t w = col[(128 * a + x0 / 2 + mm) * SLOTS];
-                    asm("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(out[2 * mm]) : "v"(w), "v"(one));
-                    asm("v_mad_u32_u16 %0, %1, %2, %0 op_sel:[1,0,0,0]" : "+v"(out[2 * mm + 1]) : "v"(w), "v"(one));
-                }
-            // the contig's single windows (every flush thread of the slot walks the same short list)
-            const uint32_t ns = scnt_s[slot];
-            const bool late = ns > PAIRS_SUB_CAP;      // too many for the list: the wave-per-contig kernel counts this item
-            const uint32_t nsl = late ? 0u : ns;
-            for (uint32_t e = 0; e < nsl; ++e) {
-                const uint32_t code = sub[slot * PAIRS_SUB_CAP + e];
-#pragma unroll
-                for (int i = 0; i < XPT; ++i) out[i] += (code == x0 + i) ? 1u : 0u;
-            }
-            const uint32_t Wc = nwin_s[slot];          // counted windows = the row sum
-            const uint32_t owner = split_s[slot];
-            phk_lds_barrier();   // every thread has read what it needs: the columns and lists may be cleared
-            uint32_t *zc = lds + (2 * x0) * SLOTS + slot;
-#pragma unroll
-            for (int i = 0; i < 2 * XPT; ++i) zc[i * SLOTS] = 0;
-            if (part == 0) { nwin_s[slot] = 0; scnt_s[slot] = 0; }
-            if (late) {
-                // hand the item over: its pieces (a piece of a cut contig: itself) to the list, a zero row for them to add onto
-                if (part == 0 && have) {
-                    if (split) {
-                        long_list[atomicAdd(long_count, 1u)] = make_uint2((uint32_t)c, item.y);
-                    } else {
-                        const uint32_t np = piece_w ? (W_all + piece_w - 1) / piece_w : 1u;
-                        const uint32_t base = atomicAdd(long_count, np);
-                        for (uint32_t pc2 = 0; pc2 < np; ++pc2) long_list[base + pc2] = make_uint2((uint32_t)c, pc2);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < XPT; ++i) out[i] = 0;
-            }
-            uint32_t *rowo = counts + c * D + x0;
-            if (owner) {                                   // a piece: onto the contig's row, zeroed by the sort
-                if (!late) {
-#pragma unroll
-                    for (int i = 0; i < XPT; ++i)
-                        if (out[i]) atomicAdd(rowo + i, out[i]);
-                    if (nwin && part == 0) atomicAdd(nwin + c, Wc);
-                }
-            } else if (have && ((!handed_over && !late) || piece_w)) {   // (an item handed over in pieces gets its zero row here)
-#pragma unroll
-                for (int i = 0; i < XPT / 4; ++i)
-                    *reinterpret_cast<uint4 *>(rowo + 4 * i) = make_uint4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]);
-                if (nwin && part == 0) nwin[c] = (handed_over || late) ? 0u : Wc;
-            }
-        }
-        phk_lds_barrier();   // the columns are clear; lists and counters may be rewritten
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // The slot kernel WITHOUT staging and stage barriers (k = 5, no validity mask, batches the statistics do not call ragged;
 // round 4): what made the two-windows-per-add kernel above fast was, as much as its halved adds, that a lane reads its
 // words straight from memory and no wave waits for another before the flush.  The bins described above
@@ -1439,9 +1186,6 @@ static int slots_instance_ok(Kern kern, bool *ok) {
 int phk_count_init_device(phk_ctx *ctx) {
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs2_kernel<1024, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs2_kernel<1024, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-    PHK_HIP(hipFuncSetAttribute((const void *)phk_count_pairs2_kernel<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     bool ok = true;
 #define PHK_DIRECT_INIT1(K_, S_, T_, M_, O_)                                                                                         \
     PHK_HIP(hipFuncSetAttribute((const void *)phk_count_direct_kernel<K_, S_, T_, M_, O_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); \
@@ -1458,9 +1202,6 @@ int phk_count_init_device(phk_ctx *ctx) {
 #undef PHK_DIRECT_INIT1
     PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<512>, &ok));
     PHK_TRY(slots_instance_ok(phk_count_pairs_kernel<1024>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_pairs2_kernel<1024, true, false>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_pairs2_kernel<1024, true, true>, &ok));
-    PHK_TRY(slots_instance_ok(phk_count_pairs2_kernel<1024, false, true>, &ok));
     ctx->slots_lds0 = ok;
     return PHK_OK;
 }
@@ -1505,8 +1246,6 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
         const uint64_t mean_len = (mean_bases ? mean_bases : T / n) + 1;
         uint64_t thr64 = 4 * mean_len + 1024;
         if (sorted && thr64 < 2ull * piece_w) thr64 = 2ull * piece_w;
-        // (k = 4: the two-windows-per-add kernels keep a pair count in 16 bits -- a whole contig or a piece holds at most 131 070 windows)
-        if (k == 4 && thr64 > 131070ull) thr64 = 131070ull;
         const uint32_t long_thr = thr64 < 0xFFFFFFFFull ? (uint32_t)thr64 : 0xFFFFFFFFu;
         // workspace: the call's control block (PhkCountCtl words, see phk_count_plan_kernel) in WS_CTL; hand-over items
         // (contig, piece) and the sorted contig order in WS_LONG
@@ -1567,29 +1306,6 @@ int phk_launch_count(phk_ctx *ctx, const uint32_t *d_packed, const uint32_t *d_m
                                d_packed, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, piece_w)));
             }
             skip_plain = 1;
-        }
-        // k = 4, masked batches and the sorted walk of ragged ones: two windows per add as well (phk_count_pairs2_kernel, round 5);
-        // the one-window-per-add slot kernel below keeps k = 3, k = 5 and the count_lanes = d / D / f comparison runs
-        if (k == 4 && pk) {
-            const size_t p2lds = (size_t)512 * 32 * 4 + 3 * 32 * 4 + 32 * PAIRS_SUB_CAP;
-            uint64_t p2blocks = phk_div_up(sorted ? max_items : n, 32);
-            const uint64_t p2cap = (uint64_t)ctx->num_cus * 2;
-            if (p2blocks > p2cap) p2blocks = p2cap;
-#define PHK_PAIRS2(M_, O_)                                                                                                          \
-            PHK_LAUNCH(ctx, "phk_count_pairs2_kernel",                                                                             \
-                       (phk_count_pairs2_kernel<1024, M_, O_><<<dim3((unsigned)p2blocks), dim3(1024), p2lds, ctx->stream>>>(        \
-                           d_packed, M_ ? d_mask : nullptr, d_offsets, n, max_word, long_thr, d_counts, d_nwin, d_long_list, d_long_count, d_ord, piece_w)))
-            if (d_mask) {
-                PHK_PAIRS2(true, false);
-                if (d_ord) { PHK_PAIRS2(true, true); }
-            } else if (d_ord) {
-                PHK_PAIRS2(false, true);
-            }
-#undef PHK_PAIRS2
-            const int rc_ = launch_count_cfg<4, PhkCountCfg<4>::copies, PhkCountCfg<4>::pack16>(
-                ctx, d_packed, d_mask, d_offsets, n, max_word, d_counts, d_nwin, d_long_list, d_long_count, piece_w);
-            if (rc_ == PHK_OK) ctx->ctl_dirty = false;
-            return rc_;
         }
         // The unstaged slot kernel (phk_count_direct_kernel) for everything else the slot kernel used to count: masked batches,
         // the sorted walk of ragged batches, k = 3 and k = 5.
