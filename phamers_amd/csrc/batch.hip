@@ -324,8 +324,11 @@ extern "C" int phk_batch_from_counts(phk_ctx *ctx, const int64_t *counts, uint64
             PHK_HIP(hipMemcpyAsync(b->d_counts + o, dst, m * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
             PHK_HIP(hipEventRecord(done[s], ctx->stream));
         }
-        PHK_LAUNCH(ctx, "phk_rowsum_kernel",
-                   phk_rowsum_kernel<<<dim3((unsigned)phk_div_up(n, 4)), dim3(256), 0, ctx->stream>>>(b->d_counts, n, D, b->d_nwin));
+        for (uint64_t r0 = 0; r0 < n; r0 += 1ull << 24) {   // (one wave per row: 2^24 rows per launch keep the grid below 2^32 threads)
+            const uint64_t nr = n - r0 < (1ull << 24) ? n - r0 : 1ull << 24;
+            PHK_LAUNCH(ctx, "phk_rowsum_kernel",
+                       phk_rowsum_kernel<<<dim3((unsigned)phk_div_up(nr, 4)), dim3(256), 0, ctx->stream>>>(b->d_counts + r0 * D, nr, D, b->d_nwin + r0));
+        }
         PHK_HIP(hipStreamSynchronize(ctx->stream));
         return PHK_OK;
     };

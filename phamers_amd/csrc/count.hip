@@ -26,8 +26,8 @@ __global__ __launch_bounds__(256) void phk_pack_kernel(const uint8_t *__restrict
                                                        uint32_t sym, uint32_t *__restrict__ packed,
                                                        uint32_t *__restrict__ mask,
                                                        uint64_t packed_words, uint64_t mask_words,
-                                                       uint32_t *any_invalid) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                       uint32_t *any_invalid, uint64_t block0) {
+    uint64_t t = (block0 + blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= mask_words) return;
     uint64_t g0 = t * 32;
     uint32_t w[2] = {0u, 0u};
@@ -73,11 +73,9 @@ int phk_launch_pack(phk_ctx *ctx, const char *d_bases, uint64_t T, const char *s
                    ((uint32_t)(uint8_t)symbols4[2] << 16) | ((uint32_t)(uint8_t)symbols4[3] << 24);
     uint64_t packed_words = phk_div_up(T, 16) + 1, mask_words = phk_div_up(T, 32) + 1;
     if (d_any_invalid) PHK_HIP(hipMemsetAsync(d_any_invalid, 0, sizeof(uint32_t), ctx->stream));
-    uint64_t blocks = phk_div_up(mask_words, 256);
-    PHK_LAUNCH(ctx, "phk_pack_kernel",
-               phk_pack_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(
-                   (const uint8_t *)d_bases, T, sym, d_packed, d_mask, packed_words, mask_words,
-                   d_any_invalid));
+    PHK_LAUNCH_SLICED(ctx, "phk_pack_kernel", phk_div_up(mask_words, 256), b0, nblk,
+                      phk_pack_kernel<<<dim3(nblk), dim3(256), 0, ctx->stream>>>(
+                          (const uint8_t *)d_bases, T, sym, d_packed, d_mask, packed_words, mask_words, d_any_invalid, b0));
     return PHK_OK;
 }
 
@@ -98,8 +96,8 @@ __global__ __launch_bounds__(256) void phk_deline_pack_kernel(const uint8_t *__r
                                                               const uint32_t *__restrict__ rlw, const uint32_t *__restrict__ rtl,
                                                               uint64_t T, uint32_t sym, uint32_t *__restrict__ packed,
                                                               uint32_t *__restrict__ mask, uint64_t packed_words,
-                                                              uint64_t mask_words, uint32_t *any_invalid) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                              uint64_t mask_words, uint32_t *any_invalid, uint64_t block0) {
+    const uint64_t t = (block0 + blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= mask_words) return;
     const uint64_t g0 = t * 32;
     uint32_t w[2] = {0u, 0u};
@@ -160,9 +158,9 @@ int phk_launch_deline_pack(phk_ctx *ctx, const uint8_t *d_raw, const uint8_t *d_
                          ((uint32_t)(uint8_t)symbols4[2] << 16) | ((uint32_t)(uint8_t)symbols4[3] << 24);
     const uint64_t packed_words = phk_div_up(T, 16) + 1, mask_words = phk_div_up(T, 32) + 1;
     if (d_any_invalid) PHK_HIP(hipMemsetAsync(d_any_invalid, 0, sizeof(uint32_t), ctx->stream));
-    PHK_LAUNCH(ctx, "phk_deline_pack_kernel",
-               phk_deline_pack_kernel<<<dim3((unsigned)phk_div_up(mask_words, 256)), dim3(256), 0, ctx->stream>>>(
-                   d_raw, d_side, d_offsets, n, d_rbegin, d_rlw, d_rtl, T, sym, d_packed, d_mask, packed_words, mask_words, d_any_invalid));
+    PHK_LAUNCH_SLICED(ctx, "phk_deline_pack_kernel", phk_div_up(mask_words, 256), b0, nblk,
+                      phk_deline_pack_kernel<<<dim3(nblk), dim3(256), 0, ctx->stream>>>(
+                          d_raw, d_side, d_offsets, n, d_rbegin, d_rlw, d_rtl, T, sym, d_packed, d_mask, packed_words, mask_words, d_any_invalid, b0));
     return PHK_OK;
 }
 

@@ -208,6 +208,16 @@ int phk_prof_end(phk_ctx *ctx, int slot);
         if ((ctx)->profile) PHK_TRY(phk_prof_end((ctx), ps__)); \
     } while (0)
 
+// A grid of 2^32 work-items or more is not launched whole: the excess is dropped without an error (round 5: a 30M-contig
+// synthetic batch came out generated for its first 2.5M contigs only).  Launchers whose grid grows with the input's bases or
+// rows go through this loop: slices of at most PHK_SLICE_BLOCKS blocks, the kernel is told the slice's first block.
+#define PHK_SLICE_BLOCKS (1ull << 22)   // x 1024 threads at most = 2^32 / 1
+#define PHK_LAUNCH_SLICED(ctx, name, total_blocks, block0, nblk, ...)                                        \
+    for (uint64_t block0 = 0, tb__ = (total_blocks); block0 < tb__; block0 += PHK_SLICE_BLOCKS) {           \
+        const unsigned nblk = (unsigned)(tb__ - block0 < PHK_SLICE_BLOCKS ? tb__ - block0 : PHK_SLICE_BLOCKS); \
+        PHK_LAUNCH(ctx, name, __VA_ARGS__);                                                                  \
+    }
+
 // host-side parallel loop for the model builders (independent iterations, disjoint outputs)
 template <typename F>
 static inline void phk_parallel_for(uint64_t n, F fn) {

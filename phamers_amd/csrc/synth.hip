@@ -16,8 +16,8 @@ __global__ __launch_bounds__(256) void phk_synth_kernel(uint64_t seed_mix, uint6
                                                         uint32_t *__restrict__ packed,
                                                         uint32_t *__restrict__ mask,
                                                         uint64_t *__restrict__ offsets,
-                                                        uint64_t packed_words, uint64_t mask_words) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                        uint64_t packed_words, uint64_t mask_words, uint64_t block0) {
+    const uint64_t t = (block0 + blockIdx.x) * blockDim.x + threadIdx.x;
     if (t <= n) offsets[t] = t * L;
     if (t >= mask_words) return;
     const uint64_t T = n * L;
@@ -71,10 +71,9 @@ int phk_launch_synth(phk_ctx *ctx, uint64_t seed, uint64_t first, uint64_t n, ui
     const uint64_t seed_mix = z ^ (z >> 31);
     const uint32_t thresh = (uint32_t)(((uint64_t)invalid_ppm << 32) / 1000000ull);
     uint64_t threads = mask_words > n + 1 ? mask_words : n + 1;
-    uint64_t blocks = phk_div_up(threads, 256);
-    PHK_LAUNCH(ctx, "phk_synth_kernel",
-               phk_synth_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(
-                   seed_mix, first, n, L, thresh, d_packed, d_mask, d_offsets, packed_words, mask_words));
+    PHK_LAUNCH_SLICED(ctx, "phk_synth_kernel", phk_div_up(threads, 256), b0, nblk,
+                      phk_synth_kernel<<<dim3(nblk), dim3(256), 0, ctx->stream>>>(
+                          seed_mix, first, n, L, thresh, d_packed, d_mask, d_offsets, packed_words, mask_words, b0));
     return PHK_OK;
 }
 
@@ -92,8 +91,8 @@ __global__ __launch_bounds__(256) void phk_synth_ragged_kernel(uint64_t seed_mix
                                                                const uint64_t *__restrict__ offsets, uint32_t spread_permille,
                                                                uint32_t inv_thresh, uint32_t *__restrict__ packed,
                                                                uint32_t *__restrict__ mask, uint64_t packed_words,
-                                                               uint64_t mask_words) {
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                                               uint64_t mask_words, uint64_t block0) {
+    const uint64_t t = (block0 + blockIdx.x) * blockDim.x + threadIdx.x;
     if (t >= mask_words) return;
     const uint64_t T = offsets[n];
     const uint64_t g0 = t * 32;
@@ -153,8 +152,8 @@ int phk_launch_synth_ragged(phk_ctx *ctx, uint64_t seed, uint64_t first, uint64_
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     const uint64_t seed_mix = z ^ (z >> 31);
     const uint32_t thresh = (uint32_t)(((uint64_t)invalid_ppm << 32) / 1000000ull);
-    PHK_LAUNCH(ctx, "phk_synth_ragged_kernel",
-               phk_synth_ragged_kernel<<<dim3((unsigned)phk_div_up(mask_words, 256)), dim3(256), 0, ctx->stream>>>(
-                   seed_mix, first, n, d_offsets, gc_spread_permille, thresh, d_packed, d_mask, packed_words, mask_words));
+    PHK_LAUNCH_SLICED(ctx, "phk_synth_ragged_kernel", phk_div_up(mask_words, 256), b0, nblk,
+                      phk_synth_ragged_kernel<<<dim3(nblk), dim3(256), 0, ctx->stream>>>(
+                          seed_mix, first, n, d_offsets, gc_spread_permille, thresh, d_packed, d_mask, packed_words, mask_words, b0));
     return PHK_OK;
 }

@@ -37,6 +37,18 @@ class DeviceArray(object):
                                                self.nbytes))
         return out
 
+    def rows_to_host(self, first, count):
+        """Rows first .. first + count of the leading axis (a piece of an array too large to bring down whole)."""
+        first, count = int(first), int(count)
+        if first < 0 or count < 0 or first + count > self.shape[0]:
+            raise IndexError("rows %d..%d of %d" % (first, first + count, self.shape[0]))
+        out = np.empty((count,) + self.shape[1:], dtype=self.dtype)
+        row = self.nbytes // self.shape[0] if self.shape[0] else 0
+        if count:
+            _lib.check(self.ctx.lib.phk_memcpy_d2h(self.ctx.handle, _lib.ptr(out), ctypes.c_void_p(self.ptr + first * row),
+                                                   count * row))
+        return out
+
     def free(self):
         if getattr(self, "ptr", None) and getattr(self.ctx, "handle", None):
             self.ctx.lib.phk_free(self.ctx.handle, ctypes.c_void_p(self.ptr))

@@ -265,3 +265,39 @@ def test_config3_per_rank_share_12_5M_contigs():
     model.close()
     for a in (packed, offsets, counts, scores, status, sl):
         a.free()
+
+
+def test_batch_beyond_two_pow_32_grid_threads():
+    """30M x 5 kb contigs in one call: 2^37.1 bases, so every one-thread-per-32-bases launch (the synthetic generator, the
+    packer) needs more than 2^32 threads and has to go out in slices -- a grid that large is otherwise launched short
+    without any error (round 5: rows beyond the first 2.5M were never generated).  Rows from the far end of the batch match
+    the oracle, every row sums to L - k + 1, and the run certifies as the 1M batch does (no flood of brute-forced rows)."""
+    from oracle import oracle
+    from phamers_amd import _lib, device, synth
+    ctx = _lib.get_context()
+    model, pos, neg, g = _model(ctx)
+    n = 30000000
+    T = n * L
+    assert (T + 31) // 32 > 1 << 32
+    d_packed = device.DeviceArray(ctx, device.packed_words(T), np.uint32)
+    d_off = device.DeviceArray(ctx, n + 1, np.uint64)
+    device.synth_packed(ctx, 0, 0, n, L, d_packed, d_off)
+    d_counts = device.DeviceArray(ctx, (n, 256), np.uint32)
+    d_scores = device.DeviceArray(ctx, n, np.float64)
+    d_status = device.DeviceArray.from_host(ctx, np.zeros(1, np.uint32))
+    device.count_score(ctx, model, d_packed, None, T, d_off, n, K, "combo", d_counts, d_scores, d_status)
+    assert d_status.to_host()[0] == 0
+    assert device.check_counts(ctx, d_counts, None, n, 256, L - K + 1) == (0, 0)
+    n_fallback, n_exact = ctx.score_stats()
+    assert n_fallback < 3000 and n_exact < n // 10
+    rng = np.random.default_rng(5)
+    sample = np.sort(np.concatenate([rng.choice(n, 40, replace=False), np.arange(n - 8, n)]))
+    rows = np.concatenate([d_counts.rows_to_host(int(r), 1) for r in sample])
+    want_counts = oracle.count([synth.synth_contig(0, int(c), L) for c in sample], K)
+    assert np.array_equal(rows.astype(np.int64), want_counts)
+    q = oracle.normalize_counts(want_counts)
+    want = oracle.knn_score_points(q, pos, neg, 3) + oracle.centroid_score_points_fast(q, g["cpos_eq"], g["cneg_eq"])
+    got = d_scores.to_host()[sample]
+    assert helpers.rel_err(got, want) < 1e-6
+    for a in (d_packed, d_off, d_counts, d_scores, d_status):
+        a.free()
