@@ -46,7 +46,8 @@
 extern "C" {
 #endif
 
-#define PHK_ABI_VERSION 1
+/* 2 (round 5): phk_kmeans_lloyd reports the smallest assignment gap; phk_batch_from_fasta_part; knobs, see phk_set_option */
+#define PHK_ABI_VERSION 2
 
 #define PHK_OK 0
 #define PHK_ERR_ARG (-1)         /* bad argument (null pointer, bad k, bad shape) */
@@ -78,13 +79,18 @@ int phk_destroy(phk_ctx *ctx);
 int phk_sync(phk_ctx *ctx);
 /* Tuning / diagnostic knobs of a context.  Each knob takes its initial value from the environment variable
  * PHK_<KEY upper case> ONCE, when the context is created; afterwards it changes only through this call (no
- * launch path reads the environment).  Keys: "count_lanes" ("0" wave-per-contig count kernel only, "2" slot
- * kernel whatever the batch looks like), "count_cfg" ("<copies>,<pack16>"), "slot_threads" ("256"),
- * "count_sort" ("0" = no length-bucketed order for ragged batches), "force_exact" ("1" = float64 scoring
- * path for every model), "proposal" ("f32" | "f16" | "" default), "cx_cfg" ("14" | "24" | "28"), "rerank"
- * ("w" | "g"), "score_batch" (queries per scoring batch), "pipeline" (chunks of phk_count_score_dev's count / score
- * pipeline at k = 4; "1" = off).  Unknown key -> PHK_ERR_ARG.  The results of every
- * entry point are the same under every setting; the parity tests use the knobs to cross-check the paths. */
+ * launch path reads the environment).  Keys: "count_lanes" ("0" wave-per-contig count kernel only, "f" the slot
+ * kernel whatever the batch looks like, "P" / "p" the two-windows-per-add kernel with 1024 / 512 threads where the
+ * batch's statistics allow it, "Q" / "q" the same forced), "count_sort" ("0" = no
+ * length-bucketed order for ragged batches), "force_exact" ("1" = float64 scoring path for every model), "proposal"
+ * ("" default: high parts only at k = 4, the two-part int8 sweep at k = 5, 6 | "f16" split-query kernel | "hi" / "cxf" /
+ * "i83": the general-D alternatives), "cx_cfg" ("24" | "28": workgroup shape of the k = 4 sweep), "rerank" ("w" | "g"),
+ * "score_batch" (queries per scoring batch), "tail_aside" ("0" = a multi-batch call keeps every batch's queue tail on
+ * the main stream), "gen_groups" / "gen_seq" / "i8_insert" (general-D sweep shapes), "ws_fail" (fault injection for
+ * the tests: the n-th workspace request from now fails with PHK_ERR_NOMEM; not read from the environment).
+ * Unknown key -> PHK_ERR_ARG.  The results of every entry point are the same under every setting; the parity tests
+ * use the knobs to cross-check the paths.  (ABI 2 dropped "count_cfg", "slot_threads", "pipeline" and the proposal
+ * values "f32" / "cx2" with the kernels behind them.) */
 int phk_set_option(phk_ctx *ctx, const char *key, const char *value);
 
 /* device buffers for hosts that do not bring their own allocator */
@@ -253,8 +259,7 @@ int phk_model_destroy(phk_ctx *ctx, phk_model *model);
  * (mask[n_pos + n_neg] host bytes in vstack(pos, neg) order, non-zero = held out, excluded from the k-NN search;
  * NULL lifts the mask) plus that fold's centroids (same counts as at creation).  Scores then equal those of a model
  * built from the unmasked rows alone: the search is translation invariant, so keeping the full matrix's centring
- * vector changes nothing but the error bounds, which are evaluated for it.  Not followed by the fp32 MFMA proposal
- * (proposal=f32), which refuses such a model. */
+ * vector changes nothing but the error bounds, which are evaluated for it. */
 int phk_model_set_centroids(phk_ctx *ctx, phk_model *model, const double *cpos, uint64_t n_cpos, const double *cneg,
                             uint64_t n_cneg);
 int phk_model_set_column_mask(phk_ctx *ctx, phk_model *model, const uint8_t *mask);

@@ -18,7 +18,7 @@ PHK_ERR_ARG, PHK_ERR_HIP, PHK_ERR_NOMEM, PHK_ERR_UNSUPPORTED, PHK_ERR_NAN, PHK_E
 METHOD_KNN, METHOD_KMEANS, METHOD_COMBO = 1, 2, 3
 METHODS = {"knn": METHOD_KNN, "kmeans": METHOD_KMEANS, "combo": METHOD_COMBO}
 MAX_K = 7
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int, c_u32, c_u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
 c_char_p, c_double = ctypes.c_char_p, ctypes.c_double

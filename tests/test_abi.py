@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "missing export: " + name
         assert name in _lib.SIGNATURES, "no ctypes signature for " + name
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.phk_abi_version() == 1
+    assert lib.phk_abi_version() == 2
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
