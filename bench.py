@@ -493,7 +493,10 @@ def main():
             bound, unit, peak, work = alg[name]
             ach = work * steps / (ms / 1e3)
             kernels[name].update({"bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak})
-    dom = max((kname for kname in kernels if kname in alg), key=lambda kname: kernels[kname]["ms_per_step"])
+    # (the second chance is never the dominant kernel: in a multi-batch call it runs on the library's second stream beside the
+    # next batch's sweep, and its event time then spans that sweep)
+    second = {"phk_knn_f16_kernel"} if first_pass else set()
+    dom = max((kname for kname in kernels if kname in alg and kname not in second), key=lambda kname: kernels[kname]["ms_per_step"])
     as_configured = not ragged and L == cfg["length"] and k == cfg["k"] and args.refs is None
     per_contig, tsrc, per_all = latest_traffic(dom, args.config) if as_configured else (None, None, None)
     roofline = {"kernel": dom, "bound": kernels[dom]["bound"], "achieved": kernels[dom]["achieved"],
@@ -545,6 +548,10 @@ def main():
                    "parallelism": "contig shards, %d rank(s), replicated reference, final all-gather of scores" % world},
         "roofline": roofline,
         "kernels": kernels,
+        # per-kernel times are HIP events around each launch on the stream it runs on: in a call of several scoring batches
+        # (more than 2^20 contigs at k = 4) a batch's tail runs on a second stream beside the next batch's sweep, so those
+        # kernels' times overlap the sweep's and the column does not add up to the step
+        "kernel_times_overlap": bool(k == 4 and n > (1 << 20)),
         "parity": parity,
         "timed_region_s": elapsed,
     }

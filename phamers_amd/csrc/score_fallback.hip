@@ -260,66 +260,110 @@ __global__ __launch_bounds__(512) void phk_fallback_group_kernel(const void *__r
 // one thread per queued query: merge its FB_CHUNKS partial records and emit the score
 __global__ __launch_bounds__(256) void phk_fallback_merge_kernel(RerankParams p) {
     const uint32_t count = *p.fb_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && p.stat_total) {   // statistics: this batch's counters into the call's totals
+    if (blockIdx.x == 0 && p.stat_total) {   // statistics: this batch's counters into the call's totals, one word per thread
         // (atomic: the striped copies are added by another workgroup of this launch)
-        atomicAdd(p.stat_total + 0, p.fb_count[0]);
-        atomicAdd(p.stat_total + 1, p.fb_count[1] + (p.exact_extra ? *p.exact_extra : 0u));
-        if (p.map_count) atomicAdd(p.stat_total + 2, *p.map_count);   // queries that took the second chance
-        if (p.q2_count) {   // general D: rows re-swept with three digits / swept by the f16 kernel (both are second chances)
-            atomicAdd(p.stat_total + 2, p.q2_count[0] + p.q2_count[1]);
-            atomicAdd(p.stat_total + 7, p.q2_count[0]);
-            atomicAdd(p.stat_total + 8, p.q2_count[1]);
-        }
-        if (p.counters)                                      // why the high-parts-only decision stage passed them on
-            for (int i = 0; i < 4; ++i) atomicAdd(p.stat_total + 3 + i, p.counters[8 + i]);
+        const uint32_t t = threadIdx.x;
+        uint32_t word = 0xFFFFFFFFu, add = 0;
+        if (t == 0) { word = 0; add = p.fb_count[0]; }
+        else if (t == 1) { word = 1; add = p.fb_count[1] + (p.exact_extra ? *p.exact_extra : 0u); }
+        else if (t == 2 && p.map_count) { word = 2; add = *p.map_count; }          // queries that took the second chance
+        else if (t == 3 && p.q2_count) { word = 2; add = p.q2_count[0] + p.q2_count[1]; }   // general D: rows re-swept with three digits / swept
+        else if (t == 4 && p.q2_count) { word = 7; add = p.q2_count[0]; }          // by the f16 kernel (both are second chances)
+        else if (t == 5 && p.q2_count) { word = 8; add = p.q2_count[1]; }
+        else if (t >= 8 && t < 12 && p.counters) { word = 3 + (t - 8); add = p.counters[t]; }   // why the high-parts-only decision stage passed them on
+        if (word != 0xFFFFFFFFu && add) atomicAdd(p.stat_total + word, add);
     }
-    if (blockIdx.x == 1 && p.stat_total && p.stripes) {          // ... and the striped copies of the same words
+    if (blockIdx.x == 1 && p.stat_total && p.stripes) {          // ... and the striped copies of the same words: summed in the
+        // workgroup, one atomic per word and wave (one per stripe and word queued 1 280 atomics on five addresses)
+        uint32_t acc[5] = {0, 0, 0, 0, 0};
         for (uint32_t sidx = threadIdx.x; sidx < PHK_STRIPES; sidx += blockDim.x) {
             const uint32_t *w = p.stripes + sidx * 32u;
-            if (w[1]) atomicAdd(p.stat_total + 1, w[1]);
-            for (int i = 0; i < 4; ++i)
-                if (w[8 + i]) atomicAdd(p.stat_total + 3 + i, w[8 + i]);
+            acc[0] += w[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[1 + i] += w[8 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const uint32_t tot = wave_sum(acc[i]);
+            if ((threadIdx.x & 63) == 0 && tot) atomicAdd(p.stat_total + (i == 0 ? 1 : 2 + i), tot);
         }
     }
+    // One WAVE per queued query, lane = chunk record (round 5: one thread walked the query's 64 records in turn -- a chain of
+    // 64 dependent-looking loads, 40 of the kernel's 45 us for the usual two rows of a batch).  The three nearest train
+    // columns under the total order (distance, column index) -- column indices are unique, so the result does not depend on
+    // the order of the merge -- by three rounds of a wave-wide minimum whose owner pops its head.
     const FbRecord *rec = static_cast<const FbRecord *>(p.fb_rec);
-    for (uint64_t qi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; qi < count;
-         qi += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t nch = fb_group_chunks(count, p.fb_rec_cap);   // 64 or FB_CHUNKS: at most one record per lane
+    const int lane = threadIdx.x & 63;
+    const uint64_t nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t qi = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; qi < count; qi += nwaves) {
         const uint64_t q = p.fb_list[qi];
-        double bd[3] = {INFINITY, INFINITY, INFINITY};
-        uint64_t bi[3] = {~0ull, ~0ull, ~0ull};
+        double d[3] = {INFINITY, INFINITY, INFINITY};
+        uint64_t ix[3] = {~0ull, ~0ull, ~0ull};
         double bp = INFINITY, bn = INFINITY;
-        const uint32_t nch = fb_group_chunks(count, p.fb_rec_cap);
-        for (uint32_t ch = 0; ch < nch; ++ch) {
-            const FbRecord r = rec[qi * nch + ch];
-            for (int k = 0; k < 3; ++k) {
+        if ((uint32_t)lane < nch) {
+            const FbRecord r = rec[qi * nch + (uint32_t)lane];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {   // the record's entries into the lane's sorted triple (absent entries: index 2^32 - 1)
                 if (r.i[k] == 0xFFFFFFFFu) continue;
-                double d = r.d[k];
-                uint64_t c = r.i[k];
-                for (int s = 0; s < 3; ++s)
-                    if (fb_less(d, c, bd[s], bi[s])) {
-                        const double td = bd[s]; const uint64_t ti = bi[s];
-                        bd[s] = d; bi[s] = c; d = td; c = ti;
+                double dk = r.d[k];
+                uint64_t ck = r.i[k];
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3)
+                    if (fb_less(dk, ck, d[s3], ix[s3])) {
+                        const double td = d[s3]; const uint64_t ti = ix[s3];
+                        d[s3] = dk; ix[s3] = ck; dk = td; ck = ti;
                     }
             }
-            bp = fmin(bp, r.minpos);
-            bn = fmin(bn, r.minneg);
+            bp = r.minpos;
+            bn = r.minneg;
         }
-        double knn = 0.0, cen = 0.0;
-        if (p.method & PHK_METHOD_KNN) {
-            int votes = 0;
-            for (int k = 0; k < p.kn; ++k) votes += p.labels[bi[k]] ? 1 : 0;
-            knn = (2 * votes > p.kn) ? 1.0 : -1.0;
+        double bd[3];
+        uint64_t bi[3];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            double md = d[0];
+            uint64_t mi = ix[0];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double od = __shfl_xor(md, off);
+                const uint64_t oi = __shfl_xor(mi, off);
+                if (fb_less(od, oi, md, mi)) { md = od; mi = oi; }
+            }
+            bd[s3] = md;
+            bi[s3] = mi;
+            if (mi != ~0ull && ix[0] == mi) {   // this lane's head won: pop it
+                d[0] = d[1]; ix[0] = ix[1];
+                d[1] = d[2]; ix[1] = ix[2];
+                d[2] = INFINITY; ix[2] = ~0ull;
+            }
         }
-        if (p.method & PHK_METHOD_KMEANS) {
-            const double ep = sqrt(bp), en = sqrt(bn);
-            cen = tanh((en - ep) / (ep + en));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            bp = fmin(bp, __shfl_xor(bp, off));
+            bn = fmin(bn, __shfl_xor(bn, off));
         }
-        p.scores[p.q_base + q] = knn + cen;
+        if (lane == 0) {
+            double knn = 0.0, cen = 0.0;
+            if (p.method & PHK_METHOD_KNN) {
+                int votes = 0;
+                for (int k = 0; k < p.kn; ++k) votes += p.labels[bi[k]] ? 1 : 0;
+                knn = (2 * votes > p.kn) ? 1.0 : -1.0;
+            }
+            if (p.method & PHK_METHOD_KMEANS) {
+                const double ep = sqrt(bp), en = sqrt(bn);
+                cen = tanh((en - ep) / (ep + en));
+            }
+            p.scores[p.q_base + q] = knn + cen;
+        }
+        (void)bd;
     }
     // the last workgroup out zeroes the set's control words: every workgroup's reads of them precede its ticket
     if (p.clean_counters) {
         __shared__ uint32_t s_last;
-        __threadfence();
+        // (this workgroup's loads of the words have returned -- their values are in registers -- once vmcnt is 0: no fence, which
+        // would also wait for the atomics above to be performed, 3.5 us)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) s_last = atomicAdd(p.clean_counters + 15, 1u) == gridDim.x - 1 ? 1u : 0u;
         __syncthreads();
