@@ -147,20 +147,20 @@ struct phk_ctx {
     // zeroed for; ctl_epoch = calls so far (its parity picks the block); ctl_dirty = a call failed half way.
     uint64_t ctl_gen = 0, ctl_epoch = 0;
     bool ctl_dirty = true;
-    // words another entry point wants zeroed by the planning kernel (phk_count_score_dev: the scorer's NaN counter and call
-    // totals), consumed by the next phk_launch_count that launches a planning kernel; `taken` says it did
-    // the scorer's control words (phk_score_fast, WS_DIST): zeroed by the kernels that read them last; see there
+    // the scorer's control words (phk_score_fast, WS_SCTL): zeroed by the kernels that read them last; see there
     uint64_t score_ctl_gen = 0;
     bool score_ctl_dirty = true;
     bool score_totals_zeroed = false;   // this call's NaN counter (and totals) were zeroed by the count planner's kernel ...
     bool score_totals_only_status = false;   // ... the NaN counter only (the totals' workspace did not exist yet)
+    // words another entry point wants zeroed by the planning kernel (phk_count_score_dev: the scorer's NaN counter and call
+    // totals), consumed by the next phk_launch_count that launches a planning kernel; `taken` says it did
     uint32_t *plan_zero[2] = {nullptr, nullptr};
     uint32_t plan_zero_words[2] = {0, 0};
     bool plan_zero_taken = false;
     int num_cus = 256;
     PhkBuf ws[WS_SLOTS];
     bool profile = false;
-    bool last_score_fast = false;  // WS_DIST holds the MFMA path's counters
+    bool last_score_fast = false;  // the last scoring call took the MFMA path: WS_SCTL's first words hold its totals (phk_score_stats)
     std::vector<PhkTimed> timed;
     std::vector<hipEvent_t> ev_pool;
     // pinned staging buffers of the sequence upload (phk_batch_from_ascii), allocated at the first multi-chunk upload
