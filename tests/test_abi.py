@@ -51,3 +51,14 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(root, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_build_entry_checks_the_version_the_binding_expects():
+    """__graft_entry__.build() asserts the library's ABI version: against the binding's constant, not a literal (round 5: the
+    bump to 2 left a literal 1 there, found by building a fresh clone)."""
+    import inspect
+
+    import __graft_entry__ as entry
+    src = inspect.getsource(entry.build)
+    assert "_lib.ABI_VERSION" in src and "phk_abi_version() == 1" not in src
+    entry.build()
