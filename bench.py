@@ -36,7 +36,6 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_F32_PEAK_TF = 157.3       # fp32-input MFMA dense peak
 F64_PEAK_TF = 78.6             # fp64 vector / matrix peak
 MFMA_F16_PEAK_TF = 2500.0      # f16/bf16 dense MFMA peak
 MFMA_I8_PEAK_TF = 5000.0       # int8 dense MFMA peak (2 x bf16 per clock: MI355X_MICROARCH.md, MFMA table)
@@ -457,20 +456,17 @@ def main():
     score_tflop = n * 2.0 * D * (M + C) / 1e12                     # 2 D (M + C) per contig
     alg = {  # kernel -> (bound, unit, peak, algorithmic work per step on this rank)
         "phk_count_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
-        "phk_count_slots_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
         "phk_count_pairs_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
         "phk_count_direct_kernel": ("hbm", "GB/s", HBM_PEAK_GBS, count_bytes),
-        "phk_knn_mfma_kernel": ("mfma", "TFLOP/s", MFMA_F32_PEAK_TF, score_tflop),
         "phk_knn_f16_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
-        "phk_knn_f16c_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
         "phk_knn_f16h_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
         "phk_knn_f16_general_kernel": ("mfma", "TFLOP/s", MFMA_F16_PEAK_TF, score_tflop),
         "phk_knn_i8_general_kernel": ("mfma", "TFLOP/s", MFMA_I8_PEAK_TF, score_tflop),
         "phk_dist2_f64_kernel": ("mfma", "TFLOP/s", F64_PEAK_TF, score_tflop),
     }
-    if "phk_count_slots_kernel" in prof or "phk_count_pairs_kernel" in prof or "phk_count_direct_kernel" in prof:
+    if "phk_count_pairs_kernel" in prof or "phk_count_direct_kernel" in prof:
         alg.pop("phk_count_kernel", None)   # the wave-per-contig kernel then only serves the hand-over list
-    slotk = [kname for kname in ("phk_count_slots_kernel", "phk_count_pairs_kernel", "phk_count_direct_kernel") if kname in prof]
+    slotk = [kname for kname in ("phk_count_pairs_kernel", "phk_count_direct_kernel") if kname in prof]
     if len(slotk) > 1:
         # two of them are launched and decide on the device which one counts the batch (the other returns at once):
         # the bytes are credited to the one that did the work
@@ -481,8 +477,7 @@ def main():
     # the split-query kernel is the whole sweep only as a first pass (float64 rows / proposal=f16); as the second
     # chance of a count-exact first pass it sees the queued rows alone: credit it with those (stats_ex[2] is the
     # last step's queue on this rank), never with the batch
-    first_pass = [kname for kname in ("phk_knn_f16h_kernel", "phk_knn_f16c_kernel", "phk_knn_f16_general_kernel",
-                                      "phk_knn_i8_general_kernel", "phk_knn_mfma_kernel") if kname in prof]
+    first_pass = [kname for kname in ("phk_knn_f16h_kernel", "phk_knn_f16_general_kernel", "phk_knn_i8_general_kernel") if kname in prof]
     if first_pass and "phk_knn_f16_kernel" in prof:
         bound, unit, peak, _ = alg["phk_knn_f16_kernel"]
         alg["phk_knn_f16_kernel"] = (bound, unit, peak, score_tflop * (stats_ex["second_chance"] / float(n) if n else 0.0))
@@ -515,11 +510,12 @@ def main():
         "algorithmic_bytes_per_contig": count_bytes * 1e9 / n,
         "hbm_bytes_per_contig_all_kernels": round(sum(per_all.values()), 1) if per_all else None}
     # MFMA flops ISSUED per algorithmic flop: 3 (split-query f16: hi.hi + hi.lo + lo.hi), 2 (count-exact: c.r_hi +
-    # c.r_lo), 1 (count-exact, high parts only: the low parts are applied to the few candidates by the decision stage),
+    # c.r_lo at general D), 17/16 (k = 4, high parts only: the low parts are applied to the few candidates by the decision stage;
+    # the 17th step carries the bias),
     # int8 (against the int8 peak): the reference column is a 24-bit fixed-point value in three int8 parts; the default sweep
     # issues the upper two (the third is applied to the window's candidates by the decision stage), proposal=i83 all three
     i8_parts = 3.0 if os.environ.get("PHK_PROPOSAL", "") == "i83" else 2.0
-    issue = {"phk_knn_f16_kernel": 3.0, "phk_knn_f16c_kernel": 2.0, "phk_knn_f16h_kernel": 1.0,
+    issue = {"phk_knn_f16_kernel": 3.0, "phk_knn_f16h_kernel": 17.0 / 16.0,
              "phk_knn_f16_general_kernel": 2.0, "phk_knn_i8_general_kernel": i8_parts}.get(dom)
     if issue:
         roofline["mfma_issue_frac"] = issue * kernels[dom]["frac"]
